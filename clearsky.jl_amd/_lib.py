@@ -1,0 +1,107 @@
+"""ctypes binding of the C ABI in include/clearsky_hip.h (libclearsky_hip.so, built in-tree by build_native()).
+
+There is no CPU fallback: if the HIP library is missing or no GPU is visible, every compute entry point raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libclearsky_hip.so")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "clearsky_hip.h")
+
+CS_MAX_GAS = 16
+CHEB_LD = 16
+SHAPES = {"voigt": 0, "lorentz": 1, "doppler": 2, "PHCO2": 3, "phco2": 3}
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); must list every symbol the header declares
+SIGNATURES = {
+    "cs_version": (C.c_int, []),
+    "cs_last_error": (C.c_char_p, []),
+    "cs_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "cs_destroy": (None, [_vp]),
+    "cs_gas_upload": (C.c_int, [_vp, C.c_int, C.c_int64, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.POINTER(C.c_int16),
+                                C.c_int, C.POINTER(C.c_int32), _dp]),
+    "cs_gas_clear": (C.c_int, [_vp, C.c_int]),
+    "cs_shape_batch": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_int64, _dp, C.c_int, _dp, _dp, _dp, _dp,
+                                 C.c_int64]),
+    "cs_fluxes_discretized": (C.c_int, [_vp, C.c_int64, _dp, C.c_int, _dp, C.c_double, C.c_int, _dp, _dp, _dp, C.c_int,
+                                        _ip, _ip, _dp, _dp, C.c_double, _dp, _dp, _dp, C.c_double, C.c_int, _dp, _dp,
+                                        _dp, _dp, _dp]),
+    "cs_column_setup": (C.c_int, [_vp, C.c_int64, _dp, _dp, C.c_int, _dp, C.c_double, C.c_int, _dp, _dp, _dp, C.c_int,
+                                  _ip, _ip, _dp, _dp, C.c_double, _dp, _dp, _dp, C.c_double, C.c_int, C.c_int, C.c_int]),
+    "cs_column_run": (C.c_int, [_vp, _vp]),
+    "cs_column_sync": (C.c_int, [_vp]),
+    "cs_column_profile": (C.c_int, [_vp, _vp, C.c_int, _dp]),
+    "cs_column_flux_ptr": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "cs_column_fetch": (C.c_int, [_vp, _dp, _dp, _dp, _dp, _dp]),
+    "cs_column_sigma_fetch": (C.c_int, [_vp, _dp]),
+    "cs_column_counts": (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "cs_column_update_state": (C.c_int, [_vp, _dp, _dp, _dp, _dp]),
+    "cs_streamnodes": (C.c_int, [C.c_int, _dp, _dp]),
+    "cs_lobattonodes": (C.c_int, [C.c_int, _dp, _dp]),
+    "cs_faddeeva_batch": (C.c_int, [_vp, C.c_int64, _dp, _dp, _dp]),
+}
+
+
+class ClearSkyHIPError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"[clearsky_hip {code}] {msg}")
+        self.code = code
+
+
+def build_native(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into csrc/libclearsky_hip.so with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, "cs_api.hip")]
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [HEADER]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (raises if it has not been built -- no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ClearSkyHIPError(-100, f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                         "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise ClearSkyHIPError(rc, lib().cs_last_error().decode("utf-8", "replace"))
+
+
+def dptr(a):
+    """double* of a C-contiguous float64 array (or NULL for None)."""
+    if a is None:
+        return None
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_dp)
+
+
+def as_f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)

@@ -1,0 +1,662 @@
+"""Host-side mirror of ClearSky.jl's operator surface for the Discretized line-by-line hot path.
+
+Same names, argument meaning and error behaviour as the reference (Julia `!` becomes a trailing underscore), so the
+parity tests read like the reference's own calls.  Everything numerical runs in the HIP library through the C ABI
+(include/clearsky_hip.h); this module only pre-evaluates the closures that cannot cross the ABI, exactly where the
+reference evaluates them, and moves arrays.  Citations are reference paths (src/...).
+
+Matrices the reference stores as [level, nu] column-major (core/shared.jl:93-101) are numpy arrays of shape
+(np, nnu) in Fortran order here -- identical memory layout, identical indexing M[i, j].
+"""
+import ctypes as C
+import math
+from typing import Callable, Optional, Sequence
+
+import numpy as np
+
+from . import constants as K
+from ._lib import (CHEB_LD, CS_MAX_GAS, SHAPES, ClearSkyHIPError, as_f64, check, dptr, lib)
+from .hitran import TMAX, TMIN, SpectralLines
+
+# ----------------------------------------------------------------------------------------------------------------
+# small numerical helpers (host)
+
+
+def chebygrid(*args):
+    """BasicInterpolators.chebygrid: Chebyshev extrema, ascending; chebygrid(n) on [-1,1], chebygrid(a,b,n) mapped."""
+    if len(args) == 1:
+        n = args[0]
+        return np.cos(np.pi * np.arange(n - 1, -1, -1) / (n - 1))
+    a, b, n = args
+    return (chebygrid(n) + 1) * (b - a) / 2 + a
+
+
+def pressuregrid(Pt, Ps, n):
+    """util.jl:19-23"""
+    assert Ps > Pt
+    assert n >= 3
+    return np.exp(chebygrid(math.log(Pt), math.log(Ps), n))
+
+
+def trapz(x, y):
+    """util.jl:26-33 (sequential sum)."""
+    x = np.asarray(x, float)
+    y = np.asarray(y, float)
+    assert len(x) == len(y), "vectors must be equal length"
+    s = 0.0
+    for i in range(len(x) - 1):
+        s += (x[i + 1] - x[i]) * (y[i] + y[i + 1]) / 2
+    return s
+
+
+def logrange(a, b, N=101, gamma=1):
+    """util.jl:43-45"""
+    return ((10.0 ** np.linspace(0, gamma, N)) - 1) * (b - a) / (10.0 ** gamma - 1) + a
+
+
+def planck(nu, T):
+    """radiation.jl:48-54, W/m^2/cm^-1/sr"""
+    num = 100.0 * np.asarray(nu, float)
+    x = K.h * K.c * num / (K.k * T)
+    p = 2 * K.h * K.c ** 2 * num ** 3
+    return 100.0 * p / (np.exp(x) - 1.0)
+
+
+def stefanboltzmann(T):
+    """radiation.jl:95"""
+    return K.sigma_sb * T ** 4
+
+
+def dtaudP(sigma, g, mu):
+    """radiation.jl:141"""
+    return 1e-4 * sigma * K.Na / (mu * g)
+
+
+def streamnodes(n: int):
+    """core/shared.jl:4-21 -> (m = 1/cos(theta_k), W_k)"""
+    m = np.zeros(n)
+    W = np.zeros(n)
+    check(lib().cs_streamnodes(n, dptr(m), dptr(W)))
+    return m, W
+
+
+def lobattonodes(n: int):
+    """core/discretized.jl:2-9 -> nodes and weights on [0,1]"""
+    x = np.zeros(n)
+    w = np.zeros(n)
+    check(lib().cs_lobattonodes(n, dptr(x), dptr(w)))
+    return x, w
+
+
+def psatH2O(T):
+    """atmospherics.jl:528-541 (Murphy & Koop 2005)"""
+    a = math.log(T)
+    b = 1 / T
+    if T >= 273.15:
+        c = 53.878 - 1331.22 * b - 9.44523 * a + 0.014025 * T
+        d = c * math.tanh(0.0415 * (T - 218.8))
+        return math.exp(54.842763 - 6763.22 * b - 4.21 * a + 3.67e-4 * T + d)
+    return math.exp(9.550426 - 5723.265 * b + 3.53068 * a - 0.00728332 * T)
+
+
+def ozonelayer(P, Cmax=8e-6):
+    """atmospherics.jl:567-578"""
+    lp = math.log(P)
+    P1, P2, P3 = 10.146433731146518, 7.3777589082278725, 4.605170185988092
+    if P2 <= lp <= P1:
+        return Cmax * (P1 - lp) / (P1 - P2)
+    if P3 <= lp <= P2:
+        return Cmax * (lp - P3) / (P2 - P3)
+    return 0.0
+
+
+class AtmosphericProfile:
+    """Linear interpolation in ln P without boundary checks (atmospherics.jl:6-26; LinearInterpolator+NoBoundaries)."""
+
+    def __init__(self, P, y):
+        P = np.asarray(P, float)
+        y = np.asarray(y, float)
+        assert len(P) == len(y), "cannot form AtmosphericProfile with unequal numbers of points"
+        idx = np.argsort(P, kind="stable")
+        self.x = np.log(P[idx])
+        self.y = y[idx]
+
+    def __call__(self, P):
+        x = math.log(P)
+        n = len(self.x)
+        i = int(np.searchsorted(self.x, x, side="right")) - 1
+        i = min(max(i, 0), n - 2)
+        return (x - self.x[i]) * (self.y[i + 1] - self.y[i]) / (self.x[i + 1] - self.x[i]) + self.y[i]
+
+
+def formprofile(P, x):
+    """fluxes.jl:13-16"""
+    if callable(x):
+        return x
+    if np.ndim(x) == 0:
+        v = float(x)
+        return lambda *a: v
+    return AtmosphericProfile(P, x)
+
+
+def lobattoevaluations(P, fT, fmu, nlobatto):
+    """core/discretized.jl:11-30 -> T, mu of shape (nlobatto, np-1), Fortran order"""
+    npl = len(P)
+    T = np.zeros((nlobatto, npl - 1), order="F")
+    mu = np.zeros((nlobatto, npl - 1), order="F")
+    xs, _ = lobattonodes(nlobatto)
+    for i in range(nlobatto):
+        for j in range(npl - 1):
+            dP = P[j + 1] - P[j]
+            Pi = P[j] + dP * xs[i]
+            Ti = fT(Pi)
+            T[i, j] = Ti
+            mu[i, j] = fmu(Ti, Pi)
+    return T, mu
+
+
+def nodepressures(P, nlobatto):
+    """Pressure of node k = i*(nlobatto-1)+n as dDepth! uses it (core/discretized.jl:150,162,169)."""
+    P = np.asarray(P, float)
+    nl = len(P) - 1
+    xs, _ = lobattonodes(nlobatto)
+    Pk = np.zeros(nl * (nlobatto - 1) + 1)
+    Pk[0] = P[0]
+    for i in range(nl):
+        dP = P[i + 1] - P[i]
+        for n in range(1, nlobatto):
+            Pk[i * (nlobatto - 1) + n] = P[i + 1] if n == nlobatto - 1 else P[i] + dP * xs[n]
+    return Pk
+
+
+def nodevalues(X, nlobatto):
+    """Flatten a (nlobatto, nl) Lobatto array to node order (node 0 = X[0,0]; node of (n>=1, i) = X[n,i])."""
+    nl = X.shape[1]
+    out = np.zeros(nl * (nlobatto - 1) + 1)
+    out[0] = X[0, 0]
+    for i in range(nl):
+        for n in range(1, nlobatto):
+            out[i * (nlobatto - 1) + n] = X[n, i]
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# device context
+
+
+class Context:
+    """One HIP context (cs_ctx) = one device + stream + resident gas tables.  Not re-entrant."""
+
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p()
+        check(lib().cs_create(int(device), C.byref(self._h)))
+        self.device = device
+        self._slots = {}   # id(sl) -> (slot, sl)
+        self._next = 0
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().cs_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def slot_of(self, sl: SpectralLines) -> int:
+        """Upload `sl` (once) and return its gas slot."""
+        key = id(sl)
+        if key in self._slots:
+            return self._slots[key][0]
+        if len(self._slots) >= CS_MAX_GAS:
+            # evict the oldest table
+            old = next(iter(self._slots))
+            slot = self._slots.pop(old)[0]
+        else:
+            slot = self._next
+            self._next += 1
+        iso = np.ascontiguousarray(sl.I, dtype=np.int16)
+        ncheb = np.ascontiguousarray(sl.ncheb, dtype=np.int32)
+        cheb = as_f64(sl.cheb)
+        assert cheb.shape[1] == CHEB_LD
+        arrs = [as_f64(a) for a in (sl.nu, sl.S, sl.gamma_a, sl.gamma_s, sl.Epp, sl.na, sl.mu)]
+        check(lib().cs_gas_upload(self._h, slot, len(arrs[0]), *[dptr(a) for a in arrs],
+                                  iso.ctypes.data_as(C.POINTER(C.c_int16)), len(ncheb),
+                                  ncheb.ctypes.data_as(C.POINTER(C.c_int32)), dptr(cheb)))
+        self._slots[key] = (slot, sl)
+        return slot
+
+
+_default_ctx = {}
+
+
+def default_context(device: int = 0) -> Context:
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# line shapes (B1)
+
+
+def shape_batch(sl: SpectralLines, shape, nu, T, P, Pp, dnu_cut=25.0, ctx: Optional[Context] = None):
+    """sigma[k, :] = shape!(.., nu, sl, T[k], P[k], Pp[k], dnu_cut) for all states in one launch (bake's inner loop,
+    gases.jl:115-126).  Returns an array of shape (K, nnu)."""
+    ctx = ctx or default_context()
+    nu = as_f64(nu)
+    T, P, Pp = (as_f64(np.atleast_1d(a)) for a in (T, P, Pp))
+    Kn = len(T)
+    assert len(P) == Kn and len(Pp) == Kn
+    out = np.zeros((Kn, len(nu)))
+    sh = SHAPES[shape] if isinstance(shape, str) else int(shape)
+    check(lib().cs_shape_batch(ctx.handle, ctx.slot_of(sl), sh, float(dnu_cut), len(nu), dptr(nu), Kn, dptr(T), dptr(P),
+                               dptr(Pp), dptr(out), len(nu)))
+    return out
+
+
+def _shape_inplace(name, default_cut):
+    def f_(sigma, nu, sl, T, P, Pp, dnu_cut=default_cut, ctx=None):
+        r = shape_batch(sl, name, nu, [T], [P], [Pp], dnu_cut, ctx)
+        sigma[...] = r[0]   # overwrite, line_shapes.jl:85
+        return None
+
+    def f(nu, sl, T, P, Pp, dnu_cut=default_cut, ctx=None):
+        if np.ndim(nu) == 0:
+            return float(shape_batch(sl, name, [float(nu)], [T], [P], [Pp], dnu_cut, ctx)[0, 0])
+        return shape_batch(sl, name, nu, [T], [P], [Pp], dnu_cut, ctx)[0]
+
+    f_.__doc__ = f"{name}!(sigma, nu, sl, T, P, Pp, dnu_cut={default_cut}) -- absorption/line_shapes.jl; fills sigma in place"
+    f.__doc__ = f"{name}(nu, sl, T, P, Pp, dnu_cut={default_cut}) -- absorption/line_shapes.jl; returns cross-sections"
+    return f_, f
+
+
+voigt_, voigt = _shape_inplace("voigt", 25.0)        # line_shapes.jl:412-448
+lorentz_, lorentz = _shape_inplace("lorentz", 25.0)  # :313-348
+doppler_, doppler = _shape_inplace("doppler", 25.0)  # :200-235
+PHCO2_, PHCO2 = _shape_inplace("PHCO2", 500.0)       # :527-564
+
+
+def faddeeva(x, y, ctx: Optional[Context] = None):
+    """Re w(x+iy) evaluated by the kernels' device function (stand-in for Faddeyeva985.faddeyeva, line_shapes.jl:375)."""
+    ctx = ctx or default_context()
+    x = as_f64(np.atleast_1d(x))
+    y = as_f64(np.atleast_1d(y))
+    out = np.zeros_like(x)
+    check(lib().cs_faddeeva_batch(ctx.handle, len(x), dptr(x), dptr(y), dptr(out)))
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# absorbers (B2)
+
+
+class AbstractGas:
+    pass
+
+
+class DirectGas(AbstractGas):
+    """Line-by-line gas evaluated directly at every (T,P) node ("Mode D").
+
+    Reference semantics: the function absorber  (nu,T,P) -> C*shape(nu, sl, T, P, C*P)  with C = fC(T,P)
+    (absorbers.jl:16,24,71,91 + line_shapes.jl:399-405); differs from a baked `Gas` (gases.jl:205-249) only by the
+    opacity-table interpolation error (gases.jl:7).  `fC` is a callable fC(T,P) or a number (molar concentration).
+    """
+
+    def __init__(self, sl: SpectralLines, fC, nu, shape="voigt", dnu_cut=None):
+        nu = np.array(nu, dtype=float)
+        assert len(nu) > 0
+        assert np.all(np.diff(nu) > 0), "wavenumbers must be unique and in ascending order"
+        assert np.all(nu >= 0), "wavenumbers must be positive"
+        self.sl = sl
+        self.name, self.formula = sl.name, sl.formula
+        self.mu = float(np.sum(sl.A * sl.mu) / np.sum(sl.A))   # gases.jl:233
+        self.nu = nu
+        self.shape = shape
+        self.dnu_cut = float(dnu_cut if dnu_cut is not None else (500.0 if SHAPES[shape] == 3 else 25.0))
+        if callable(fC):
+            self.fC = fC
+        else:
+            cval = float(fC)
+            assert 0 <= cval <= 1.0, f"gas molar concentrations must be in [0,1], not {cval}"
+            self.fC = lambda T, P: cval
+
+    def concentration(self, T, P):
+        return self.fC(T, P)
+
+
+class GrayGas(AbstractGas):
+    """gases.jl:342-360: constant cross-section [cm^2/molecule] for any arguments."""
+
+    def __init__(self, sigma, nu):
+        self.name = self.formula = "Gray"
+        self.mu = float("nan")
+        self.nu = np.array(nu, dtype=float)
+        self.sigma = float(sigma)
+
+    def __call__(self, *a):
+        return self.sigma
+
+
+class UnifiedAbsorber:
+    """absorbers.jl:18-77: gases + functions sigma(nu,T,P) on one wavenumber grid."""
+
+    def __init__(self, *absorbers):
+        if len(absorbers) == 1 and isinstance(absorbers[0], (tuple, list)):
+            absorbers = tuple(absorbers[0])
+        assert len(absorbers) > 0, "no absorbers... nothing to group"
+        assert len(absorbers) == len(set(map(id, absorbers))), "duplicate absorbers"
+        for a in absorbers:
+            if not (isinstance(a, AbstractGas) or callable(a)):
+                raise TypeError("absorbers must only be gases (<: Gas), CIA objects, or functions in the form σ(ν, T, P)")
+        self.gas = tuple(a for a in absorbers if isinstance(a, AbstractGas))
+        if not self.gas:
+            raise ValueError("must have at least one Gas object, which specifies wavenumber samples")
+        self.fun = tuple(a for a in absorbers if not isinstance(a, AbstractGas))
+        nu0 = self.gas[0].nu
+        assert all(len(g.nu) == len(nu0) and np.array_equal(g.nu, nu0) for g in self.gas), \
+            "gases must have identical wavenumber vectors"
+        self.nu = nu0
+        self.nnu = len(nu0)
+
+
+def unifyabsorbers(absorbers):
+    """absorbers.jl:214-223"""
+    if len(absorbers) == 0:
+        raise ValueError("no absorbers")
+    if len(absorbers) == 1 and isinstance(absorbers[0], UnifiedAbsorber):
+        U = absorbers[0]
+    else:
+        U = UnifiedAbsorber(*absorbers)
+    return U, U.nu, U.nnu
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# numerical core selector and output container
+
+
+class Discretized:
+    """core/shared.jl:55-66"""
+
+    def __init__(self, nstream: int = 5, nlobatto: int = 2):
+        self.nstream, self.nlobatto = int(nstream), int(nlobatto)
+
+    def __repr__(self):
+        return f"Discretized(nstream={self.nstream}, nlobatto={self.nlobatto})"
+
+
+class FluxPack:
+    """core/shared.jl:73-106.  tau (np-1, nnu), Mup/Mdn (np, nnu) Fortran order; Fup, Fdn, Fnet (np)."""
+
+    def __init__(self, npl, nnu):
+        if not isinstance(npl, (int, np.integer)):
+            npl, nnu = len(npl), len(nnu)
+        self.tau = np.zeros((npl - 1, nnu), order="F")
+        self.Mup = np.zeros((npl, nnu), order="F")
+        self.Mdn = np.zeros((npl, nnu), order="F")
+        self.Fup = np.zeros(npl)
+        self.Fdn = np.zeros(npl)
+        self.Fnet = np.zeros(npl)
+
+    @property
+    def size(self):
+        return self.Mup.shape
+
+
+def checkstreams(n):
+    if n < 4:
+        import warnings
+        warnings.warn("careful! using nstream < 4 is likely to be inaccurate!")
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# whole-column evaluation (B3)
+
+
+class Column:
+    """A column resident in HBM: inputs uploaded once, evaluated any number of times (cs_column_* in the C ABI).
+
+    Pre-evaluates the closures exactly where monochromaticfluxes!(…, core::Discretized, …) does (fluxes.jl:250-267):
+    lobattoevaluations (T, mu at Lobatto nodes), T at the levels for Planck, fC at the nodes, fS(nu), fa(nu).
+    `nu_range=(j0, j1)` restricts the device work to a contiguous shard of the grid with the global trapezoid
+    weights, so shards' Fup/Fdn simply add (multi-GPU).
+    """
+
+    def __init__(self, P, g, T, mu, fS, fa, *absorbers, core: Optional[Discretized] = None, theta_s: float = 0.841,
+                 want_tau: bool = True, want_M: bool = True, nu_range=None, ctx: Optional[Context] = None):
+        self.ctx = ctx or default_context()
+        core = core or Discretized()
+        U, nu, nnu = unifyabsorbers(absorbers)
+        P = as_f64(P)
+        assert np.all(np.diff(P) >= 0), "pressure coordinates must be in ascending order (sorted)"
+        fT, fmu = formprofile(P, T), formprofile(P, mu)
+        self.U, self.core, self.P, self.g, self.theta_s = U, core, P, float(g), float(theta_s)
+        assert 0 <= theta_s < math.pi / 2, "azimuth angle θ must be ∈ [0,π/2)"
+        checkstreams(core.nstream)
+        self.np, self.nl = len(P), len(P) - 1
+        nlob = core.nlobatto
+        self.K = self.nl * (nlob - 1) + 1
+        nu = as_f64(nu)
+        # trapezoid weights on the global grid (util.jl:26-33 rewritten as per-point weights)
+        w = np.zeros(nnu)
+        if nnu > 1:
+            d = np.diff(nu)
+            w[:-1] += d / 2
+            w[1:] += d / 2
+        j0, j1 = (0, nnu) if nu_range is None else nu_range
+        self.j0, self.j1 = int(j0), int(j1)
+        self.nu_all = nu
+        self.nu = np.ascontiguousarray(nu[j0:j1])
+        self.wts = np.ascontiguousarray(w[j0:j1])
+        self.nnu = len(self.nu)
+        self.Pk = nodepressures(P, nlob)
+        self._fS, self._fa = fS, fa
+
+        def evalv(f):   # fS(nu), fa(nu): discretized.jl:299,309
+            if f is None:
+                return None
+            if callable(f):
+                return as_f64([f(v) for v in self.nu])
+            return np.full(self.nnu, float(f))
+
+        self.S_toa = evalv(fS)
+        self.albedo = evalv(fa)
+        self.gases = [g_ for g_ in U.gas if isinstance(g_, DirectGas)]
+        self.sigma_gray = float(sum(g_.sigma for g_ in U.gas if isinstance(g_, GrayGas)))
+        for g_ in U.gas:
+            if not isinstance(g_, (DirectGas, GrayGas)):
+                raise TypeError(f"unsupported gas type {type(g_).__name__} for the HIP Discretized core")
+        self.slots = np.array([self.ctx.slot_of(g_.sl) for g_ in self.gases], dtype=np.int32)
+        self.shapes = np.array([SHAPES[g_.shape] for g_ in self.gases], dtype=np.int32)
+        self.cuts = as_f64([g_.dnu_cut for g_ in self.gases])
+        self.want_tau, self.want_M = bool(want_tau), bool(want_M)
+        self._set = False
+        self._state(fT, fmu)
+        self._setup()
+
+    # -- closures -> arrays ---------------------------------------------------------------------------------------
+    def _state(self, fT, fmu):
+        nlob = self.core.nlobatto
+        self.Tn, self.mun = lobattoevaluations(self.P, fT, fmu, nlob)
+        self.Tlev = as_f64([fT(p) for p in self.P])          # planckevaluations, discretized.jl:51
+        self.Tk = nodevalues(self.Tn, nlob)
+        self.muk = nodevalues(self.mun, nlob)
+        ng = len(self.gases)
+        conc = np.zeros((ng, self.K), order="F")
+        for gi, g_ in enumerate(self.gases):
+            for k in range(self.K):
+                conc[gi, k] = g_.fC(self.Tk[k], self.Pk[k])
+        self.conc = conc
+        if self.U.fun:
+            ex = np.zeros((self.K, self.nnu))
+            for k in range(self.K):
+                for f in self.U.fun:
+                    try:
+                        ex[k] += np.asarray(f(self.nu, self.Tk[k], self.Pk[k]), float)
+                    except Exception:
+                        ex[k] += np.array([f(v, self.Tk[k], self.Pk[k]) for v in self.nu], float)
+            self.sigma_extra = ex
+        else:
+            self.sigma_extra = None
+
+    def _setup(self):
+        ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int)) if len(a) else None
+        check(lib().cs_column_setup(
+            self.ctx.handle, self.nnu, dptr(self.nu), dptr(self.wts), self.np, dptr(self.P), self.g, self.core.nlobatto,
+            dptr(np.asfortranarray(self.Tn).ravel(order="F").copy()), dptr(np.asfortranarray(self.mun).ravel(order="F").copy()),
+            dptr(self.Tlev), len(self.gases), ip(self.slots), ip(self.shapes), dptr(self.cuts) if len(self.cuts) else None,
+            dptr(self.conc.ravel(order="F").copy()) if self.conc.size else None, self.sigma_gray,
+            dptr(self.sigma_extra) if self.sigma_extra is not None else None, dptr(self.S_toa), dptr(self.albedo),
+            self.theta_s, self.core.nstream, int(self.want_tau), int(self.want_M)))
+        self._set = True
+
+    def update(self, T, mu=None):
+        """New temperature (and molar-mass) profile on the same grid: re-evaluates the closures and uploads the node
+        states only (the RCM inner loop, radiative_convective.jl:109-113)."""
+        fT = formprofile(self.P, T)
+        fmu = formprofile(self.P, mu) if mu is not None else (lambda *a: self.muk[0])
+        self._state(fT, fmu)
+        if self.sigma_extra is not None:
+            self._setup()
+            return
+        check(lib().cs_column_update_state(self.ctx.handle, dptr(self.Tn.ravel(order="F").copy()),
+                                           dptr(self.mun.ravel(order="F").copy()), dptr(self.Tlev),
+                                           dptr(self.conc.ravel(order="F").copy()) if self.conc.size else None))
+
+    # -- execution -------------------------------------------------------------------------------------------------
+    def run(self, stream: int = 0):
+        """Enqueue one evaluation (asynchronous).  `stream` is a raw hipStream_t (e.g. torch's cuda_stream) or 0."""
+        check(lib().cs_column_run(self.ctx.handle, C.c_void_p(stream) if stream else None))
+
+    def sync(self):
+        check(lib().cs_column_sync(self.ctx.handle))
+
+    def profile(self, reps: int = 3, stream: int = 0):
+        """HIP-event time per kernel class, ms per evaluation: dict(prep, linesum, rt, reduce)."""
+        ms = np.zeros(4)
+        check(lib().cs_column_profile(self.ctx.handle, C.c_void_p(stream) if stream else None, reps, dptr(ms)))
+        return dict(prep=ms[0], linesum=ms[1], rt=ms[2], reduce=ms[3])
+
+    def flux_ptr(self) -> int:
+        p = C.c_void_p()
+        check(lib().cs_column_flux_ptr(self.ctx.handle, C.byref(p)))
+        return p.value
+
+    def counts(self):
+        a, b = C.c_int64(), C.c_int64()
+        check(lib().cs_column_counts(self.ctx.handle, C.byref(a), C.byref(b)))
+        return dict(pair_evals=a.value, lines_in_range=b.value)
+
+    def fetch(self, tau=None, Mup=None, Mdn=None):
+        """Copy results to host.  Returns (Fup, Fdn); fills the optional Fortran-order matrices in place."""
+        Fup, Fdn = np.zeros(self.np), np.zeros(self.np)
+        bufs = []
+        ptrs = []
+        for a, rows in ((tau, self.nl), (Mup, self.np), (Mdn, self.np)):
+            if a is None:
+                ptrs.append(None)
+                bufs.append(None)
+                continue
+            assert a.shape == (rows, self.nnu), f"expected shape {(rows, self.nnu)}, got {a.shape}"
+            b = a if (a.flags["F_CONTIGUOUS"] and a.dtype == np.float64) else np.zeros(a.shape, order="F")
+            bufs.append(b)
+            ptrs.append(b.ctypes.data_as(C.POINTER(C.c_double)))
+        check(lib().cs_column_fetch(self.ctx.handle, ptrs[0], ptrs[1], ptrs[2], dptr(Fup), dptr(Fdn)))
+        for a, b in zip((tau, Mup, Mdn), bufs):
+            if a is not None and b is not a:
+                a[...] = b
+        return Fup, Fdn
+
+    def sigma_nodes(self):
+        """Total cross-section at the nodes, shape (K, nnu) (test hook)."""
+        out = np.zeros((self.K, self.nnu))
+        check(lib().cs_column_sigma_fetch(self.ctx.handle, dptr(out)))
+        return out
+
+
+def monochromaticfluxes_(Mup, Mdn, tau, core: Discretized, P, g, T, mu, fS, fa, *absorbers, theta_s=0.841, ctx=None):
+    """monochromaticfluxes!(M+, M-, tau, core::Discretized, P, g, T, mu, fS, fa, absorbers...; theta_s) fluxes.jl:238-279"""
+    col = Column(P, g, T, mu, fS, fa, *absorbers, core=core, theta_s=theta_s, want_tau=True, want_M=True, ctx=ctx)
+    col.run()
+    col.fetch(tau, Mup, Mdn)
+    return None
+
+
+def monochromaticfluxes(P, g, T, mu, fS, fa, *absorbers, core: Optional[Discretized] = None, theta_s=0.841, ctx=None):
+    """fluxes.jl:281-306 -> (M+, M-)"""
+    U, _, nnu = unifyabsorbers(absorbers)
+    npl = len(P)
+    Mup = np.zeros((npl, nnu), order="F")
+    Mdn = np.zeros((npl, nnu), order="F")
+    tau = np.zeros((npl - 1, nnu), order="F")
+    monochromaticfluxes_(Mup, Mdn, tau, core or Discretized(), P, g, T, mu, fS, fa, U, theta_s=theta_s, ctx=ctx)
+    return Mup, Mdn
+
+
+def fluxes(P, g, T, mu, fS, fa, *absorbers, core: Optional[Discretized] = None, theta_s=0.841, ctx=None):
+    """fluxes.jl:311-340 -> (F+, F-) [W/m^2] at every level; the nu-integral (intF!, shared.jl:125-137) runs on device."""
+    col = Column(P, g, T, mu, fS, fa, *absorbers, core=core, theta_s=theta_s, want_tau=False, want_M=False, ctx=ctx)
+    col.run()
+    return col.fetch()
+
+
+def netfluxes(P, g, T, mu, fS, fa, *absorbers, **kw):
+    """fluxes.jl:342-352"""
+    Fup, Fdn = fluxes(P, g, T, mu, fS, fa, *absorbers, **kw)
+    return Fup - Fdn
+
+
+def radiate_(F: FluxPack, core: Discretized, P, g, T, mu, fS, fa, *absorbers, theta_s=0.841, ctx=None):
+    """radiate!(F, core, P, g, T, mu, fS, fa, absorbers...) fluxes.jl:357-383"""
+    U, nu, nnu = unifyabsorbers(absorbers)
+    assert F.size == (len(P), nnu), "size of FluxPack does not match number of pressure or wavenumber coordinates"
+    col = Column(P, g, T, mu, fS, fa, U, core=core, theta_s=theta_s, want_tau=True, want_M=True, ctx=ctx)
+    col.run()
+    Fup, Fdn = col.fetch(F.tau, F.Mup, F.Mdn)
+    F.Fup[:] = Fup
+    F.Fdn[:] = Fdn
+    F.Fnet[:] = Fup - Fdn
+    return None
+
+
+def radiate(P, g, T, mu, fS, fa, *absorbers, core: Optional[Discretized] = None, theta_s=0.841, ctx=None) -> FluxPack:
+    """fluxes.jl:385-404.  OLR = F.Fup[0] (index 0 = top of atmosphere)."""
+    U, nu, nnu = unifyabsorbers(absorbers)
+    F = FluxPack(len(P), nnu)
+    radiate_(F, core or Discretized(), P, g, T, mu, fS, fa, U, theta_s=theta_s, ctx=ctx)
+    return F
+
+
+def opticaldepth(P, g, T, mu, theta, *absorbers, nlobatto: int = 4, ctx=None):
+    """opticaldepth(P::Vector, g, T, mu, theta, absorbers...; nlobatto=4) fluxes.jl:68-97: total slant optical depth per
+    wavenumber via dDepth (discretized.jl:92-134, no 1e-6 floor).  The node cross-sections come from the device; the
+    O(nnu*K) Lobatto sum is done here."""
+    assert 0 <= theta < math.pi / 2, "azimuth angle θ must be ∈ [0,π/2)"
+    P = np.sort(as_f64(P))
+    col = Column(P, g, T, mu, None, None, *absorbers, core=Discretized(5, nlobatto), want_tau=False, want_M=False, ctx=ctx)
+    col.run()
+    sig = col.sigma_nodes()
+    Cc = 1e-4 * K.Na / g
+    _, ws = lobattonodes(nlobatto)
+    m = 1 / math.cos(theta)
+    beta = Cc * (sig / col.muk[:, None])
+    tau = np.zeros(col.nnu)
+    nl = len(P) - 1
+    for i in range(nl):
+        dP = P[i + 1] - P[i]
+        ti = np.zeros(col.nnu)
+        for n in range(nlobatto):
+            ti = ti + (dP * ws[n]) * beta[i * (nlobatto - 1) + n]
+        tau = tau + ti * m
+    return tau
+
+
+def transmittance(*args, **kw):
+    """fluxes.jl:109"""
+    return np.exp(-opticaldepth(*args, **kw))

@@ -1,0 +1,715 @@
+// cs_api.hip -- host side of the C ABI declared in include/clearsky_hip.h (context, uploads, launches).
+// Reference interfaces replaced are cited in the header; orchestration follows fluxes.jl:238-279 / :357-383.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/clearsky_hip.h"
+#include "cs_kernels.h"
+
+using namespace csdev;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(CS_EHIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    hipError_t reserve(size_t n)
+    {
+        if (n <= bytes && p) return hipSuccess;
+        release();
+        if (n == 0) n = 8;
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+template <class T> int upload(DevBuf &b, const T *h, size_t n, hipStream_t s)
+{
+    HIPCHK(b.reserve(n * sizeof(T)));
+    if (n) HIPCHK(hipMemcpyAsync(b.p, h, n * sizeof(T), hipMemcpyHostToDevice, s));
+    return CS_OK;
+}
+
+struct GasTable {
+    bool present = false;
+    int64_t L = 0;
+    int niso = 0;
+    std::vector<double> h_nu;
+    std::vector<int16_t> h_iso;
+    std::vector<int32_t> h_ncheb;
+    DevBuf nu, S, ga, gs, Epp, na, mu, iso, ncheb, cheb;
+    GasDev dev() const
+    {
+        GasDev g;
+        g.L = L;
+        g.nu = nu.as<double>(); g.S = S.as<double>(); g.ga = ga.as<double>(); g.gs = gs.as<double>();
+        g.Epp = Epp.as<double>(); g.na = na.as<double>(); g.mu = mu.as<double>();
+        g.iso = iso.as<int16_t>(); g.ncheb = ncheb.as<int32_t>(); g.cheb = cheb.as<double>();
+        return g;
+    }
+};
+
+struct ColGas {
+    int slot = 0, shape = 0;
+    double cut = 25.0;
+    DevBuf conc, Pp, J0, J1;  // [K], [K], [ntile], [ntile]
+    int64_t pairs_per_state = 0, lines_in_range = 0;
+};
+
+struct Column {
+    bool ready = false;
+    int64_t nnu = 0;
+    int np = 0, nl = 0, nlob = 0, K = 0, nstream = 0, ngas = 0, ntile = 0;
+    bool want_tau = false, want_M = false, has_extra = false, has_S = false, has_alb = false;
+    double g = 0, sigma_gray = 0, theta_s = 0;
+    RtParams rt;
+    std::vector<double> h_P, h_Pk, h_xs;
+    std::vector<ColGas> gas;
+    DevBuf nu, wts, P, Pk, Tk, muk, Tlev, extra, S_toa, albedo;
+    DevBuf hot, cold, sigma, tau, Mup, Mdn, partial, F, stage;
+};
+
+}  // namespace
+
+struct cs_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    GasTable gas[CS_MAX_GAS];
+    Column col;
+    DevBuf tmpA, tmpB, tmpC;
+};
+
+namespace {
+
+// Gauss-Legendre / Gauss-Lobatto rules on [-1,1] (FastGaussQuadrature.gausslegendre / gausslobatto are the
+// mathematically unique rules), ascending nodes.  Newton on P_n with the three-term recurrence.
+void legendre(int n, double z, double &pn, double &pnm1)
+{
+    double p0 = 1.0, p1 = z;
+    if (n == 0) { pn = 1.0; pnm1 = 0.0; return; }
+    for (int j = 1; j < n; j++) {
+        double p2 = ((2.0 * j + 1.0) * z * p1 - j * p0) / (j + 1.0);
+        p0 = p1;
+        p1 = p2;
+    }
+    pn = p1;
+    pnm1 = p0;
+}
+
+void gauss_legendre(int n, double *x, double *w)
+{
+    for (int i = 0; i < n; i++) {
+        double z = std::cos(M_PI * (i + 0.75) / (n + 0.5));
+        double pn, pm, dp = 1.0;
+        for (int it = 0; it < 64; it++) {
+            legendre(n, z, pn, pm);
+            dp = n * (z * pn - pm) / (z * z - 1.0);
+            double dz = pn / dp;
+            z -= dz;
+            if (std::fabs(dz) < 1e-16) break;
+        }
+        legendre(n, z, pn, pm);
+        dp = n * (z * pn - pm) / (z * z - 1.0);
+        x[n - 1 - i] = z;
+        w[n - 1 - i] = 2.0 / ((1.0 - z * z) * dp * dp);
+    }
+}
+
+void gauss_lobatto(int n, double *x, double *w)
+{
+    const int N = n - 1;
+    x[0] = -1.0;
+    x[N] = 1.0;
+    w[0] = w[N] = 2.0 / (N * (N + 1.0));
+    for (int i = 1; i < N; i++) {
+        double z = -std::cos(M_PI * i / N), pn, pm;
+        for (int it = 0; it < 64; it++) {
+            legendre(N, z, pn, pm);
+            double d1 = N * (pm - z * pn) / (1.0 - z * z);
+            double d2 = (2.0 * z * d1 - N * (N + 1.0) * pn) / (1.0 - z * z);
+            double dz = d1 / d2;
+            z -= dz;
+            if (std::fabs(dz) < 1e-16) break;
+        }
+        legendre(N, z, pn, pm);
+        x[i] = z;
+        w[i] = 2.0 / (N * (N + 1.0) * pn * pn);
+    }
+}
+
+template <int SHAPE>
+void launch_linesum(dim3 grid, hipStream_t s, const double *nu, int64_t nnu, int64_t L, const LineHot *hot,
+                    const LineCold *cold, const int32_t *J0, const int32_t *J1, double cut, const double *Tk,
+                    double base, const double *extra, double *sigma, int accumulate)
+{
+    hipLaunchKernelGGL(k_linesum<SHAPE>, grid, dim3(256), 0, s, nu, nnu, L, hot, cold, J0, J1, cut, Tk, base, extra,
+                       sigma, accumulate);
+}
+
+void launch_linesum_shape(int shape, dim3 grid, hipStream_t s, const double *nu, int64_t nnu, int64_t L,
+                          const LineHot *hot, const LineCold *cold, const int32_t *J0, const int32_t *J1, double cut,
+                          const double *Tk, double base, const double *extra, double *sigma, int accumulate)
+{
+    switch (shape) {
+    case SH_LORENTZ: launch_linesum<SH_LORENTZ>(grid, s, nu, nnu, L, hot, cold, J0, J1, cut, Tk, base, extra, sigma, accumulate); break;
+    case SH_DOPPLER: launch_linesum<SH_DOPPLER>(grid, s, nu, nnu, L, hot, cold, J0, J1, cut, Tk, base, extra, sigma, accumulate); break;
+    case SH_PHCO2: launch_linesum<SH_PHCO2>(grid, s, nu, nnu, L, hot, cold, J0, J1, cut, Tk, base, extra, sigma, accumulate); break;
+    default: launch_linesum<SH_VOIGT>(grid, s, nu, nnu, L, hot, cold, J0, J1, cut, Tk, base, extra, sigma, accumulate); break;
+    }
+}
+
+template <int NS>
+void launch_rt_ns(int nblk, size_t shmem, hipStream_t s, const RtParams &p, const double *nu, const double *wts,
+                  int64_t nnu, const double *sigma, const double *muk, const double *P, const double *Tlev,
+                  const double *S, const double *alb, double *tau, double *Mup, double *Mdn, double *partial)
+{
+    hipLaunchKernelGGL(k_rt<NS>, dim3(nblk), dim3(256), shmem, s, p, nu, wts, nnu, sigma, muk, P, Tlev, S, alb, tau, Mup,
+                       Mdn, partial);
+}
+
+void launch_rt(int ns, int nblk, size_t shmem, hipStream_t s, const RtParams &p, const double *nu, const double *wts,
+               int64_t nnu, const double *sigma, const double *muk, const double *P, const double *Tlev,
+               const double *S, const double *alb, double *tau, double *Mup, double *Mdn, double *partial)
+{
+#define CS_RT_CASE(N) case N: launch_rt_ns<N>(nblk, shmem, s, p, nu, wts, nnu, sigma, muk, P, Tlev, S, alb, tau, Mup, Mdn, partial); break;
+    switch (ns) {
+        CS_RT_CASE(1) CS_RT_CASE(2) CS_RT_CASE(3) CS_RT_CASE(4) CS_RT_CASE(5) CS_RT_CASE(6) CS_RT_CASE(7) CS_RT_CASE(8)
+        CS_RT_CASE(9) CS_RT_CASE(10) CS_RT_CASE(11) CS_RT_CASE(12) CS_RT_CASE(13) CS_RT_CASE(14) CS_RT_CASE(15) CS_RT_CASE(16)
+    }
+#undef CS_RT_CASE
+}
+
+// includedlines(::Vector) line_shapes.jl:18-22 -> [g0, g1) ; strict = 0 keeps every line (scalar-nu method :12-16)
+void included_range(const std::vector<double> &nul, double numin, double numax, double cut, bool strict, int64_t &g0,
+                    int64_t &g1)
+{
+    const int64_t L = (int64_t)nul.size();
+    g0 = 0;
+    g1 = L;
+    if (strict) {
+        const double lo = numin - cut, hi = numax + cut;
+        while (g0 < L && !(nul[g0] > lo)) g0++;
+        while (g1 > g0 && !(nul[g1 - 1] < hi)) g1--;
+    }
+}
+
+// per-tile union windows (a superset of every lane's |nu - nul| <= cut run; the kernel applies the exact test)
+void tile_windows(const std::vector<double> &nul, int64_t g0, int64_t g1, const double *nu, int64_t nnu, double cut,
+                  std::vector<int32_t> &J0, std::vector<int32_t> &J1, int64_t &pairs, int64_t &inrange)
+{
+    const int ntile = (int)((nnu + 255) / 256);
+    J0.resize(ntile);
+    J1.resize(ntile);
+    auto b = nul.begin() + g0, e = nul.begin() + g1;
+    for (int t = 0; t < ntile; t++) {
+        const int64_t i0 = (int64_t)t * 256, i1 = std::min<int64_t>(nnu, i0 + 256) - 1;
+        const double lo = nu[i0] - cut, hi = nu[i1] + cut;
+        const double tol = 1e-9 * (std::fabs(hi) + cut + 1.0);
+        J0[t] = (int32_t)(std::lower_bound(b, e, lo - tol) - nul.begin());
+        J1[t] = (int32_t)(std::upper_bound(b, e, hi + tol) - nul.begin());
+    }
+    pairs = 0;
+    for (int64_t i = 0; i < nnu; i++)
+        pairs += (std::upper_bound(b, e, nu[i] + cut) - std::lower_bound(b, e, nu[i] - cut));
+    inrange = (std::upper_bound(b, e, nu[nnu - 1] + cut) - std::lower_bound(b, e, nu[0] - cut));
+}
+
+int check_gas_states(const GasTable &G, int K, const double *T)
+{
+    for (int k = 0; k < K; k++)
+        if (!(T[k] >= kTmin && T[k] <= kTmax))
+            return fail(CS_ETEMP, "temperature %g K outside of Qref/Q interpolation range [25, 1000]", T[k]);
+    for (int64_t j = 0; j < G.L; j++) {
+        int I = G.h_iso[j];
+        if (I < 1 || I > G.niso || G.h_ncheb[I - 1] <= 0)
+            return fail(CS_ENOCHEB, "no interpolating polynomial available to compute Qref/Q for isotopologue %d", I);
+    }
+    return CS_OK;
+}
+
+int check_ascending(const double *nu, int64_t n)
+{
+    if (n < 1) return fail(CS_EINVAL, "empty wavenumber vector");
+    for (int64_t i = 1; i < n; i++)
+        if (!(nu[i] > nu[i - 1])) return fail(CS_EORDER, "wavenumber vectors must be sorted in ascending order");
+    return CS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cs_version(void) { return 100; }
+const char *cs_last_error(void) { return g_err.c_str(); }
+
+int cs_create(int device, cs_ctx **out)
+{
+    if (!out) return fail(CS_EINVAL, "out is NULL");
+    int n = 0;
+    HIPCHK(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(CS_EINVAL, "device %d out of range (%d devices)", device, n);
+    HIPCHK(hipSetDevice(device));
+    cs_ctx *c = new cs_ctx();
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return fail(CS_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    *out = c;
+    return CS_OK;
+}
+
+void cs_destroy(cs_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int cs_gas_upload(cs_ctx *ctx, int slot, int64_t L, const double *nu, const double *S, const double *gamma_a,
+                  const double *gamma_s, const double *Epp, const double *na, const double *mu_iso,
+                  const int16_t *iso, int niso, const int32_t *ncheb, const double *cheb)
+{
+    if (!ctx) return fail(CS_EINVAL, "ctx is NULL");
+    if (slot < 0 || slot >= CS_MAX_GAS) return fail(CS_EINVAL, "gas slot %d out of range", slot);
+    if (L < 1 || niso < 1) return fail(CS_EINVAL, "empty line table");
+    for (int64_t j = 1; j < L; j++)
+        if (!(nu[j] >= nu[j - 1])) return fail(CS_EORDER, "line table must be sorted by wavenumber (par.jl:267)");
+    if (L > INT32_MAX) return fail(CS_EINVAL, "line table too long");
+    HIPCHK(hipSetDevice(ctx->device));
+    GasTable &G = ctx->gas[slot];
+    hipStream_t s = ctx->stream;
+    G.L = L;
+    G.niso = niso;
+    G.h_nu.assign(nu, nu + L);
+    G.h_iso.assign(iso, iso + L);
+    G.h_ncheb.assign(ncheb, ncheb + niso);
+    int rc;
+    if ((rc = upload(G.nu, nu, L, s)) || (rc = upload(G.S, S, L, s)) || (rc = upload(G.ga, gamma_a, L, s)) ||
+        (rc = upload(G.gs, gamma_s, L, s)) || (rc = upload(G.Epp, Epp, L, s)) || (rc = upload(G.na, na, L, s)) ||
+        (rc = upload(G.mu, mu_iso, L, s)) || (rc = upload(G.iso, iso, L, s)) || (rc = upload(G.ncheb, ncheb, niso, s)) ||
+        (rc = upload(G.cheb, cheb, (size_t)niso * CS_CHEB_LD, s)))
+        return rc;
+    HIPCHK(hipStreamSynchronize(s));
+    G.present = true;
+    return CS_OK;
+}
+
+int cs_gas_clear(cs_ctx *ctx, int slot)
+{
+    if (!ctx || slot < 0 || slot >= CS_MAX_GAS) return fail(CS_EINVAL, "bad slot");
+    ctx->gas[slot] = GasTable();
+    return CS_OK;
+}
+
+int cs_shape_batch(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t nnu, const double *nu, int K,
+                   const double *T, const double *P, const double *Pp, double *sigma, int64_t ld_state)
+{
+    if (!ctx) return fail(CS_EINVAL, "ctx is NULL");
+    if (slot < 0 || slot >= CS_MAX_GAS || !ctx->gas[slot].present) return fail(CS_EINVAL, "gas slot %d is empty", slot);
+    if (shape < 0 || shape > 3) return fail(CS_EINVAL, "unknown shape %d", shape);
+    if (K < 1 || ld_state < nnu) return fail(CS_EINVAL, "bad K/ld_state");
+    int rc;
+    if ((rc = check_ascending(nu, nnu))) return rc;
+    GasTable &G = ctx->gas[slot];
+    if ((rc = check_gas_states(G, K, T))) return rc;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    int64_t g0, g1, pairs, inr;
+    included_range(G.h_nu, nu[0], nu[nnu - 1], dnu_cut, true, g0, g1);
+    std::vector<int32_t> J0, J1;
+    tile_windows(G.h_nu, g0, g1, nu, nnu, dnu_cut, J0, J1, pairs, inr);
+    const int ntile = (int)J0.size();
+    DevBuf dnu, dT, dP, dPp, dJ0, dJ1, hot, cold, dsig;
+    if ((rc = upload(dnu, nu, nnu, s)) || (rc = upload(dT, T, K, s)) || (rc = upload(dP, P, K, s)) ||
+        (rc = upload(dPp, Pp, K, s)) || (rc = upload(dJ0, J0.data(), ntile, s)) || (rc = upload(dJ1, J1.data(), ntile, s)))
+        return rc;
+    // bound the workspace: process the states in chunks
+    const size_t per_state = (size_t)G.L * (sizeof(LineHot) + sizeof(LineCold)) + (size_t)nnu * sizeof(double);
+    int kc = (int)std::max<size_t>(1, std::min<size_t>((size_t)K, ((size_t)4 << 30) / per_state));
+    HIPCHK(hot.reserve((size_t)kc * G.L * sizeof(LineHot)));
+    HIPCHK(cold.reserve((size_t)kc * G.L * sizeof(LineCold)));
+    HIPCHK(dsig.reserve((size_t)kc * nnu * sizeof(double)));
+    for (int k0 = 0; k0 < K; k0 += kc) {
+        const int kn = std::min(kc, K - k0);
+        const int64_t tot = (int64_t)kn * G.L;
+        hipLaunchKernelGGL(k_prep, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, shape, G.dev(), kn,
+                           dT.as<double>() + k0, dP.as<double>() + k0, dPp.as<double>() + k0, (const double *)nullptr,
+                           hot.as<LineHot>(), cold.as<LineCold>());
+        launch_linesum_shape(shape, dim3(ntile, kn), s, dnu.as<double>(), nnu, G.L, hot.as<LineHot>(), cold.as<LineCold>(),
+                             dJ0.as<int32_t>(), dJ1.as<int32_t>(), dnu_cut, dT.as<double>() + k0, 0.0, nullptr,
+                             dsig.as<double>(), 0);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpy2DAsync(sigma + (size_t)k0 * ld_state, ld_state * sizeof(double), dsig.p, nnu * sizeof(double),
+                                nnu * sizeof(double), kn, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    return CS_OK;
+}
+
+int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wts, int np, const double *P, double g,
+                    int nlobatto, const double *T_nodes, const double *mu_nodes, const double *T_levels, int ngas,
+                    const int *gas_slots, const int *shapes, const double *dnu_cuts, const double *conc,
+                    double sigma_gray, const double *sigma_extra, const double *S_toa, const double *albedo,
+                    double theta_s, int nstream, int want_tau, int want_M)
+{
+    if (!ctx) return fail(CS_EINVAL, "ctx is NULL");
+    Column &c = ctx->col;
+    c.ready = false;
+    if (np < 2) return fail(CS_EINVAL, "need at least two pressure levels");
+    if (nlobatto < 2 || nlobatto > CS_MAX_LOBATTO) return fail(CS_EINVAL, "nlobatto must be in [2,%d]", CS_MAX_LOBATTO);
+    if (nstream < 1 || nstream > CS_MAX_STREAM) return fail(CS_EINVAL, "nstream must be in [1,%d]", CS_MAX_STREAM);
+    if (ngas < 0 || ngas > CS_MAX_GAS) return fail(CS_EINVAL, "ngas out of range");
+    if (!(theta_s >= 0 && theta_s < M_PI / 2)) return fail(CS_EINVAL, "azimuth angle theta must be in [0,pi/2)");
+    if (!(g > 0)) return fail(CS_EINVAL, "g must be positive");
+    int rc;
+    if ((rc = check_ascending(nu, nnu))) return rc;
+    for (int i = 1; i < np; i++)
+        if (!(P[i] >= P[i - 1])) return fail(CS_EORDER, "pressure coordinates must be in ascending order (sorted)");
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    c.nnu = nnu; c.np = np; c.nl = np - 1; c.nlob = nlobatto; c.K = (np - 1) * (nlobatto - 1) + 1;
+    c.nstream = nstream; c.ngas = ngas; c.ntile = (int)((nnu + 255) / 256);
+    c.want_tau = want_tau != 0; c.want_M = want_M != 0;
+    c.g = g; c.sigma_gray = sigma_gray; c.theta_s = theta_s;
+    const int K = c.K, nl = c.nl;
+    // quadrature rules
+    double x[CS_MAX_STREAM], w[CS_MAX_STREAM];
+    RtParams &rt = c.rt;
+    memset(&rt, 0, sizeof rt);
+    rt.np = np; rt.nlobatto = nlobatto; rt.K = K; rt.nstream = nstream;
+    rt.C = 1e-4 * kNa / g;
+    rt.cos_ts = std::cos(theta_s);
+    c.h_xs.assign(nlobatto, 0.0);
+    cs_lobattonodes(nlobatto, c.h_xs.data(), rt.ws);
+    cs_streamnodes(nstream, rt.m, rt.W);
+    (void)x; (void)w;
+    // node states: k = i*(nlobatto-1) + n   (discretized.jl:150,162,169)
+    c.h_P.assign(P, P + np);
+    c.h_Pk.assign(K, 0.0);
+    c.h_Pk[0] = P[0];
+    for (int i = 0; i < nl; i++) {
+        const double dP = P[i + 1] - P[i];
+        for (int n = 1; n < nlobatto; n++)
+            c.h_Pk[i * (nlobatto - 1) + n] = (n == nlobatto - 1) ? P[i + 1] : P[i] + dP * c.h_xs[n];
+    }
+    std::vector<double> wt(nnu);
+    if (wts) {
+        std::copy(wts, wts + nnu, wt.begin());
+    } else {  // trapz (util.jl:26-33) as per-point weights
+        for (int64_t j = 0; j < nnu; j++) {
+            double a = j > 0 ? nu[j] - nu[j - 1] : 0.0, b = j + 1 < nnu ? nu[j + 1] - nu[j] : 0.0;
+            wt[j] = (a + b) / 2;
+        }
+    }
+    if ((rc = upload(c.nu, nu, nnu, s)) || (rc = upload(c.wts, wt.data(), nnu, s)) || (rc = upload(c.P, P, np, s)) ||
+        (rc = upload(c.Pk, c.h_Pk.data(), K, s)))
+        return rc;
+    c.has_extra = sigma_extra != nullptr;
+    c.has_S = S_toa != nullptr;
+    c.has_alb = albedo != nullptr;
+    if (c.has_extra && (rc = upload(c.extra, sigma_extra, (size_t)nnu * K, s))) return rc;
+    if (c.has_S && (rc = upload(c.S_toa, S_toa, nnu, s))) return rc;
+    if (c.has_alb && (rc = upload(c.albedo, albedo, nnu, s))) return rc;
+    // gases: tile windows and workspace
+    c.gas.clear();
+    c.gas.resize(ngas);
+    size_t maxL = 0;
+    for (int gi = 0; gi < ngas; gi++) {
+        ColGas &cg = c.gas[gi];
+        cg.slot = gas_slots[gi];
+        cg.shape = shapes ? shapes[gi] : CS_SHAPE_VOIGT;
+        cg.cut = dnu_cuts ? dnu_cuts[gi] : 25.0;
+        if (cg.slot < 0 || cg.slot >= CS_MAX_GAS || !ctx->gas[cg.slot].present)
+            return fail(CS_EINVAL, "gas slot %d is empty", cg.slot);
+        if (cg.shape < 0 || cg.shape > 3) return fail(CS_EINVAL, "unknown shape %d", cg.shape);
+        GasTable &G = ctx->gas[cg.slot];
+        int64_t g0, g1;
+        included_range(G.h_nu, nu[0], nu[nnu - 1], cg.cut, false, g0, g1);
+        std::vector<int32_t> J0, J1;
+        tile_windows(G.h_nu, g0, g1, nu, nnu, cg.cut, J0, J1, cg.pairs_per_state, cg.lines_in_range);
+        if ((rc = upload(cg.J0, J0.data(), J0.size(), s)) || (rc = upload(cg.J1, J1.data(), J1.size(), s))) return rc;
+        maxL = std::max(maxL, (size_t)G.L);
+    }
+    HIPCHK(c.hot.reserve((size_t)K * maxL * sizeof(LineHot)));
+    HIPCHK(c.cold.reserve((size_t)K * maxL * sizeof(LineCold)));
+    HIPCHK(c.sigma.reserve((size_t)K * nnu * sizeof(double)));
+    HIPCHK(c.tau.reserve((size_t)nl * nnu * sizeof(double)));
+    if (c.want_M) {
+        HIPCHK(c.Mup.reserve((size_t)np * nnu * sizeof(double)));
+        HIPCHK(c.Mdn.reserve((size_t)np * nnu * sizeof(double)));
+    }
+    HIPCHK(c.partial.reserve((size_t)c.ntile * 2 * np * sizeof(double)));
+    HIPCHK(c.F.reserve((size_t)2 * np * sizeof(double)));
+    HIPCHK(hipStreamSynchronize(s));
+    c.ready = true;  // state upload below needs the sizes
+    if ((rc = cs_column_update_state(ctx, T_nodes, mu_nodes, T_levels, conc))) { c.ready = false; return rc; }
+    return CS_OK;
+}
+
+int cs_column_update_state(cs_ctx *ctx, const double *T_nodes, const double *mu_nodes, const double *T_levels,
+                           const double *conc)
+{
+    if (!ctx || !ctx->col.ready) return fail(CS_ESTATE, "cs_column_setup has not been called");
+    Column &c = ctx->col;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const int K = c.K, nl = c.nl, nlob = c.nlob;
+    std::vector<double> Tk(K), muk(K);
+    Tk[0] = T_nodes[0];
+    muk[0] = mu_nodes[0];
+    for (int i = 0; i < nl; i++)
+        for (int n = 1; n < nlob; n++) {
+            Tk[i * (nlob - 1) + n] = T_nodes[n + (size_t)nlob * i];
+            muk[i * (nlob - 1) + n] = mu_nodes[n + (size_t)nlob * i];
+        }
+    int rc;
+    for (int gi = 0; gi < c.ngas; gi++)
+        if ((rc = check_gas_states(ctx->gas[c.gas[gi].slot], K, Tk.data()))) return rc;
+    if ((rc = upload(c.Tk, Tk.data(), K, s)) || (rc = upload(c.muk, muk.data(), K, s)) ||
+        (rc = upload(c.Tlev, T_levels, c.np, s)))
+        return rc;
+    std::vector<double> cc(K), pp(K);
+    for (int gi = 0; gi < c.ngas; gi++) {
+        for (int k = 0; k < K; k++) {
+            cc[k] = conc[gi + (size_t)c.ngas * k];
+            if (!(cc[k] >= 0 && cc[k] <= 1))
+                return fail(CS_EINVAL, "gas molar concentrations must be in [0,1], not %g", cc[k]);
+            pp[k] = cc[k] * c.h_Pk[k];  // Pp = C*P, gases.jl:126
+        }
+        if ((rc = upload(c.gas[gi].conc, cc.data(), K, s)) || (rc = upload(c.gas[gi].Pp, pp.data(), K, s))) return rc;
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    return CS_OK;
+}
+
+// enqueue one evaluation; when ev != NULL an event is recorded before/after every kernel (ev must hold 2*ngas+4)
+static int run_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev)
+{
+    Column &c = ctx->col;
+    const int K = c.K;
+    double *sig = c.sigma.as<double>();
+    const double *extra = c.has_extra ? c.extra.as<double>() : nullptr;
+    int e = 0;
+    if (ev) HIPCHK(hipEventRecord(ev[e++], s));
+    if (c.ngas == 0) {
+        const int64_t tot = (int64_t)K * c.nnu;
+        hipLaunchKernelGGL(k_fill, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, tot, c.sigma_gray, extra, sig);
+    }
+    for (int gi = 0; gi < c.ngas; gi++) {
+        ColGas &cg = c.gas[gi];
+        GasTable &G = ctx->gas[cg.slot];
+        const int64_t tot = (int64_t)K * G.L;
+        hipLaunchKernelGGL(k_prep, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, cg.shape, G.dev(), K,
+                           c.Tk.as<double>(), c.Pk.as<double>(), cg.Pp.as<double>(), cg.conc.as<double>(),
+                           c.hot.as<LineHot>(), c.cold.as<LineCold>());
+        if (ev) HIPCHK(hipEventRecord(ev[e++], s));
+        launch_linesum_shape(cg.shape, dim3(c.ntile, K), s, c.nu.as<double>(), c.nnu, G.L, c.hot.as<LineHot>(),
+                             c.cold.as<LineCold>(), cg.J0.as<int32_t>(), cg.J1.as<int32_t>(), cg.cut, c.Tk.as<double>(),
+                             c.sigma_gray, extra, sig, gi > 0);
+        if (ev) HIPCHK(hipEventRecord(ev[e++], s));
+    }
+    launch_rt(c.nstream, c.ntile, (size_t)2 * c.np * 4 * sizeof(double), s, c.rt, c.nu.as<double>(), c.wts.as<double>(),
+              c.nnu, sig, c.muk.as<double>(), c.P.as<double>(), c.Tlev.as<double>(),
+              c.has_S ? c.S_toa.as<double>() : nullptr, c.has_alb ? c.albedo.as<double>() : nullptr, c.tau.as<double>(),
+              c.want_M ? c.Mup.as<double>() : nullptr, c.want_M ? c.Mdn.as<double>() : nullptr, c.partial.as<double>());
+    if (ev) HIPCHK(hipEventRecord(ev[e++], s));
+    hipLaunchKernelGGL(k_freduce, dim3(2 * c.np), dim3(256), 0, s, c.partial.as<double>(), c.ntile, 2 * c.np,
+                       c.F.as<double>());
+    if (ev) HIPCHK(hipEventRecord(ev[e++], s));
+    HIPCHK(hipGetLastError());
+    return CS_OK;
+}
+
+int cs_column_run(cs_ctx *ctx, void *stream)
+{
+    if (!ctx || !ctx->col.ready) return fail(CS_ESTATE, "cs_column_setup has not been called");
+    return run_impl(ctx, stream ? (hipStream_t)stream : ctx->stream, nullptr);
+}
+
+int cs_column_profile(cs_ctx *ctx, void *stream, int reps, double *ms)
+{
+    if (!ctx || !ctx->col.ready) return fail(CS_ESTATE, "cs_column_setup has not been called");
+    if (reps < 1 || !ms) return fail(CS_EINVAL, "bad arguments");
+    Column &c = ctx->col;
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int nev = 2 * c.ngas + 3;
+    std::vector<hipEvent_t> ev(nev);
+    for (auto &e : ev) HIPCHK(hipEventCreate(&e));
+    ms[0] = ms[1] = ms[2] = ms[3] = 0.0;
+    int rc = CS_OK;
+    for (int r = 0; r < reps && rc == CS_OK; r++) {
+        rc = run_impl(ctx, s, ev.data());
+        if (rc) break;
+        if (hipStreamSynchronize(s) != hipSuccess) { rc = fail(CS_EHIP, "hipStreamSynchronize failed"); break; }
+        float t;
+        for (int gi = 0; gi < c.ngas; gi++) {
+            (void)hipEventElapsedTime(&t, ev[2 * gi], ev[2 * gi + 1]); ms[0] += t;
+            (void)hipEventElapsedTime(&t, ev[2 * gi + 1], ev[2 * gi + 2]); ms[1] += t;
+        }
+        (void)hipEventElapsedTime(&t, ev[2 * c.ngas], ev[2 * c.ngas + 1]); ms[2] += t;
+        (void)hipEventElapsedTime(&t, ev[2 * c.ngas + 1], ev[2 * c.ngas + 2]); ms[3] += t;
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    for (int i = 0; i < 4; i++) ms[i] /= reps;
+    return rc;
+}
+
+int cs_column_sync(cs_ctx *ctx)
+{
+    if (!ctx) return fail(CS_EINVAL, "ctx is NULL");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipDeviceSynchronize());
+    return CS_OK;
+}
+
+int cs_column_flux_ptr(cs_ctx *ctx, double **dF)
+{
+    if (!ctx || !ctx->col.ready || !dF) return fail(CS_ESTATE, "no resident column");
+    *dF = ctx->col.F.as<double>();
+    return CS_OK;
+}
+
+static int fetch_transposed(cs_ctx *ctx, const double *dsrc, int R, int64_t Cn, double *hdst)
+{
+    Column &c = ctx->col;
+    hipStream_t s = ctx->stream;
+    HIPCHK(c.stage.reserve((size_t)R * Cn * sizeof(double)));
+    dim3 grid((unsigned)((Cn + 31) / 32), (unsigned)((R + 31) / 32));
+    hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, s, dsrc, R, Cn, c.stage.as<double>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(hdst, c.stage.p, (size_t)R * Cn * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return CS_OK;
+}
+
+int cs_column_fetch(cs_ctx *ctx, double *tau, double *Mup, double *Mdn, double *Fup, double *Fdn)
+{
+    if (!ctx || !ctx->col.ready) return fail(CS_ESTATE, "no resident column");
+    Column &c = ctx->col;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipDeviceSynchronize());
+    int rc;
+    if (tau && (rc = fetch_transposed(ctx, c.tau.as<double>(), c.nl, c.nnu, tau))) return rc;
+    if ((Mup || Mdn) && !c.want_M) return fail(CS_ESTATE, "column was set up without want_M");
+    if (Mup && (rc = fetch_transposed(ctx, c.Mup.as<double>(), c.np, c.nnu, Mup))) return rc;
+    if (Mdn && (rc = fetch_transposed(ctx, c.Mdn.as<double>(), c.np, c.nnu, Mdn))) return rc;
+    if (Fup) HIPCHK(hipMemcpy(Fup, c.F.as<double>(), c.np * sizeof(double), hipMemcpyDeviceToHost));
+    if (Fdn) HIPCHK(hipMemcpy(Fdn, c.F.as<double>() + c.np, c.np * sizeof(double), hipMemcpyDeviceToHost));
+    return CS_OK;
+}
+
+int cs_column_sigma_fetch(cs_ctx *ctx, double *sigma)
+{
+    if (!ctx || !ctx->col.ready || !sigma) return fail(CS_ESTATE, "no resident column");
+    Column &c = ctx->col;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(sigma, c.sigma.p, (size_t)c.K * c.nnu * sizeof(double), hipMemcpyDeviceToHost));
+    return CS_OK;
+}
+
+int cs_column_counts(cs_ctx *ctx, int64_t *pair_evals, int64_t *lines_in_range)
+{
+    if (!ctx || !ctx->col.ready) return fail(CS_ESTATE, "no resident column");
+    Column &c = ctx->col;
+    int64_t p = 0, l = 0;
+    for (auto &g : c.gas) { p += g.pairs_per_state * c.K; l += g.lines_in_range; }
+    if (pair_evals) *pair_evals = p;
+    if (lines_in_range) *lines_in_range = l;
+    return CS_OK;
+}
+
+int cs_fluxes_discretized(cs_ctx *ctx, int64_t nnu, const double *nu, int np, const double *P, double g, int nlobatto,
+                          const double *T_nodes, const double *mu_nodes, const double *T_levels, int ngas,
+                          const int *gas_slots, const int *shapes, const double *dnu_cuts, const double *conc,
+                          double sigma_gray, const double *sigma_extra, const double *S_toa, const double *albedo,
+                          double theta_s, int nstream, double *tau, double *Mup, double *Mdn, double *Fup, double *Fdn)
+{
+    int rc = cs_column_setup(ctx, nnu, nu, nullptr, np, P, g, nlobatto, T_nodes, mu_nodes, T_levels, ngas, gas_slots,
+                             shapes, dnu_cuts, conc, sigma_gray, sigma_extra, S_toa, albedo, theta_s, nstream,
+                             tau != nullptr, (Mup || Mdn) ? 1 : 0);
+    if (rc) return rc;
+    if ((rc = cs_column_run(ctx, nullptr))) return rc;
+    return cs_column_fetch(ctx, tau, Mup, Mdn, Fup, Fdn);
+}
+
+int cs_streamnodes(int n, double *m, double *W)
+{
+    if (n < 1 || n > CS_MAX_STREAM) return fail(CS_EINVAL, "nstream must be in [1,%d]", CS_MAX_STREAM);
+    double x[CS_MAX_STREAM], w[CS_MAX_STREAM];
+    gauss_legendre(n, x, w);
+    for (int i = 0; i < n; i++) {  // core/shared.jl:10-19
+        const double th = (M_PI / 2) * (x[i] + 1) / 2;
+        const double wi = (M_PI / 2) * w[i] / 2;
+        m[i] = 1 / std::cos(th);
+        W[i] = 2 * M_PI * wi * std::cos(th) * std::sin(th);
+    }
+    return CS_OK;
+}
+
+int cs_lobattonodes(int n, double *xs, double *ws)
+{
+    if (n < 2 || n > CS_MAX_LOBATTO) return fail(CS_EINVAL, "nlobatto must be in [2,%d]", CS_MAX_LOBATTO);
+    double x[CS_MAX_LOBATTO], w[CS_MAX_LOBATTO];
+    gauss_lobatto(n, x, w);
+    for (int i = 0; i < n; i++) {  // core/discretized.jl:6-7
+        xs[i] = (x[i] + 1) / 2;
+        ws[i] = w[i] / 2;
+    }
+    return CS_OK;
+}
+
+int cs_faddeeva_batch(cs_ctx *ctx, int64_t n, const double *x, const double *y, double *out)
+{
+    if (!ctx || n < 0) return fail(CS_EINVAL, "bad arguments");
+    if (n == 0) return CS_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    int rc;
+    if ((rc = upload(ctx->tmpA, x, n, s)) || (rc = upload(ctx->tmpB, y, n, s))) return rc;
+    HIPCHK(ctx->tmpC.reserve(n * sizeof(double)));
+    hipLaunchKernelGGL(k_faddeeva, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, ctx->tmpA.as<double>(),
+                       ctx->tmpB.as<double>(), ctx->tmpC.as<double>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, ctx->tmpC.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return CS_OK;
+}
+
+}  // extern "C"

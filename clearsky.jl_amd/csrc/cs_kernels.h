@@ -1,0 +1,352 @@
+// cs_kernels.h -- gfx950 kernels of the line-by-line hot path (fp64).
+//   K1 k_prep      per-(node state, line) parameters            line_shapes.jl:107-132,144,255-257
+//   K2 k_linesum   windowed line-shape sum over sorted lines    line_shapes.jl:53-87 (surf!), :366-392
+//   K3 k_rt        tau (Lobatto), Planck, multi-stream sweeps,  discretized.jl:76-87,136-177,249-326; radiation.jl:48-54
+//                  per-block nu-trapezoid partial sums          shared.jl:125-137, util.jl:26-33
+//   K4 k_freduce   fixed-order reduction of the block partials
+// Paths are relative to the reference root.  No MFMA: nothing here is a contraction.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "cs_faddeeva.h"
+
+namespace csdev {
+
+// src/constants.jl:1-26, verbatim (k is the CODATA-2014 value on purpose)
+constexpr double kC = 299792458.0;
+constexpr double kHp = 6.62607015e-34;
+constexpr double kKb = 1.38064852e-23;
+constexpr double kRgas = 8.31446262;
+constexpr double kAtm = 101325.0;
+constexpr double kNa = 6.02214076e23;
+constexpr double kTref = 296.0;
+constexpr double kTmin = 25.0, kTmax = 1000.0;
+constexpr double kSqLn2 = 0.8325546111576977;     // sqrt(ln 2)            line_shapes.jl:4
+constexpr double kOSqPiLn2 = 0.46971863934982566;  // 1/sqrt(pi/ln 2)       line_shapes.jl:3
+constexpr double kC2 = 100.0 * kHp * kC / kKb;     // 100 h c / k           line_shapes.jl:5
+
+enum { SH_VOIGT = 0, SH_LORENTZ = 1, SH_DOPPLER = 2, SH_PHCO2 = 3 };
+
+// per-(state, line) parameters.  "hot" is what the far-wing loop reads, "cold" only the near-line code.
+//   Voigt/PHCO2: hot = {nul, d = sqrt(ln2)/alpha, y^2, A*y/sqrt(pi)},  cold = {y = gamma*d, A = C*S(T)/sqrt(pi/ln2)/alpha}
+//   Lorentz    : hot = {nul, gamma^2, C*S(T)*gamma/pi, 0}
+//   Doppler    : hot = {nul, 1/alpha^2, C*S(T)/(alpha*sqrt(pi)), 0}
+struct __attribute__((aligned(32))) LineHot { double nul, p1, p2, p3; };
+struct __attribute__((aligned(16))) LineCold { double y, A; };
+
+struct GasDev {
+    int64_t L;
+    const double *nu, *S, *ga, *gs, *Epp, *na, *mu;
+    const int16_t *iso;
+    const int32_t *ncheb;
+    const double *cheb;  // [niso][16]
+};
+
+// line_shapes.jl:27-48
+__device__ __forceinline__ double cheby_qrefq(double T, int n, const double *__restrict__ a)
+{
+    double tau = 2.0 * (T - kTmin) / (kTmax - kTmin) - 1.0;
+    double c1 = 1.0, c2 = tau;
+    double y = a[0] + a[1] * c2;
+    for (int k = 2; k < n; k++) {
+        double c3 = 2.0 * tau * c2 - c1;
+        y += a[k] * c3;
+        c1 = c2;
+        c2 = c3;
+    }
+    return 1.0 / y;
+}
+
+// K1: one thread per (state k, line j); j fastest so the SoA line table is read coalesced.
+__global__ __launch_bounds__(256) void k_prep(int shape, GasDev g, int K, const double *__restrict__ Tk,
+                                               const double *__restrict__ Pk, const double *__restrict__ Ppk,
+                                               const double *__restrict__ scale, LineHot *__restrict__ hot,
+                                               LineCold *__restrict__ cold)
+{
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t total = (int64_t)K * g.L;
+    if (idx >= total) return;
+    int k = (int)(idx / g.L);
+    int64_t j = idx - (int64_t)k * g.L;
+    double T = Tk[k], P = Pk[k], Pp = Ppk[k], C = scale ? scale[k] : 1.0;
+    double nul = g.nu[j];
+    // scaleintensity, line_shapes.jl:107-123
+    double a = -kC2 * g.Epp[j];
+    double b = -kC2 * nul;
+    double n = exp(a / T) * (1.0 - exp(b / T));
+    double d = exp(a / kTref) * (1.0 - exp(b / kTref));
+    int I = g.iso[j];
+    double QrefQ = cheby_qrefq(T, g.ncheb[I - 1], g.cheb + (size_t)(I - 1) * 16);
+    double S = g.S[j] * QrefQ * (n / d);
+    // alphadoppler :144, gammalorentz :255-257
+    double alpha = (nul / kC) * sqrt(2.0 * kRgas * T / g.mu[j]);
+    double gamma = pow(kTref / T, g.na[j]) * (g.ga[j] * (P - Pp) + g.gs[j] * Pp) / kAtm;
+    LineHot h;
+    LineCold c;
+    h.nul = nul;
+    if (shape == SH_LORENTZ) {
+        h.p1 = gamma * gamma; h.p2 = C * S * gamma / kPi; h.p3 = 0.0;
+        c.y = gamma; c.A = C * S;
+    } else if (shape == SH_DOPPLER) {
+        h.p1 = 1.0 / (alpha * alpha); h.p2 = C * S / (alpha * 1.7724538509055159); h.p3 = 0.0;
+        c.y = alpha; c.A = C * S;
+    } else {
+        double beta = 1.0 / alpha;
+        double dd = kSqLn2 * beta;
+        double y = gamma * dd;
+        double A = C * (S * (kOSqPiLn2 * beta));
+        h.p1 = dd; h.p2 = y * y; h.p3 = A * y * kIsqPi;
+        c.y = y; c.A = A;
+    }
+    hot[idx] = h;
+    cold[idx] = c;
+}
+
+// line_shapes.jl:467-481 with the two temperature-only factors hoisted
+__device__ __forceinline__ double chi_phco2(double dn, double B1, double B2)
+{
+    if (dn < 3.0) return 1.0;
+    if (dn < 30.0) return exp(-B1 * (dn - 3.0));
+    if (dn < 120.0) return exp(-B1 * 27.0 - B2 * (dn - 30.0));
+    return exp(-B1 * 27.0 - B2 * 90.0 - 0.0232 * (dn - 120.0));
+}
+
+// K2 (generic form): block = 256 consecutive wavenumbers x one node state; every lane walks the block's union
+// window of lines in ascending order (the order surf! sums in) with wave-uniform parameter loads.
+//   sigma[k][i] (nu-fastest) is overwritten when accumulate == 0, else added to (second and later gases).
+template <int SHAPE>
+__global__ __launch_bounds__(256) void k_linesum(const double *__restrict__ nu, int64_t nnu, int64_t L,
+                                                  const LineHot *__restrict__ hot, const LineCold *__restrict__ cold,
+                                                  const int32_t *__restrict__ tileJ0, const int32_t *__restrict__ tileJ1,
+                                                  double cut, const double *__restrict__ Tk, double base,
+                                                  const double *__restrict__ extra, double *__restrict__ sigma,
+                                                  int accumulate)
+{
+    const int tile = blockIdx.x, k = blockIdx.y;
+    const int64_t i = (int64_t)tile * 256 + threadIdx.x;
+    const int J0 = tileJ0[tile], J1 = tileJ1[tile];
+    const LineHot *__restrict__ hk = hot + (size_t)k * L;
+    const LineCold *__restrict__ ck = cold + (size_t)k * L;
+    const double v = nu[i < nnu ? i : nnu - 1];
+    double B1 = 0.0, B2 = 0.0;
+    if (SHAPE == SH_PHCO2) {
+        double T = Tk[k];
+        B1 = 0.0888 - 0.16 * exp(-0.0041 * T);
+        B2 = 0.0526 * exp(-0.00152 * T);
+    }
+    double acc = 0.0;
+    for (int j = J0; j < J1; j++) {
+        const LineHot h = hk[j];
+        const double dv = v - h.nul;
+        if (!(fabs(dv) > cut)) {  // cutline is a strict >, line_shapes.jl:10
+            if (SHAPE == SH_LORENTZ) {
+                acc += h.p2 / __builtin_fma(dv, dv, h.p1);
+            } else if (SHAPE == SH_DOPPLER) {
+                acc += h.p2 * exp(-(dv * dv) * h.p1);
+            } else if (SHAPE == SH_VOIGT) {
+                const double x = dv * h.p1;
+                const double s = __builtin_fma(x, x, h.p2);
+                if (s >= kFarS) {
+                    acc = __builtin_fma(h.p3, fad_far_core(h.p2, 1.0 / s), acc);
+                } else {
+                    const LineCold c = ck[j];
+                    acc = __builtin_fma(c.A, s >= kMidS ? fad_mid(fabs(x), c.y) : fad_near(fabs(x), c.y), acc);
+                }
+            } else {
+                const LineCold c = ck[j];
+                const double chi = chi_phco2(fabs(dv), B1, B2);
+                acc = __builtin_fma(c.A, fad_re(dv * h.p1, chi * c.y), acc);
+            }
+        }
+    }
+    if (i < nnu) {
+        const size_t o = (size_t)k * nnu + i;
+        double prev = accumulate ? sigma[o] : (base + (extra ? extra[o] : 0.0));
+        sigma[o] = prev + acc;
+    }
+}
+
+// radiation.jl:48-54
+__device__ __forceinline__ double planck(double nu, double T)
+{
+    double num = 100.0 * nu;
+    double x = kHp * kC * num / (kKb * T);
+    double p = 2.0 * kHp * (kC * kC) * (num * num * num);
+    return 100.0 * p / (exp(x) - 1.0);
+}
+
+// discretized.jl:85-87
+__device__ __forceinline__ double layerplanck(double B1, double B2, double tau, double t)
+{
+    return B2 * (1.0 - t) - (B1 - B2) * t + (1.0 - t) * (B1 - B2) / tau;
+}
+
+struct RtParams {
+    int np, nlobatto, K, nstream;
+    double C;        // 1e-4*Na/g, fluxes.jl:259
+    double cos_ts;   // cos(theta_s)
+    double ws[16];   // Lobatto weights on [0,1]
+    double m[16];    // 1/cos(theta_k)
+    double W[16];    // stream weights
+};
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// K3: one lane per wavenumber.  Pass 1 walks TOA -> surface: layer optical depths from the node cross-sections
+// (dDepth!) and the downward sweep of all NS streams at once; pass 2 walks surface -> TOA (upward sweep).
+// All NS intensities advance together, so M-[i+1] = sum_k W_k I_k + stellar beam is complete when layer i is done --
+// same summation order as the reference's stream-outer loops, no [np] scratch per lane.
+// tau is kept nu-fastest in HBM between the passes (the caller's tau output); Mup/Mdn are optional outputs.
+// red : per-block partial sums of w_j*M[i][j], layout [block][2*np] (Fup then Fdn).
+template <int NS>
+__global__ __launch_bounds__(256) void k_rt(RtParams p, const double *__restrict__ nu, const double *__restrict__ wts,
+                                             int64_t nnu, const double *__restrict__ sigma,
+                                             const double *__restrict__ muk, const double *__restrict__ P,
+                                             const double *__restrict__ Tlev, const double *__restrict__ S_toa,
+                                             const double *__restrict__ albedo, double *__restrict__ tau,
+                                             double *__restrict__ Mup, double *__restrict__ Mdn,
+                                             double *__restrict__ partial)
+{
+    extern __shared__ double red[];  // [2*np][4 waves]
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = j < nnu;
+    const int64_t jj = live ? j : nnu - 1;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int np = p.np, nl = np - 1, nlob = p.nlobatto;
+    const double v = nu[jj];
+    const double w = live ? wts[jj] : 0.0;
+    const double fS = S_toa ? S_toa[jj] : 0.0;
+    const double fa = albedo ? albedo[jj] : 0.0;
+    const double c = p.cos_ts;
+
+    double I[NS];
+#pragma unroll
+    for (int k = 0; k < NS; k++) I[k] = 0.0;
+    double b1 = p.C * (sigma[jj] / muk[0]);  // beta at node 0, discretized.jl:150
+    double Ms = c * fS;                      // M-[1] = c*fS(nu), discretized.jl:299
+    double Md = Ms;
+    double Bprev = planck(v, Tlev[0]);
+    {
+        double r = wave_sum(w * Md);
+        if (lane == 0) red[(np + 0) * 4 + wv] = r;
+        if (Mdn && live) Mdn[j] = Md;
+    }
+    for (int i = 0; i < nl; i++) {
+        const double dP = P[i + 1] - P[i];
+        double ti = (dP * p.ws[0]) * b1;
+        for (int n = 1; n < nlob - 1; n++) {
+            const int k = i * (nlob - 1) + n;
+            ti += (dP * p.ws[n]) * (p.C * (sigma[(size_t)k * nnu + jj] / muk[k]));
+        }
+        const int ke = (i + 1) * (nlob - 1);
+        const double bn = p.C * (sigma[(size_t)ke * nnu + jj] / muk[ke]);
+        ti += (dP * p.ws[nlob - 1]) * bn;
+        b1 = bn;
+        const double t = ti > 1e-6 ? ti : 1e-6;  // floor, discretized.jl:147,174
+        if (live) tau[(size_t)i * nnu + j] = t;
+        const double Bnext = planck(v, Tlev[i + 1]);
+        Md = 0.0;
+#pragma unroll
+        for (int k = 0; k < NS; k++) {
+            const double tk = t * p.m[k];
+            const double tr = exp(-tk);
+            const double Be = layerplanck(Bprev, Bnext, tk, tr);
+            I[k] = I[k] * tr + Be;
+            Md += p.W[k] * I[k];
+        }
+        Ms *= exp(-t / c);
+        Md += Ms;
+        Bprev = Bnext;
+        double r = wave_sum(w * Md);
+        if (lane == 0) red[(np + i + 1) * 4 + wv] = r;
+        if (Mdn && live) Mdn[(size_t)(i + 1) * nnu + j] = Md;
+    }
+    // surface: Lambertian reflection + Planck emission, discretized.jl:309-310
+    const double Is = Md * fa / kPi + Bprev;
+    double Mu = Is * kPi;
+    {
+        double r = wave_sum(w * Mu);
+        if (lane == 0) red[(np - 1) * 4 + wv] = r;
+        if (Mup && live) Mup[(size_t)(np - 1) * nnu + j] = Mu;
+    }
+#pragma unroll
+    for (int k = 0; k < NS; k++) I[k] = Is;
+    double Bhi = Bprev;  // B at level i+1
+    for (int i = nl - 1; i >= 0; i--) {
+        const double t = live ? tau[(size_t)i * nnu + j] : 1.0;
+        const double Blo = planck(v, Tlev[i]);
+        Mu = 0.0;
+#pragma unroll
+        for (int k = 0; k < NS; k++) {
+            const double tk = t * p.m[k];
+            const double tr = exp(-tk);
+            const double Be = layerplanck(Bhi, Blo, tk, tr);
+            I[k] = I[k] * tr + Be;
+            Mu += p.W[k] * I[k];
+        }
+        Bhi = Blo;
+        double r = wave_sum(w * Mu);
+        if (lane == 0) red[i * 4 + wv] = r;
+        if (Mup && live) Mup[(size_t)i * nnu + j] = Mu;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * np; e += 256) {
+        const double *q = red + e * 4;
+        partial[(size_t)blockIdx.x * 2 * np + e] = ((q[0] + q[1]) + q[2]) + q[3];
+    }
+}
+
+// K4: F[e] = sum over blocks of partial[b][e], fixed order (bitwise reproducible run to run)
+__global__ __launch_bounds__(256) void k_freduce(const double *__restrict__ partial, int nblk, int n2, double *__restrict__ F)
+{
+    __shared__ double sh[256];
+    const int e = blockIdx.x;
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 256) s += partial[(size_t)b * n2 + e];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) F[e] = sh[0];
+}
+
+// out[c*R + r] = in[r*C + c]   (nu-fastest [R][C] -> the reference's level-fastest [R, C] column-major)
+__global__ __launch_bounds__(256) void k_transpose(const double *__restrict__ in, int R, int64_t Cn, double *__restrict__ out)
+{
+    __shared__ double t[32][33];
+    const int64_t c0 = (int64_t)blockIdx.x * 32;
+    const int r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int yy = ty; yy < 32; yy += 8) {
+        int r = r0 + yy;
+        int64_t cc = c0 + tx;
+        if (r < R && cc < Cn) t[yy][tx] = in[(size_t)r * Cn + cc];
+    }
+    __syncthreads();
+    for (int yy = ty; yy < 32; yy += 8) {
+        int64_t cc = c0 + yy;
+        int r = r0 + tx;
+        if (r < R && cc < Cn) out[(size_t)cc * R + r] = t[tx][yy];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fill(int64_t n, double base, const double *__restrict__ extra, double *__restrict__ sigma)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) sigma[i] = base + (extra ? extra[i] : 0.0);
+}
+
+__global__ void k_faddeeva(int64_t n, const double *__restrict__ x, const double *__restrict__ y, double *__restrict__ out)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = fad_re(x[i], y[i]);
+}
+
+}  // namespace csdev

@@ -1,0 +1,142 @@
+/*
+ * clearsky_hip.h -- C ABI of the MI355X (gfx950) line-by-line radiative-transfer core.
+ *
+ * Drop-in boundary for ClearSky.jl's Discretized hot path.  The reference has no FFI; each
+ * entry point below names the Julia interface it replaces (paths relative to the reference root) and is what
+ * a `ccall` from the Julia glue in julia/ClearSkyHIP.jl binds.  Plain C linkage, plain pointers and sizes.
+ *
+ * Conventions
+ *   - return 0 on success, a negative CS_E* code on failure; cs_last_error() returns a thread-local message.
+ *   - "host" pointers are borrowed for the duration of the call (Julia: GC.@preserve); device memory is owned
+ *     by the opaque context.  Host entry points are synchronous.
+ *   - a context is not re-entrant: use one per host thread (the reference calls shape! from @threads,
+ *     gases.jl:115).
+ *   - all reals are IEEE fp64, as in the reference.
+ *   - matrices the reference stores column-major [level, nu] (core/shared.jl:93-101) are exchanged in exactly
+ *     that layout unless a call says "nu-fastest".
+ */
+#ifndef CLEARSKY_HIP_H
+#define CLEARSKY_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cs_ctx cs_ctx;
+
+enum {
+    CS_OK = 0,
+    CS_EINVAL = -1,    /* bad argument (the reference's @assert / error paths) */
+    CS_ETEMP = -2,     /* temperature outside [TMIN,TMAX] = [25,1000] K, line_shapes.jl:29 */
+    CS_ENOCHEB = -3,   /* isotopologue without a Qref/Q Chebyshev fit, line_shapes.jl:115-120 */
+    CS_EORDER = -4,    /* nu not strictly ascending (line_shapes.jl:59) or P not ascending (fluxes.jl:257) */
+    CS_EHIP = -5,      /* HIP runtime error */
+    CS_ESTATE = -6     /* call sequence error (e.g. run before setup) */
+};
+
+/* line shapes: voigt! line_shapes.jl:412, lorentz! :313, doppler! :200, PHCO2! :527 */
+enum { CS_SHAPE_VOIGT = 0, CS_SHAPE_LORENTZ = 1, CS_SHAPE_DOPPLER = 2, CS_SHAPE_PHCO2 = 3 };
+
+#define CS_MAX_GAS 16
+#define CS_CHEB_LD 16 /* leading dimension of the Chebyshev coefficient table */
+#define CS_MAX_STREAM 16
+#define CS_MAX_LOBATTO 16
+
+int cs_version(void);
+const char *cs_last_error(void);
+
+/* Create a context on HIP device `device` (one per host thread). */
+int cs_create(int device, cs_ctx **out);
+void cs_destroy(cs_ctx *ctx);
+
+/*
+ * Upload one gas's line table into `slot` (0 <= slot < CS_MAX_GAS).
+ * Replaces: SpectralLines (hitran/par.jl:224-251; lines sorted by nu, :267-283) plus the MOLPARAM rows of its
+ * molecule (hitran/molparam.jl; struct hitran/par.jl:18-45).
+ *   nu,S,gamma_a,gamma_s,Epp,na : [L] as in SpectralLines;  mu_iso : [L] molar mass of each line's isotopologue
+ *   iso : [L] 1-based local isotopologue number (par.jl:263);  ncheb : [niso] (0 = no fit, hascheb=false)
+ *   cheb : [niso][CS_CHEB_LD] Chebyshev coefficients of Q/Qref (line_shapes.jl:27-48)
+ */
+int cs_gas_upload(cs_ctx *ctx, int slot, int64_t L, const double *nu, const double *S, const double *gamma_a,
+                  const double *gamma_s, const double *Epp, const double *na, const double *mu_iso,
+                  const int16_t *iso, int niso, const int32_t *ncheb, const double *cheb);
+int cs_gas_clear(cs_ctx *ctx, int slot);
+
+/*
+ * B1: batched in-place line shape.  For every state k:  sigma[k*ld_state + i] = shape(nu[i]; T[k], P[k], Pp[k]).
+ * Replaces: shape!(sigma, nu, sl, T, P, Pp, dnu_cut) -- voigt!/lorentz!/doppler!/PHCO2!, line_shapes.jl:412-424,
+ * :313-324, :200-211, :527-540 -- as invoked by bake, gases.jl:126 (K = nT*nP states in one launch instead of
+ * nT*nP calls).  sigma is overwritten (line_shapes.jl:85).  Semantics of includedlines(::Vector) (:18-22) and
+ * surf! (:53-87) are reproduced, including the strict end-point pre-filter and the inclusive cut-off.
+ * All pointers are host pointers.
+ */
+int cs_shape_batch(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t nnu, const double *nu, int K,
+                   const double *T, const double *P, const double *Pp, double *sigma, int64_t ld_state);
+
+/*
+ * B3: whole-column monochromatic fluxes + band integrals with the Discretized core, line-by-line at every
+ * Lobatto node ("Mode D").
+ * Replaces: monochromaticfluxes!(M+, M-, tau, core::Discretized, P, g, T, mu, fS, fa, absorbers...; theta_s)
+ * fluxes.jl:238-279, followed by intF! core/shared.jl:125-137 (as radiate! fluxes.jl:357-383 does).
+ * Closures cannot cross the ABI; the caller pre-evaluates them where the reference does:
+ *   T_nodes, mu_nodes : [nlobatto, np-1] column-major = lobattoevaluations(P, fT, fmu, nlobatto) discretized.jl:11-30
+ *   T_levels          : [np] = fT(P[i])  (planckevaluations, discretized.jl:46-58)
+ *   conc              : [ngas, K] column-major, conc[g + ngas*k] = fC_g(T_k, P_k) at node k (gases.jl:270,278),
+ *                       K = (np-1)*(nlobatto-1) + 1, node k = i*(nlobatto-1) + n for Lobatto point n of layer i
+ *   sigma_gray        : constant cross-section added everywhere (GrayGas, gases.jl:342-360); 0 for none
+ *   sigma_extra       : NULL or [nnu, K] nu-fastest, host-evaluated sigma(nu,T,P) functions / CIA (absorbers.jl:84-92)
+ *   S_toa, albedo     : NULL (= 0) or [nnu] = fS(nu[j]), fa(nu[j])  (discretized.jl:299,309)
+ * Outputs (any of tau/Mup/Mdn may be NULL):
+ *   tau : [np-1, nnu];  Mup, Mdn : [np, nnu]  column-major, level fastest;  Fup, Fdn : [np]
+ * P must be ascending (index 0 = top of atmosphere), nu strictly ascending.
+ */
+int cs_fluxes_discretized(cs_ctx *ctx, int64_t nnu, const double *nu, int np, const double *P, double g,
+                          int nlobatto, const double *T_nodes, const double *mu_nodes, const double *T_levels,
+                          int ngas, const int *gas_slots, const int *shapes, const double *dnu_cuts,
+                          const double *conc, double sigma_gray, const double *sigma_extra, const double *S_toa,
+                          const double *albedo, double theta_s, int nstream, double *tau, double *Mup,
+                          double *Mdn, double *Fup, double *Fdn);
+
+/*
+ * Device-resident form of B3 for callers that keep the column in HBM (benchmarks, torch/RCCL plumbing, RCM loops):
+ *   cs_column_setup  uploads the inputs of cs_fluxes_discretized once and allocates all workspaces;
+ *                    `wts` is NULL (trapezoid weights of `nu`, util.jl:26-33) or [nnu] weights of a nu-shard
+ *                    taken from the global grid (multi-GPU: SURVEY.md 8e);
+ *   cs_column_run    enqueues the kernels on `stream` (a hipStream_t, NULL = the context's stream); asynchronous;
+ *                    results stay in HBM;
+ *   cs_column_flux_ptr  device address of [2*np] doubles (Fup then Fdn) for an in-place RCCL all-reduce;
+ *   cs_column_fetch  synchronises and copies results to host (NULL = skip), layouts as in cs_fluxes_discretized;
+ *   cs_column_sigma_fetch  copies the total cross-section at the nodes, [nnu, K] nu-fastest (test hook);
+ *   cs_column_counts line-shape evaluations of one run (sum over nu, node, gas of lines inside the cut-off).
+ */
+int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wts, int np, const double *P,
+                    double g, int nlobatto, const double *T_nodes, const double *mu_nodes, const double *T_levels,
+                    int ngas, const int *gas_slots, const int *shapes, const double *dnu_cuts, const double *conc,
+                    double sigma_gray, const double *sigma_extra, const double *S_toa, const double *albedo,
+                    double theta_s, int nstream, int want_tau, int want_M);
+int cs_column_run(cs_ctx *ctx, void *stream);
+int cs_column_sync(cs_ctx *ctx);
+/* run `reps` evaluations with HIP events around every kernel on `stream`; ms[4] = average milliseconds per
+ * evaluation spent in {k_prep, k_linesum, k_rt, k_freduce} (summed over gases) */
+int cs_column_profile(cs_ctx *ctx, void *stream, int reps, double *ms);
+int cs_column_flux_ptr(cs_ctx *ctx, double **dF);
+int cs_column_fetch(cs_ctx *ctx, double *tau, double *Mup, double *Mdn, double *Fup, double *Fdn);
+int cs_column_sigma_fetch(cs_ctx *ctx, double *sigma);
+int cs_column_counts(cs_ctx *ctx, int64_t *pair_evals, int64_t *lines_in_range);
+/* update only the temperature-dependent inputs of a resident column (RCM stepping, radiative_convective.jl:109-144) */
+int cs_column_update_state(cs_ctx *ctx, const double *T_nodes, const double *mu_nodes, const double *T_levels,
+                           const double *conc);
+
+/* Scalar helpers exported for tests of the host logic (same formulas the kernels use). */
+int cs_streamnodes(int n, double *m, double *W);    /* core/shared.jl:4-21 */
+int cs_lobattonodes(int n, double *x, double *w);   /* core/discretized.jl:2-9 */
+/* Re w(x+iy) evaluated on the device for n points (host pointers): the kernels' Faddeeva, test hook for
+ * Faddeyeva985.faddeyeva (call site line_shapes.jl:375). */
+int cs_faddeeva_batch(cs_ctx *ctx, int64_t n, const double *x, const double *y, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

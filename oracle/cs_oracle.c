@@ -1,0 +1,534 @@
+/*
+ * cs_oracle.c -- CPU restatement (plain C99, fp64) of ClearSky.jl's line-by-line hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it.  The shipped path (clearsky.jl_amd/csrc) never links or calls it.
+ *
+ * PARITY STATUS: the reference (Julia) cannot run in this pipeline and its own tests hold no golden
+ * vectors for this path, so this oracle is pinned by (i) the formulas it cites below,
+ * (ii) the goldens in tests/golden/ that an independent numpy/scipy script (tools/gen_golden.py)
+ * produces from the same formulas with scipy.special.wofz, and (iii) analytic identities
+ * (test_gray.jl:13-24 gray-gas OLR, sum(W)=pi, int(pi*B)=sigma*T^4, int(fvoigt)=1).
+ * "parity unpinned" for the third-party Faddeeva (Faddeyeva985.faddeyeva, line_shapes.jl:375, version
+ * unpinned, source absent): this file evaluates Re w(x+iy) to ~1e-14 relative, so Julia-reference
+ * cross-sections may differ from it by up to Faddeyeva985's own error (Algorithm 985, ~4e-5 rel).
+ *
+ * Every function names the reference file:line it restates (paths relative to the reference root).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ---- src/constants.jl:1-26 (verbatim values; k is the CODATA-2014 value on purpose) ---- */
+#define CS_C 299792458.0
+#define CS_H 6.62607015e-34
+#define CS_K 1.38064852e-23
+#define CS_SB 5.67037442e-8
+#define CS_R 8.31446262
+#define CS_ATM 101325.0
+#define CS_NA 6.02214076e23
+#define CS_TREF 296.0
+#define CS_TMIN 25.0
+#define CS_TMAX 1000.0
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+enum { SHAPE_VOIGT = 0, SHAPE_LORENTZ = 1, SHAPE_DOPPLER = 2, SHAPE_PHCO2 = 3 };
+
+/* ------------------------------------------------------------------------------------------
+ * Re w(x+iy), y >= 0.  Stands in for Faddeyeva985.faddeyeva(x,y) (call site line_shapes.jl:375).
+ * Three regions in s = x^2+y^2 (validated against mpmath in tools/faddeeva_proto.py):
+ *   s >= 1e4 : real asymptotic series  sqrt(pi) K = sum_k (2k-1)!!/2^k rho^-(2k+1) sin((2k+1)theta), 4 terms
+ *   s >= 100 : 10-term Laplace continued fraction, written as the rational z*PA(z^2)/PB(z^2)
+ *   s <  100 : trapezoid rule (h = 1/2) for (i/pi) int exp(-t^2)/(z-t) dt on the integer or half-shifted
+ *              grid (whichever keeps x >= h/4 away from a node) plus the pole (Poisson) correction
+ *              2 exp(-z^2)/(1 -+ exp(-2 pi i z/h)) when y < pi/h.
+ * ------------------------------------------------------------------------------------------ */
+#define FAD_H 0.5
+#define FAD_N 12
+static double fad_c0[FAD_N + 1]; /* exp(-(k h)^2)        k = 0..N   */
+static double fad_c1[FAD_N];     /* exp(-((k+1/2) h)^2)  k = 0..N-1 */
+static int fad_init_done = 0;
+
+static void fad_init(void)
+{
+    if (fad_init_done) return;
+    for (int k = 0; k <= FAD_N; k++) { double t = k * FAD_H; fad_c0[k] = exp(-t * t); }
+    for (int k = 0; k < FAD_N; k++) { double t = (k + 0.5) * FAD_H; fad_c1[k] = exp(-t * t); }
+    fad_init_done = 1;
+}
+
+static double fad_far(double x, double y, double s)
+{
+    const double isqpi = 0.56418958354775628695; /* 1/sqrt(pi) */
+    double inv = 1.0 / s;
+    double t = y * y * inv;
+    double p1 = 1.5 - 2.0 * t;
+    double p2 = 3.75 + t * (-15.0 + 12.0 * t);
+    double p3 = 1.875 * (7.0 + t * (-56.0 + t * (112.0 - 64.0 * t)));
+    double inner = p1 + inv * (p2 + inv * p3);
+    return isqpi * y * inv * (1.0 + inv * inner);
+}
+
+static double fad_mid(double x, double y)
+{
+    const double isqpi = 0.56418958354775628695;
+    /* convergents of i/sqrt(pi) * 1/(z - (1/2)/(z - 1/(z - (3/2)/(z - ...)))), 10 terms */
+    static const double PA[5] = {180.9375, -330.0, 147.0, -22.0, 1.0};
+    static const double PB[6] = {-29.53125, 295.3125, -393.75, 157.5, -22.5, 1.0};
+    double ur = x * x - y * y, ui = 2.0 * x * y;
+    double ar = PA[4], ai = 0.0, br = PB[5], bi = 0.0, tr;
+    for (int k = 3; k >= 0; k--) { tr = ar * ur - ai * ui + PA[k]; ai = ar * ui + ai * ur; ar = tr; }
+    for (int k = 4; k >= 0; k--) { tr = br * ur - bi * ui + PB[k]; bi = br * ui + bi * ur; br = tr; }
+    double nr = x * ar - y * ai, ni = x * ai + y * ar;
+    return isqpi * (nr * bi - ni * br) / (br * br + bi * bi);
+}
+
+static double fad_near(double x, double y)
+{
+    double y2 = y * y;
+    double u = x / FAD_H;
+    double fr = u - floor(u);
+    int shift = fabs(fr - 0.5) > 0.25; /* x close to an integer node -> use the half-shifted grid */
+    double acc = 0.0;
+    if (!shift) {
+        acc = fad_c0[0] / (x * x + y2);
+        for (int k = 1; k <= FAD_N; k++) {
+            double t = k * FAD_H, a = x - t, b = x + t;
+            acc += fad_c0[k] * (1.0 / (a * a + y2) + 1.0 / (b * b + y2));
+        }
+    } else {
+        for (int k = 0; k < FAD_N; k++) {
+            double t = (k + 0.5) * FAD_H, a = x - t, b = x + t;
+            acc += fad_c1[k] * (1.0 / (a * a + y2) + 1.0 / (b * b + y2));
+        }
+    }
+    double res = FAD_H * y / M_PI * acc;
+    if (y < M_PI / FAD_H) {
+        /* corr = 2 exp(-z^2) / (1 + sgn*E), E = exp(-2 pi i z/h) = exp(-i phi)/g, g = exp(-2 pi y/h) */
+        double sgn = shift ? 1.0 : -1.0;
+        double g = exp(-2.0 * M_PI * y / FAD_H);
+        /* phi = 2 pi x/h = pi*(4x): reduce 4x modulo 2 exactly */
+        double q = 4.0 * x;
+        q -= 2.0 * nearbyint(0.5 * q);
+        double cph = cos(M_PI * q), sph = sin(M_PI * q);
+        /* 1 + sgn*E = (g + sgn*(cph - i sph))/g  ->  corr = 2 g exp(-z^2) / (dr + i di) */
+        double dr = g + sgn * cph, di = -sgn * sph;
+        double em = exp(y2 - x * x);
+        double a2 = 2.0 * x * y;
+        double cr = cos(a2), ci = -sin(a2); /* exp(-z^2) = em*(cr + i ci) */
+        /* Re[(cr + i ci)/(dr + i di)] = (cr dr + ci di)/|d|^2 */
+        res += 2.0 * g * em * (cr * dr + ci * di) / (dr * dr + di * di);
+    }
+    return res;
+}
+
+double cso_faddeeva_re(double x, double y)
+{
+    fad_init();
+    x = fabs(x);
+    double s = x * x + y * y;
+    if (s >= 1.0e4) return fad_far(x, y, s);
+    if (s >= 100.0) return fad_mid(x, y);
+    return fad_near(x, y);
+}
+
+void cso_faddeeva_re_vec(int64_t n, const double *x, const double *y, double *out)
+{
+    fad_init();
+    for (int64_t i = 0; i < n; i++) out[i] = cso_faddeeva_re(x[i], y[i]);
+}
+
+/* ---- line_shapes.jl:27-48  chebyQrefQ(T, n, a): Qref/Q by Chebyshev recurrence; returns 1/y; no 1/2 on a[1] ---- */
+double cso_chebyQrefQ(double T, int n, const double *a, int *err)
+{
+    if (!(T >= CS_TMIN && T <= CS_TMAX)) { if (err) *err = -2; return NAN; } /* @assert :29 */
+    double tau = 2.0 * (T - CS_TMIN) / (CS_TMAX - CS_TMIN) - 1.0;
+    double c1 = 1.0, c2 = tau;
+    double y = a[0] + a[1] * c2;
+    for (int k = 2; k < n; k++) {
+        double c3 = 2.0 * tau * c2 - c1;
+        y += a[k] * c3;
+        c1 = c2;
+        c2 = c3;
+    }
+    return 1.0 / y;
+}
+
+/* A gas's SpectralLines (hitran/par.jl:224-251) + the MOLPARAM rows it needs (molparam.jl). */
+typedef struct {
+    int64_t L;
+    const double *nu, *S, *ga, *gs, *Epp, *na, *mu; /* mu = molar mass of each line's isotopologue */
+    const int16_t *iso;                              /* 1-based local isotopologue number (par.jl:263) */
+    int niso;
+    const int32_t *ncheb;   /* [niso]; 0 means hascheb == false */
+    const double *cheb;     /* [niso][16] */
+} cso_lines;
+
+#define CHEB_LD 16
+
+/* ---- line_shapes.jl:107-123 scaleintensity ---- */
+static double scaleintensity(const cso_lines *sl, int64_t j, double T, int *err)
+{
+    const double c2 = 100.0 * CS_H * CS_C / CS_K; /* line_shapes.jl:5 */
+    double a = -c2 * sl->Epp[j];
+    double b = -c2 * sl->nu[j];
+    double n = exp(a / T) * (1.0 - exp(b / T));
+    double d = exp(a / CS_TREF) * (1.0 - exp(b / CS_TREF));
+    int I = sl->iso[j];
+    if (I < 1 || I > sl->niso || sl->ncheb[I - 1] <= 0) { *err = -3; return NAN; } /* throw :118 */
+    double QrefQ = cso_chebyQrefQ(T, sl->ncheb[I - 1], sl->cheb + (size_t)(I - 1) * CHEB_LD, err);
+    return sl->S[j] * QrefQ * (n / d);
+}
+/* ---- line_shapes.jl:144 ---- */
+static double alpha_doppler(double nul, double mu, double T) { return (nul / CS_C) * sqrt(2.0 * CS_R * T / mu); }
+/* ---- line_shapes.jl:255-257 (the air exponent na is applied to the self width too) ---- */
+static double gamma_lorentz(double ga, double gs, double na, double T, double P, double Pp)
+{
+    return pow(CS_TREF / T, na) * (ga * (P - Pp) + gs * Pp) / CS_ATM;
+}
+/* ---- line_shapes.jl:160,173 ---- */
+static double f_doppler(double nu, double nul, double a) { double d = nu - nul; return exp(-(d * d) / (a * a)) / (a * sqrt(M_PI)); }
+/* ---- line_shapes.jl:273 ---- */
+static double f_lorentz(double nu, double nul, double g) { return g / (M_PI * ((nu - nul) * (nu - nul) + g * g)); }
+/* ---- line_shapes.jl:366-378 fvoigt (alpha used as a Gaussian HWHM: quirk 1 of SURVEY.md 7) ---- */
+static double f_voigt(double nu, double nul, double alpha, double gamma)
+{
+    const double sqln2 = sqrt(log(2.0));                 /* line_shapes.jl:4 */
+    const double osqpiln2 = 1.0 / sqrt(M_PI / log(2.0)); /* line_shapes.jl:3 */
+    double beta = 1.0 / alpha;
+    double d = sqln2 * beta;
+    double x = (nu - nul) * d;
+    double y = gamma * d;
+    double f = cso_faddeeva_re(x, y);
+    return osqpiln2 * beta * f;
+}
+/* ---- line_shapes.jl:467-481 ---- */
+static double chi_phco2(double nu, double nul, double T)
+{
+    double dn = fabs(nu - nul);
+    if (dn < 3.0) return 1.0;
+    double B1 = 0.0888 - 0.16 * exp(-0.0041 * T);
+    if (dn < 30.0) return exp(-B1 * (dn - 3.0));
+    double B2 = 0.0526 * exp(-0.00152 * T);
+    if (dn < 120.0) return exp(-B1 * 27.0 - B2 * (dn - 30.0));
+    return exp(-B1 * 27.0 - B2 * 90.0 - 0.0232 * (dn - 120.0));
+}
+
+static double profile(int shape, double nu, double nul, double S, double alpha, double gamma, double T)
+{
+    switch (shape) {
+    case SHAPE_VOIGT: return S * f_voigt(nu, nul, alpha, gamma);             /* :392 */
+    case SHAPE_LORENTZ: return S * f_lorentz(nu, nul, gamma);                /* :286 */
+    case SHAPE_DOPPLER: return S * f_doppler(nu, nul, alpha);                /* :173 */
+    default: return S * f_voigt(nu, nul, alpha, chi_phco2(nu, nul, T) * gamma); /* :496-499 */
+    }
+}
+
+/*
+ * shape!(sigma, nu, sl, T, P, Pp, dnu_cut): line_shapes.jl:412-424 (voigt!), :313-324, :200-211, :527-540
+ *   = includedlines(vector) :18-22  (strict > / < on min(nu)-cut, max(nu)+cut)
+ *   + scaleintensity / alphadoppler / gammalorentz for the included lines
+ *   + surf! :53-87 (ascending nu, sequential sum over the contiguous run with |nu-nul| <= cut, sigma overwritten)
+ * strict_ends = 0 gives the scalar-nu method's semantics (:399-405, includedlines(::Real) :12-16), i.e. no
+ * pre-filter on the grid end points.
+ */
+int cso_shape_bang(int shape, int strict_ends, int64_t nnu, const double *nu, const cso_lines *sl, double T, double P,
+                   double Pp, double cut, double *sigma)
+{
+    fad_init();
+    for (int64_t i = 1; i < nnu; i++)
+        if (!(nu[i] > nu[i - 1])) return -1; /* @assert :59 */
+    int64_t L = sl->L;
+    int err = 0;
+    double lo = nu[0] - cut, hi = nu[nnu - 1] + cut;
+    /* includedlines: first/last index (lines are sorted, so the mask is one contiguous run) */
+    int64_t j0 = 0, j1 = L;
+    if (strict_ends) {
+        while (j0 < L && !(sl->nu[j0] > lo)) j0++;
+        while (j1 > j0 && !(sl->nu[j1 - 1] < hi)) j1--;
+    }
+    int64_t n = j1 - j0;
+    double *S = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    double *al = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    double *gm = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    for (int64_t j = 0; j < n; j++) {
+        int64_t jj = j0 + j;
+        S[j] = scaleintensity(sl, jj, T, &err);
+        al[j] = alpha_doppler(sl->nu[jj], sl->mu[jj], T);
+        gm[j] = gamma_lorentz(sl->ga[jj], sl->gs[jj], sl->na[jj], T, P, Pp);
+    }
+    if (err) { free(S); free(al); free(gm); return err; }
+    const double *nul = sl->nu + j0;
+    int64_t js = 0; /* j1 of surf! (0-based) */
+    for (int64_t i = 0; i < nnu; i++) {
+        double si = 0.0;
+        int64_t j = js;
+        while (j < n && fabs(nu[i] - nul[j]) > cut) j++; /* cutline :10 is strict > */
+        if (j < n) {
+            js = j;
+            while (j < n && !(fabs(nu[i] - nul[j]) > cut)) {
+                si += profile(shape, nu[i], nul[j], S[j], al[j], gm[j], T);
+                j++;
+            }
+        }
+        sigma[i] = si;
+    }
+    free(S); free(al); free(gm);
+    return 0;
+}
+
+/* ---- radiation.jl:48-54 ---- */
+double cso_planck(double nu, double T)
+{
+    double num = 100.0 * nu;
+    double x = CS_H * CS_C * num / (CS_K * T);
+    double p = 2.0 * CS_H * (CS_C * CS_C) * (num * num * num);
+    return 100.0 * p / (exp(x) - 1.0);
+}
+
+/* Gauss-Legendre nodes/weights on [-1,1] (FastGaussQuadrature.gausslegendre; mathematically unique), ascending */
+static void gausslegendre(int n, double *x, double *w)
+{
+    for (int i = 0; i < n; i++) {
+        double z = cos(M_PI * (i + 0.75) / (n + 0.5)), pp = 1.0;
+        for (int it = 0; it < 100; it++) {
+            double p1 = 1.0, p2 = 0.0;
+            for (int j = 0; j < n; j++) { double p3 = p2; p2 = p1; p1 = ((2.0 * j + 1.0) * z * p2 - j * p3) / (j + 1.0); }
+            pp = n * (z * p1 - p2) / (z * z - 1.0);
+            double dz = p1 / pp;
+            z -= dz;
+            if (fabs(dz) < 1e-16) break;
+        }
+        /* recompute derivative at the converged node for the weight */
+        double p1 = 1.0, p2 = 0.0;
+        for (int j = 0; j < n; j++) { double p3 = p2; p2 = p1; p1 = ((2.0 * j + 1.0) * z * p2 - j * p3) / (j + 1.0); }
+        pp = n * (z * p1 - p2) / (z * z - 1.0);
+        x[n - 1 - i] = z;
+        w[n - 1 - i] = 2.0 / ((1.0 - z * z) * pp * pp);
+    }
+}
+
+/* Gauss-Lobatto nodes/weights on [-1,1] (FastGaussQuadrature.gausslobatto), ascending */
+static void gausslobatto(int n, double *x, double *w)
+{
+    int N = n - 1;
+    x[0] = -1.0; x[N] = 1.0;
+    w[0] = w[N] = 2.0 / (N * (N + 1.0));
+    for (int i = 1; i < N; i++) {
+        /* interior nodes are the zeros of P'_N; Newton from the Chebyshev-Gauss-Lobatto guess */
+        double z = -cos(M_PI * i / N), PN = 0.0;
+        for (int it = 0; it < 100; it++) {
+            double p0 = 1.0, p1 = z;
+            for (int j = 1; j < N; j++) { double p2 = ((2.0 * j + 1.0) * z * p1 - j * p0) / (j + 1.0); p0 = p1; p1 = p2; }
+            PN = p1; /* P_N(z), p0 = P_{N-1}(z) */
+            double dP = N * (p0 - z * p1) / (1.0 - z * z);                       /* P'_N */
+            double d2P = (2.0 * z * dP - N * (N + 1.0) * p1) / (1.0 - z * z);    /* P''_N */
+            double dz = dP / d2P;
+            z -= dz;
+            if (fabs(dz) < 1e-16) break;
+        }
+        {
+            double p0 = 1.0, p1 = z;
+            for (int j = 1; j < N; j++) { double p2 = ((2.0 * j + 1.0) * z * p1 - j * p0) / (j + 1.0); p0 = p1; p1 = p2; }
+            PN = p1;
+        }
+        x[i] = z;
+        w[i] = 2.0 / (N * (N + 1.0) * PN * PN);
+    }
+}
+
+/* ---- core/shared.jl:4-21 streamnodes ---- */
+void cso_streamnodes(int n, double *m, double *W)
+{
+    double x[64], w[64];
+    gausslegendre(n, x, w);
+    for (int i = 0; i < n; i++) {
+        double th = (M_PI / 2) * (x[i] + 1) / 2;
+        double wi = (M_PI / 2) * w[i] / 2;
+        m[i] = 1 / cos(th);
+        W[i] = 2 * M_PI * wi * cos(th) * sin(th);
+    }
+}
+/* ---- core/discretized.jl:2-9 lobattonodes ---- */
+void cso_lobattonodes(int n, double *xs, double *ws)
+{
+    double x[64], w[64];
+    gausslobatto(n, x, w);
+    for (int i = 0; i < n; i++) { xs[i] = (x[i] + 1) / 2; ws[i] = w[i] / 2; }
+}
+
+/* ---- core/discretized.jl:85-87 layerplanck ---- */
+static double layerplanck(double B1, double B2, double tau, double t)
+{
+    return B2 * (1.0 - t) - (B1 - B2) * t + (1.0 - t) * (B1 - B2) / tau;
+}
+
+/*
+ * ---- core/discretized.jl:136-177  dDepth!  for one wavenumber.
+ * beta[k] = C*Sigma/mu at node k (discretized.jl:76-81), node numbering k = i*(nlobatto-1) + n.
+ */
+void cso_depth_bang(double *tau, int np, const double *P, const double *beta, int nlobatto, const double *ws)
+{
+    const double taumin = 1e-6;
+    double b1 = beta[0];
+    for (int i = 0; i < np - 1; i++) {
+        double dP = P[i + 1] - P[i];
+        double ti = 0.0;
+        ti += (dP * ws[0]) * b1;
+        for (int n = 1; n < nlobatto - 1; n++) ti += (dP * ws[n]) * beta[i * (nlobatto - 1) + n];
+        double bn = beta[(i + 1) * (nlobatto - 1)];
+        ti += (dP * ws[nlobatto - 1]) * bn;
+        b1 = bn;
+        tau[i] = ti > taumin ? ti : taumin;
+    }
+}
+
+/* ---- core/discretized.jl:249-326  dMonoflux!  for one wavenumber (index 0 = TOA) ---- */
+void cso_monoflux_bang(double *Mup, double *Mdn, const double *tau, int np, const double *B, double fS, double fa,
+                       double theta_s, int nstream, const double *m, const double *W)
+{
+    int L = np - 1;
+    double c = cos(theta_s);
+    for (int i = 0; i < np; i++) { Mup[i] = 0.0; Mdn[i] = 0.0; }
+    for (int k = 0; k < nstream; k++) { /* downward atmospheric emission :282-294 */
+        double I = 0.0;
+        for (int i = 0; i < L; i++) {
+            double ti = tau[i] * m[k];
+            double tr = exp(-ti);
+            double Be = layerplanck(B[i], B[i + 1], ti, tr);
+            I = I * tr + Be;
+            Mdn[i + 1] += W[k] * I;
+        }
+    }
+    Mdn[0] += c * fS; /* stellar beam :299-304 */
+    double Ms = Mdn[0];
+    for (int i = 0; i < L; i++) {
+        Ms *= exp(-tau[i] / c);
+        Mdn[i + 1] += Ms;
+    }
+    double Is = Mdn[np - 1] * fa / M_PI + B[np - 1]; /* :309-310 */
+    Mup[np - 1] = Is * M_PI;
+    for (int k = 0; k < nstream; k++) { /* :311-322 */
+        double I = Is;
+        for (int i = L - 1; i >= 0; i--) {
+            double ti = tau[i] * m[k];
+            double tr = exp(-ti);
+            double Be = layerplanck(B[i + 1], B[i], ti, tr);
+            I = I * tr + Be;
+            Mup[i] += W[k] * I;
+        }
+    }
+}
+
+/* ---- util.jl:26-33 trapz ---- */
+double cso_trapz(int64_t n, const double *x, const double *y, int64_t incy)
+{
+    double s = 0.0;
+    for (int64_t i = 0; i < n - 1; i++) s += (x[i + 1] - x[i]) * (y[i * incy] + y[(i + 1) * incy]) / 2;
+    return s;
+}
+
+/*
+ * Whole-column evaluation, Discretized core: fluxes.jl:238-279 (monochromaticfluxes!) + shared.jl:125-137 (intF!)
+ * in "Mode D" (SURVEY.md 8a): the absorber is  Sigma(nu,T,P) = sum_g C_g * shape(nu, sl_g, T, P, C_g*P)  evaluated
+ * line-by-line at every Lobatto node, + an optional gray cross-section and an optional host-evaluated extra term.
+ *   Tn, mun : [nlobatto, np-1] column-major (discretized.jl:15-16);  conc : [ngas, K] column-major (gas fastest)
+ *   sigma_extra : NULL or [nnu, K] (nu fastest);  S_toa, albedo : [nnu]
+ *   tau : NULL or [np-1, nnu];  Mup, Mdn : NULL or [np, nnu] (level fastest, shared.jl:93-101);  Fup, Fdn : [np]
+ *   sigma_out : NULL or [nnu, K] total cross-section at every node (nu fastest)
+ * Threading mirrors the reference: states for the line stage (gases.jl:115), nu for the flux stage (fluxes.jl:270).
+ */
+int cso_fluxes_discretized(int64_t nnu, const double *nu, int np, const double *P, double g, int nlobatto,
+                           const double *Tn, const double *mun, const double *Tlev, int ngas,
+                           const cso_lines *const *gases, const int *shapes, const double *cuts, const double *conc,
+                           double sigma_gray, const double *sigma_extra, const double *S_toa, const double *albedo,
+                           double theta_s, int nstream, double *tau, double *Mup, double *Mdn, double *Fup,
+                           double *Fdn, double *sigma_out)
+{
+    fad_init();
+    int nl = np - 1;
+    int K = nl * (nlobatto - 1) + 1;
+    for (int i = 1; i < np; i++)
+        if (!(P[i] >= P[i - 1])) return -4; /* @assert issorted(P) fluxes.jl:257 */
+    double xs[64], ws[64], m[64], W[64];
+    cso_lobattonodes(nlobatto, xs, ws);
+    cso_streamnodes(nstream, m, W);
+    double C = 1e-4 * CS_NA / g; /* fluxes.jl:259 */
+    /* node states */
+    double *Pk = (double *)malloc(sizeof(double) * K), *Tk = (double *)malloc(sizeof(double) * K),
+           *muk = (double *)malloc(sizeof(double) * K);
+    Pk[0] = P[0]; Tk[0] = Tn[0]; muk[0] = mun[0];
+    for (int i = 0; i < nl; i++) {
+        double dP = P[i + 1] - P[i];
+        for (int n = 1; n < nlobatto; n++) {
+            int k = i * (nlobatto - 1) + n;
+            Pk[k] = (n == nlobatto - 1) ? P[i + 1] : P[i] + dP * xs[n]; /* discretized.jl:162,169 */
+            Tk[k] = Tn[n + (size_t)nlobatto * i];
+            muk[k] = mun[n + (size_t)nlobatto * i];
+        }
+    }
+    double *sig = (double *)calloc((size_t)nnu * K, sizeof(double)); /* [K][nnu] */
+    int rc = 0;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int k = 0; k < K; k++) {
+        double *row = sig + (size_t)k * nnu;
+        double *tmp = (double *)malloc(sizeof(double) * (size_t)nnu);
+        for (int64_t i = 0; i < nnu; i++) row[i] = sigma_gray;
+        for (int gi = 0; gi < ngas; gi++) {
+            double Cg = conc[gi + (size_t)ngas * k];
+            int e = cso_shape_bang(shapes[gi], 0, nnu, nu, gases[gi], Tk[k], Pk[k], Cg * Pk[k], cuts[gi], tmp);
+            if (e) {
+#pragma omp critical
+                rc = e;
+            }
+            for (int64_t i = 0; i < nnu; i++) row[i] += Cg * tmp[i]; /* gases.jl:278 */
+        }
+        if (sigma_extra)
+            for (int64_t i = 0; i < nnu; i++) row[i] += sigma_extra[i + (size_t)nnu * k];
+        free(tmp);
+    }
+    if (rc) { free(Pk); free(Tk); free(muk); free(sig); return rc; }
+    if (sigma_out) memcpy(sigma_out, sig, sizeof(double) * (size_t)nnu * K);
+    /* B at levels (discretized.jl:46-58), tau, fluxes per nu */
+    double *Mu = Mup ? Mup : (double *)malloc(sizeof(double) * (size_t)np * nnu);
+    double *Md = Mdn ? Mdn : (double *)malloc(sizeof(double) * (size_t)np * nnu);
+#pragma omp parallel
+    {
+        double *beta = (double *)malloc(sizeof(double) * K);
+        double *B = (double *)malloc(sizeof(double) * np);
+        double *tl = (double *)malloc(sizeof(double) * nl);
+#pragma omp for schedule(static)
+        for (int64_t j = 0; j < nnu; j++) {
+            for (int k = 0; k < K; k++) beta[k] = C * (sig[(size_t)k * nnu + j] / muk[k]); /* discretized.jl:80 */
+            for (int i = 0; i < np; i++) B[i] = cso_planck(nu[j], Tlev[i]);
+            cso_depth_bang(tl, np, P, beta, nlobatto, ws);
+            cso_monoflux_bang(Mu + (size_t)np * j, Md + (size_t)np * j, tl, np, B, S_toa ? S_toa[j] : 0.0,
+                              albedo ? albedo[j] : 0.0, theta_s, nstream, m, W);
+            if (tau) memcpy(tau + (size_t)nl * j, tl, sizeof(double) * nl);
+        }
+        free(beta); free(B); free(tl);
+    }
+    for (int i = 0; i < np; i++) { /* intF! shared.jl:125-137 */
+        Fup[i] = cso_trapz(nnu, nu, Mu + i, np);
+        Fdn[i] = cso_trapz(nnu, nu, Md + i, np);
+    }
+    if (!Mup) free(Mu);
+    if (!Mdn) free(Md);
+    free(Pk); free(Tk); free(muk); free(sig);
+    return 0;
+}
+
+int cso_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
