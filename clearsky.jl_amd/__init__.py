@@ -12,6 +12,6 @@ from .core import (AtmosphericProfile, Column, Context, DirectGas, Discretized, 
                    lobattoevaluations, lobattonodes, logrange, lorentz, lorentz_, monochromaticfluxes,
                    monochromaticfluxes_, netfluxes, nodepressures, nodevalues, opticaldepth, ozonelayer, planck,
                    pressuregrid, psatH2O, radiate, radiate_, shape_batch, stefanboltzmann, streamnodes, transmittance,
-                   trapz, unifyabsorbers, voigt, voigt_)
+                   trapz, trapz_weights, unifyabsorbers, voigt, voigt_)
 
 __version__ = "0.1.0"

@@ -49,6 +49,17 @@ def trapz(x, y):
     return s
 
 
+def trapz_weights(x):
+    """Per-point weights w with sum(w*y) == trapz(x, y) (util.jl:26-33); shards of a grid use slices of these."""
+    x = np.asarray(x, float)
+    w = np.zeros(len(x))
+    if len(x) > 1:
+        d = np.diff(x)
+        w[:-1] += d / 2
+        w[1:] += d / 2
+    return w
+
+
 def logrange(a, b, N=101, gamma=1):
     """util.jl:43-45"""
     return ((10.0 ** np.linspace(0, gamma, N)) - 1) * (b - a) / (10.0 ** gamma - 1) + a
@@ -444,11 +455,7 @@ class Column:
         self.K = self.nl * (nlob - 1) + 1
         nu = as_f64(nu)
         # trapezoid weights on the global grid (util.jl:26-33 rewritten as per-point weights)
-        w = np.zeros(nnu)
-        if nnu > 1:
-            d = np.diff(nu)
-            w[:-1] += d / 2
-            w[1:] += d / 2
+        w = trapz_weights(nu)
         j0, j1 = (0, nnu) if nu_range is None else nu_range
         self.j0, self.j1 = int(j0), int(j1)
         self.nu_all = nu
@@ -515,6 +522,11 @@ class Column:
             dptr(self.sigma_extra) if self.sigma_extra is not None else None, dptr(self.S_toa), dptr(self.albedo),
             self.theta_s, self.core.nstream, int(self.want_tau), int(self.want_M)))
         self._set = True
+        self.ctx._resident = self      # a context holds ONE resident column
+
+    def _ensure_resident(self):
+        if getattr(self.ctx, "_resident", None) is not self:
+            self._setup()
 
     def update(self, T, mu=None):
         """New temperature (and molar-mass) profile on the same grid: re-evaluates the closures and uploads the node
@@ -522,7 +534,7 @@ class Column:
         fT = formprofile(self.P, T)
         fmu = formprofile(self.P, mu) if mu is not None else (lambda *a: self.muk[0])
         self._state(fT, fmu)
-        if self.sigma_extra is not None:
+        if self.sigma_extra is not None or getattr(self.ctx, "_resident", None) is not self:
             self._setup()
             return
         check(lib().cs_column_update_state(self.ctx.handle, dptr(self.Tn.ravel(order="F").copy()),
@@ -532,6 +544,7 @@ class Column:
     # -- execution -------------------------------------------------------------------------------------------------
     def run(self, stream: int = 0):
         """Enqueue one evaluation (asynchronous).  `stream` is a raw hipStream_t (e.g. torch's cuda_stream) or 0."""
+        self._ensure_resident()
         check(lib().cs_column_run(self.ctx.handle, C.c_void_p(stream) if stream else None))
 
     def sync(self):
@@ -540,6 +553,7 @@ class Column:
     def profile(self, reps: int = 3, stream: int = 0):
         """HIP-event time per kernel class, ms per evaluation: dict(prep, linesum, rt, reduce)."""
         ms = np.zeros(4)
+        self._ensure_resident()
         check(lib().cs_column_profile(self.ctx.handle, C.c_void_p(stream) if stream else None, reps, dptr(ms)))
         return dict(prep=ms[0], linesum=ms[1], rt=ms[2], reduce=ms[3])
 
@@ -547,6 +561,10 @@ class Column:
         p = C.c_void_p()
         check(lib().cs_column_flux_ptr(self.ctx.handle, C.byref(p)))
         return p.value
+
+    def flux_to(self, device_ptr: int, stream: int = 0):
+        """Async copy of [Fup; Fdn] (2*np doubles) into caller-owned device memory (e.g. a torch tensor's data_ptr())."""
+        check(lib().cs_column_flux_to(self.ctx.handle, C.c_void_p(device_ptr), C.c_void_p(stream) if stream else None))
 
     def counts(self):
         a, b = C.c_int64(), C.c_int64()

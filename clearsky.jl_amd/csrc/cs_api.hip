@@ -605,6 +605,14 @@ int cs_column_flux_ptr(cs_ctx *ctx, double **dF)
     return CS_OK;
 }
 
+int cs_column_flux_to(cs_ctx *ctx, double *dst_device, void *stream)
+{
+    if (!ctx || !ctx->col.ready || !dst_device) return fail(CS_ESTATE, "no resident column");
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    HIPCHK(hipMemcpyAsync(dst_device, ctx->col.F.p, (size_t)2 * ctx->col.np * sizeof(double), hipMemcpyDeviceToDevice, s));
+    return CS_OK;
+}
+
 static int fetch_transposed(cs_ctx *ctx, const double *dsrc, int R, int64_t Cn, double *hdst)
 {
     Column &c = ctx->col;

@@ -1,0 +1,77 @@
+"""Synthetic inputs of the BASELINE.json configurations (SURVEY.md 8d "Concrete synthetic inputs")."""
+import os
+
+import numpy as np
+
+from . import constants as K
+from .core import DirectGas, Discretized, GrayGas, pressuregrid, psatH2O
+from .hitran import SpectralLines
+
+_HITRAN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "hitran")
+
+
+def fixture(name: str) -> str:
+    return os.path.join(_HITRAN, name)
+
+
+def earth_temperature(P):
+    """T_k = max(288 (P/1e5)^(R/(0.029*1040)), 200) K at the levels"""
+    return np.maximum(288.0 * (np.asarray(P) / 1e5) ** (K.R / (0.029 * 1040.0)), 200.0)
+
+
+def fC_h2o(T, P):
+    return min(0.8 * psatH2O(T) / P, 0.04)
+
+
+_cache = {}
+
+
+def lines(kind: str, which: str):
+    """which in {"H2O","CO2","CH4"}; kind "fixture" (reference test/HITRAN files) or "synthetic" (5e4 seeded lines)."""
+    key = (kind, which)
+    if key not in _cache:
+        if kind == "fixture":
+            _cache[key] = SpectralLines(fixture(which + ".par"))
+        else:
+            M = {"H2O": 1, "CO2": 2, "O3": 3, "CH4": 6}[which]
+            _cache[key] = SpectralLines.synthetic(M, 50000, 20260101 + M)
+    return _cache[key]
+
+
+def config(name: str, nnu=None, nl=None, lines_kind=None):
+    """Returns dict(P, g, T, mu, fS, fa, absorbers, core, theta_s, nu) for
+    "C2" CO2 fixture, 1e4 nu x 40 layers;  "C3" H2O+CO2, 1e5 nu x 60 layers (synthetic ~1e5-line table by default)."""
+    if name == "C2":
+        nnu, nl, lines_kind = nnu or 10_000, nl or 40, lines_kind or "fixture"
+        gases = ["CO2"]
+    elif name == "C3":
+        nnu, nl, lines_kind = nnu or 100_000, nl or 60, lines_kind or "synthetic"
+        gases = ["H2O", "CO2"]
+    else:
+        raise ValueError(name)
+    nu = np.linspace(1.0, 2500.0, nnu)
+    P = pressuregrid(1.0, 1e5, nl + 1)
+    T = earth_temperature(P)
+    absorbers = []
+    for gname in gases:
+        fC = fC_h2o if gname == "H2O" else 400e-6
+        absorbers.append(DirectGas(lines(lines_kind, gname), fC, nu))
+    return dict(name=name, nu=nu, P=P, g=9.8, T=T, mu=0.029, fS=0.0, fa=0.0, absorbers=absorbers,
+                core=Discretized(5, 2), theta_s=0.841, lines_kind=lines_kind, nl=nl)
+
+
+def balanced_ranges(nu, absorbers, nparts: int):
+    """Contiguous nu ranges with equal line-evaluation work (sum over gases of lines inside the cut-off per point):
+    the multi-GPU partition of SURVEY.md 8e."""
+    nu = np.asarray(nu)
+    w = np.ones(len(nu))  # flux sweeps: constant work per point
+    for a in absorbers:
+        if isinstance(a, DirectGas):
+            nl = a.sl.nu
+            w += (np.searchsorted(nl, nu + a.dnu_cut, "right") - np.searchsorted(nl, nu - a.dnu_cut, "left")) * 0.35
+    c = np.concatenate([[0.0], np.cumsum(w)])
+    edges = [int(np.searchsorted(c, c[-1] * r / nparts)) for r in range(nparts + 1)]
+    edges[0], edges[-1] = 0, len(nu)
+    for r in range(1, nparts + 1):
+        edges[r] = max(edges[r], edges[r - 1] + 1) if r < nparts else len(nu)
+    return [(edges[r], edges[r + 1]) for r in range(nparts)]

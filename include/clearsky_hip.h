@@ -122,6 +122,8 @@ int cs_column_sync(cs_ctx *ctx);
  * evaluation spent in {k_prep, k_linesum, k_rt, k_freduce} (summed over gases) */
 int cs_column_profile(cs_ctx *ctx, void *stream, int reps, double *ms);
 int cs_column_flux_ptr(cs_ctx *ctx, double **dF);
+/* asynchronously copy the [2*np] band fluxes (Fup then Fdn) into caller-owned DEVICE memory on `stream` */
+int cs_column_flux_to(cs_ctx *ctx, double *dst_device, void *stream);
 int cs_column_fetch(cs_ctx *ctx, double *tau, double *Mup, double *Mdn, double *Fup, double *Fdn);
 int cs_column_sigma_fetch(cs_ctx *ctx, double *sigma);
 int cs_column_counts(cs_ctx *ctx, int64_t *pair_evals, int64_t *lines_in_range);

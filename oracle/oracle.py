@@ -28,13 +28,30 @@ def build(force=False):
     return LIB
 
 
+def use_native_build():
+    """Rebuild the oracle with -O3 -march=native ON THE HOST IT RUNS ON and load that copy (bench.py's cpu_baseline
+    leg, so the CPU number is not handicapped by a generic x86-64 build).  Falls back to the portable build."""
+    global _lib
+    nat = os.path.join(_HERE, "libcs_oracle_native.so")
+    try:
+        subprocess.run(["gcc", "-O3", "-march=native", "-fPIC", "-fopenmp", "-std=c99", "-ffp-contract=off", "-shared",
+                        "-o", nat, os.path.join(_HERE, "cs_oracle.c"), "-lm"], check=True)
+    except Exception:
+        return False
+    _lib = None
+    globals()["LIB"] = nat
+    lib()
+    return True
+
+
 _lib = None
 
 
 def lib():
     global _lib
     if _lib is None:
-        build()
+        if not LIB.endswith("_native.so"):
+            build()
         L = C.CDLL(LIB)
         L.cso_faddeeva_re.restype = C.c_double
         L.cso_faddeeva_re.argtypes = [C.c_double, C.c_double]

@@ -1,0 +1,58 @@
+"""world_size-2 gloo test of the multi-GPU decomposition on CPU: contiguous work-balanced nu shards,
+global trapezoid weights, ONE all-reduce of 2*np doubles.  The per-shard compute is the oracle here (no GPU in this
+container); on the GPU box the same decomposition is exercised by tests/test_gpu_parity.py::test_shards_add_up."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    import clearsky_jl_amd as cs
+    from clearsky_jl_amd import workloads as W
+    from oracle import oracle as O
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = W.config("C2", nnu=1200, nl=10)
+    nu, P = cfg["nu"], cfg["P"]
+    j0, j1 = W.balanced_ranges(nu, cfg["absorbers"], world)[rank]
+    fT, fmu = cs.formprofile(P, cfg["T"]), cs.formprofile(P, cfg["mu"])
+    Tn, mun = cs.lobattoevaluations(P, fT, fmu, 2)
+    Tlev = np.array([fT(p) for p in P])
+    gas = cfg["absorbers"][0]
+    conc = np.full((1, len(P)), 400e-6)
+    kw = dict(theta_s=0.841, nstream=5)
+    part = O.fluxes_discretized(nu[j0:j1], P, 9.8, 2, Tn, mun, Tlev, [gas.sl], ["voigt"], [25.0], conc, **kw)
+    w = cs.trapz_weights(nu)[j0:j1]
+    F = torch.from_numpy(np.concatenate([part["Mup"] @ w, part["Mdn"] @ w]))
+    dist.all_reduce(F)
+    if rank == 0:
+        full = O.fluxes_discretized(nu, P, 9.8, 2, Tn, mun, Tlev, [gas.sl], ["voigt"], [25.0], conc, **kw)
+        ref = np.concatenate([full["Fup"], full["Fdn"]])
+        q.put(float(np.max(np.abs(F.numpy() - ref) / np.maximum(np.abs(ref), 1e-6 * ref.max()))))
+    dist.destroy_process_group()
+
+
+def test_two_rank_shards_reduce_to_full_column():
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    err = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert err < 1e-12

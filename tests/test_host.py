@@ -1,0 +1,161 @@
+"""CPU tests of the host logic and the C-ABI surface (no compute calls: there is no GPU here)."""
+import ctypes
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import HITRAN, ROOT
+
+
+def test_library_exports_every_declared_symbol(cs):
+    """The shared library loads and exports every cs_* function include/clearsky_hip.h declares."""
+    hdr = open(os.path.join(ROOT, "include", "clearsky_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(cs_[a-z_0-9]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    assert os.path.exists(cs.LIB_PATH), "libclearsky_hip.so must be built in-tree by __graft_entry__.build()"
+    L = ctypes.CDLL(cs.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in the header but not exported"
+    assert declared == set(cs.SIGNATURES), declared ^ set(cs.SIGNATURES)
+    assert cs.lib().cs_version() >= 100
+
+
+def test_no_oracle_in_product():
+    """The shipped path must not import, link or call anything under oracle/."""
+    pkg = os.path.join(ROOT, "clearsky.jl_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                assert "oracle" not in txt.lower().replace("# oracle", ""), f"{f} mentions the oracle"
+
+
+def test_molparam_structure(cs):
+    """Mirror of the reference's only active test, test/test_molparam.jl:1-18."""
+    for M, mp in cs.MOLPARAM.items():
+        assert mp.M == M
+        if len(mp.I) > 1:
+            assert np.all(mp.maxrelerr[mp.hascheb] <= 0.01)
+            for j in range(len(mp.I)):
+                assert mp.ncheb[j] == len(mp.cheb[j])
+                assert not np.any(np.isnan(mp.cheb[j]))
+            assert mp.A.sum() <= 1.001
+    assert cs.TMIN == 25.0 and cs.TMAX == 1000.0
+    assert not cs.MOLPARAM[34].hascheb[0] and not cs.MOLPARAM[42].hascheb[0]   # O, CF4: no fit (quirk 5)
+
+
+@pytest.mark.parametrize("name,count,niso", [("CO2", 5599, 12), ("H2O", 3058, 7), ("CH4", 4504, 4)])
+def test_readpar_fixtures(cs, name, count, niso):
+    sl = cs.SpectralLines(os.path.join(HITRAN, name + ".par"))
+    assert sl.N == count == len(sl.nu)
+    assert np.all(np.diff(sl.nu) >= 0)
+    assert set(np.unique(sl.I)) <= set(range(1, niso + 1))
+    mp = cs.MOLPARAM[sl.M]
+    assert np.array_equal(sl.mu, mp.mu[sl.I - 1]) and np.array_equal(sl.A, mp.A[sl.I - 1])
+    assert sl.cheb.shape == (niso, 16)
+
+
+def test_readpar_filters(cs):
+    f = os.path.join(HITRAN, "CO2.par")
+    p = cs.readpar(f, numin=600, numax=700)
+    assert p["nu"].min() >= 600 and p["nu"].max() <= 700
+    p2 = cs.readpar(f, I=[1])
+    assert set(p2["I"]) == {"1"}
+    p3 = cs.readpar(f, maxlines=100)
+    assert len(p3["nu"]) == 100 and np.all(np.diff(p3["nu"]) >= 0)
+    full = cs.readpar(f)
+    assert np.sort(p3["S"])[0] >= np.sort(full["S"])[-100]
+    with pytest.raises(AssertionError):
+        cs.readpar(f, numin=1e9)
+    with pytest.raises(AssertionError):
+        cs.readpar("foo.txt")
+
+
+def test_first_line_fields(cs):
+    p = cs.readpar(os.path.join(HITRAN, "CO2.par"))
+    j = int(np.argmin(np.abs(p["nu"] - 0.757206)))
+    assert p["M"][j] == 2 and p["I"][j] == "4"
+    assert p["S"][j] == 1.751e-34 and p["gamma_a"][j] == 0.0927 and p["gamma_s"][j] == 0.125
+    assert p["Epp"][j] == 0.0 and p["na"][j] == 0.78
+
+
+def test_grids_and_quadrature_anchors(cs):
+    assert np.allclose(cs.pressuregrid(1.0, 1e5, 5), [1, 5.39800207, 316.227766, 18525.3727, 1e5], rtol=1e-8)
+    m, W = cs.streamnodes(5)        # SURVEY.md 4 anchors
+    assert np.allclose(m, [1.00272098, 1.06949766, 1.41421356, 2.82008548, 13.58335526], rtol=1e-8)
+    assert np.allclose(W, [0.08584143, 0.78311645, 1.40367707, 0.78311645, 0.08584143], rtol=1e-7)
+    m2, W2 = cs.streamnodes(2)
+    assert np.allclose(m2, [1.05774, 3.06856], rtol=1e-5) and np.allclose(W2, [1.52039, 1.52039], rtol=1e-5)
+    x, w = cs.lobattonodes(4)
+    assert np.allclose(x, [0, 0.5 - 0.5 / math.sqrt(5), 0.5 + 0.5 / math.sqrt(5), 1], atol=1e-15)
+    assert np.allclose(w, [1 / 12, 5 / 12, 5 / 12, 1 / 12], atol=1e-15)
+    assert cs.planck(667.0, 288.0) == pytest.approx(0.13090535521240354, rel=1e-14)
+    assert cs.dtaudP(1e-20, 9.8, 0.029) == pytest.approx(2.1189798592540465, rel=1e-14)
+    with pytest.raises(cs.ClearSkyHIPError):
+        cs.streamnodes(99)
+
+
+def test_host_quadrature_matches_golden(cs, golden):
+    q = golden("quadrature")
+    for n in (1, 2, 3, 5, 8, 16):
+        m, W = cs.streamnodes(n)
+        assert np.max(np.abs(m / q[f"m{n}"] - 1)) < 1e-13 and np.max(np.abs(W / q[f"W{n}"] - 1)) < 1e-13
+    for n in (2, 3, 4, 5):
+        x, w = cs.lobattonodes(n)
+        assert np.max(np.abs(x - q[f"lx{n}"])) < 1e-15 and np.max(np.abs(w - q[f"lw{n}"])) < 1e-15
+
+
+def test_profiles_and_lobatto_evaluations(cs):
+    P = cs.pressuregrid(1.0, 1e5, 11)
+    T = np.linspace(200, 288, 11)
+    f = cs.AtmosphericProfile(P, T)
+    assert f(P[3]) == pytest.approx(T[3], rel=1e-14)
+    mid = math.exp(0.5 * (math.log(P[3]) + math.log(P[4])))
+    assert f(mid) == pytest.approx(0.5 * (T[3] + T[4]), rel=1e-13)
+    assert f(2e5) > T[-1]          # NoBoundaries: linear extrapolation
+    Tn, mun = cs.lobattoevaluations(P, f, lambda T_, P_: 0.029, 3)
+    assert Tn.shape == (3, 10) and np.all(mun == 0.029)
+    assert Tn[0, 2] == pytest.approx(T[2], rel=1e-13) and Tn[2, 2] == pytest.approx(T[3], rel=1e-12)
+    Pk = cs.nodepressures(P, 3)
+    assert len(Pk) == 21 and Pk[0] == P[0] and Pk[2] == P[1] and Pk[1] == P[0] + (P[1] - P[0]) * 0.5
+    assert np.array_equal(cs.nodevalues(Tn, 3)[[0, 2, 4]], [Tn[0, 0], Tn[2, 0], Tn[2, 1]])
+
+
+def test_absorber_validation(cs, lines):
+    nu = np.linspace(600, 700, 11)
+    g1 = cs.DirectGas(lines("CO2"), 400e-6, nu)
+    with pytest.raises(AssertionError):
+        cs.UnifiedAbsorber(g1, g1)                       # duplicate absorbers
+    with pytest.raises(ValueError):
+        cs.UnifiedAbsorber(lambda v, T, P: 0.0)          # needs a gas for the wavenumber grid
+    with pytest.raises(AssertionError):
+        cs.UnifiedAbsorber(g1, cs.GrayGas(1e-25, nu[:-1]))   # identical wavenumber vectors required
+    with pytest.raises(AssertionError):
+        cs.DirectGas(lines("CO2"), 1.5, nu)              # concentration in [0,1]
+    with pytest.raises(AssertionError):
+        cs.DirectGas(lines("CO2"), 1e-4, nu[::-1])       # ascending wavenumbers
+    U = cs.UnifiedAbsorber(g1, cs.GrayGas(1e-26, nu), lambda v, T, P: 0 * v)
+    assert U.nnu == 11 and len(U.gas) == 2 and len(U.fun) == 1
+    assert g1.mu == pytest.approx(np.sum(lines("CO2").A * lines("CO2").mu) / np.sum(lines("CO2").A))
+
+
+def test_balanced_ranges(cs):
+    from clearsky_jl_amd import workloads as W
+    cfg = W.config("C2", nnu=3000)
+    for n in (1, 2, 3, 8):
+        r = W.balanced_ranges(cfg["nu"], cfg["absorbers"], n)
+        assert r[0][0] == 0 and r[-1][1] == 3000 and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+        assert all(b > a for a, b in r)
+
+
+def test_missing_library_fails_loudly(cs, monkeypatch, tmp_path):
+    import importlib
+    lib_mod = importlib.import_module("clearsky_jl_amd._lib")
+    monkeypatch.setattr(lib_mod, "_lib", None)
+    monkeypatch.setattr(lib_mod, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(cs.ClearSkyHIPError, match="no CPU fallback"):
+        lib_mod.lib()
