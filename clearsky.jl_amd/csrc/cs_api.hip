@@ -68,6 +68,7 @@ struct GasTable {
     bool present = false;
     int64_t L = 0;
     int niso = 0;
+    double mu_min = 0.0;
     std::vector<double> h_nu;
     std::vector<int16_t> h_iso;
     std::vector<int32_t> h_ncheb;
@@ -87,6 +88,7 @@ struct ColGas {
     int slot = 0, shape = 0;
     double cut = 25.0;
     DevBuf conc, Pp, J0, J1;  // [K], [K], [ntile], [ntile]
+    DevBuf win, zones;        // [ntile64] WaveWin, [K][ntile64] int2 (Voigt fast path)
     int64_t pairs_per_state = 0, lines_in_range = 0;
 };
 
@@ -248,6 +250,51 @@ void tile_windows(const std::vector<double> &nul, int64_t g0, int64_t g1, const 
     inrange = (std::upper_bound(b, e, nu[nnu - 1] + cut) - std::lower_bound(b, e, nu[0] - cut));
 }
 
+// per-64-point windows of the Voigt fast path: [W0,W1) superset window, [E0,E1) lines inside every lane's cut-off
+void wave_windows(const std::vector<double> &nul, int64_t g0, int64_t g1, const double *nu, int64_t nnu, double cut,
+                  std::vector<WaveWin> &win)
+{
+    const int nt = (int)((nnu + 63) / 64);
+    win.resize(nt);
+    auto b = nul.begin() + g0, e = nul.begin() + g1;
+    for (int t = 0; t < nt; t++) {
+        const int64_t i0 = (int64_t)t * 64, i1 = std::min<int64_t>(nnu, i0 + 64) - 1;
+        const double vlo = nu[i0], vhi = nu[i1];
+        const double tol = 1e-9 * (std::fabs(vhi) + cut + 1.0);
+        WaveWin w;
+        w.W0 = (int32_t)(std::lower_bound(b, e, vlo - cut - tol) - nul.begin());
+        w.W1 = (int32_t)(std::upper_bound(b, e, vhi + cut + tol) - nul.begin());
+        w.E0 = (int32_t)(std::lower_bound(b, e, vhi - cut + tol) - nul.begin());
+        w.E1 = (int32_t)(std::upper_bound(b, e, vlo + cut - tol) - nul.begin());
+        w.E0 = std::min(std::max(w.E0, w.W0), w.W1);
+        w.E1 = std::min(std::max(w.E1, w.E0), w.W1);
+        win[t] = w;
+    }
+}
+
+// K1 + K2 for one gas on `s`: parameters for `kn` states, then the line sum into sigma ([kn][nnu])
+void launch_gas(hipStream_t s, int shape, const GasTable &G, int kn, const double *Tk, const double *Pk, const double *Ppk,
+                const double *scale, LineHot *hot, LineCold *cold, const double *dnu, int64_t nnu, int ntile256,
+                const int32_t *J0, const int32_t *J1, const WaveWin *win, int2 *zones, double cut, double base,
+                const double *extra, double *sigma, int accumulate, hipEvent_t ev_mid)
+{
+    const int64_t tot = (int64_t)kn * G.L;
+    hipLaunchKernelGGL(k_prep, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, shape, G.dev(), kn, Tk, Pk, Ppk, scale,
+                       hot, cold);
+    if (shape == SH_VOIGT) {
+        const int nt64 = (int)((nnu + 63) / 64);
+        hipLaunchKernelGGL(k_zones, dim3((unsigned)(((int64_t)nt64 * kn + 255) / 256)), dim3(256), 0, s, dnu, nnu, nt64, kn,
+                           G.nu.as<double>(), win, Tk, G.mu_min, cut, zones);
+        if (ev_mid) (void)hipEventRecord(ev_mid, s);
+        hipLaunchKernelGGL(k_linesum_voigt, dim3((unsigned)((nt64 + 3) / 4), kn), dim3(256), 0, s, dnu, nnu, G.L, hot, cold, win,
+                           zones, nt64, cut, base, extra, sigma, accumulate);
+    } else {
+        if (ev_mid) (void)hipEventRecord(ev_mid, s);
+        launch_linesum_shape(shape, dim3(ntile256, kn), s, dnu, nnu, G.L, hot, cold, J0, J1, cut, Tk, base, extra, sigma,
+                             accumulate);
+    }
+}
+
 int check_gas_states(const GasTable &G, int K, const double *T)
 {
     for (int k = 0; k < K; k++)
@@ -318,6 +365,8 @@ int cs_gas_upload(cs_ctx *ctx, int slot, int64_t L, const double *nu, const doub
     G.h_nu.assign(nu, nu + L);
     G.h_iso.assign(iso, iso + L);
     G.h_ncheb.assign(ncheb, ncheb + niso);
+    G.mu_min = *std::min_element(mu_iso, mu_iso + L);
+    if (!(G.mu_min > 0)) return fail(CS_EINVAL, "isotopologue molar masses must be positive");
     int rc;
     if ((rc = upload(G.nu, nu, L, s)) || (rc = upload(G.S, S, L, s)) || (rc = upload(G.ga, gamma_a, L, s)) ||
         (rc = upload(G.gs, gamma_s, L, s)) || (rc = upload(G.Epp, Epp, L, s)) || (rc = upload(G.na, na, L, s)) ||
@@ -354,9 +403,12 @@ int cs_shape_batch(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t nnu
     std::vector<int32_t> J0, J1;
     tile_windows(G.h_nu, g0, g1, nu, nnu, dnu_cut, J0, J1, pairs, inr);
     const int ntile = (int)J0.size();
-    DevBuf dnu, dT, dP, dPp, dJ0, dJ1, hot, cold, dsig;
+    DevBuf dnu, dT, dP, dPp, dJ0, dJ1, hot, cold, dsig, dwin, dzones;
+    std::vector<WaveWin> win;
+    wave_windows(G.h_nu, g0, g1, nu, nnu, dnu_cut, win);
     if ((rc = upload(dnu, nu, nnu, s)) || (rc = upload(dT, T, K, s)) || (rc = upload(dP, P, K, s)) ||
-        (rc = upload(dPp, Pp, K, s)) || (rc = upload(dJ0, J0.data(), ntile, s)) || (rc = upload(dJ1, J1.data(), ntile, s)))
+        (rc = upload(dPp, Pp, K, s)) || (rc = upload(dJ0, J0.data(), ntile, s)) || (rc = upload(dJ1, J1.data(), ntile, s)) ||
+        (rc = upload(dwin, win.data(), win.size(), s)))
         return rc;
     // bound the workspace: process the states in chunks
     const size_t per_state = (size_t)G.L * (sizeof(LineHot) + sizeof(LineCold)) + (size_t)nnu * sizeof(double);
@@ -364,15 +416,12 @@ int cs_shape_batch(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t nnu
     HIPCHK(hot.reserve((size_t)kc * G.L * sizeof(LineHot)));
     HIPCHK(cold.reserve((size_t)kc * G.L * sizeof(LineCold)));
     HIPCHK(dsig.reserve((size_t)kc * nnu * sizeof(double)));
+    HIPCHK(dzones.reserve((size_t)kc * win.size() * sizeof(int2)));
     for (int k0 = 0; k0 < K; k0 += kc) {
         const int kn = std::min(kc, K - k0);
-        const int64_t tot = (int64_t)kn * G.L;
-        hipLaunchKernelGGL(k_prep, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, shape, G.dev(), kn,
-                           dT.as<double>() + k0, dP.as<double>() + k0, dPp.as<double>() + k0, (const double *)nullptr,
-                           hot.as<LineHot>(), cold.as<LineCold>());
-        launch_linesum_shape(shape, dim3(ntile, kn), s, dnu.as<double>(), nnu, G.L, hot.as<LineHot>(), cold.as<LineCold>(),
-                             dJ0.as<int32_t>(), dJ1.as<int32_t>(), dnu_cut, dT.as<double>() + k0, 0.0, nullptr,
-                             dsig.as<double>(), 0);
+        launch_gas(s, shape, G, kn, dT.as<double>() + k0, dP.as<double>() + k0, dPp.as<double>() + k0, nullptr,
+                   hot.as<LineHot>(), cold.as<LineCold>(), dnu.as<double>(), nnu, ntile, dJ0.as<int32_t>(), dJ1.as<int32_t>(),
+                   dwin.as<WaveWin>(), dzones.as<int2>(), dnu_cut, 0.0, nullptr, dsig.as<double>(), 0, nullptr);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpy2DAsync(sigma + (size_t)k0 * ld_state, ld_state * sizeof(double), dsig.p, nnu * sizeof(double),
                                 nnu * sizeof(double), kn, hipMemcpyDeviceToHost, s));
@@ -462,7 +511,12 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
         included_range(G.h_nu, nu[0], nu[nnu - 1], cg.cut, false, g0, g1);
         std::vector<int32_t> J0, J1;
         tile_windows(G.h_nu, g0, g1, nu, nnu, cg.cut, J0, J1, cg.pairs_per_state, cg.lines_in_range);
-        if ((rc = upload(cg.J0, J0.data(), J0.size(), s)) || (rc = upload(cg.J1, J1.data(), J1.size(), s))) return rc;
+        std::vector<WaveWin> win;
+        wave_windows(G.h_nu, g0, g1, nu, nnu, cg.cut, win);
+        if ((rc = upload(cg.J0, J0.data(), J0.size(), s)) || (rc = upload(cg.J1, J1.data(), J1.size(), s)) ||
+            (rc = upload(cg.win, win.data(), win.size(), s)))
+            return rc;
+        HIPCHK(cg.zones.reserve((size_t)c.K * win.size() * sizeof(int2)));
         maxL = std::max(maxL, (size_t)G.L);
     }
     HIPCHK(c.hot.reserve((size_t)K * maxL * sizeof(LineHot)));
@@ -533,14 +587,10 @@ static int run_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev)
     for (int gi = 0; gi < c.ngas; gi++) {
         ColGas &cg = c.gas[gi];
         GasTable &G = ctx->gas[cg.slot];
-        const int64_t tot = (int64_t)K * G.L;
-        hipLaunchKernelGGL(k_prep, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, cg.shape, G.dev(), K,
-                           c.Tk.as<double>(), c.Pk.as<double>(), cg.Pp.as<double>(), cg.conc.as<double>(),
-                           c.hot.as<LineHot>(), c.cold.as<LineCold>());
-        if (ev) HIPCHK(hipEventRecord(ev[e++], s));
-        launch_linesum_shape(cg.shape, dim3(c.ntile, K), s, c.nu.as<double>(), c.nnu, G.L, c.hot.as<LineHot>(),
-                             c.cold.as<LineCold>(), cg.J0.as<int32_t>(), cg.J1.as<int32_t>(), cg.cut, c.Tk.as<double>(),
-                             c.sigma_gray, extra, sig, gi > 0);
+        launch_gas(s, cg.shape, G, K, c.Tk.as<double>(), c.Pk.as<double>(), cg.Pp.as<double>(), cg.conc.as<double>(),
+                   c.hot.as<LineHot>(), c.cold.as<LineCold>(), c.nu.as<double>(), c.nnu, c.ntile, cg.J0.as<int32_t>(),
+                   cg.J1.as<int32_t>(), cg.win.as<WaveWin>(), cg.zones.as<int2>(), cg.cut, c.sigma_gray, extra, sig, gi > 0,
+                   ev ? ev[e++] : nullptr);
         if (ev) HIPCHK(hipEventRecord(ev[e++], s));
     }
     launch_rt(c.nstream, c.ntile, (size_t)2 * c.np * 4 * sizeof(double), s, c.rt, c.nu.as<double>(), c.wts.as<double>(),

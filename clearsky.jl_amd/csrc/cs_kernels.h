@@ -166,6 +166,131 @@ __global__ __launch_bounds__(256) void k_linesum(const double *__restrict__ nu, 
     }
 }
 
+
+// ---- K2, Voigt fast path ---------------------------------------------------------------------------------------------
+// One wave = 64 consecutive wavenumbers x one node state.  The wave's window of lines [W0,W1) (sorted by nul) is cut
+// into five wave-uniform segments so that 95 % of the (nu, line) pairs run a branch-free far-wing body whose line
+// parameters arrive through scalar loads:
+//   [W0,a)  left edge  : far wing + cut-off predicate      (lines not within the cut-off of every lane)
+//   [a,N0)  far left   : far wing, no predicate
+//   [N0,N1) near zone  : lines within  d_A = 100*alpha_max/sqrt(ln2)  of the wave's span (x^2 < 1e4 possible)
+//   [N1,b)  far right, [b,W1) right edge
+// In the near zone every lane still takes the far-wing body where s >= 1e4 and records the index range of its own
+// s < 1e4 (and s < 100) lines; two short per-lane loops then evaluate the continued-fraction and the near-centre
+// forms only for those, so the expensive bodies run ~20 and ~4 times per (wave, state) instead of once per line.
+struct WaveWin { int32_t W0, W1, E0, E1; };  // per 64-point tile: window, first line inside every lane's cut-off, one past the last
+
+// node-state dependent near-zone bounds, one thread per (state, tile)
+__global__ __launch_bounds__(256) void k_zones(const double *__restrict__ nu, int64_t nnu, int ntile, int K,
+                                                const double *__restrict__ nul, const WaveWin *__restrict__ win,
+                                                const double *__restrict__ Tk, double mu_min, double cut,
+                                                int2 *__restrict__ zones)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= ntile * K) return;
+    const int k = idx / ntile, t = idx - k * ntile;
+    const int64_t i0 = (int64_t)t * 64, i1 = (i0 + 63 < nnu ? i0 + 63 : nnu - 1);
+    const double vlo = nu[i0], vhi = nu[i1];
+    const WaveWin w = win[t];
+    // largest Doppler width any line of the window can have at this temperature (alphadoppler, line_shapes.jl:144)
+    const double amax = ((vhi + cut) / kC) * sqrt(2.0 * kRgas * Tk[k] / mu_min);
+    const double dA = 100.0 * amax / kSqLn2 * (1.0 + 1e-6);
+    const double lo = vlo - dA, hi = vhi + dA;
+    int a = w.W0, b = w.W1;
+    while (a < b) { int m = (a + b) >> 1; if (nul[m] < lo) a = m + 1; else b = m; }
+    const int N0 = a;
+    a = N0; b = w.W1;
+    while (a < b) { int m = (a + b) >> 1; if (nul[m] <= hi) a = m + 1; else b = m; }
+    zones[idx] = make_int2(N0, a);
+}
+
+template <bool PRED>
+__device__ __forceinline__ double far_segment(double acc, double v, const LineHot *__restrict__ hk, int j0, int j1, double cut)
+{
+#pragma unroll 4
+    for (int j = j0; j < j1; j++) {
+        const LineHot h = hk[j];
+        const double dv = v - h.nul;
+        const double x = dv * h.p1;
+        const double s = __builtin_fma(x, x, h.p2);
+        double r = h.p3 * fad_far_core(h.p2, rcp_fast(s));
+        if (PRED) r = (fabs(dv) > cut) ? 0.0 : r;
+        acc += r;
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void k_linesum_voigt(const double *__restrict__ nu, int64_t nnu, int64_t L,
+                                                        const LineHot *__restrict__ hot, const LineCold *__restrict__ cold,
+                                                        const WaveWin *__restrict__ win, const int2 *__restrict__ zones,
+                                                        int ntile, double cut, double base,
+                                                        const double *__restrict__ extra, double *__restrict__ sigma,
+                                                        int accumulate)
+{
+    const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (tile >= ntile) return;
+    const int k = blockIdx.y;
+    const int64_t i = (int64_t)tile * 64 + (threadIdx.x & 63);
+    const LineHot *__restrict__ hk = hot + (size_t)k * L;
+    const LineCold *__restrict__ ck = cold + (size_t)k * L;
+    const double v = nu[i < nnu ? i : nnu - 1];
+    const WaveWin w = win[tile];
+    const int2 z = zones[(size_t)k * ntile + tile];
+    const int N0 = z.x, N1 = z.y;
+    const int a = min(max(w.E0, w.W0), N0), b = max(min(w.E1, w.W1), N1);
+    double acc = 0.0;
+    acc = far_segment<true>(acc, v, hk, w.W0, a, cut);
+    acc = far_segment<false>(acc, v, hk, a, N0, cut);
+    // near zone, pass 1: far-wing body where it applies + per-lane index ranges of the rest
+    int bl = 0x3fffffff, bh = -1, cl = 0x3fffffff, ch = -1;   // empty ranges: bh - bl < 0 (no overflow when adding t)
+    for (int j = N0; j < N1; j++) {
+        const LineHot h = hk[j];
+        const double dv = v - h.nul;
+        const double x = dv * h.p1;
+        const double s = __builtin_fma(x, x, h.p2);
+        const bool in = !(fabs(dv) > cut);
+        const double r = h.p3 * fad_far_core(h.p2, rcp_fast(s));
+        acc += (in && s >= kFarS) ? r : 0.0;
+        if (in && s < kFarS) { bl = min(bl, j); bh = j; }
+        if (in && s < kMidS) { cl = min(cl, j); ch = j; }
+    }
+    // pass 2: continued-fraction region, each lane walks its own candidates
+    for (int t = 0; __any(t <= bh - bl); t++) {
+        const int j = bl + t;
+        if (t <= bh - bl) {
+            const LineHot h = hk[j];
+            const double dv = v - h.nul;
+            const double x = dv * h.p1;
+            const double s = __builtin_fma(x, x, h.p2);
+            if (!(fabs(dv) > cut) && s < kFarS && s >= kMidS) {
+                const LineCold c = ck[j];
+                acc = __builtin_fma(c.A, fad_mid(fabs(x), c.y), acc);
+            }
+        }
+    }
+    // pass 3: near-centre region
+    for (int t = 0; __any(t <= ch - cl); t++) {
+        const int j = cl + t;
+        if (t <= ch - cl) {
+            const LineHot h = hk[j];
+            const double dv = v - h.nul;
+            const double x = dv * h.p1;
+            const double s = __builtin_fma(x, x, h.p2);
+            if (!(fabs(dv) > cut) && s < kMidS) {
+                const LineCold c = ck[j];
+                acc = __builtin_fma(c.A, fad_near(fabs(x), c.y), acc);
+            }
+        }
+    }
+    acc = far_segment<false>(acc, v, hk, N1, b, cut);
+    acc = far_segment<true>(acc, v, hk, b, w.W1, cut);
+    if (i < nnu) {
+        const size_t o = (size_t)k * nnu + i;
+        const double prev = accumulate ? sigma[o] : (base + (extra ? extra[o] : 0.0));
+        sigma[o] = prev + acc;
+    }
+}
+
 // radiation.jl:48-54
 __device__ __forceinline__ double planck(double nu, double T)
 {

@@ -116,8 +116,8 @@ def _column_vs(cs, r, F, scale_M=None, tol=1e-11):
     assert relerr(F.tau, r["tau"]) < tol
     sm = np.max(r["Mup"])
     assert np.max(np.abs(F.Mup - r["Mup"])) < tol * sm and np.max(np.abs(F.Mdn - r["Mdn"])) < tol * sm
-    assert relerr(F.Fup, r["Fup"]) < tol
-    assert relerr(F.Fdn, r["Fdn"], floor=1e-6 * np.max(r["Fdn"]) + 1e-300) < tol
+    assert np.max(np.abs(F.Fup - r["Fup"])) < tol * np.max(r["Fup"])
+    assert np.max(np.abs(F.Fdn - r["Fdn"])) < tol * max(np.max(r["Fdn"]), np.max(r["Fup"]))
     assert np.array_equal(F.Fnet, F.Fup - F.Fdn)
 
 
