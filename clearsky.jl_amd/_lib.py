@@ -10,7 +10,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libclearsky_hip.so")
+LIB_PATH = os.environ.get("CLEARSKY_HIP_LIB", os.path.join(CSRC, "libclearsky_hip.so"))   # override: kernel A/B builds
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "clearsky_hip.h")
 
 CS_MAX_GAS = 16

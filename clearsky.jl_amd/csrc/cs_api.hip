@@ -68,7 +68,7 @@ struct GasTable {
     bool present = false;
     int64_t L = 0;
     int niso = 0;
-    double mu_min = 0.0;
+    double mu_min = 0.0, mu_max = 0.0, ga_max = 0.0, gs_max = 0.0, na_min = 0.0, na_max = 0.0;
     std::vector<double> h_nu;
     std::vector<int16_t> h_iso;
     std::vector<int32_t> h_ncheb;
@@ -88,7 +88,7 @@ struct ColGas {
     int slot = 0, shape = 0;
     double cut = 25.0;
     DevBuf conc, Pp, J0, J1;  // [K], [K], [ntile], [ntile]
-    DevBuf win, zones;        // [ntile64] WaveWin, [K][ntile64] int2 (Voigt fast path)
+    DevBuf win, zones, gmax;  // [ntile64] WaveWin, [K][ntile64] Zone, [K] max Lorentz width (Voigt fast path)
     int64_t pairs_per_state = 0, lines_in_range = 0;
 };
 
@@ -272,10 +272,22 @@ void wave_windows(const std::vector<double> &nul, int64_t g0, int64_t g1, const 
     }
 }
 
+// upper bound of gammalorentz (line_shapes.jl:255-257) over a gas's lines at every state
+std::vector<double> gamma_bound(const GasTable &G, int K, const double *T, const double *P, const double *Pp)
+{
+    std::vector<double> g(K);
+    for (int k = 0; k < K; k++) {
+        const double r = kTref / T[k];
+        const double f = std::max(std::pow(r, G.na_min), std::pow(r, G.na_max));
+        g[k] = f * (std::fabs(G.ga_max * (P[k] - Pp[k])) + std::fabs(G.gs_max * Pp[k])) / kAtm * (1.0 + 1e-12);
+    }
+    return g;
+}
+
 // K1 + K2 for one gas on `s`: parameters for `kn` states, then the line sum into sigma ([kn][nnu])
 void launch_gas(hipStream_t s, int shape, const GasTable &G, int kn, const double *Tk, const double *Pk, const double *Ppk,
                 const double *scale, LineHot *hot, LineCold *cold, const double *dnu, int64_t nnu, int ntile256,
-                const int32_t *J0, const int32_t *J1, const WaveWin *win, int2 *zones, double cut, double base,
+                const int32_t *J0, const int32_t *J1, const WaveWin *win, Zone *zones, const double *gbound, double cut, double base,
                 const double *extra, double *sigma, int accumulate, hipEvent_t ev_mid)
 {
     const int64_t tot = (int64_t)kn * G.L;
@@ -284,10 +296,13 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int kn, const doubl
     if (shape == SH_VOIGT) {
         const int nt64 = (int)((nnu + 63) / 64);
         hipLaunchKernelGGL(k_zones, dim3((unsigned)(((int64_t)nt64 * kn + 255) / 256)), dim3(256), 0, s, dnu, nnu, nt64, kn,
-                           G.nu.as<double>(), win, Tk, G.mu_min, cut, zones);
+                           G.nu.as<double>(), win, Tk, G.mu_min, G.mu_max, cut, gbound, zones);
         if (ev_mid) (void)hipEventRecord(ev_mid, s);
-        hipLaunchKernelGGL(k_linesum_voigt, dim3((unsigned)((nt64 + 3) / 4), kn), dim3(256), 0, s, dnu, nnu, G.L, hot, cold, win,
-                           zones, nt64, cut, base, extra, sigma, accumulate);
+        const int nblk = (nt64 + 3) / 4;
+        const dim3 grid((unsigned)((nblk + 7) / 8 * 8), kn);   // multiple of 8: XCD-aware tile mapping (k_voigt_far)
+        hipLaunchKernelGGL(k_voigt_far, grid, dim3(256), 0, s, dnu, nnu, G.L, hot, win, zones, nt64, nblk, cut, base, extra,
+                           sigma, accumulate);
+        hipLaunchKernelGGL(k_voigt_near, grid, dim3(256), 0, s, dnu, nnu, G.L, hot, cold, zones, nt64, nblk, cut, sigma);
     } else {
         if (ev_mid) (void)hipEventRecord(ev_mid, s);
         launch_linesum_shape(shape, dim3(ntile256, kn), s, dnu, nnu, G.L, hot, cold, J0, J1, cut, Tk, base, extra, sigma,
@@ -366,6 +381,11 @@ int cs_gas_upload(cs_ctx *ctx, int slot, int64_t L, const double *nu, const doub
     G.h_iso.assign(iso, iso + L);
     G.h_ncheb.assign(ncheb, ncheb + niso);
     G.mu_min = *std::min_element(mu_iso, mu_iso + L);
+    G.mu_max = *std::max_element(mu_iso, mu_iso + L);
+    G.ga_max = *std::max_element(gamma_a, gamma_a + L);
+    G.gs_max = *std::max_element(gamma_s, gamma_s + L);
+    G.na_min = *std::min_element(na, na + L);
+    G.na_max = *std::max_element(na, na + L);
     if (!(G.mu_min > 0)) return fail(CS_EINVAL, "isotopologue molar masses must be positive");
     int rc;
     if ((rc = upload(G.nu, nu, L, s)) || (rc = upload(G.S, S, L, s)) || (rc = upload(G.ga, gamma_a, L, s)) ||
@@ -403,7 +423,7 @@ int cs_shape_batch(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t nnu
     std::vector<int32_t> J0, J1;
     tile_windows(G.h_nu, g0, g1, nu, nnu, dnu_cut, J0, J1, pairs, inr);
     const int ntile = (int)J0.size();
-    DevBuf dnu, dT, dP, dPp, dJ0, dJ1, hot, cold, dsig, dwin, dzones;
+    DevBuf dnu, dT, dP, dPp, dJ0, dJ1, hot, cold, dsig, dwin, dzones, dgmax;
     std::vector<WaveWin> win;
     wave_windows(G.h_nu, g0, g1, nu, nnu, dnu_cut, win);
     if ((rc = upload(dnu, nu, nnu, s)) || (rc = upload(dT, T, K, s)) || (rc = upload(dP, P, K, s)) ||
@@ -413,15 +433,20 @@ int cs_shape_batch(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t nnu
     // bound the workspace: process the states in chunks
     const size_t per_state = (size_t)G.L * (sizeof(LineHot) + sizeof(LineCold)) + (size_t)nnu * sizeof(double);
     int kc = (int)std::max<size_t>(1, std::min<size_t>((size_t)K, ((size_t)4 << 30) / per_state));
-    HIPCHK(hot.reserve((size_t)kc * G.L * sizeof(LineHot)));
+    HIPCHK(hot.reserve(((size_t)kc * G.L + 4) * sizeof(LineHot)));
     HIPCHK(cold.reserve((size_t)kc * G.L * sizeof(LineCold)));
     HIPCHK(dsig.reserve((size_t)kc * nnu * sizeof(double)));
-    HIPCHK(dzones.reserve((size_t)kc * win.size() * sizeof(int2)));
+    HIPCHK(dzones.reserve((size_t)kc * win.size() * sizeof(Zone)));
+    HIPCHK(dgmax.reserve((size_t)K * sizeof(double)));
+    {
+        std::vector<double> gb = gamma_bound(G, K, T, P, Pp);
+        if ((rc = upload(dgmax, gb.data(), K, s))) return rc;
+    }
     for (int k0 = 0; k0 < K; k0 += kc) {
         const int kn = std::min(kc, K - k0);
         launch_gas(s, shape, G, kn, dT.as<double>() + k0, dP.as<double>() + k0, dPp.as<double>() + k0, nullptr,
                    hot.as<LineHot>(), cold.as<LineCold>(), dnu.as<double>(), nnu, ntile, dJ0.as<int32_t>(), dJ1.as<int32_t>(),
-                   dwin.as<WaveWin>(), dzones.as<int2>(), dnu_cut, 0.0, nullptr, dsig.as<double>(), 0, nullptr);
+                   dwin.as<WaveWin>(), dzones.as<Zone>(), dgmax.as<double>() + k0, dnu_cut, 0.0, nullptr, dsig.as<double>(), 0, nullptr);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpy2DAsync(sigma + (size_t)k0 * ld_state, ld_state * sizeof(double), dsig.p, nnu * sizeof(double),
                                 nnu * sizeof(double), kn, hipMemcpyDeviceToHost, s));
@@ -516,10 +541,11 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
         if ((rc = upload(cg.J0, J0.data(), J0.size(), s)) || (rc = upload(cg.J1, J1.data(), J1.size(), s)) ||
             (rc = upload(cg.win, win.data(), win.size(), s)))
             return rc;
-        HIPCHK(cg.zones.reserve((size_t)c.K * win.size() * sizeof(int2)));
+        HIPCHK(cg.zones.reserve((size_t)c.K * win.size() * sizeof(Zone)));
+        HIPCHK(cg.gmax.reserve((size_t)c.K * sizeof(double)));
         maxL = std::max(maxL, (size_t)G.L);
     }
-    HIPCHK(c.hot.reserve((size_t)K * maxL * sizeof(LineHot)));
+    HIPCHK(c.hot.reserve(((size_t)K * maxL + 4) * sizeof(LineHot)));
     HIPCHK(c.cold.reserve((size_t)K * maxL * sizeof(LineCold)));
     HIPCHK(c.sigma.reserve((size_t)K * nnu * sizeof(double)));
     HIPCHK(c.tau.reserve((size_t)nl * nnu * sizeof(double)));
@@ -565,7 +591,10 @@ int cs_column_update_state(cs_ctx *ctx, const double *T_nodes, const double *mu_
                 return fail(CS_EINVAL, "gas molar concentrations must be in [0,1], not %g", cc[k]);
             pp[k] = cc[k] * c.h_Pk[k];  // Pp = C*P, gases.jl:126
         }
-        if ((rc = upload(c.gas[gi].conc, cc.data(), K, s)) || (rc = upload(c.gas[gi].Pp, pp.data(), K, s))) return rc;
+        std::vector<double> gb = gamma_bound(ctx->gas[c.gas[gi].slot], K, Tk.data(), c.h_Pk.data(), pp.data());
+        if ((rc = upload(c.gas[gi].conc, cc.data(), K, s)) || (rc = upload(c.gas[gi].Pp, pp.data(), K, s)) ||
+            (rc = upload(c.gas[gi].gmax, gb.data(), K, s)))
+            return rc;
     }
     HIPCHK(hipStreamSynchronize(s));
     return CS_OK;
@@ -589,7 +618,7 @@ static int run_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev)
         GasTable &G = ctx->gas[cg.slot];
         launch_gas(s, cg.shape, G, K, c.Tk.as<double>(), c.Pk.as<double>(), cg.Pp.as<double>(), cg.conc.as<double>(),
                    c.hot.as<LineHot>(), c.cold.as<LineCold>(), c.nu.as<double>(), c.nnu, c.ntile, cg.J0.as<int32_t>(),
-                   cg.J1.as<int32_t>(), cg.win.as<WaveWin>(), cg.zones.as<int2>(), cg.cut, c.sigma_gray, extra, sig, gi > 0,
+                   cg.J1.as<int32_t>(), cg.win.as<WaveWin>(), cg.zones.as<Zone>(), cg.gmax.as<double>(), cg.cut, c.sigma_gray, extra, sig, gi > 0,
                    ev ? ev[e++] : nullptr);
         if (ev) HIPCHK(hipEventRecord(ev[e++], s));
     }

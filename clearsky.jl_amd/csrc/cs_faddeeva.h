@@ -61,7 +61,7 @@ __device__ __forceinline__ double fad_mid(double x, double y)
     CS_H(br, bi, -22.5) CS_H(br, bi, 157.5) CS_H(br, bi, -393.75) CS_H(br, bi, 295.3125) CS_H(br, bi, -29.53125)
 #undef CS_H
     double nr = x * ar - y * ai, ni = x * ai + y * ar;
-    return kIsqPi * (nr * bi - ni * br) / (br * br + bi * bi);
+    return kIsqPi * (nr * bi - ni * br) * rcp_nr(__builtin_fma(br, br, bi * bi));
 }
 
 __device__ __forceinline__ double fad_near(double x, double y)
@@ -78,17 +78,15 @@ __device__ __forceinline__ double fad_near(double x, double y)
     double u = 2.0 * x;
     double fr = u - floor(u);
     bool shift = fabs(fr - 0.5) > 0.25;  // x near an integer node -> half-shifted grid
-    double off = shift ? 0.25 : 0.0;     // node k of the chosen grid sits at k*h + off
-    double acc = shift ? 0.0 : c0[0] / __builtin_fma(x, x, y2);
+    double acc = shift ? 0.0 : rcp_nr(__builtin_fma(x, x, y2));
 #pragma unroll
     for (int k = 0; k < 12; k++) {
         double t = 0.5 * (k + 1) - (shift ? 0.25 : 0.0);  // shifted: (k+1/2)h ; integer: (k+1)h
         double c = shift ? c1[k] : c0[k + 1];
         double a = x - t, b = x + t;
         double da = __builtin_fma(a, a, y2), db = __builtin_fma(b, b, y2);
-        acc = __builtin_fma(c, (da + db) / (da * db), acc);
+        acc = __builtin_fma(c * (da + db), rcp_nr(da * db), acc);
     }
-    (void)off;
     double res = (0.5 / kPi) * y * acc;
     if (y < 2.0 * kPi) {
         double sgn = shift ? 1.0 : -1.0;
@@ -102,7 +100,7 @@ __device__ __forceinline__ double fad_near(double x, double y)
         double sa, ca;
         sincos(2.0 * x * y, &sa, &ca);
         // Re[(ca - i sa)/(dr + i di)] = (ca*dr - sa*di)/|d|^2
-        res += 2.0 * g * em * (ca * dr - sa * di) / __builtin_fma(dr, dr, di * di);
+        res += 2.0 * g * em * (ca * dr - sa * di) * rcp_nr(__builtin_fma(dr, dr, di * di));
     }
     return res;
 }

@@ -27,7 +27,9 @@ constexpr double kC2 = 100.0 * kHp * kC / kKb;     // 100 h c / k           line
 
 enum { SH_VOIGT = 0, SH_LORENTZ = 1, SH_DOPPLER = 2, SH_PHCO2 = 3 };
 
-// per-(state, line) parameters.  "hot" is what the far-wing loop reads, "cold" only the near-line code.
+// per-(state, line) parameters.  "hot" is what the far-wing loops read through scalar loads -- 32 bytes per line is
+// the budget at which those loops stay VALU-bound (64-byte records made them SMEM-bound: profiles/r01_notes.md);
+// "cold" is read only by the near-line code.
 //   Voigt/PHCO2: hot = {nul, d = sqrt(ln2)/alpha, y^2, A*y/sqrt(pi)},  cold = {y = gamma*d, A = C*S(T)/sqrt(pi/ln2)/alpha}
 //   Lorentz    : hot = {nul, gamma^2, C*S(T)*gamma/pi, 0}
 //   Doppler    : hot = {nul, 1/alpha^2, C*S(T)/(alpha*sqrt(pi)), 0}
@@ -95,7 +97,8 @@ __global__ __launch_bounds__(256) void k_prep(int shape, GasDev g, int K, const 
         double dd = kSqLn2 * beta;
         double y = gamma * dd;
         double A = C * (S * (kOSqPiLn2 * beta));
-        h.p1 = dd; h.p2 = y * y; h.p3 = A * y * kIsqPi;
+        const double y2 = y * y;
+        h.p1 = dd; h.p2 = y2; h.p3 = A * y * kIsqPi;
         c.y = y; c.A = A;
     }
     hot[idx] = h;
@@ -179,12 +182,15 @@ __global__ __launch_bounds__(256) void k_linesum(const double *__restrict__ nu, 
 // s < 1e4 (and s < 100) lines; two short per-lane loops then evaluate the continued-fraction and the near-centre
 // forms only for those, so the expensive bodies run ~20 and ~4 times per (wave, state) instead of once per line.
 struct WaveWin { int32_t W0, W1, E0, E1; };  // per 64-point tile: window, first line inside every lane's cut-off, one past the last
+// per (state, tile): [M0,N0) and [N1,M1) mid-far lines (1e4 <= x^2 possible < 1e6), [N0,N1) near zone (x^2 < 1e4 possible);
+// smally = 1 when y^2 <= 60 for every line of the window (then the u^2 t, u^2 t^2 terms of the series are < 1e-15)
+struct __attribute__((aligned(16))) Zone { int32_t M0, N0, N1, M1, smally, pad0, pad1, pad2; };
 
-// node-state dependent near-zone bounds, one thread per (state, tile)
+// node-state dependent zone bounds, one thread per (state, tile)
 __global__ __launch_bounds__(256) void k_zones(const double *__restrict__ nu, int64_t nnu, int ntile, int K,
                                                 const double *__restrict__ nul, const WaveWin *__restrict__ win,
-                                                const double *__restrict__ Tk, double mu_min, double cut,
-                                                int2 *__restrict__ zones)
+                                                const double *__restrict__ Tk, double mu_min, double mu_max, double cut,
+                                                const double *__restrict__ gbound, Zone *__restrict__ zones)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= ntile * K) return;
@@ -193,68 +199,170 @@ __global__ __launch_bounds__(256) void k_zones(const double *__restrict__ nu, in
     const double vlo = nu[i0], vhi = nu[i1];
     const WaveWin w = win[t];
     // largest Doppler width any line of the window can have at this temperature (alphadoppler, line_shapes.jl:144)
-    const double amax = ((vhi + cut) / kC) * sqrt(2.0 * kRgas * Tk[k] / mu_min);
-    const double dA = 100.0 * amax / kSqLn2 * (1.0 + 1e-6);
-    const double lo = vlo - dA, hi = vhi + dA;
-    int a = w.W0, b = w.W1;
-    while (a < b) { int m = (a + b) >> 1; if (nul[m] < lo) a = m + 1; else b = m; }
-    const int N0 = a;
-    a = N0; b = w.W1;
-    while (a < b) { int m = (a + b) >> 1; if (nul[m] <= hi) a = m + 1; else b = m; }
-    zones[idx] = make_int2(N0, a);
+    const double vth = sqrt(2.0 * kRgas * Tk[k]);
+    const double amax = ((vhi + cut) / kC) * vth / sqrt(mu_min);
+    const double dA = 100.0 * amax / kSqLn2 * (1.0 + 1e-6);  // |dnu| >= dA  =>  x^2 >= 1e4 (4-term series good to 1e-14)
+    const double dAA = 10.0 * dA;                             // |dnu| >= dAA =>  x^2 >= 1e6 (its u^3 terms < 1e-16)
+    auto lower = [&](double val, int a, int b) { while (a < b) { int m = (a + b) >> 1; if (nul[m] < val) a = m + 1; else b = m; } return a; };
+    auto upper = [&](double val, int a, int b) { while (a < b) { int m = (a + b) >> 1; if (nul[m] <= val) a = m + 1; else b = m; } return a; };
+    Zone z;
+    z.M0 = lower(vlo - dAA, w.W0, w.W1);
+    z.N0 = lower(vlo - dA, z.M0, w.W1);
+    z.N1 = upper(vhi + dA, z.N0, w.W1);
+    z.M1 = upper(vhi + dAA, z.N1, w.W1);
+    // y = gamma*sqrt(ln2)/alpha <= gbound[k]*sqrt(ln2)/alpha_min(window); gbound = host-side bound on gammalorentz
+    const double vmin = vlo - cut;
+    double y2b = 1e300;
+    if (vmin > 0.0 && w.W1 > w.W0) {
+        const double amin = (fmax(vmin, nul[w.W0]) / kC) * vth / sqrt(mu_max);
+        const double yb = gbound[k] * kSqLn2 / amin;
+        y2b = yb * yb;
+    }
+    z.smally = y2b <= 60.0;
+    z.pad0 = z.pad1 = z.pad2 = 0;
+    zones[idx] = z;
 }
 
-template <bool PRED>
-__device__ __forceinline__ double far_segment(double acc, double v, const LineHot *__restrict__ hk, int j0, int j1, double cut)
+// constants of the series kept in VGPRs for the whole kernel (gfx950 VALU instructions take one constant-bus operand:
+// the line parameter; a second literal would cost a v_mov per use).  Loaded from memory so they are not rematerialised.
+struct FarK { double k1p5, k3p75, k12, km15, km105, k13p125, k210, km120; };
+__device__ const double kFarTable[8] = {1.5, 3.75, 12.0, -15.0, -105.0, 13.125, 210.0, -120.0};
+__device__ __forceinline__ FarK load_fark()
+{
+    const volatile double *t = kFarTable;
+    FarK c;
+    c.k1p5 = t[0]; c.k3p75 = t[1]; c.k12 = t[2]; c.km15 = t[3]; c.km105 = t[4]; c.k13p125 = t[5]; c.k210 = t[6]; c.km120 = t[7];
+    return c;
+}
+
+// Far-wing term  A y/sqrt(pi) * u (1 + u p1(t) + u^2 p2(t) + u^3 p3(t)),  u = 1/s, t = y^2 u.  MODE:
+//   0  s >= 1e6 and y^2 <= 60 : 1 + u (1.5 + u (3.75 - 2 y^2))                          13 VALU instructions
+//   1  s >= 1e6               : 1 + u (1.5 + u (3.75 - 2 y^2 + t (12 t - 15)))           16
+//   2  s >= 1e4               : all four terms                                           20
+template <bool PRED, int MODE>
+__device__ __forceinline__ double far_term(const LineHot &h, double v, double cut, const FarK &c)
+{
+    const double dv = v - h.nul;
+    const double x = dv * h.p1;
+    const double s = __builtin_fma(x, x, h.p2);
+    const double u = rcp_fast(s);
+    double P;
+    if (MODE == 2) {
+        const double t = h.p2 * u;
+        const double p3 = __builtin_fma(__builtin_fma(__builtin_fma(c.km120, t, c.k210), t, c.km105), t, c.k13p125);
+        const double p2 = __builtin_fma(__builtin_fma(c.k12, t, c.km15), t, c.k3p75);
+        const double p1 = __builtin_fma(-2.0, t, c.k1p5);
+        P = __builtin_fma(u, __builtin_fma(u, __builtin_fma(u, p3, p2), p1), 1.0);
+    } else {
+        double q = __builtin_fma(h.p2, -2.0, c.k3p75);  // 3.75 - 2 y^2 (wave-uniform)
+        if (MODE == 1) {
+            const double t = h.p2 * u;
+            q = __builtin_fma(t, __builtin_fma(c.k12, t, c.km15), q);
+        }
+        P = __builtin_fma(__builtin_fma(q, u, c.k1p5), u, 1.0);
+    }
+    double r = (h.p3 * u) * P;
+    if (PRED) r = (fabs(dv) > cut) ? 0.0 : r;
+    return r;
+}
+
+template <bool PRED, int MODE>
+__device__ __forceinline__ double far_segment(double acc, double v, const LineHot *__restrict__ hk, int j0, int j1, double cut,
+                                              const FarK &c)
 {
 #pragma unroll 4
-    for (int j = j0; j < j1; j++) {
-        const LineHot h = hk[j];
-        const double dv = v - h.nul;
-        const double x = dv * h.p1;
-        const double s = __builtin_fma(x, x, h.p2);
-        double r = h.p3 * fad_far_core(h.p2, rcp_fast(s));
-        if (PRED) r = (fabs(dv) > cut) ? 0.0 : r;
-        acc += r;
-    }
+    for (int j = j0; j < j1; j++) acc += far_term<PRED, MODE>(hk[j], v, cut, c);
     return acc;
 }
 
-__global__ __launch_bounds__(256) void k_linesum_voigt(const double *__restrict__ nu, int64_t nnu, int64_t L,
-                                                        const LineHot *__restrict__ hot, const LineCold *__restrict__ cold,
-                                                        const WaveWin *__restrict__ win, const int2 *__restrict__ zones,
-                                                        int ntile, double cut, double base,
-                                                        const double *__restrict__ extra, double *__restrict__ sigma,
-                                                        int accumulate)
+// blockIdx.x -> block of 4 wave tiles.  Workgroups are dealt round-robin over the 8 XCDs, so block b and b+8 share an
+// L2: give each XCD one contiguous eighth of the spectrum, whose overlapping line windows then stay in that L2.
+// gridDim.x is a multiple of 8 (speed only: any placement is correct).
+__device__ __forceinline__ int tile_block(int nblk)
 {
-    const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (tile >= ntile) return;
+    const int chunk = (nblk + 7) >> 3;
+    return (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+}
+
+// K2a: far wings.  One wave = 64 consecutive wavenumbers x one node state; its window of lines [W0,W1) (sorted by nul)
+// is cut into wave-uniform segments so that ~90 % of the (nu, line) pairs run a 13-16 instruction branch-free body whose
+// line parameters arrive through scalar loads:
+//   [W0,a) left edge (cut-off predicate) | [a,M0) far | [M0,N0) mid-far | [N0,N1) near zone | [N1,M1) | [M1,b) | [b,W1)
+// In the near zone only the pairs with s >= 1e4 are summed here; the others belong to k_voigt_near.
+__global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu, int64_t nnu, int64_t L,
+                                                    const LineHot *__restrict__ hot, const WaveWin *__restrict__ win,
+                                                    const Zone *__restrict__ zones, int ntile, int nblk, double cut,
+                                                    double base, const double *__restrict__ extra,
+                                                    double *__restrict__ sigma, int accumulate)
+{
+    const int tb = tile_block(nblk);
+    const int tile = __builtin_amdgcn_readfirstlane(tb * 4 + (threadIdx.x >> 6));
+    if (tb >= nblk || tile >= ntile) return;
+    const int k = blockIdx.y;
+    const int64_t i = (int64_t)tile * 64 + (threadIdx.x & 63);
+    const LineHot *__restrict__ hk = hot + (size_t)k * L;
+    const double v = nu[i < nnu ? i : nnu - 1];
+    const WaveWin w = win[tile];
+    const Zone z = zones[(size_t)k * ntile + tile];
+    const int a = min(max(w.E0, w.W0), z.M0), b = max(min(w.E1, w.W1), z.M1);
+    const FarK c = load_fark();
+    double acc = 0.0;
+    if (z.smally) {
+        acc = far_segment<true, 0>(acc, v, hk, w.W0, a, cut, c);
+        acc = far_segment<false, 0>(acc, v, hk, a, z.M0, cut, c);
+    } else {
+        acc = far_segment<true, 1>(acc, v, hk, w.W0, a, cut, c);
+        acc = far_segment<false, 1>(acc, v, hk, a, z.M0, cut, c);
+    }
+    acc = far_segment<true, 2>(acc, v, hk, z.M0, z.N0, cut, c);
+    for (int j = z.N0; j < z.N1; j++) {
+        const LineHot h = hk[j];
+        const double x = (v - h.nul) * h.p1;
+        const double r = far_term<true, 2>(h, v, cut, c);
+        acc += (__builtin_fma(x, x, h.p2) >= kFarS) ? r : 0.0;
+    }
+    acc = far_segment<true, 2>(acc, v, hk, z.N1, z.M1, cut, c);
+    if (z.smally) {
+        acc = far_segment<false, 0>(acc, v, hk, z.M1, b, cut, c);
+        acc = far_segment<true, 0>(acc, v, hk, b, w.W1, cut, c);
+    } else {
+        acc = far_segment<false, 1>(acc, v, hk, z.M1, b, cut, c);
+        acc = far_segment<true, 1>(acc, v, hk, b, w.W1, cut, c);
+    }
+    if (i < nnu) {
+        const size_t o = (size_t)k * nnu + i;
+        const double prev = accumulate ? sigma[o] : (base + (extra ? extra[o] : 0.0));
+        sigma[o] = prev + acc;
+    }
+}
+
+// K2b: the pairs with s < 1e4.  Every lane finds the index range of its own such lines in the near zone, then walks
+// them: continued fraction for 100 <= s < 1e4, trapezoid + pole correction for s < 100.  Adds into sigma.
+__global__ __launch_bounds__(256) void k_voigt_near(const double *__restrict__ nu, int64_t nnu, int64_t L,
+                                                     const LineHot *__restrict__ hot, const LineCold *__restrict__ cold,
+                                                     const Zone *__restrict__ zones, int ntile, int nblk, double cut,
+                                                     double *__restrict__ sigma)
+{
+    const int tb = tile_block(nblk);
+    const int tile = __builtin_amdgcn_readfirstlane(tb * 4 + (threadIdx.x >> 6));
+    if (tb >= nblk || tile >= ntile) return;
     const int k = blockIdx.y;
     const int64_t i = (int64_t)tile * 64 + (threadIdx.x & 63);
     const LineHot *__restrict__ hk = hot + (size_t)k * L;
     const LineCold *__restrict__ ck = cold + (size_t)k * L;
     const double v = nu[i < nnu ? i : nnu - 1];
-    const WaveWin w = win[tile];
-    const int2 z = zones[(size_t)k * ntile + tile];
-    const int N0 = z.x, N1 = z.y;
-    const int a = min(max(w.E0, w.W0), N0), b = max(min(w.E1, w.W1), N1);
-    double acc = 0.0;
-    acc = far_segment<true>(acc, v, hk, w.W0, a, cut);
-    acc = far_segment<false>(acc, v, hk, a, N0, cut);
-    // near zone, pass 1: far-wing body where it applies + per-lane index ranges of the rest
-    int bl = 0x3fffffff, bh = -1, cl = 0x3fffffff, ch = -1;   // empty ranges: bh - bl < 0 (no overflow when adding t)
-    for (int j = N0; j < N1; j++) {
+    const Zone z = zones[(size_t)k * ntile + tile];
+    int bl = 0x3fffffff, bh = -1, cl = 0x3fffffff, ch = -1;  // empty ranges: bh - bl < 0 (no overflow when adding t)
+    for (int j = z.N0; j < z.N1; j++) {
         const LineHot h = hk[j];
         const double dv = v - h.nul;
         const double x = dv * h.p1;
         const double s = __builtin_fma(x, x, h.p2);
         const bool in = !(fabs(dv) > cut);
-        const double r = h.p3 * fad_far_core(h.p2, rcp_fast(s));
-        acc += (in && s >= kFarS) ? r : 0.0;
         if (in && s < kFarS) { bl = min(bl, j); bh = j; }
         if (in && s < kMidS) { cl = min(cl, j); ch = j; }
     }
-    // pass 2: continued-fraction region, each lane walks its own candidates
+    double acc = 0.0;
     for (int t = 0; __any(t <= bh - bl); t++) {
         const int j = bl + t;
         if (t <= bh - bl) {
@@ -268,7 +376,6 @@ __global__ __launch_bounds__(256) void k_linesum_voigt(const double *__restrict_
             }
         }
     }
-    // pass 3: near-centre region
     for (int t = 0; __any(t <= ch - cl); t++) {
         const int j = cl + t;
         if (t <= ch - cl) {
@@ -282,13 +389,7 @@ __global__ __launch_bounds__(256) void k_linesum_voigt(const double *__restrict_
             }
         }
     }
-    acc = far_segment<false>(acc, v, hk, N1, b, cut);
-    acc = far_segment<true>(acc, v, hk, b, w.W1, cut);
-    if (i < nnu) {
-        const size_t o = (size_t)k * nnu + i;
-        const double prev = accumulate ? sigma[o] : (base + (extra ? extra[o] : 0.0));
-        sigma[o] = prev + acc;
-    }
+    if (i < nnu && acc != 0.0) sigma[(size_t)k * nnu + i] += acc;
 }
 
 // radiation.jl:48-54
