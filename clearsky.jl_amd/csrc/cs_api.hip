@@ -99,7 +99,7 @@ struct Column {
     bool want_tau = false, want_M = false, has_extra = false, has_S = false, has_alb = false;
     double g = 0, sigma_gray = 0, theta_s = 0;
     RtParams rt;
-    std::vector<double> h_P, h_Pk, h_xs;
+    std::vector<double> h_P, h_Pk, h_xs, h_nu;
     std::vector<ColGas> gas;
     DevBuf nu, wts, P, Pk, Tk, muk, Tlev, extra, S_toa, albedo;
     DevBuf hot, cold, sigma, tau, Mup, Mdn, partial, F, stage;
@@ -244,10 +244,16 @@ void tile_windows(const std::vector<double> &nul, int64_t g0, int64_t g1, const 
         J0[t] = (int32_t)(std::lower_bound(b, e, lo - tol) - nul.begin());
         J1[t] = (int32_t)(std::upper_bound(b, e, hi + tol) - nul.begin());
     }
-    pairs = 0;
-    for (int64_t i = 0; i < nnu; i++)
-        pairs += (std::upper_bound(b, e, nu[i] + cut) - std::lower_bound(b, e, nu[i] - cut));
+    pairs = -1;  // counted on demand (cs_column_counts): O(nnu log L) on the host
     inrange = (std::upper_bound(b, e, nu[nnu - 1] + cut) - std::lower_bound(b, e, nu[0] - cut));
+}
+
+int64_t count_pairs(const std::vector<double> &nul, const double *nu, int64_t nnu, double cut)
+{
+    int64_t pairs = 0;
+    for (int64_t i = 0; i < nnu; i++)
+        pairs += (std::upper_bound(nul.begin(), nul.end(), nu[i] + cut) - std::lower_bound(nul.begin(), nul.end(), nu[i] - cut));
+    return pairs;
 }
 
 // per-64-point windows of the Voigt fast path: [W0,W1) superset window, [E0,E1) lines inside every lane's cut-off
@@ -494,6 +500,7 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
     (void)x; (void)w;
     // node states: k = i*(nlobatto-1) + n   (discretized.jl:150,162,169)
     c.h_P.assign(P, P + np);
+    c.h_nu.assign(nu, nu + nnu);
     c.h_Pk.assign(K, 0.0);
     c.h_Pk[0] = P[0];
     for (int i = 0; i < nl; i++) {
@@ -736,7 +743,11 @@ int cs_column_counts(cs_ctx *ctx, int64_t *pair_evals, int64_t *lines_in_range)
     if (!ctx || !ctx->col.ready) return fail(CS_ESTATE, "no resident column");
     Column &c = ctx->col;
     int64_t p = 0, l = 0;
-    for (auto &g : c.gas) { p += g.pairs_per_state * c.K; l += g.lines_in_range; }
+    for (auto &g : c.gas) {
+        if (g.pairs_per_state < 0) g.pairs_per_state = count_pairs(ctx->gas[g.slot].h_nu, c.h_nu.data(), c.nnu, g.cut);
+        p += g.pairs_per_state * c.K;
+        l += g.lines_in_range;
+    }
     if (pair_evals) *pair_evals = p;
     if (lines_in_range) *lines_in_range = l;
     return CS_OK;

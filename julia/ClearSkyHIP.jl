@@ -1,0 +1,192 @@
+# ClearSkyHIP.jl -- Julia-side glue for the MI355X line-by-line core (libclearsky_hip.so, include/clearsky_hip.h).
+#
+# SOURCE ONLY: no Julia toolchain exists in the build or GPU environments of this project, so this file has never
+# been executed.  It shows exactly what a ClearSky.jl maintainer would add; the same C ABI is exercised end to end by
+# the Python/ctypes host mirror (clearsky.jl_amd/core.py) and by tests/test_gpu_parity.py.
+#
+# What it adds to ClearSky.jl (reference paths in brackets):
+#   * `HIPDiscretized <: ClearSky.AbstractNumericalCore`  [src/core/shared.jl:36,55-62] and a method of
+#     `ClearSky.monochromaticfluxes!(M⁺, M⁻, τ, core::HIPDiscretized, P, g, T, μ, 𝒻S, 𝒻a, absorbers...; θₛ)`
+#     [src/fluxes.jl:238-249] -- so `radiate!`, `fluxes`, `netfluxes`, `monochromaticfluxes`, `heating!` work unchanged
+#     with `core=HIPDiscretized()`.
+#   * `DirectGas <: ClearSky.AbstractGas`: a gas evaluated line-by-line at every (T,P) node instead of through baked
+#     opacity tables ("Mode D"); equivalent to the function absorber (ν,T,P) -> C*voigt(ν, sl, T, P, C*P)
+#     [src/absorption/absorbers.jl:16,24; src/absorption/line_shapes.jl:399-405].
+#   * `hipvoigt!`, `hiplorentz!`, `hipdoppler!`, `hipPHCO2!`: drop-in `shape!` arguments of `Gas(sl, fC, ν, Ω, shape!, Δνcut)`
+#     [src/absorption/gases.jl:225-231, invoked at :126], and `hipbake`, which evaluates all nT*nP states in ONE launch.
+module ClearSkyHIP
+
+using ClearSky
+using ClearSky: AbstractNumericalCore, AbstractGas, SpectralLines, GrayGas, MOLPARAM, formprofiles,
+                lobattoevaluations, lobattonodes, checkstreams, checkazimuth, ∫F!
+
+const LIB = get(ENV, "CLEARSKY_HIP_LIB", joinpath(@__DIR__, "..", "clearsky.jl_amd", "csrc", "libclearsky_hip.so"))
+const CHEB_LD = 16
+const SHAPES = Dict(:voigt=>0, :lorentz=>1, :doppler=>2, :PHCO2=>3)
+
+lasterror() = unsafe_string(ccall((:cs_last_error, LIB), Cstring, ()))
+check(rc::Cint) = rc == 0 ? nothing : error("clearsky_hip ($rc): $(lasterror())")
+
+#-------------------------------------------------------------------------------
+# context: one per Julia thread (a context is not re-entrant and bake calls shape! from @threads, gases.jl:115)
+
+mutable struct Context
+    handle::Ptr{Cvoid}
+    slots::IdDict{SpectralLines,Cint}
+    function Context(device::Integer=0)
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:cs_create, LIB), Cint, (Cint, Ref{Ptr{Cvoid}}), device, h))
+        c = new(h[], IdDict{SpectralLines,Cint}())
+        finalizer(x -> ccall((:cs_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.handle), c)
+        return c
+    end
+end
+
+const CONTEXTS = Dict{Int,Context}()
+const CTXLOCK = ReentrantLock()
+context() = lock(CTXLOCK) do
+    get!(() -> Context(parse(Int, get(ENV, "CLEARSKY_HIP_DEVICE", "0"))), CONTEXTS, Threads.threadid())
+end
+
+# upload a SpectralLines table (hitran/par.jl:224-251) + the MOLPARAM rows of its molecule, once per context
+function slot!(ctx::Context, sl::SpectralLines)::Cint
+    haskey(ctx.slots, sl) && return ctx.slots[sl]
+    slot = Cint(length(ctx.slots))
+    mp = MOLPARAM[sl.M]
+    niso = length(mp.I)
+    ncheb = Int32[mp.hascheb[i] ? mp.ncheb[i] : 0 for i in 1:niso]
+    cheb = zeros(Float64, CHEB_LD, niso)            # column-major: [niso][CHEB_LD] in C
+    for i in 1:niso, k in 1:length(mp.cheb[i])
+        cheb[k,i] = mp.cheb[i][k]
+    end
+    check(ccall((:cs_gas_upload, LIB), Cint,
+        (Ptr{Cvoid}, Cint, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+         Ptr{Float64}, Ptr{Int16}, Cint, Ptr{Int32}, Ptr{Float64}),
+        ctx.handle, slot, sl.N, sl.ν, sl.S, sl.γa, sl.γs, sl.Epp, sl.na, sl.μ, sl.I, niso, ncheb, cheb))
+    ctx.slots[sl] = slot
+    return slot
+end
+
+#-------------------------------------------------------------------------------
+# B1: shape! operators [line_shapes.jl:412-424, :313-324, :200-211, :527-540]
+
+function hipshape!(shape::Symbol, σ::AbstractVector{Float64}, ν::AbstractVector, sl::SpectralLines, T, P, Pₚ, Δνcut)
+    ctx = context()
+    νv = collect(Float64, ν)
+    out = σ isa Vector{Float64} ? σ : Vector{Float64}(undef, length(σ))     # views of σ[:,i,j] are unit-stride: write straight in
+    Tv, Pv, Pp = Float64[T], Float64[P], Float64[Pₚ]
+    GC.@preserve νv out Tv Pv Pp begin
+        dst = σ isa Vector{Float64} ? pointer(out) : (stride(σ,1) == 1 ? pointer(σ) : pointer(out))
+        check(ccall((:cs_shape_batch, LIB), Cint,
+            (Ptr{Cvoid}, Cint, Cint, Float64, Int64, Ptr{Float64}, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+             Ptr{Float64}, Int64),
+            ctx.handle, slot!(ctx, sl), SHAPES[shape], Float64(Δνcut), length(νv), νv, 1, Tv, Pv, Pp, dst, length(νv)))
+        if dst == pointer(out) && !(σ isa Vector{Float64})
+            copyto!(σ, out)
+        end
+    end
+    nothing
+end
+
+hipvoigt!(σ, ν, sl, T, P, Pₚ, Δνcut=25.0)   = hipshape!(:voigt,   σ, ν, sl, T, P, Pₚ, Δνcut)
+hiplorentz!(σ, ν, sl, T, P, Pₚ, Δνcut=25.0) = hipshape!(:lorentz, σ, ν, sl, T, P, Pₚ, Δνcut)
+hipdoppler!(σ, ν, sl, T, P, Pₚ, Δνcut=25.0) = hipshape!(:doppler, σ, ν, sl, T, P, Pₚ, Δνcut)
+hipPHCO2!(σ, ν, sl, T, P, Pₚ, Δνcut=500.0)  = hipshape!(:PHCO2,   σ, ν, sl, T, P, Pₚ, Δνcut)
+
+# all nT*nP states of bake [gases.jl:109-130] in one launch: σ[nν, nT, nP] is exactly [state][ν] with ld = nν
+function hipbake!(σ::Array{Float64,3}, sl::SpectralLines, fC, ν::Vector{Float64}, Ω; shape::Symbol=:voigt, Δνcut=25.0)
+    ctx = context()
+    nT, nP = Ω.nT, Ω.nP
+    T  = Float64[Ω.T[i] for i in 1:nT, j in 1:nP][:]
+    P  = Float64[Ω.P[j] for i in 1:nT, j in 1:nP][:]
+    Pp = Float64[fC(Ω.T[i], Ω.P[j])*Ω.P[j] for i in 1:nT, j in 1:nP][:]
+    GC.@preserve σ ν T P Pp check(ccall((:cs_shape_batch, LIB), Cint,
+        (Ptr{Cvoid}, Cint, Cint, Float64, Int64, Ptr{Float64}, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+         Ptr{Float64}, Int64),
+        ctx.handle, slot!(ctx, sl), SHAPES[shape], Float64(Δνcut), length(ν), ν, nT*nP, T, P, Pp, σ, length(ν)))
+    σ
+end
+
+#-------------------------------------------------------------------------------
+# B2: a gas evaluated directly at the nodes
+
+struct DirectGas{F} <: AbstractGas
+    name::String
+    formula::String
+    μ::Float64
+    ν::Vector{Float64}
+    sl::SpectralLines
+    fC::F
+    shape::Symbol
+    Δνcut::Float64
+end
+
+function DirectGas(sl::SpectralLines, fC, ν::AbstractVector{<:Real}; shape::Symbol=:voigt, Δνcut::Real=(shape == :PHCO2 ? 500 : 25))
+    ClearSky.checkν(collect(Float64, ν))
+    f = fC isa Real ? ((T,P)->float(fC)) : fC
+    DirectGas(sl.name, sl.formula, sum(sl.A .* sl.μ)/sum(sl.A), collect(Float64, ν), sl, f, shape, Float64(Δνcut))
+end
+
+# scalar access keeps the reference semantics (σchain, absorbers.jl:84-92), e.g. for the Radau core
+(g::DirectGas)(i::Int, T, P) = (C = g.fC(T,P); C*ClearSky.voigt(g.ν[i], g.sl, T, P, C*P, g.Δνcut))
+
+#-------------------------------------------------------------------------------
+# B3: numerical core dispatch [shared.jl:36,55-62; fluxes.jl:238-279]
+
+struct HIPDiscretized <: AbstractNumericalCore
+    nstream::Int64
+    nlobatto::Int64
+end
+HIPDiscretized(; nstream::Int=5, nlobatto::Int=2) = HIPDiscretized(nstream, nlobatto)
+
+function ClearSky.monochromaticfluxes!(M⁺::AbstractMatrix, M⁻::AbstractMatrix, τ::AbstractMatrix, core::HIPDiscretized,
+                                       P::AbstractVector{<:Real}, g::Real, T, μ, 𝒻S, 𝒻a, absorbers...; θₛ::Real=0.841)::Nothing
+    𝒜, ν, nν = ClearSky.unifyabsorbers(absorbers)
+    𝒻T, 𝒻μ = formprofiles(P, T, μ)
+    nstream, nlobatto = core.nstream, core.nlobatto
+    @assert issorted(P) "pressure coordinates must be in ascending order (sorted)"
+    # closures are evaluated here, exactly where fluxes.jl:253-267 / discretized.jl:11-30,46-58 evaluate them
+    Tn, μn = lobattoevaluations(P, 𝒻T, 𝒻μ, nlobatto)
+    Tlev = Float64[𝒻T(p) for p in P]
+    checkstreams(nstream); checkazimuth(θₛ)
+    np = length(P); nl = np - 1; K = nl*(nlobatto - 1) + 1
+    𝓍, _ = lobattonodes(nlobatto)
+    Pk = Vector{Float64}(undef, K); Tk = similar(Pk)
+    Pk[1] = P[1]; Tk[1] = Tn[1,1]
+    for i in 1:nl, n in 2:nlobatto
+        k = (i-1)*(nlobatto-1) + n
+        Pk[k] = n == nlobatto ? P[i+1] : P[i] + (P[i+1]-P[i])*𝓍[n]
+        Tk[k] = Tn[n,i]
+    end
+    direct = filter(x -> x isa DirectGas, collect(𝒜.gas))
+    gray   = filter(x -> x isa GrayGas, collect(𝒜.gas))
+    length(direct) + length(gray) == length(𝒜.gas) || error("HIPDiscretized needs DirectGas / GrayGas members (baked Gas objects: see DESIGN.md, row f1)")
+    ctx = context()
+    ngas = length(direct)
+    slots  = Cint[slot!(ctx, x.sl) for x in direct]
+    shapes = Cint[SHAPES[x.shape] for x in direct]
+    cuts   = Float64[x.Δνcut for x in direct]
+    conc   = Float64[direct[gi].fC(Tk[k], Pk[k]) for gi in 1:ngas, k in 1:K]      # [ngas, K] column-major
+    σgray  = isempty(gray) ? 0.0 : sum(x.σ for x in gray)
+    # functions σ(ν,T,P) and CIA objects are evaluated on the host, [nν, K]
+    extra  = (isempty(𝒜.fun) && isempty(𝒜.cia)) ? nothing :
+             Float64[ClearSky.σchain(𝒜.cia, ν[j], Tk[k], Pk[k]) + ClearSky.σchain(𝒜.fun, ν[j], Tk[k], Pk[k]) for j in 1:nν, k in 1:K]
+    Stoa = Float64[𝒻S(x) for x in ν]; alb = Float64[𝒻a(x) for x in ν]
+    F⁺ = Vector{Float64}(undef, np); F⁻ = similar(F⁺)
+    dense(A) = (A isa Matrix{Float64}) ? A : Matrix{Float64}(undef, size(A))
+    Mu, Md, Ta = dense(M⁺), dense(M⁻), dense(τ)
+    GC.@preserve ν P Tn μn Tlev slots shapes cuts conc extra Stoa alb Mu Md Ta F⁺ F⁻ begin
+        check(ccall((:cs_fluxes_discretized, LIB), Cint,
+            (Ptr{Cvoid}, Int64, Ptr{Float64}, Cint, Ptr{Float64}, Float64, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+             Cint, Ptr{Cint}, Ptr{Cint}, Ptr{Float64}, Ptr{Float64}, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+             Float64, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+            ctx.handle, nν, ν, np, collect(Float64, P), Float64(g), nlobatto, Tn, μn, Tlev, ngas, slots, shapes, cuts, conc,
+            σgray, extra === nothing ? C_NULL : pointer(extra), Stoa, alb, Float64(θₛ), nstream, Ta, Mu, Md, F⁺, F⁻))
+    end
+    Mu === M⁺ || copyto!(M⁺, Mu); Md === M⁻ || copyto!(M⁻, Md); Ta === τ || copyto!(τ, Ta)
+    nothing
+end
+
+export HIPDiscretized, DirectGas, hipvoigt!, hiplorentz!, hipdoppler!, hipPHCO2!, hipbake!
+
+end # module
