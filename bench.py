@@ -20,8 +20,8 @@ import numpy as np
 _ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, _ROOT)
 
-# fp64 ops of one far-wing Voigt term in k_linesum (sub, mul, fma x? ... counted from the ISA: 17 VALU ops, FMAs = 2 flops)
-FLOPS_PER_PAIR = 34.0
+# flops of one far-wing Voigt term in k_voigt_far: 14 fp64 VALU instructions (ISA count, mode 0/1 mix), FMAs = 2 flops
+FLOPS_PER_PAIR = 24.0
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 
@@ -35,7 +35,8 @@ def main():
     ap.add_argument("--lines", default=None, help="synthetic | fixture")
     ap.add_argument("--nnu", type=int, default=None)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--cpu-stride", type=int, default=8, help="cpu_baseline evaluates every n-th wavenumber")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL, default) | gloo (rehearsal of N>1 on fewer GPUs)")
+    ap.add_argument("--cpu-stride", type=int, default=0, help="cpu_baseline evaluates every n-th wavenumber (0 = size the sample for ~15 s)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -51,26 +52,36 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the HIP path)")
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    dev = local_rank % ndev          # gloo rehearsals may put several ranks on one card
+    torch.cuda.set_device(dev)
     dist = None
     if N > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(args.dist_backend)
 
     cfg = W.config(args.config, nnu=args.nnu, lines_kind=args.lines)
     nu, nl = cfg["nu"], cfg["nl"]
     ranges = W.balanced_ranges(nu, cfg["absorbers"], N)
-    ctx = cs.Context(local_rank)
+    ctx = cs.Context(dev)
     col = cs.Column(cfg["P"], cfg["g"], cfg["T"], cfg["mu"], cfg["fS"], cfg["fa"], *cfg["absorbers"], core=cfg["core"],
                     theta_s=cfg["theta_s"], want_tau=True, want_M=True, nu_range=ranges[rank], ctx=ctx)
     stream = torch.cuda.current_stream().cuda_stream
-    F = torch.zeros(2 * col.np, dtype=torch.float64, device=f"cuda:{local_rank}")
+    F = torch.zeros(2 * col.np, dtype=torch.float64, device=f"cuda:{dev}")
 
     def step():
         col.run(stream)
         col.flux_to(F.data_ptr(), stream)
         if N > 1:
-            dist.all_reduce(F)   # RCCL over xGMI: 2*np doubles
+            if args.dist_backend == "nccl":
+                dist.all_reduce(F)   # RCCL over xGMI: 2*np doubles, the only collective of the path
+            else:
+                Fc = F.cpu()
+                dist.all_reduce(Fc)
+                F.copy_(Fc)
 
     def fence():
         torch.cuda.synchronize()
@@ -87,7 +98,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if N > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{dev}" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms = dt / args.steps * 1e3
@@ -102,36 +113,53 @@ def main():
     ngas = len(col.gases)
     K = col.K
     lines_total = sum(len(g.sl.nu) for g in col.gases)
-    # algorithmic HBM bytes of the k_linesum launches of one evaluation (DESIGN.md "Kernels"):
-    #   read nu (8 B/point/launch) + read the 32-B hot parameter record of every (node, line) once
-    #   + write sigma (8 B per (nu,node)), + re-read it when a later gas accumulates
-    ls_bytes = ngas * 8 * col.nnu + 32 * K * lines_total + 8 * col.nnu * K * (2 * ngas - 1)
-    ls_ms = prof["linesum"]
-    achieved = ls_bytes / (ls_ms * 1e-3) / 1e9 if ls_ms > 0 else 0.0
-    roofline = dict(bound="hbm", kernel="k_linesum", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=achieved / HBM_PEAK_GBS, traffic=None,
-                    launches_per_step=ngas, avg_launch_ms=ls_ms / max(ngas, 1), algorithmic_bytes_per_step=ls_bytes,
-                    valu_fp64=dict(achieved=cnt["pair_evals"] * FLOPS_PER_PAIR / (ls_ms * 1e-3) / 1e12 if ls_ms > 0 else 0.0,
-                                   peak=FP64_VALU_PEAK_TFLOPS, unit="TFLOP/s",
-                                   frac=cnt["pair_evals"] * FLOPS_PER_PAIR / (ls_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS
-                                   if ls_ms > 0 else 0.0, pair_evals=cnt["pair_evals"]),
+    # k_voigt_far (one launch per gas).  Algorithmic HBM bytes per launch: the 32-B record of every
+    # (node, line) read once + sigma written (8 B per (nu, node)) + sigma re-read when a later gas accumulates + nu.
+    far_bytes = [32 * K * len(g.sl.nu) + 8 * col.nnu * K * (2 if gi > 0 else 1) + 8 * col.nnu for gi, g in enumerate(col.gases)]
+    far_ms = prof["far"] / max(ngas, 1)
+    alg = float(np.mean(far_bytes)) if far_bytes else 0.0
+    achieved = alg / (far_ms * 1e-3) / 1e9 if far_ms > 0 else 0.0
+    traffic = None
+    try:   # PMC traffic is collected offline (rocprofv3 --pmc, separate passes) for this exact workload: profiles/
+        pm = json.load(open(os.path.join(_ROOT, "profiles", "r01_pmc_traffic.json")))
+        if args.config == "C3" and args.nnu is None and args.lines is None and N == 1:
+            kk = pm["kernels"]["k_voigt_far"]
+            traffic = (kk["FETCH_SIZE_KB"] + kk["WRITE_SIZE_KB"]) * 1024.0
+    except Exception:
+        traffic = None
+    flops = cnt["pair_evals"] * FLOPS_PER_PAIR
+    line_ms = prof["far"] + prof["near"]
+    roofline = dict(bound="hbm", kernel="k_voigt_far", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=achieved / HBM_PEAK_GBS, traffic=traffic, launches_per_step=ngas, avg_launch_ms=far_ms,
+                    algorithmic_bytes_per_launch=alg,
+                    note="elementwise fp64 accumulate over (nu,line) pairs: VALU-bound by construction, see valu_fp64",
+                    valu_fp64=dict(achieved=flops / (line_ms * 1e-3) / 1e12 if line_ms > 0 else 0.0, peak=FP64_VALU_PEAK_TFLOPS,
+                                   unit="TFLOP/s", frac=flops / (line_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS if line_ms > 0 else 0.0,
+                                   pair_evals=cnt["pair_evals"], flops_per_pair=FLOPS_PER_PAIR),
                     kernel_ms=prof)
 
     cpu = None
     if rank == 0 and N == 1 and not args.no_cpu:
         from oracle import oracle as O
         O.use_native_build()
-        stride = max(1, args.cpu_stride)
-        sub = np.ascontiguousarray(nu[::stride])
-        full = col   # node states (Tn, mun, Tlev, conc) do not depend on the wavenumber shard
-        t1 = time.perf_counter()
-        ref = O.fluxes_discretized(sub, cfg["P"], cfg["g"], cfg["core"].nlobatto, full.Tn, full.mun, full.Tlev,
-                                   [g.sl for g in col.gases], [g.shape for g in col.gases], [g.dnu_cut for g in col.gases],
-                                   full.conc, theta_s=cfg["theta_s"], nstream=cfg["core"].nstream)
-        tc = time.perf_counter() - t1
+        # calibrate on a thin sample, then size the sample for roughly 15 s of CPU work
+        def run_cpu(stride):
+            sub = np.ascontiguousarray(nu[::stride])
+            t1 = time.perf_counter()
+            ref = O.fluxes_discretized(sub, cfg["P"], cfg["g"], cfg["core"].nlobatto, col.Tn, col.mun, col.Tlev,
+                                       [g.sl for g in col.gases], [g.shape for g in col.gases], [g.dnu_cut for g in col.gases],
+                                       col.conc, theta_s=cfg["theta_s"], nstream=cfg["core"].nstream)
+            return sub, ref, time.perf_counter() - t1
+        if args.cpu_stride > 0:
+            stride = args.cpu_stride
+        else:
+            sub, ref, tc = run_cpu(64)
+            stride = int(min(max(1, round(tc * 64 / 15.0)), 64))
+        sub, ref, tc = run_cpu(stride)
         cpu = dict(value=len(sub) * nl / tc, unit="spectral-points/s", cores=O.num_threads(), kind="port",
                    sample=f"every {stride}th wavenumber of the same column ({len(sub)} x {nl} points, {tc:.1f} s)",
-                   olr_sample=float(ref["Fup"][0]))
+                   olr_sample=float(ref["Fup"][0]),
+                   olr_abs_err_wm2=(abs(olr - float(ref["Fup"][0])) if stride == 1 else None))
 
     if rank == 0:
         out = dict(metric="spectral-points/s (nu x layers), whole-column LBL flux evaluation", value=value,

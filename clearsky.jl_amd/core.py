@@ -551,11 +551,11 @@ class Column:
         check(lib().cs_column_sync(self.ctx.handle))
 
     def profile(self, reps: int = 3, stream: int = 0):
-        """HIP-event time per kernel class, ms per evaluation: dict(prep, linesum, rt, reduce)."""
-        ms = np.zeros(4)
+        """HIP-event time per kernel class, ms per evaluation: dict(prep, far, near, rt, reduce), summed over gases."""
+        ms = np.zeros(5)
         self._ensure_resident()
         check(lib().cs_column_profile(self.ctx.handle, C.c_void_p(stream) if stream else None, reps, dptr(ms)))
-        return dict(prep=ms[0], linesum=ms[1], rt=ms[2], reduce=ms[3])
+        return dict(prep=ms[0], far=ms[1], near=ms[2], rt=ms[3], reduce=ms[4])
 
     def flux_ptr(self) -> int:
         p = C.c_void_p()

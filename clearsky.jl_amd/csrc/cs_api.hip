@@ -294,7 +294,7 @@ std::vector<double> gamma_bound(const GasTable &G, int K, const double *T, const
 void launch_gas(hipStream_t s, int shape, const GasTable &G, int kn, const double *Tk, const double *Pk, const double *Ppk,
                 const double *scale, LineHot *hot, LineCold *cold, const double *dnu, int64_t nnu, int ntile256,
                 const int32_t *J0, const int32_t *J1, const WaveWin *win, Zone *zones, const double *gbound, double cut, double base,
-                const double *extra, double *sigma, int accumulate, hipEvent_t ev_mid)
+                const double *extra, double *sigma, int accumulate, hipEvent_t ev_mid, hipEvent_t ev_far = nullptr)
 {
     const int64_t tot = (int64_t)kn * G.L;
     hipLaunchKernelGGL(k_prep, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, shape, G.dev(), kn, Tk, Pk, Ppk, scale,
@@ -308,11 +308,13 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int kn, const doubl
         const dim3 grid((unsigned)((nblk + 7) / 8 * 8), kn);   // multiple of 8: XCD-aware tile mapping (k_voigt_far)
         hipLaunchKernelGGL(k_voigt_far, grid, dim3(256), 0, s, dnu, nnu, G.L, hot, win, zones, nt64, nblk, cut, base, extra,
                            sigma, accumulate);
+        if (ev_far) (void)hipEventRecord(ev_far, s);
         hipLaunchKernelGGL(k_voigt_near, grid, dim3(256), 0, s, dnu, nnu, G.L, hot, cold, zones, nt64, nblk, cut, sigma);
     } else {
         if (ev_mid) (void)hipEventRecord(ev_mid, s);
         launch_linesum_shape(shape, dim3(ntile256, kn), s, dnu, nnu, G.L, hot, cold, J0, J1, cut, Tk, base, extra, sigma,
                              accumulate);
+        if (ev_far) (void)hipEventRecord(ev_far, s);
     }
 }
 
@@ -607,7 +609,7 @@ int cs_column_update_state(cs_ctx *ctx, const double *T_nodes, const double *mu_
     return CS_OK;
 }
 
-// enqueue one evaluation; when ev != NULL an event is recorded before/after every kernel (ev must hold 2*ngas+4)
+// enqueue one evaluation; when ev != NULL an event is recorded between the kernel classes (ev must hold 3*ngas+3)
 static int run_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev)
 {
     Column &c = ctx->col;
@@ -626,8 +628,8 @@ static int run_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev)
         launch_gas(s, cg.shape, G, K, c.Tk.as<double>(), c.Pk.as<double>(), cg.Pp.as<double>(), cg.conc.as<double>(),
                    c.hot.as<LineHot>(), c.cold.as<LineCold>(), c.nu.as<double>(), c.nnu, c.ntile, cg.J0.as<int32_t>(),
                    cg.J1.as<int32_t>(), cg.win.as<WaveWin>(), cg.zones.as<Zone>(), cg.gmax.as<double>(), cg.cut, c.sigma_gray, extra, sig, gi > 0,
-                   ev ? ev[e++] : nullptr);
-        if (ev) HIPCHK(hipEventRecord(ev[e++], s));
+                   ev ? ev[e] : nullptr, ev ? ev[e + 1] : nullptr);
+        if (ev) { e += 2; HIPCHK(hipEventRecord(ev[e++], s)); }
     }
     launch_rt(c.nstream, c.ntile, (size_t)2 * c.np * 4 * sizeof(double), s, c.rt, c.nu.as<double>(), c.wts.as<double>(),
               c.nnu, sig, c.muk.as<double>(), c.P.as<double>(), c.Tlev.as<double>(),
@@ -654,10 +656,10 @@ int cs_column_profile(cs_ctx *ctx, void *stream, int reps, double *ms)
     Column &c = ctx->col;
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     HIPCHK(hipSetDevice(ctx->device));
-    const int nev = 2 * c.ngas + 3;
+    const int nev = 3 * c.ngas + 3;
     std::vector<hipEvent_t> ev(nev);
     for (auto &e : ev) HIPCHK(hipEventCreate(&e));
-    ms[0] = ms[1] = ms[2] = ms[3] = 0.0;
+    for (int i = 0; i < 5; i++) ms[i] = 0.0;
     int rc = CS_OK;
     for (int r = 0; r < reps && rc == CS_OK; r++) {
         rc = run_impl(ctx, s, ev.data());
@@ -665,14 +667,15 @@ int cs_column_profile(cs_ctx *ctx, void *stream, int reps, double *ms)
         if (hipStreamSynchronize(s) != hipSuccess) { rc = fail(CS_EHIP, "hipStreamSynchronize failed"); break; }
         float t;
         for (int gi = 0; gi < c.ngas; gi++) {
-            (void)hipEventElapsedTime(&t, ev[2 * gi], ev[2 * gi + 1]); ms[0] += t;
-            (void)hipEventElapsedTime(&t, ev[2 * gi + 1], ev[2 * gi + 2]); ms[1] += t;
+            (void)hipEventElapsedTime(&t, ev[3 * gi], ev[3 * gi + 1]); ms[0] += t;
+            (void)hipEventElapsedTime(&t, ev[3 * gi + 1], ev[3 * gi + 2]); ms[1] += t;
+            (void)hipEventElapsedTime(&t, ev[3 * gi + 2], ev[3 * gi + 3]); ms[2] += t;
         }
-        (void)hipEventElapsedTime(&t, ev[2 * c.ngas], ev[2 * c.ngas + 1]); ms[2] += t;
-        (void)hipEventElapsedTime(&t, ev[2 * c.ngas + 1], ev[2 * c.ngas + 2]); ms[3] += t;
+        (void)hipEventElapsedTime(&t, ev[3 * c.ngas], ev[3 * c.ngas + 1]); ms[3] += t;
+        (void)hipEventElapsedTime(&t, ev[3 * c.ngas + 1], ev[3 * c.ngas + 2]); ms[4] += t;
     }
     for (auto &e : ev) (void)hipEventDestroy(e);
-    for (int i = 0; i < 4; i++) ms[i] /= reps;
+    for (int i = 0; i < 5; i++) ms[i] /= reps;
     return rc;
 }
 

@@ -118,8 +118,8 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
                     double theta_s, int nstream, int want_tau, int want_M);
 int cs_column_run(cs_ctx *ctx, void *stream);
 int cs_column_sync(cs_ctx *ctx);
-/* run `reps` evaluations with HIP events around every kernel on `stream`; ms[4] = average milliseconds per
- * evaluation spent in {k_prep, k_linesum, k_rt, k_freduce} (summed over gases) */
+/* run `reps` evaluations with HIP events between the kernel classes on `stream`; ms[5] = average milliseconds per
+ * evaluation spent in {k_prep+k_zones, k_voigt_far (or k_linesum), k_voigt_near, k_rt, k_freduce}, summed over gases */
 int cs_column_profile(cs_ctx *ctx, void *stream, int reps, double *ms);
 int cs_column_flux_ptr(cs_ctx *ctx, double **dF);
 /* asynchronously copy the [2*np] band fluxes (Fup then Fdn) into caller-owned DEVICE memory on `stream` */

@@ -23,6 +23,8 @@
 #include <omp.h>
 #endif
 
+int cso_num_threads(void);
+
 /* ---- src/constants.jl:1-26 (verbatim values; k is the CODATA-2014 value on purpose) ---- */
 #define CS_C 299792458.0
 #define CS_H 6.62607015e-34
@@ -252,6 +254,9 @@ int cso_shape_bang(int shape, int strict_ends, int64_t nnu, const double *nu, co
     if (strict_ends) {
         while (j0 < L && !(sl->nu[j0] > lo)) j0++;
         while (j1 > j0 && !(sl->nu[j1 - 1] < hi)) j1--;
+    } else { /* only lines that can pass the inclusive cut-off test for some nu need their parameters */
+        while (j0 < L && sl->nu[j0] < lo) j0++;
+        while (j1 > j0 && sl->nu[j1 - 1] > hi) j1--;
     }
     int64_t n = j1 - j0;
     double *S = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
@@ -475,22 +480,31 @@ int cso_fluxes_discretized(int64_t nnu, const double *nu, int np, const double *
     }
     double *sig = (double *)calloc((size_t)nnu * K, sizeof(double)); /* [K][nnu] */
     int rc = 0;
+    /* tasks = (state, nu chunk): the reference threads over states only (gases.jl:115); chunking nu as well keeps
+       every host core busy when there are more cores than states (shape! is exact on any sorted nu subset) */
+    int nth = cso_num_threads();
+    int nchunk = (4 * nth + K - 1) / K;
+    if (nchunk < 1) nchunk = 1;
+    if ((int64_t)nchunk > nnu) nchunk = (int)nnu;
 #pragma omp parallel for schedule(dynamic, 1)
-    for (int k = 0; k < K; k++) {
-        double *row = sig + (size_t)k * nnu;
-        double *tmp = (double *)malloc(sizeof(double) * (size_t)nnu);
-        for (int64_t i = 0; i < nnu; i++) row[i] = sigma_gray;
+    for (int task = 0; task < K * nchunk; task++) {
+        int k = task / nchunk, ch = task % nchunk;
+        int64_t i0 = nnu * ch / nchunk, i1 = nnu * (ch + 1) / nchunk, n = i1 - i0;
+        if (n <= 0) continue;
+        double *row = sig + (size_t)k * nnu + i0;
+        double *tmp = (double *)malloc(sizeof(double) * (size_t)n);
+        for (int64_t i = 0; i < n; i++) row[i] = sigma_gray;
         for (int gi = 0; gi < ngas; gi++) {
             double Cg = conc[gi + (size_t)ngas * k];
-            int e = cso_shape_bang(shapes[gi], 0, nnu, nu, gases[gi], Tk[k], Pk[k], Cg * Pk[k], cuts[gi], tmp);
+            int e = cso_shape_bang(shapes[gi], 0, n, nu + i0, gases[gi], Tk[k], Pk[k], Cg * Pk[k], cuts[gi], tmp);
             if (e) {
 #pragma omp critical
                 rc = e;
             }
-            for (int64_t i = 0; i < nnu; i++) row[i] += Cg * tmp[i]; /* gases.jl:278 */
+            for (int64_t i = 0; i < n; i++) row[i] += Cg * tmp[i]; /* gases.jl:278 */
         }
         if (sigma_extra)
-            for (int64_t i = 0; i < nnu; i++) row[i] += sigma_extra[i + (size_t)nnu * k];
+            for (int64_t i = 0; i < n; i++) row[i] += sigma_extra[i0 + i + (size_t)nnu * k];
         free(tmp);
     }
     if (rc) { free(Pk); free(Tk); free(muk); free(sig); return rc; }
