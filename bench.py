@@ -69,7 +69,12 @@ def main():
     ctx = cs.Context(dev)
     col = cs.Column(cfg["P"], cfg["g"], cfg["T"], cfg["mu"], cfg["fS"], cfg["fa"], *cfg["absorbers"], core=cfg["core"],
                     theta_s=cfg["theta_s"], want_tau=True, want_M=True, nu_range=ranges[rank], ctx=ctx)
-    stream = torch.cuda.current_stream().cuda_stream
+    # one explicit torch stream carries the kernels, the D2D copy of the band fluxes and the collective, so they are
+    # ordered by the stream (torch's default stream has handle 0, which the C ABI reads as "use the context's stream")
+    tstream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+    assert stream != 0
     F = torch.zeros(2 * col.np, dtype=torch.float64, device=f"cuda:{dev}")
 
     def step():

@@ -198,6 +198,19 @@ def test_opticaldepth_and_transmittance(cs, O, lines, ctx):
     assert np.array_equal(cs.transmittance(P, 9.8, 260.0, 0.029, 0.3, gas, nlobatto=4, ctx=ctx), np.exp(-tau))
 
 
+def test_c2_full_parity_vs_oracle(cs, O, ctx):
+    """BASELINE configs[1] at full size: CO2 fixture, 1e4 wavenumbers x 40 layers -- every output against the oracle."""
+    from clearsky_jl_amd import workloads as W
+    cfg = W.config("C2")
+    F = cs.radiate(cfg["P"], cfg["g"], cfg["T"], cfg["mu"], cfg["fS"], cfg["fa"], *cfg["absorbers"], core=cfg["core"], ctx=ctx)
+    col = cs.Column(cfg["P"], cfg["g"], cfg["T"], cfg["mu"], cfg["fS"], cfg["fa"], *cfg["absorbers"], core=cfg["core"],
+                    want_tau=False, want_M=False, ctx=ctx)
+    r = O.fluxes_discretized(cfg["nu"], cfg["P"], cfg["g"], 2, col.Tn, col.mun, col.Tlev, [g.sl for g in col.gases], ["voigt"],
+                             [25.0], col.conc)
+    _column_vs(cs, r, F)
+    assert abs(F.Fup[0] - r["Fup"][0]) < 1e-9          # OLR error [W/m^2]
+
+
 # ---- full BASELINE sizes: size-independent properties + sparse direct parity ---------------------------------------
 
 @pytest.fixture(scope="module")
