@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("CLEARSKY_HIP_LIB", os.path.join(CSRC, "libclearsky_hi
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "clearsky_hip.h")
 
 CS_MAX_GAS = 16
+CS_MAX_TABLE = 16
 CHEB_LD = 16
 SHAPES = {"voigt": 0, "lorentz": 1, "doppler": 2, "PHCO2": 3, "phco2": 3}
 
@@ -32,6 +33,10 @@ SIGNATURES = {
     "cs_gas_clear": (C.c_int, [_vp, C.c_int]),
     "cs_shape_batch": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_int64, _dp, C.c_int, _dp, _dp, _dp, _dp,
                                  C.c_int64]),
+    "cs_bake": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int64, _dp, C.c_int, _dp, C.c_int, _dp, _dp, _dp]),
+    "cs_table_clear": (C.c_int, [_vp, C.c_int]),
+    "cs_table_eval": (C.c_int, [_vp, C.c_int, C.c_double, C.c_double, C.c_int64, C.c_int64, _dp]),
+    "cs_column_set_tables": (C.c_int, [_vp, C.c_int, _ip, _dp]),
     "cs_fluxes_discretized": (C.c_int, [_vp, C.c_int64, _dp, C.c_int, _dp, C.c_double, C.c_int, _dp, _dp, _dp, C.c_int,
                                         _ip, _ip, _dp, _dp, C.c_double, _dp, _dp, _dp, C.c_double, C.c_int, _dp, _dp,
                                         _dp, _dp, _dp]),
@@ -45,7 +50,7 @@ SIGNATURES = {
     "cs_column_fetch": (C.c_int, [_vp, _dp, _dp, _dp, _dp, _dp]),
     "cs_column_sigma_fetch": (C.c_int, [_vp, _dp]),
     "cs_column_counts": (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
-    "cs_column_update_state": (C.c_int, [_vp, _dp, _dp, _dp, _dp]),
+    "cs_column_update_state": (C.c_int, [_vp, _dp, _dp, _dp, _dp, _dp]),
     "cs_streamnodes": (C.c_int, [C.c_int, _dp, _dp]),
     "cs_lobattonodes": (C.c_int, [C.c_int, _dp, _dp]),
     "cs_faddeeva_batch": (C.c_int, [_vp, C.c_int64, _dp, _dp, _dp]),

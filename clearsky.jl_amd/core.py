@@ -15,7 +15,7 @@ from typing import Callable, Optional, Sequence
 import numpy as np
 
 from . import constants as K
-from ._lib import (CHEB_LD, CS_MAX_GAS, SHAPES, ClearSkyHIPError, as_f64, check, dptr, lib)
+from ._lib import (CHEB_LD, CS_MAX_GAS, CS_MAX_TABLE, SHAPES, ClearSkyHIPError, as_f64, check, dptr, lib)
 from .hitran import TMAX, TMIN, SpectralLines
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -204,6 +204,8 @@ class Context:
         self.device = device
         self._slots = {}   # id(sl) -> (slot, sl)
         self._next = 0
+        self._tables = {}  # id(Gas) -> slot
+        self._free_tables = list(range(CS_MAX_TABLE))
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
@@ -242,6 +244,21 @@ class Context:
                                   ncheb.ctypes.data_as(C.POINTER(C.c_int32)), dptr(cheb)))
         self._slots[key] = (slot, sl)
         return slot
+
+
+    def table_slot(self, owner) -> int:
+        """Reserve an opacity-table slot for a baked Gas (released when the Gas is garbage collected)."""
+        if not self._free_tables:
+            raise ClearSkyHIPError(-1, "no free opacity-table slot (CS_MAX_TABLE baked gases per context)")
+        slot = self._free_tables.pop(0)
+        self._tables[id(owner)] = slot
+        return slot
+
+    def release_table(self, owner):
+        slot = self._tables.pop(id(owner), None)
+        if slot is not None and getattr(self, "_h", None) and self._h.value:
+            lib().cs_table_clear(self._h, slot)
+            self._free_tables.append(slot)
 
 
 _default_ctx = {}
@@ -353,6 +370,111 @@ class GrayGas(AbstractGas):
 
     def __call__(self, *a):
         return self.sigma
+
+
+class AtmosphericDomain:
+    """gases.jl:26-61: Chebyshev-extrema grids in T and ln P over which cross-sections are baked."""
+
+    def __init__(self, Trange, nT: int, Prange, nP: int):
+        assert all(t > 0 for t in Trange), "temperature range must be positive"
+        assert all(p > 0 for p in Prange), "pressure range must be positive"
+        assert all(t >= TMIN for t in Trange), f"minimum temperature with Qref/Q accuracy is {TMIN} K"
+        assert all(t <= TMAX for t in Trange), f"maximum temperature with Qref/Q accuracy is {TMAX} K"
+        assert Trange[0] < Trange[1], f"Trange[1] ({Trange[0]}) can't be greater than Trange[2] ({Trange[1]})"
+        assert Prange[0] < Prange[1], f"Prange[1] ({Prange[0]}) can't be greater than Prange[2] ({Prange[1]})"
+        self.T = chebygrid(float(Trange[0]), float(Trange[1]), nT)
+        self.Tmin, self.Tmax, self.nT = float(Trange[0]), float(Trange[1]), int(nT)
+        self.P = np.exp(chebygrid(math.log(Prange[0]), math.log(Prange[1]), nP))
+        self.Pmin, self.Pmax, self.nP = float(Prange[0]), float(Prange[1]), int(nP)
+
+    def __repr__(self):
+        return (f"AtmosphericDomain:\n  {self.nT} temperature nodes ∈ [{self.Tmin},{self.Tmax}] K\n"
+                f"  {self.nP} pressure nodes ∈ [{self.Pmin},{self.Pmax}] Pa")
+
+
+class Gas(AbstractGas):
+    """Gas(sl, fC, nu, Omega, shape='voigt', dnu_cut=25) -- the reference's baked gas object (gases.jl:205-249): cross-sections
+    are evaluated once on Omega's (T, ln P) Chebyshev grid (`bake`, gases.jl:97-145 -- all nT*nP states in one device launch)
+    and interpolated afterwards (`OpacityTable`, gases.jl:68-85).  The ln(sigma) tables stay resident in HBM."""
+
+    def __init__(self, sl, fC, nu, Omega: AtmosphericDomain, shape="voigt", dnu_cut=25.0, ctx: Optional["Context"] = None,
+                 keep_host_tables: bool = False, **readpar_kwargs):
+        if isinstance(sl, str):
+            sl = SpectralLines(sl, **readpar_kwargs)
+        nu = np.array(nu, dtype=float)
+        assert len(nu) > 0
+        assert np.all(np.diff(nu) > 0), "wavenumbers must be unique and in ascending order"
+        assert np.all(nu >= 0), "wavenumbers must be positive"
+        self.ctx = ctx or default_context()
+        self.sl, self.name, self.formula = sl, sl.name, sl.formula
+        self.mu = float(np.sum(sl.A * sl.mu) / np.sum(sl.A))      # gases.jl:233
+        self.nu, self.Omega, self.shape, self.dnu_cut = nu, Omega, shape, float(dnu_cut)
+        self.fC = fC if callable(fC) else (lambda T, P, _c=float(fC): _c)
+        conc = np.zeros((Omega.nT, Omega.nP), order="F")
+        for i, T in enumerate(Omega.T):
+            for j, P in enumerate(Omega.P):
+                Cv = self.fC(T, P)
+                assert 0 <= Cv <= 1, f"gas molar concentrations must be in [0,1], not {Cv} (encountered @ {T} K, {P} Pa)"
+                conc[i, j] = Cv
+        self.slot = self.ctx.table_slot(self)
+        out = np.zeros((len(nu), Omega.nT, Omega.nP), order="F") if keep_host_tables else None
+        try:
+            check(lib().cs_bake(self.ctx.handle, self.ctx.slot_of(sl), self.slot, SHAPES[shape], self.dnu_cut, len(nu), dptr(nu),
+                                Omega.nT, dptr(as_f64(Omega.T)), Omega.nP, dptr(as_f64(Omega.P)), dptr(conc.ravel(order="F").copy()),
+                                out.ctypes.data_as(C.POINTER(C.c_double)) if out is not None else None))
+        except Exception:
+            self.ctx.release_table(self)
+            raise
+        self.lnsigma = out     # [nnu, nT, nP] like the reference's sigma block (only when keep_host_tables)
+
+    def __del__(self):
+        try:
+            self.ctx.release_table(self)
+        except Exception:
+            pass
+
+    def concentration(self, T, P):
+        """gases.jl:270"""
+        return self.fC(T, P)
+
+    def rawsigma(self, T, P, i=None):
+        """rawσ(g, T, P) / rawσ(g, i, T, P): interpolated cross-section(s) WITHOUT the concentration factor (gases.jl:256-263)"""
+        n = len(self.nu)
+        i0, cnt = (0, n) if i is None else (int(i), 1)
+        out = np.zeros(cnt)
+        check(lib().cs_table_eval(self.ctx.handle, self.slot, float(T), float(P), i0, cnt, dptr(out)))
+        return out if i is None else float(out[0])
+
+    def __call__(self, *a):
+        """g(i, T, P) or g(T, P): concentration-scaled cross-section(s) (gases.jl:278-281)"""
+        if len(a) == 3:
+            i, T, P = a
+            return self.concentration(T, P) * self.rawsigma(T, P, i)
+        T, P = a
+        return self.concentration(T, P) * self.rawsigma(T, P)
+
+    def reconcentrate(self, fC):
+        """gases.jl:292-320: same tables, new concentration function (self-broadening is NOT recomputed, as in the reference)"""
+        f = fC if callable(fC) else (lambda T, P, _c=float(fC): _c)
+        for P in self.Omega.P:
+            for T in self.Omega.T:
+                Cv = f(T, P)
+                assert 0 <= Cv <= 1.0, f"gas molar concentrations must be in [0,1], not {Cv}, which was encountered at T={T} P={P}"
+        g = object.__new__(Gas)
+        g.__dict__.update(self.__dict__)
+        g.fC = f
+        g._shared_with = self      # keeps the table owner alive; the copy does not own the slot
+        g.__class__ = _GasView
+        return g
+
+
+class _GasView(Gas):
+    def __del__(self):
+        pass
+
+
+def reconcentrate(g: Gas, fC):
+    return g.reconcentrate(fC)
 
 
 class UnifiedAbsorber:
@@ -475,9 +597,17 @@ class Column:
         self.S_toa = evalv(fS)
         self.albedo = evalv(fa)
         self.gases = [g_ for g_ in U.gas if isinstance(g_, DirectGas)]
+        self.baked = [g_ for g_ in U.gas if isinstance(g_, Gas)]
+        for g_ in self.baked:
+            assert g_.ctx is self.ctx, "baked Gas objects live on the context they were baked on"
+            # checkpressures, absorbers.jl:237-246
+            assert P[-1] > P[0], "Pₛ must be greater than Pₜ"
+            for p_ in (P[-1], P[0]):
+                assert p_ >= g_.Omega.Pmin, f"Pressure {p_} Pa too low, domain minimum is {g_.Omega.Pmin}"
+                assert p_ <= g_.Omega.Pmax, f"Pressure {p_} Pa too low, domain minimum is {g_.Omega.Pmax}"
         self.sigma_gray = float(sum(g_.sigma for g_ in U.gas if isinstance(g_, GrayGas)))
         for g_ in U.gas:
-            if not isinstance(g_, (DirectGas, GrayGas)):
+            if not isinstance(g_, (DirectGas, GrayGas, Gas)):
                 raise TypeError(f"unsupported gas type {type(g_).__name__} for the HIP Discretized core")
         self.slots = np.array([self.ctx.slot_of(g_.sl) for g_ in self.gases], dtype=np.int32)
         self.shapes = np.array([SHAPES[g_.shape] for g_ in self.gases], dtype=np.int32)
@@ -500,6 +630,11 @@ class Column:
             for k in range(self.K):
                 conc[gi, k] = g_.fC(self.Tk[k], self.Pk[k])
         self.conc = conc
+        ct = np.zeros((len(self.baked), self.K), order="F")
+        for ti, g_ in enumerate(self.baked):
+            for k in range(self.K):
+                ct[ti, k] = g_.fC(self.Tk[k], self.Pk[k])
+        self.conc_tab = ct
         if self.U.fun:
             ex = np.zeros((self.K, self.nnu))
             for k in range(self.K):
@@ -521,6 +656,10 @@ class Column:
             dptr(self.conc.ravel(order="F").copy()) if self.conc.size else None, self.sigma_gray,
             dptr(self.sigma_extra) if self.sigma_extra is not None else None, dptr(self.S_toa), dptr(self.albedo),
             self.theta_s, self.core.nstream, int(self.want_tau), int(self.want_M)))
+        if self.baked:
+            slots = np.array([g_.slot for g_ in self.baked], dtype=np.int32)
+            check(lib().cs_column_set_tables(self.ctx.handle, len(slots), slots.ctypes.data_as(C.POINTER(C.c_int)),
+                                             dptr(self.conc_tab.ravel(order="F").copy())))
         self._set = True
         self.ctx._resident = self      # a context holds ONE resident column
 
@@ -539,7 +678,8 @@ class Column:
             return
         check(lib().cs_column_update_state(self.ctx.handle, dptr(self.Tn.ravel(order="F").copy()),
                                            dptr(self.mun.ravel(order="F").copy()), dptr(self.Tlev),
-                                           dptr(self.conc.ravel(order="F").copy()) if self.conc.size else None))
+                                           dptr(self.conc.ravel(order="F").copy()) if self.conc.size else None,
+                                           dptr(self.conc_tab.ravel(order="F").copy()) if self.conc_tab.size else None))
 
     # -- execution -------------------------------------------------------------------------------------------------
     def run(self, stream: int = 0):

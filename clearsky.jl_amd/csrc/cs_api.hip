@@ -84,6 +84,19 @@ struct GasTable {
     }
 };
 
+struct TableDev {
+    bool present = false;
+    int64_t nnu = 0;
+    int nT = 0, nP = 0;
+    std::vector<double> T, lnP, nu;
+    DevBuf Z;  // [nT*nP][nnu] ln sigma
+};
+
+struct ColTab {
+    int slot = 0;
+    DevBuf W, conc;  // [M][K], [K]
+};
+
 struct ColGas {
     int slot = 0, shape = 0;
     double cut = 25.0;
@@ -101,6 +114,8 @@ struct Column {
     RtParams rt;
     std::vector<double> h_P, h_Pk, h_xs, h_nu;
     std::vector<ColGas> gas;
+    std::vector<ColTab> tab;
+    std::vector<double> h_Tk;
     DevBuf nu, wts, P, Pk, Tk, muk, Tlev, extra, S_toa, albedo;
     DevBuf hot, cold, sigma, tau, Mup, Mdn, partial, F, stage;
 };
@@ -111,6 +126,7 @@ struct cs_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     GasTable gas[CS_MAX_GAS];
+    TableDev tab[CS_MAX_TABLE];
     Column col;
     DevBuf tmpA, tmpB, tmpC;
 };
@@ -171,6 +187,24 @@ void gauss_lobatto(int n, double *x, double *w)
         x[i] = z;
         w[i] = 2.0 / (N * (N + 1.0) * pn * pn);
     }
+}
+
+// Lagrange basis of the interpolating polynomial on Chebyshev extrema x[0..n) (ascending), barycentric form:
+// l_i(v) = (w_i/(v-x_i)) / sum_j (w_j/(v-x_j)),  w_i = (-1)^i * (1/2 at the two ends).  This is the unique polynomial
+// BichebyshevInterpolator evaluates (gases.jl:80,85); only rounding can differ from the reference's algorithm.
+void cheb_basis(const std::vector<double> &x, double v, std::vector<double> &l)
+{
+    const int n = (int)x.size();
+    l.assign(n, 0.0);
+    for (int i = 0; i < n; i++)
+        if (v == x[i]) { l[i] = 1.0; return; }
+    double den = 0.0;
+    for (int i = 0; i < n; i++) {
+        double w = ((i & 1) ? -1.0 : 1.0) * ((i == 0 || i == n - 1) ? 0.5 : 1.0);
+        l[i] = w / (v - x[i]);
+        den += l[i];
+    }
+    for (int i = 0; i < n; i++) l[i] /= den;
 }
 
 template <int SHAPE>
@@ -463,6 +497,165 @@ int cs_shape_batch(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t nnu
     return CS_OK;
 }
 
+int cs_bake(cs_ctx *ctx, int gas_slot, int table_slot, int shape, double dnu_cut, int64_t nnu, const double *nu, int nT,
+            const double *T, int nP, const double *P, const double *conc, double *lnsigma_out)
+{
+    if (!ctx) return fail(CS_EINVAL, "ctx is NULL");
+    if (gas_slot < 0 || gas_slot >= CS_MAX_GAS || !ctx->gas[gas_slot].present) return fail(CS_EINVAL, "gas slot %d is empty", gas_slot);
+    if (table_slot < 0 || table_slot >= CS_MAX_TABLE) return fail(CS_EINVAL, "table slot %d out of range", table_slot);
+    if (shape < 0 || shape > 3) return fail(CS_EINVAL, "unknown shape %d", shape);
+    if (nT < 2 || nP < 2) return fail(CS_EINVAL, "need at least 2 x 2 grid points");
+    int rc;
+    if ((rc = check_ascending(nu, nnu))) return rc;
+    for (int64_t i = 0; i < nnu; i++)
+        if (!(nu[i] >= 0)) return fail(CS_EINVAL, "wavenumbers must be positive");
+    const int M = nT * nP;
+    std::vector<double> Ts(M), Ps(M), Pp(M);
+    for (int j = 0; j < nP; j++)
+        for (int i = 0; i < nT; i++) {
+            const double C = conc[i + (size_t)nT * j];
+            if (!(C >= 0 && C <= 1)) return fail(CS_EINVAL, "gas molar concentrations must be in [0,1], not %g (encountered @ %g K, %g Pa)", C, T[i], P[j]);
+            Ts[i + nT * j] = T[i];
+            Ps[i + nT * j] = P[j];
+            Pp[i + nT * j] = C * P[j];
+        }
+    GasTable &G = ctx->gas[gas_slot];
+    if ((rc = check_gas_states(G, M, Ts.data()))) return rc;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    TableDev &tb = ctx->tab[table_slot];
+    tb.present = false;
+    int64_t g0, g1, pairs, inr;
+    included_range(G.h_nu, nu[0], nu[nnu - 1], dnu_cut, true, g0, g1);
+    std::vector<int32_t> J0, J1;
+    tile_windows(G.h_nu, g0, g1, nu, nnu, dnu_cut, J0, J1, pairs, inr);
+    std::vector<WaveWin> win;
+    wave_windows(G.h_nu, g0, g1, nu, nnu, dnu_cut, win);
+    const int ntile = (int)J0.size();
+    DevBuf dnu, dT, dP, dPp, dJ0, dJ1, hot, cold, dwin, dzones, dgb;
+    std::vector<double> gb = gamma_bound(G, M, Ts.data(), Ps.data(), Pp.data());
+    if ((rc = upload(dnu, nu, nnu, s)) || (rc = upload(dT, Ts.data(), M, s)) || (rc = upload(dP, Ps.data(), M, s)) ||
+        (rc = upload(dPp, Pp.data(), M, s)) || (rc = upload(dJ0, J0.data(), ntile, s)) || (rc = upload(dJ1, J1.data(), ntile, s)) ||
+        (rc = upload(dwin, win.data(), win.size(), s)) || (rc = upload(dgb, gb.data(), M, s)))
+        return rc;
+    HIPCHK(tb.Z.reserve((size_t)M * nnu * sizeof(double)));
+    const size_t per_state = (size_t)G.L * (sizeof(LineHot) + sizeof(LineCold));
+    const int kc = (int)std::max<size_t>(1, std::min<size_t>((size_t)M, ((size_t)4 << 30) / per_state));
+    HIPCHK(hot.reserve(((size_t)kc * G.L + 4) * sizeof(LineHot)));
+    HIPCHK(cold.reserve((size_t)kc * G.L * sizeof(LineCold)));
+    HIPCHK(dzones.reserve((size_t)kc * win.size() * sizeof(Zone)));
+    for (int k0 = 0; k0 < M; k0 += kc) {
+        const int kn = std::min(kc, M - k0);
+        launch_gas(s, shape, G, kn, dT.as<double>() + k0, dP.as<double>() + k0, dPp.as<double>() + k0, nullptr, hot.as<LineHot>(),
+                   cold.as<LineCold>(), dnu.as<double>(), nnu, ntile, dJ0.as<int32_t>(), dJ1.as<int32_t>(), dwin.as<WaveWin>(),
+                   dzones.as<Zone>(), dgb.as<double>() + k0, dnu_cut, 0.0, nullptr, tb.Z.as<double>() + (size_t)k0 * nnu, 0, nullptr);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    hipLaunchKernelGGL(k_table_log, dim3((unsigned)((nnu + 255) / 256)), dim3(256), 0, s, tb.Z.as<double>(), M, nnu);
+    HIPCHK(hipGetLastError());
+    if (lnsigma_out) HIPCHK(hipMemcpyAsync(lnsigma_out, tb.Z.p, (size_t)M * nnu * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    tb.nnu = nnu; tb.nT = nT; tb.nP = nP;
+    tb.T.assign(T, T + nT);
+    tb.lnP.resize(nP);
+    for (int j = 0; j < nP; j++) tb.lnP[j] = std::log(P[j]);
+    tb.nu.assign(nu, nu + nnu);
+    tb.present = true;
+    return CS_OK;
+}
+
+int cs_table_clear(cs_ctx *ctx, int table_slot)
+{
+    if (!ctx || table_slot < 0 || table_slot >= CS_MAX_TABLE) return fail(CS_EINVAL, "bad table slot");
+    ctx->tab[table_slot] = TableDev();
+    return CS_OK;
+}
+
+// W[m][k] = a_i(T_k) b_j(ln P_k), m = i + nT*j
+static int table_weights(const TableDev &tb, int K, const double *Tk, const double *Pk, std::vector<double> &W)
+{
+    const int M = tb.nT * tb.nP;
+    W.assign((size_t)M * K, 0.0);
+    std::vector<double> a, b;
+    for (int k = 0; k < K; k++) {
+        const double lp = std::log(Pk[k]);
+        if (!(Tk[k] >= tb.T.front() && Tk[k] <= tb.T.back()))
+            return fail(CS_EINVAL, "temperature %g K outside the opacity table's domain [%g, %g]", Tk[k], tb.T.front(), tb.T.back());
+        if (!(lp >= tb.lnP.front() - 1e-12 && lp <= tb.lnP.back() + 1e-12))
+            return fail(CS_EINVAL, "Pressure %g Pa outside the opacity table's domain [%g, %g]", Pk[k], std::exp(tb.lnP.front()), std::exp(tb.lnP.back()));
+        cheb_basis(tb.T, Tk[k], a);
+        cheb_basis(tb.lnP, std::min(std::max(lp, tb.lnP.front()), tb.lnP.back()), b);
+        for (int j = 0; j < tb.nP; j++)
+            for (int i = 0; i < tb.nT; i++) W[(size_t)(i + tb.nT * j) * K + k] = a[i] * b[j];
+    }
+    return CS_OK;
+}
+
+int cs_table_eval(cs_ctx *ctx, int table_slot, double T, double P, int64_t i0, int64_t n, double *sigma_out)
+{
+    if (!ctx || table_slot < 0 || table_slot >= CS_MAX_TABLE || !ctx->tab[table_slot].present) return fail(CS_EINVAL, "table slot is empty");
+    TableDev &tb = ctx->tab[table_slot];
+    if (i0 < 0 || n < 1 || i0 + n > tb.nnu) return fail(CS_EINVAL, "wavenumber range out of bounds");
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    std::vector<double> W;
+    int rc;
+    if ((rc = table_weights(tb, 1, &T, &P, W))) return rc;
+    const int M = tb.nT * tb.nP;
+    const double one = 1.0;
+    if ((rc = upload(ctx->tmpA, W.data(), M, s)) || (rc = upload(ctx->tmpB, &one, 1, s))) return rc;
+    HIPCHK(ctx->tmpC.reserve((size_t)tb.nnu * sizeof(double)));
+    HIPCHK(hipMemsetAsync(ctx->tmpC.p, 0, (size_t)tb.nnu * sizeof(double), s));
+    hipLaunchKernelGGL(k_table_eval, dim3((unsigned)((tb.nnu + 255) / 256), 1), dim3(256), (size_t)M * CS_TAB_KC * sizeof(double), s,
+                       tb.Z.as<double>(), M, tb.nnu, ctx->tmpA.as<double>(), 1, ctx->tmpB.as<double>(), ctx->tmpC.as<double>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(sigma_out, ctx->tmpC.as<double>() + i0, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return CS_OK;
+}
+
+static int upload_tables(cs_ctx *ctx, const double *conc_tab)
+{
+    Column &c = ctx->col;
+    hipStream_t s = ctx->stream;
+    const int nt = (int)c.tab.size();
+    std::vector<double> W, cc(c.K);
+    int rc;
+    for (int t = 0; t < nt; t++) {
+        TableDev &tb = ctx->tab[c.tab[t].slot];
+        if ((rc = table_weights(tb, c.K, c.h_Tk.data(), c.h_Pk.data(), W))) return rc;
+        for (int k = 0; k < c.K; k++) {
+            cc[k] = conc_tab[t + (size_t)nt * k];
+            if (!(cc[k] >= 0 && cc[k] <= 1)) return fail(CS_EINVAL, "gas molar concentrations must be in [0,1], not %g", cc[k]);
+        }
+        if ((rc = upload(c.tab[t].W, W.data(), W.size(), s)) || (rc = upload(c.tab[t].conc, cc.data(), c.K, s))) return rc;
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    return CS_OK;
+}
+
+int cs_column_set_tables(cs_ctx *ctx, int ntab, const int *table_slots, const double *conc_tab)
+{
+    if (!ctx || !ctx->col.ready) return fail(CS_ESTATE, "cs_column_setup has not been called");
+    if (ntab < 0 || ntab > CS_MAX_TABLE) return fail(CS_EINVAL, "ntab out of range");
+    Column &c = ctx->col;
+    HIPCHK(hipSetDevice(ctx->device));
+    c.tab.clear();
+    c.tab.resize(ntab);
+    for (int t = 0; t < ntab; t++) {
+        const int sl = table_slots[t];
+        if (sl < 0 || sl >= CS_MAX_TABLE || !ctx->tab[sl].present) return fail(CS_EINVAL, "table slot %d is empty", sl);
+        TableDev &tb = ctx->tab[sl];
+        if (tb.nnu != c.nnu || !std::equal(tb.nu.begin(), tb.nu.end(), c.h_nu.begin()))
+            return fail(CS_EINVAL, "gases must have identical wavenumber vectors");
+        c.tab[t].slot = sl;
+    }
+    int rc = upload_tables(ctx, conc_tab);
+    if (rc) c.tab.clear();
+    return rc;
+}
+
 int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wts, int np, const double *P, double g,
                     int nlobatto, const double *T_nodes, const double *mu_nodes, const double *T_levels, int ngas,
                     const int *gas_slots, const int *shapes, const double *dnu_cuts, const double *conc,
@@ -566,12 +759,13 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
     HIPCHK(c.F.reserve((size_t)2 * np * sizeof(double)));
     HIPCHK(hipStreamSynchronize(s));
     c.ready = true;  // state upload below needs the sizes
-    if ((rc = cs_column_update_state(ctx, T_nodes, mu_nodes, T_levels, conc))) { c.ready = false; return rc; }
+    c.tab.clear();
+    if ((rc = cs_column_update_state(ctx, T_nodes, mu_nodes, T_levels, conc, nullptr))) { c.ready = false; return rc; }
     return CS_OK;
 }
 
 int cs_column_update_state(cs_ctx *ctx, const double *T_nodes, const double *mu_nodes, const double *T_levels,
-                           const double *conc)
+                           const double *conc, const double *conc_tab)
 {
     if (!ctx || !ctx->col.ready) return fail(CS_ESTATE, "cs_column_setup has not been called");
     Column &c = ctx->col;
@@ -587,6 +781,7 @@ int cs_column_update_state(cs_ctx *ctx, const double *T_nodes, const double *mu_
             muk[i * (nlob - 1) + n] = mu_nodes[n + (size_t)nlob * i];
         }
     int rc;
+    c.h_Tk = Tk;
     for (int gi = 0; gi < c.ngas; gi++)
         if ((rc = check_gas_states(ctx->gas[c.gas[gi].slot], K, Tk.data()))) return rc;
     if ((rc = upload(c.Tk, Tk.data(), K, s)) || (rc = upload(c.muk, muk.data(), K, s)) ||
@@ -606,6 +801,10 @@ int cs_column_update_state(cs_ctx *ctx, const double *T_nodes, const double *mu_
             return rc;
     }
     HIPCHK(hipStreamSynchronize(s));
+    if (!c.tab.empty()) {
+        if (!conc_tab) return fail(CS_EINVAL, "the resident column has opacity tables: conc_tab is required");
+        if ((rc = upload_tables(ctx, conc_tab))) return rc;
+    }
     return CS_OK;
 }
 
@@ -630,6 +829,15 @@ static int run_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev)
                    cg.J1.as<int32_t>(), cg.win.as<WaveWin>(), cg.zones.as<Zone>(), cg.gmax.as<double>(), cg.cut, c.sigma_gray, extra, sig, gi > 0,
                    ev ? ev[e] : nullptr, ev ? ev[e + 1] : nullptr);
         if (ev) { e += 2; HIPCHK(hipEventRecord(ev[e++], s)); }
+    }
+    for (auto &t : c.tab) {  // baked gases: sigma += fC * exp(Phi(T, ln P))
+        TableDev &tb = ctx->tab[t.slot];
+        const int M = tb.nT * tb.nP;
+        if ((size_t)M * CS_TAB_KC * sizeof(double) > 65536)
+            HIPCHK(hipFuncSetAttribute((const void *)k_table_eval, hipFuncAttributeMaxDynamicSharedMemorySize, M * CS_TAB_KC * (int)sizeof(double)));
+        hipLaunchKernelGGL(k_table_eval, dim3((unsigned)c.ntile, (unsigned)((K + CS_TAB_KC - 1) / CS_TAB_KC)), dim3(256),
+                           (size_t)M * CS_TAB_KC * sizeof(double), s, tb.Z.as<double>(), M, c.nnu, t.W.as<double>(), K,
+                           t.conc.as<double>(), sig);
     }
     launch_rt(c.nstream, c.ntile, (size_t)2 * c.np * 4 * sizeof(double), s, c.rt, c.nu.as<double>(), c.wts.as<double>(),
               c.nnu, sig, c.muk.as<double>(), c.P.as<double>(), c.Tlev.as<double>(),

@@ -569,6 +569,55 @@ __global__ __launch_bounds__(256) void k_fill(int64_t n, double base, const doub
     if (i < n) sigma[i] = base + (extra ? extra[i] : 0.0);
 }
 
+
+// ---- opacity tables ("Mode T": the reference's baked Gas objects, gases.jl:68-145) --------------------------------------
+// Z[m][nu], m = iT + nT*iP, holds sigma after cs_bake's line sums.  Reproduce the tail of bake + OpacityTable:
+//   * a wavenumber whose states mix exact zeros with non-zeros is zeroed for every state (gases.jl:132-142);
+//   * ln(sigma), or ln(floatmin) everywhere when no state exceeds floatmin (gases.jl:76-79).
+__global__ __launch_bounds__(256) void k_table_log(double *__restrict__ Z, int M, int64_t nnu)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nnu) return;
+    const double tiny = 2.2250738585072014e-308;
+    double mn = 1e300, mx = 0.0;
+    for (int m = 0; m < M; m++) { const double v = Z[(size_t)m * nnu + i]; mn = fmin(mn, v); mx = fmax(mx, v); }
+    const bool zero = (mn == 0.0 && mx > 0.0) || !(mx > tiny);
+    const double lt = log(tiny);
+    for (int m = 0; m < M; m++) { const size_t o = (size_t)m * nnu + i; Z[o] = zero ? lt : log(Z[o]); }
+}
+
+// sigma[k][nu] += conc[k] * exp( sum_m Z[m][nu] * W[m][k] ):  the Gas functor fC(T,P)*exp(Phi(T, ln P)) (gases.jl:85,278)
+// with the 2-D Chebyshev interpolant written as a contraction against the Lagrange-basis weights W = a(T_k) (x) b(ln P_k).
+// Block = 256 wavenumbers x 16 node states; the 16 weight columns are staged in LDS and read as broadcasts.
+#define CS_TAB_KC 16
+__global__ __launch_bounds__(256) void k_table_eval(const double *__restrict__ Z, int M, int64_t nnu, const double *__restrict__ W,
+                                                     int K, const double *__restrict__ conc, double *__restrict__ sigma)
+{
+    extern __shared__ double wsh[];  // [M][CS_TAB_KC]
+    const int k0 = blockIdx.y * CS_TAB_KC;
+    for (int e = threadIdx.x; e < M * CS_TAB_KC; e += 256) {
+        const int m = e / CS_TAB_KC, kk = e - m * CS_TAB_KC;
+        wsh[e] = (k0 + kk < K) ? W[(size_t)m * K + k0 + kk] : 0.0;
+    }
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t ii = i < nnu ? i : nnu - 1;
+    double acc[CS_TAB_KC];
+#pragma unroll
+    for (int kk = 0; kk < CS_TAB_KC; kk++) acc[kk] = 0.0;
+    for (int m = 0; m < M; m++) {
+        const double z = Z[(size_t)m * nnu + ii];
+        const double *w = wsh + m * CS_TAB_KC;
+#pragma unroll
+        for (int kk = 0; kk < CS_TAB_KC; kk++) acc[kk] = __builtin_fma(z, w[kk], acc[kk]);
+    }
+    if (i < nnu) {
+#pragma unroll
+        for (int kk = 0; kk < CS_TAB_KC; kk++)
+            if (k0 + kk < K) sigma[(size_t)(k0 + kk) * nnu + i] += conc[k0 + kk] * exp(acc[kk]);
+    }
+}
+
 __global__ void k_faddeeva(int64_t n, const double *__restrict__ x, const double *__restrict__ y, double *__restrict__ out)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -40,6 +40,7 @@ enum {
 enum { CS_SHAPE_VOIGT = 0, CS_SHAPE_LORENTZ = 1, CS_SHAPE_DOPPLER = 2, CS_SHAPE_PHCO2 = 3 };
 
 #define CS_MAX_GAS 16
+#define CS_MAX_TABLE 16
 #define CS_CHEB_LD 16 /* leading dimension of the Chebyshev coefficient table */
 #define CS_MAX_STREAM 16
 #define CS_MAX_LOBATTO 16
@@ -74,6 +75,22 @@ int cs_gas_clear(cs_ctx *ctx, int slot);
  */
 int cs_shape_batch(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t nnu, const double *nu, int K,
                    const double *T, const double *P, const double *Pp, double *sigma, int64_t ld_state);
+
+/*
+ * Bake a gas into a resident opacity table ("Mode T": the reference's default Gas objects).
+ * Replaces: bake(sl, fC, shape!, dnu_cut, nu, Omega) gases.jl:97-145 (all nT*nP line sums in one launch, the
+ * zero-row scrub :132-142) and OpacityTable(T, P, sigma) gases.jl:75-82 (ln sigma, or ln(floatmin) for empty rows).
+ *   T[nT], P[nP] : Omega.T, Omega.P (Chebyshev extrema in T and ln P, gases.jl:57-58)
+ *   conc         : [nT, nP] column-major, conc[i + nT*j] = fC(T_i, P_j) (partial pressure = conc*P, gases.jl:126)
+ *   lnsigma_out  : NULL or host [nnu, nT, nP] column-major (nu fastest) -- the tables themselves, for inspection
+ * The table stays in HBM as slot `table_slot` and is evaluated by cs_column_set_tables / cs_column_run through the
+ * 2-D Chebyshev interpolant (BichebyshevInterpolator, gases.jl:80,85) in barycentric form.
+ */
+int cs_bake(cs_ctx *ctx, int gas_slot, int table_slot, int shape, double dnu_cut, int64_t nnu, const double *nu, int nT,
+            const double *T, int nP, const double *P, const double *conc, double *lnsigma_out);
+int cs_table_clear(cs_ctx *ctx, int table_slot);
+/* sigma(nu[i0..i0+n), T, P) of a baked table WITHOUT the concentration factor: rawsigma(g, T, P) gases.jl:256-263 */
+int cs_table_eval(cs_ctx *ctx, int table_slot, double T, double P, int64_t i0, int64_t n, double *sigma_out);
 
 /*
  * B3: whole-column monochromatic fluxes + band integrals with the Discretized core, line-by-line at every
@@ -116,6 +133,10 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
                     int ngas, const int *gas_slots, const int *shapes, const double *dnu_cuts, const double *conc,
                     double sigma_gray, const double *sigma_extra, const double *S_toa, const double *albedo,
                     double theta_s, int nstream, int want_tau, int want_M);
+/* add baked gases to the resident column: the Gas functor fC(T,P)*exp(Phi_i(T, ln P)) (gases.jl:278) at every node.
+ * conc_tab: [ntab, K] column-major = fC_t(T_k, P_k).  Node states outside a table's (T,P) domain are an error
+ * (checkpressures absorbers.jl:237-246; the interpolator's own bounds check for T). */
+int cs_column_set_tables(cs_ctx *ctx, int ntab, const int *table_slots, const double *conc_tab);
 int cs_column_run(cs_ctx *ctx, void *stream);
 int cs_column_sync(cs_ctx *ctx);
 /* run `reps` evaluations with HIP events between the kernel classes on `stream`; ms[5] = average milliseconds per
@@ -129,7 +150,7 @@ int cs_column_sigma_fetch(cs_ctx *ctx, double *sigma);
 int cs_column_counts(cs_ctx *ctx, int64_t *pair_evals, int64_t *lines_in_range);
 /* update only the temperature-dependent inputs of a resident column (RCM stepping, radiative_convective.jl:109-144) */
 int cs_column_update_state(cs_ctx *ctx, const double *T_nodes, const double *mu_nodes, const double *T_levels,
-                           const double *conc);
+                           const double *conc, const double *conc_tab);
 
 /* Scalar helpers exported for tests of the host logic (same formulas the kernels use). */
 int cs_streamnodes(int n, double *m, double *W);    /* core/shared.jl:4-21 */

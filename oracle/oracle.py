@@ -203,3 +203,48 @@ def fluxes_discretized(nu, P, g, nlobatto, Tn, mun, Tlev, gases, shapes, cuts, c
 
 def num_threads():
     return lib().cso_num_threads()
+
+
+# ---- opacity tables (gases.jl:68-145): numpy restatement, test infrastructure only ------------------------------------
+
+def bake(sl, conc, nu, Tgrid, Pgrid, shape="voigt", cut=25.0):
+    """bake + OpacityTable: ln(sigma) of shape [nnu, nT, nP]; conc[i, j] = fC(T_i, P_j).  Zero-row scrub gases.jl:132-142,
+    ln(floatmin) for all-zero rows gases.jl:76-79."""
+    nu = _f64(nu)
+    L = sl if isinstance(sl, Lines) else Lines(sl)
+    sig = np.zeros((len(nu), len(Tgrid), len(Pgrid)))
+    for i, T in enumerate(Tgrid):
+        for j, P in enumerate(Pgrid):
+            sig[:, i, j] = shape_bang(shape, nu, L, T, P, conc[i, j] * P, cut)      # shape!(sigma_ij, nu, sl, T, P, C*P, cut) :126
+    flat = sig.reshape(len(nu), -1)
+    z = (flat.min(axis=1) == 0) & (flat.max(axis=1) > 0)
+    sig[z] = 0.0
+    tiny = np.finfo(float).tiny
+    out = np.empty_like(sig)
+    for n in range(len(nu)):
+        out[n] = np.log(tiny) if np.all(sig[n] <= tiny) else np.log(sig[n])
+    return out
+
+
+def cheb_basis(x, v):
+    """Lagrange basis on Chebyshev extrema x (ascending) at v, barycentric form (the unique interpolating polynomial
+    that BichebyshevInterpolator evaluates, gases.jl:80,85)."""
+    x = np.asarray(x, float)
+    n = len(x)
+    hit = np.nonzero(x == v)[0]
+    if len(hit):
+        l = np.zeros(n)
+        l[hit[0]] = 1.0
+        return l
+    w = np.where(np.arange(n) % 2 == 1, -1.0, 1.0)
+    w[0] *= 0.5
+    w[-1] *= 0.5
+    t = w / (v - x)
+    return t / t.sum()
+
+
+def table_sigma(lnsig, Tgrid, Pgrid, T, P):
+    """OpacityTable functor: exp(Phi(T, ln P)) for every wavenumber (gases.jl:85)"""
+    a = cheb_basis(Tgrid, T)
+    b = cheb_basis(np.log(Pgrid), np.log(P))
+    return np.exp(np.einsum("nij,i,j->n", lnsig, a, b))
