@@ -15,6 +15,7 @@ HEADER = os.path.join(os.path.dirname(_HERE), "include", "clearsky_hip.h")
 
 CS_MAX_GAS = 16
 CS_MAX_TABLE = 16
+CS_MAX_CIA = 8
 CHEB_LD = 16
 SHAPES = {"voigt": 0, "lorentz": 1, "doppler": 2, "PHCO2": 3, "phco2": 3}
 
@@ -36,6 +37,10 @@ SIGNATURES = {
     "cs_bake": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int64, _dp, C.c_int, _dp, C.c_int, _dp, _dp, _dp]),
     "cs_table_clear": (C.c_int, [_vp, C.c_int]),
     "cs_table_eval": (C.c_int, [_vp, C.c_int, C.c_double, C.c_double, C.c_int64, C.c_int64, _dp]),
+    "cs_cia_begin": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "cs_cia_band": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp, C.c_int, _dp, _dp]),
+    "cs_cia_clear": (C.c_int, [_vp, C.c_int]),
+    "cs_column_set_cia": (C.c_int, [_vp, C.c_int, _ip, _ip, _dp, _dp]),
     "cs_column_set_tables": (C.c_int, [_vp, C.c_int, _ip, _dp]),
     "cs_fluxes_discretized": (C.c_int, [_vp, C.c_int64, _dp, C.c_int, _dp, C.c_double, C.c_int, _dp, _dp, _dp, C.c_int,
                                         _ip, _ip, _dp, _dp, C.c_double, _dp, _dp, _dp, C.c_double, C.c_int, _dp, _dp,

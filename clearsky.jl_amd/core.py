@@ -15,8 +15,9 @@ from typing import Callable, Optional, Sequence
 import numpy as np
 
 from . import constants as K
-from ._lib import (CHEB_LD, CS_MAX_GAS, CS_MAX_TABLE, SHAPES, ClearSkyHIPError, as_f64, check, dptr, lib)
+from ._lib import (CHEB_LD, CS_MAX_CIA, CS_MAX_GAS, CS_MAX_TABLE, SHAPES, ClearSkyHIPError, as_f64, check, dptr, lib)
 from .hitran import TMAX, TMIN, SpectralLines
+from .cia import CIATables, cia, readcia
 
 # ----------------------------------------------------------------------------------------------------------------
 # small numerical helpers (host)
@@ -245,6 +246,28 @@ class Context:
         self._slots[key] = (slot, sl)
         return slot
 
+
+    def cia_slot(self, x: CIATables) -> int:
+        """Upload a CIATables object (once) and return its slot."""
+        if not hasattr(self, "_cia"):
+            self._cia = {}
+        key = id(x)
+        if key in self._cia:
+            return self._cia[key][0]
+        if len(self._cia) >= CS_MAX_CIA:
+            raise ClearSkyHIPError(-1, "no free CIA slot")
+        slot = len(self._cia)
+        nb = len(x.grids) + len(x.single)
+        check(lib().cs_cia_begin(self._h, slot, nb))
+        b = 0
+        for g_nu, g_T, lnk in x.grids:
+            check(lib().cs_cia_band(self._h, slot, b, len(g_nu), dptr(as_f64(g_nu)), len(g_T), dptr(as_f64(g_T)), dptr(as_f64(lnk))))
+            b += 1
+        for s_nu, s_lnk, s_T in x.single:
+            check(lib().cs_cia_band(self._h, slot, b, len(s_nu), dptr(as_f64(s_nu)), 1, dptr(as_f64([s_T])), dptr(as_f64(s_lnk))))
+            b += 1
+        self._cia[key] = (slot, x)
+        return slot
 
     def table_slot(self, owner) -> int:
         """Reserve an opacity-table slot for a baked Gas (released when the Gas is garbage collected)."""
@@ -486,17 +509,39 @@ class UnifiedAbsorber:
         assert len(absorbers) > 0, "no absorbers... nothing to group"
         assert len(absorbers) == len(set(map(id, absorbers))), "duplicate absorbers"
         for a in absorbers:
-            if not (isinstance(a, AbstractGas) or callable(a)):
+            if not (isinstance(a, (AbstractGas, CIATables)) or callable(a)):
                 raise TypeError("absorbers must only be gases (<: Gas), CIA objects, or functions in the form σ(ν, T, P)")
         self.gas = tuple(a for a in absorbers if isinstance(a, AbstractGas))
         if not self.gas:
             raise ValueError("must have at least one Gas object, which specifies wavenumber samples")
-        self.fun = tuple(a for a in absorbers if not isinstance(a, AbstractGas))
+        realgas = [g_ for g_ in self.gas if isinstance(g_, (Gas, DirectGas))]     # "real gases, ignoring Gray" absorbers.jl:67
+        self.cia = tuple(CIA(x, realgas) for x in absorbers if isinstance(x, CIATables))   # absorbers.jl:69
+        self.fun = tuple(a for a in absorbers if not isinstance(a, (AbstractGas, CIATables)))
         nu0 = self.gas[0].nu
         assert all(len(g.nu) == len(nu0) and np.array_equal(g.nu, nu0) for g in self.gas), \
             "gases must have identical wavenumber vectors"
         self.nu = nu0
         self.nnu = len(nu0)
+
+
+class CIA:
+    """CIA(ciatables, gases): a CIATables object paired with the two gases whose partial pressures it needs
+    (collision_induced_absorption.jl:431-465).  chi(nu, T, P) = cia(nu, tables, T, P, P*C1(T,P), P*C2(T,P))."""
+
+    def __init__(self, x: CIATables, gases):
+        if len(gases) == 0:
+            raise ValueError("no Gas objects provided, cannot create CIA object")
+
+        def find(f):
+            m = [g_ for g_ in gases if g_.formula == f]
+            assert len(m) > 0, f"pairing failed for {x.name} CIA, gas {f} is missing"
+            assert len(m) == 1, f"pairing failed for {x.name} CIA, duplicate {f} gases found"
+            return m[0]
+        self.name, self.formulae, self.x = x.name, x.formulae, x
+        self.g1, self.g2 = find(x.formulae[0]), find(x.formulae[1])
+
+    def __call__(self, nu, T, P):
+        return cia(nu, self.x, T, P, P * self.g1.concentration(T, P), P * self.g2.concentration(T, P))
 
 
 def unifyabsorbers(absorbers):
@@ -635,6 +680,13 @@ class Column:
             for k in range(self.K):
                 ct[ti, k] = g_.fC(self.Tk[k], self.Pk[k])
         self.conc_tab = ct
+        nc = len(self.U.cia)
+        self.cia_P1 = np.zeros((nc, self.K), order="F")
+        self.cia_P2 = np.zeros((nc, self.K), order="F")
+        for ci, x in enumerate(self.U.cia):
+            for k in range(self.K):
+                self.cia_P1[ci, k] = self.Pk[k] * x.g1.concentration(self.Tk[k], self.Pk[k])   # cia…jl:378-382
+                self.cia_P2[ci, k] = self.Pk[k] * x.g2.concentration(self.Tk[k], self.Pk[k])
         if self.U.fun:
             ex = np.zeros((self.K, self.nnu))
             for k in range(self.K):
@@ -660,8 +712,18 @@ class Column:
             slots = np.array([g_.slot for g_ in self.baked], dtype=np.int32)
             check(lib().cs_column_set_tables(self.ctx.handle, len(slots), slots.ctypes.data_as(C.POINTER(C.c_int)),
                                              dptr(self.conc_tab.ravel(order="F").copy())))
+        self._set_cia()
         self._set = True
         self.ctx._resident = self      # a context holds ONE resident column
+
+    def _set_cia(self):
+        if not self.U.cia:
+            return
+        slots = np.array([self.ctx.cia_slot(x.x) for x in self.U.cia], dtype=np.int32)
+        flags = np.array([int(x.x.extrapolate) | (int(x.x.singles) << 1) for x in self.U.cia], dtype=np.int32)
+        check(lib().cs_column_set_cia(self.ctx.handle, len(slots), slots.ctypes.data_as(C.POINTER(C.c_int)),
+                                      flags.ctypes.data_as(C.POINTER(C.c_int)), dptr(self.cia_P1.ravel(order="F").copy()),
+                                      dptr(self.cia_P2.ravel(order="F").copy())))
 
     def _ensure_resident(self):
         if getattr(self.ctx, "_resident", None) is not self:
@@ -680,6 +742,7 @@ class Column:
                                            dptr(self.mun.ravel(order="F").copy()), dptr(self.Tlev),
                                            dptr(self.conc.ravel(order="F").copy()) if self.conc.size else None,
                                            dptr(self.conc_tab.ravel(order="F").copy()) if self.conc_tab.size else None))
+        self._set_cia()
 
     # -- execution -------------------------------------------------------------------------------------------------
     def run(self, stream: int = 0):

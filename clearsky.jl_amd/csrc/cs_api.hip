@@ -97,6 +97,21 @@ struct ColTab {
     DevBuf W, conc;  // [M][K], [K]
 };
 
+struct CiaBandHost {
+    std::vector<double> nu, T;
+    DevBuf dnu, dlnk;
+};
+struct CiaDev {
+    bool present = false;
+    std::vector<CiaBandHost> bands;
+    int filled = 0;
+};
+struct ColCia {
+    int slot = 0, flags = 0;
+    DevBuf bands, st, rho1, rho2, rhoa;
+    int nband = 0;
+};
+
 struct ColGas {
     int slot = 0, shape = 0;
     double cut = 25.0;
@@ -115,6 +130,7 @@ struct Column {
     std::vector<double> h_P, h_Pk, h_xs, h_nu;
     std::vector<ColGas> gas;
     std::vector<ColTab> tab;
+    std::vector<ColCia> cia;
     std::vector<double> h_Tk;
     DevBuf nu, wts, P, Pk, Tk, muk, Tlev, extra, S_toa, albedo;
     DevBuf hot, cold, sigma, tau, Mup, Mdn, partial, F, stage;
@@ -127,6 +143,7 @@ struct cs_ctx {
     hipStream_t stream = nullptr;
     GasTable gas[CS_MAX_GAS];
     TableDev tab[CS_MAX_TABLE];
+    CiaDev cia[CS_MAX_CIA];
     Column col;
     DevBuf tmpA, tmpB, tmpC;
 };
@@ -656,6 +673,122 @@ int cs_column_set_tables(cs_ctx *ctx, int ntab, const int *table_slots, const do
     return rc;
 }
 
+int cs_cia_begin(cs_ctx *ctx, int cia_slot, int nband)
+{
+    if (!ctx || cia_slot < 0 || cia_slot >= CS_MAX_CIA) return fail(CS_EINVAL, "bad CIA slot");
+    if (nband < 1 || nband > CS_MAX_CIA_BAND) return fail(CS_EINVAL, "a CIA object holds 1..%d bands", CS_MAX_CIA_BAND);
+    ctx->cia[cia_slot] = CiaDev();
+    ctx->cia[cia_slot].bands.resize(nband);
+    return CS_OK;
+}
+
+int cs_cia_band(cs_ctx *ctx, int cia_slot, int band, int nb, const double *nu_b, int nt, const double *T_b, const double *lnk)
+{
+    if (!ctx || cia_slot < 0 || cia_slot >= CS_MAX_CIA) return fail(CS_EINVAL, "bad CIA slot");
+    CiaDev &cd = ctx->cia[cia_slot];
+    if (band < 0 || band >= (int)cd.bands.size()) return fail(CS_EINVAL, "band index out of range");
+    if (nb < 2 || nt < 1) return fail(CS_EINVAL, "a band needs at least 2 wavenumbers and 1 temperature");
+    for (int i = 1; i < nb; i++)
+        if (!(nu_b[i] > nu_b[i - 1])) return fail(CS_EORDER, "band wavenumbers must be ascending");
+    for (int j = 1; j < nt; j++)
+        if (!(T_b[j] > T_b[j - 1])) return fail(CS_EORDER, "band temperatures must be ascending");
+    HIPCHK(hipSetDevice(ctx->device));
+    CiaBandHost &b = cd.bands[band];
+    b.nu.assign(nu_b, nu_b + nb);
+    b.T.assign(T_b, T_b + nt);
+    int rc;
+    if ((rc = upload(b.dnu, nu_b, nb, ctx->stream)) || (rc = upload(b.dlnk, lnk, (size_t)nb * nt, ctx->stream))) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    cd.filled++;
+    cd.present = cd.filled >= (int)cd.bands.size();
+    return CS_OK;
+}
+
+int cs_cia_clear(cs_ctx *ctx, int cia_slot)
+{
+    if (!ctx || cia_slot < 0 || cia_slot >= CS_MAX_CIA) return fail(CS_EINVAL, "bad CIA slot");
+    ctx->cia[cia_slot] = CiaDev();
+    return CS_OK;
+}
+
+// per-node inputs of a CIA pair: temperature cells of every band + number densities (cia(k,T,Pa,P1,P2), :295-303)
+static int upload_cia_state(cs_ctx *ctx, ColCia &cc, const double *P1, const double *P2, int stride, int idx)
+{
+    Column &c = ctx->col;
+    CiaDev &cd = ctx->cia[cc.slot];
+    const int K = c.K, nband = (int)cd.bands.size();
+    const bool extrap = cc.flags & 1, singles = cc.flags & 2;
+    std::vector<CiaState> st((size_t)nband * K);
+    for (int b = 0; b < nband; b++) {
+        const std::vector<double> &Tg = cd.bands[b].T;
+        const int nt = (int)Tg.size();
+        for (int k = 0; k < K; k++) {
+            CiaState s;
+            s.use = 0; s.jT = 0; s.fT = 0.0;
+            const double T = c.h_Tk[k];
+            if (nt == 1) {
+                s.use = singles ? 1 : 0;
+            } else {
+                double Te = T;
+                if (T >= Tg.front() && T <= Tg.back()) s.use = 1;                       // :258
+                else if (extrap) { s.use = 1; Te = T > Tg.back() ? Tg.back() : Tg.front(); }  // :261-263
+                if (s.use) {
+                    int j = (int)(std::upper_bound(Tg.begin(), Tg.end(), Te) - Tg.begin()) - 1;
+                    j = std::min(std::max(j, 0), nt - 2);
+                    s.jT = j;
+                    s.fT = (Te - Tg[j]) / (Tg[j + 1] - Tg[j]);
+                }
+            }
+            st[(size_t)b * K + k] = s;
+        }
+    }
+    std::vector<double> r1(K), r2(K), ra(K);
+    for (int k = 0; k < K; k++) {
+        const double T = c.h_Tk[k], Pa = c.h_Pk[k];
+        r1[k] = (P1[idx + (size_t)stride * k] / kAtm) * (273.15 / T);   // amagat, :297-298 (T0 = 273.15, constants.jl:23)
+        r2[k] = (P2[idx + (size_t)stride * k] / kAtm) * (273.15 / T);
+        ra[k] = 1e-6 * Pa / (kKb * T);                                  // molecules/cm^3, :300
+    }
+    hipStream_t s = ctx->stream;
+    int rc;
+    if ((rc = upload(cc.st, st.data(), st.size(), s)) || (rc = upload(cc.rho1, r1.data(), K, s)) ||
+        (rc = upload(cc.rho2, r2.data(), K, s)) || (rc = upload(cc.rhoa, ra.data(), K, s)))
+        return rc;
+    return CS_OK;
+}
+
+int cs_column_set_cia(cs_ctx *ctx, int ncia, const int *cia_slots, const int *flags, const double *P1, const double *P2)
+{
+    if (!ctx || !ctx->col.ready) return fail(CS_ESTATE, "cs_column_setup has not been called");
+    if (ncia < 0 || ncia > CS_MAX_CIA) return fail(CS_EINVAL, "ncia out of range");
+    Column &c = ctx->col;
+    HIPCHK(hipSetDevice(ctx->device));
+    c.cia.clear();
+    c.cia.resize(ncia);
+    int rc;
+    for (int t = 0; t < ncia; t++) {
+        ColCia &cc = c.cia[t];
+        cc.slot = cia_slots[t];
+        cc.flags = flags ? flags[t] : 0;
+        if (cc.slot < 0 || cc.slot >= CS_MAX_CIA || !ctx->cia[cc.slot].present) { c.cia.clear(); return fail(CS_EINVAL, "CIA slot %d is empty", cc.slot); }
+        CiaDev &cd = ctx->cia[cc.slot];
+        cc.nband = (int)cd.bands.size();
+        std::vector<CiaBand> hb(cc.nband);
+        for (int b = 0; b < cc.nband; b++) {
+            hb[b].nu = cd.bands[b].dnu.as<double>();
+            hb[b].lnk = cd.bands[b].dlnk.as<double>();
+            hb[b].nb = (int)cd.bands[b].nu.size();
+            hb[b].nt = (int)cd.bands[b].T.size();
+        }
+        if ((rc = upload(cc.bands, hb.data(), hb.size(), ctx->stream)) || (rc = upload_cia_state(ctx, cc, P1, P2, ncia, t))) {
+            c.cia.clear();
+            return rc;
+        }
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return CS_OK;
+}
+
 int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wts, int np, const double *P, double g,
                     int nlobatto, const double *T_nodes, const double *mu_nodes, const double *T_levels, int ngas,
                     const int *gas_slots, const int *shapes, const double *dnu_cuts, const double *conc,
@@ -760,6 +893,7 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
     HIPCHK(hipStreamSynchronize(s));
     c.ready = true;  // state upload below needs the sizes
     c.tab.clear();
+    c.cia.clear();
     if ((rc = cs_column_update_state(ctx, T_nodes, mu_nodes, T_levels, conc, nullptr))) { c.ready = false; return rc; }
     return CS_OK;
 }
@@ -839,6 +973,9 @@ static int run_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev)
                            (size_t)M * CS_TAB_KC * sizeof(double), s, tb.Z.as<double>(), M, c.nnu, t.W.as<double>(), K,
                            t.conc.as<double>(), sig);
     }
+    for (auto &cc : c.cia)  // CIA pairs
+        hipLaunchKernelGGL(k_cia, dim3((unsigned)c.ntile), dim3(256), 0, s, cc.nband, cc.bands.as<CiaBand>(), cc.st.as<CiaState>(),
+                           c.nu.as<double>(), c.nnu, K, cc.rho1.as<double>(), cc.rho2.as<double>(), cc.rhoa.as<double>(), sig);
     launch_rt(c.nstream, c.ntile, (size_t)2 * c.np * 4 * sizeof(double), s, c.rt, c.nu.as<double>(), c.wts.as<double>(),
               c.nnu, sig, c.muk.as<double>(), c.P.as<double>(), c.Tlev.as<double>(),
               c.has_S ? c.S_toa.as<double>() : nullptr, c.has_alb ? c.albedo.as<double>() : nullptr, c.tau.as<double>(),

@@ -618,6 +618,67 @@ __global__ __launch_bounds__(256) void k_table_eval(const double *__restrict__ Z
     }
 }
 
+// ---- collision-induced absorption (collision_induced_absorption.jl:145-303) ----------------------------------------------
+// One CIA object = a few bands; a band is ln k on a (nu, T) grid evaluated bilinearly (BilinearInterpolator of ln k with
+// NoBoundaries, :207) or a single-temperature range evaluated linearly in nu (:188).  Per node state the host prepares the
+// temperature cell (wave-uniform); each lane finds its own wavenumber cell once per band.
+struct CiaBand {
+    const double *nu;   // [nb] ascending
+    const double *lnk;  // [nb][nt], nu fastest
+    int nb, nt;
+};
+struct CiaState {       // per (band, node): temperature cell of the band's T grid, or "skip"
+    int use, jT;        // use = 0: T outside the band and no extrapolation (or a single range while singles = false)
+    double fT;          // fractional position in the T cell (0 for single ranges)
+};
+#define CS_MAX_CIA_BAND 24
+
+// sigma[k][nu] += (ktot*Lo^2)*rho1*rho2/rhoa   (cia(k,T,Pa,P1,P2), :295-303)
+__global__ __launch_bounds__(256) void k_cia(int nband, const CiaBand *__restrict__ bands, const CiaState *__restrict__ st,
+                                              const double *__restrict__ nu, int64_t nnu, int K,
+                                              const double *__restrict__ rho1, const double *__restrict__ rho2,
+                                              const double *__restrict__ rhoa, double *__restrict__ sigma)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nnu) return;
+    const double v = nu[i];
+    int cell[CS_MAX_CIA_BAND];
+    double fx[CS_MAX_CIA_BAND];
+    for (int b = 0; b < nband; b++) {
+        const CiaBand B = bands[b];
+        cell[b] = -1;
+        fx[b] = 0.0;
+        if (B.nu[0] <= v && v <= B.nu[B.nb - 1]) {  // Phi.G.xa <= nu <= Phi.G.xb, :255
+            int lo = 0, hi = B.nb - 1;              // cell index c with nu[c] <= v < nu[c+1] (last cell when v == nu[nb-1])
+            while (hi - lo > 1) { int m = (lo + hi) >> 1; if (B.nu[m] <= v) lo = m; else hi = m; }
+            cell[b] = lo;
+            fx[b] = (v - B.nu[lo]) / (B.nu[lo + 1] - B.nu[lo]);
+        }
+    }
+    const double Lo2 = 7.21879268e38;  // constants.jl:18
+    for (int k = 0; k < K; k++) {
+        double ktot = 0.0;
+        for (int b = 0; b < nband; b++) {
+            const CiaState s = st[(size_t)b * K + k];
+            if (cell[b] < 0 || !s.use) continue;
+            const CiaBand B = bands[b];
+            const int c = cell[b];
+            const double x = fx[b];
+            double lnk;
+            if (B.nt == 1) {
+                const double y0 = B.lnk[c], y1 = B.lnk[c + 1];
+                lnk = (v - B.nu[c]) * (y1 - y0) / (B.nu[c + 1] - B.nu[c]) + y0;
+            } else {
+                const double *z0 = B.lnk + (size_t)s.jT * B.nb, *z1 = z0 + B.nb;
+                const double y = s.fT;
+                lnk = (1.0 - x) * (1.0 - y) * z0[c] + x * (1.0 - y) * z0[c + 1] + (1.0 - x) * y * z1[c] + x * y * z1[c + 1];
+            }
+            ktot += exp(lnk);
+        }
+        if (ktot != 0.0) sigma[(size_t)k * nnu + i] += (ktot * Lo2) * rho1[k] * rho2[k] / rhoa[k];
+    }
+}
+
 __global__ void k_faddeeva(int64_t n, const double *__restrict__ x, const double *__restrict__ y, double *__restrict__ out)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -41,6 +41,7 @@ enum { CS_SHAPE_VOIGT = 0, CS_SHAPE_LORENTZ = 1, CS_SHAPE_DOPPLER = 2, CS_SHAPE_
 
 #define CS_MAX_GAS 16
 #define CS_MAX_TABLE 16
+#define CS_MAX_CIA 8
 #define CS_CHEB_LD 16 /* leading dimension of the Chebyshev coefficient table */
 #define CS_MAX_STREAM 16
 #define CS_MAX_LOBATTO 16
@@ -93,6 +94,17 @@ int cs_table_clear(cs_ctx *ctx, int table_slot);
 int cs_table_eval(cs_ctx *ctx, int table_slot, double T, double P, int64_t i0, int64_t n, double *sigma_out);
 
 /*
+ * Collision-induced absorption tables.  Replaces: CIATables (collision_induced_absorption.jl:145-235) and its functor
+ * (:251-276).  A CIA object is a set of bands; band b holds ln k [cm^5/molecule^2] on nu_b[nb] x T_b[nt] (nu fastest),
+ * evaluated bilinearly inside the grid (BilinearInterpolator of ln k, :207); nt == 1 marks a single-temperature range
+ * (LinearInterpolator in nu, :188), used only when `singles` is set.  k <= 0 must already be replaced as the reference
+ * does (floatmin for grids :205, 0 -> ln 0 = -inf for singles :187).
+ */
+int cs_cia_begin(cs_ctx *ctx, int cia_slot, int nband);
+int cs_cia_band(cs_ctx *ctx, int cia_slot, int band, int nb, const double *nu_b, int nt, const double *T_b, const double *lnk);
+int cs_cia_clear(cs_ctx *ctx, int cia_slot);
+
+/*
  * B3: whole-column monochromatic fluxes + band integrals with the Discretized core, line-by-line at every
  * Lobatto node ("Mode D").
  * Replaces: monochromaticfluxes!(M+, M-, tau, core::Discretized, P, g, T, mu, fS, fa, absorbers...; theta_s)
@@ -137,6 +149,10 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
  * conc_tab: [ntab, K] column-major = fC_t(T_k, P_k).  Node states outside a table's (T,P) domain are an error
  * (checkpressures absorbers.jl:237-246; the interpolator's own bounds check for T). */
 int cs_column_set_tables(cs_ctx *ctx, int ntab, const int *table_slots, const double *conc_tab);
+/* add CIA pairs to the resident column: sigma += cia(nu, tables, T, P, P1, P2) (collision_induced_absorption.jl:295-303,
+ * :318-323, the CIA functor :465).  P1, P2: [ncia, K] column-major partial pressures of the two gases at the nodes
+ * (= P*concentration(g, T, P), :378-382); flags[c] bit 0 = extrapolate, bit 1 = singles (:163). */
+int cs_column_set_cia(cs_ctx *ctx, int ncia, const int *cia_slots, const int *flags, const double *P1, const double *P2);
 int cs_column_run(cs_ctx *ctx, void *stream);
 int cs_column_sync(cs_ctx *ctx);
 /* run `reps` evaluations with HIP events between the kernel classes on `stream`; ms[5] = average milliseconds per

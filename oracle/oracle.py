@@ -248,3 +248,49 @@ def table_sigma(lnsig, Tgrid, Pgrid, T, P):
     a = cheb_basis(Tgrid, T)
     b = cheb_basis(np.log(Pgrid), np.log(P))
     return np.exp(np.einsum("nij,i,j->n", lnsig, a, b))
+
+
+# ---- collision-induced absorption (collision_induced_absorption.jl:161-303): numpy restatement, test infrastructure -----
+
+def cia_sigma(data, nu, T, Pa, P1, P2, extrapolate=False, singles=False):
+    """cia(nu, CIATables(data), T, Pa, P1, P2) for a vector of wavenumbers.  `data` = list of dicts as produced by a .cia
+    reader (keys numin, numax, T, nu, k)."""
+    nu = np.asarray(nu, float)
+    ranges = sorted(set((d["numin"], d["numax"]) for d in data))
+    ktot = np.zeros(len(nu))
+    for lo, hi in ranges:
+        sel = sorted([d for d in data if np.isclose(d["numin"], lo) and np.isclose(d["numax"], hi)], key=lambda d: d["T"])
+        g = sel[0]["nu"]
+        inside = (nu >= g[0]) & (nu <= g[-1])
+        if not inside.any():
+            continue
+        v = nu[inside]
+        i = np.clip(np.searchsorted(g, v, side="right") - 1, 0, len(g) - 2)
+        xx = (v - g[i]) / (g[i + 1] - g[i])
+        if len(sel) == 1:
+            if not singles:
+                continue
+            k = sel[0]["k"].copy()
+            k[k <= 0] = 0.0
+            with np.errstate(divide="ignore", invalid="ignore"):
+                ln = np.log(k)
+                ktot[inside] += np.exp((v - g[i]) * (ln[i + 1] - ln[i]) / (g[i + 1] - g[i]) + ln[i])
+            continue
+        Tg = np.array([d["T"] for d in sel])
+        if Tg[0] <= T <= Tg[-1]:
+            Te = T
+        elif extrapolate:
+            Te = Tg[-1] if T > Tg[-1] else Tg[0]
+        else:
+            continue
+        z = np.array([d["k"] for d in sel], float)
+        z[z <= 0] = np.finfo(float).tiny
+        z = np.log(z)
+        j = int(np.clip(np.searchsorted(Tg, Te, side="right") - 1, 0, len(Tg) - 2))
+        yy = (Te - Tg[j]) / (Tg[j + 1] - Tg[j])
+        ktot[inside] += np.exp((1 - xx) * (1 - yy) * z[j, i] + xx * (1 - yy) * z[j, i + 1] + (1 - xx) * yy * z[j + 1, i]
+                               + xx * yy * z[j + 1, i + 1])
+    rho1 = (P1 / 101325.0) * (273.15 / T)
+    rho2 = (P2 / 101325.0) * (273.15 / T)
+    rhoa = 1e-6 * Pa / (1.38064852e-23 * T)
+    return (ktot * 7.21879268e38) * rho1 * rho2 / rhoa
