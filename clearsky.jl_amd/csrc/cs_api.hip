@@ -133,7 +133,7 @@ struct Column {
     std::vector<ColCia> cia;
     std::vector<double> h_Tk;
     DevBuf nu, wts, P, Pk, Tk, muk, Tlev, extra, S_toa, albedo;
-    DevBuf hot, cold, sigma, tau, Mup, Mdn, partial, F, stage;
+    DevBuf hot, cold, sigma, tau, Mup, Mdn, partial, F, stage, ranges;
 };
 
 }  // namespace
@@ -344,7 +344,7 @@ std::vector<double> gamma_bound(const GasTable &G, int K, const double *T, const
 // K1 + K2 for one gas on `s`: parameters for `kn` states, then the line sum into sigma ([kn][nnu])
 void launch_gas(hipStream_t s, int shape, const GasTable &G, int kn, const double *Tk, const double *Pk, const double *Ppk,
                 const double *scale, LineHot *hot, LineCold *cold, const double *dnu, int64_t nnu, int ntile256,
-                const int32_t *J0, const int32_t *J1, const WaveWin *win, Zone *zones, const double *gbound, double cut, double base,
+                const int32_t *J0, const int32_t *J1, const WaveWin *win, Zone *zones, int4 *ranges, const double *gbound, double cut, double base,
                 const double *extra, double *sigma, int accumulate, hipEvent_t ev_mid, hipEvent_t ev_far = nullptr)
 {
     const int64_t tot = (int64_t)kn * G.L;
@@ -358,9 +358,9 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int kn, const doubl
         const int nblk = (nt64 + 3) / 4;
         const dim3 grid((unsigned)((nblk + 7) / 8 * 8), kn);   // multiple of 8: XCD-aware tile mapping (k_voigt_far)
         hipLaunchKernelGGL(k_voigt_far, grid, dim3(256), 0, s, dnu, nnu, G.L, hot, win, zones, nt64, nblk, cut, base, extra,
-                           sigma, accumulate);
+                           sigma, accumulate, ranges);
         if (ev_far) (void)hipEventRecord(ev_far, s);
-        hipLaunchKernelGGL(k_voigt_near, grid, dim3(256), 0, s, dnu, nnu, G.L, hot, cold, zones, nt64, nblk, cut, sigma);
+        hipLaunchKernelGGL(k_voigt_near, grid, dim3(256), 0, s, dnu, nnu, G.L, hot, cold, zones, nt64, nblk, cut, sigma, ranges);
     } else {
         if (ev_mid) (void)hipEventRecord(ev_mid, s);
         launch_linesum_shape(shape, dim3(ntile256, kn), s, dnu, nnu, G.L, hot, cold, J0, J1, cut, Tk, base, extra, sigma,
@@ -482,7 +482,7 @@ int cs_shape_batch(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t nnu
     std::vector<int32_t> J0, J1;
     tile_windows(G.h_nu, g0, g1, nu, nnu, dnu_cut, J0, J1, pairs, inr);
     const int ntile = (int)J0.size();
-    DevBuf dnu, dT, dP, dPp, dJ0, dJ1, hot, cold, dsig, dwin, dzones, dgmax;
+    DevBuf dnu, dT, dP, dPp, dJ0, dJ1, hot, cold, dsig, dwin, dzones, dgmax, dranges;
     std::vector<WaveWin> win;
     wave_windows(G.h_nu, g0, g1, nu, nnu, dnu_cut, win);
     if ((rc = upload(dnu, nu, nnu, s)) || (rc = upload(dT, T, K, s)) || (rc = upload(dP, P, K, s)) ||
@@ -490,13 +490,14 @@ int cs_shape_batch(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t nnu
         (rc = upload(dwin, win.data(), win.size(), s)))
         return rc;
     // bound the workspace: process the states in chunks
-    const size_t per_state = (size_t)G.L * (sizeof(LineHot) + sizeof(LineCold)) + (size_t)nnu * sizeof(double);
+    const size_t per_state = (size_t)G.L * (sizeof(LineHot) + sizeof(LineCold)) + (size_t)nnu * (sizeof(double) + sizeof(int4));
     int kc = (int)std::max<size_t>(1, std::min<size_t>((size_t)K, ((size_t)4 << 30) / per_state));
     HIPCHK(hot.reserve(((size_t)kc * G.L + 4) * sizeof(LineHot)));
     HIPCHK(cold.reserve((size_t)kc * G.L * sizeof(LineCold)));
     HIPCHK(dsig.reserve((size_t)kc * nnu * sizeof(double)));
     HIPCHK(dzones.reserve((size_t)kc * win.size() * sizeof(Zone)));
     HIPCHK(dgmax.reserve((size_t)K * sizeof(double)));
+    HIPCHK(dranges.reserve((size_t)kc * nnu * sizeof(int4)));
     {
         std::vector<double> gb = gamma_bound(G, K, T, P, Pp);
         if ((rc = upload(dgmax, gb.data(), K, s))) return rc;
@@ -505,7 +506,7 @@ int cs_shape_batch(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t nnu
         const int kn = std::min(kc, K - k0);
         launch_gas(s, shape, G, kn, dT.as<double>() + k0, dP.as<double>() + k0, dPp.as<double>() + k0, nullptr,
                    hot.as<LineHot>(), cold.as<LineCold>(), dnu.as<double>(), nnu, ntile, dJ0.as<int32_t>(), dJ1.as<int32_t>(),
-                   dwin.as<WaveWin>(), dzones.as<Zone>(), dgmax.as<double>() + k0, dnu_cut, 0.0, nullptr, dsig.as<double>(), 0, nullptr);
+                   dwin.as<WaveWin>(), dzones.as<Zone>(), dranges.as<int4>(), dgmax.as<double>() + k0, dnu_cut, 0.0, nullptr, dsig.as<double>(), 0, nullptr);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpy2DAsync(sigma + (size_t)k0 * ld_state, ld_state * sizeof(double), dsig.p, nnu * sizeof(double),
                                 nnu * sizeof(double), kn, hipMemcpyDeviceToHost, s));
@@ -549,23 +550,24 @@ int cs_bake(cs_ctx *ctx, int gas_slot, int table_slot, int shape, double dnu_cut
     std::vector<WaveWin> win;
     wave_windows(G.h_nu, g0, g1, nu, nnu, dnu_cut, win);
     const int ntile = (int)J0.size();
-    DevBuf dnu, dT, dP, dPp, dJ0, dJ1, hot, cold, dwin, dzones, dgb;
+    DevBuf dnu, dT, dP, dPp, dJ0, dJ1, hot, cold, dwin, dzones, dgb, dranges;
     std::vector<double> gb = gamma_bound(G, M, Ts.data(), Ps.data(), Pp.data());
     if ((rc = upload(dnu, nu, nnu, s)) || (rc = upload(dT, Ts.data(), M, s)) || (rc = upload(dP, Ps.data(), M, s)) ||
         (rc = upload(dPp, Pp.data(), M, s)) || (rc = upload(dJ0, J0.data(), ntile, s)) || (rc = upload(dJ1, J1.data(), ntile, s)) ||
         (rc = upload(dwin, win.data(), win.size(), s)) || (rc = upload(dgb, gb.data(), M, s)))
         return rc;
     HIPCHK(tb.Z.reserve((size_t)M * nnu * sizeof(double)));
-    const size_t per_state = (size_t)G.L * (sizeof(LineHot) + sizeof(LineCold));
+    const size_t per_state = (size_t)G.L * (sizeof(LineHot) + sizeof(LineCold)) + (size_t)nnu * sizeof(int4);
     const int kc = (int)std::max<size_t>(1, std::min<size_t>((size_t)M, ((size_t)4 << 30) / per_state));
     HIPCHK(hot.reserve(((size_t)kc * G.L + 4) * sizeof(LineHot)));
     HIPCHK(cold.reserve((size_t)kc * G.L * sizeof(LineCold)));
     HIPCHK(dzones.reserve((size_t)kc * win.size() * sizeof(Zone)));
+    HIPCHK(dranges.reserve((size_t)kc * nnu * sizeof(int4)));
     for (int k0 = 0; k0 < M; k0 += kc) {
         const int kn = std::min(kc, M - k0);
         launch_gas(s, shape, G, kn, dT.as<double>() + k0, dP.as<double>() + k0, dPp.as<double>() + k0, nullptr, hot.as<LineHot>(),
                    cold.as<LineCold>(), dnu.as<double>(), nnu, ntile, dJ0.as<int32_t>(), dJ1.as<int32_t>(), dwin.as<WaveWin>(),
-                   dzones.as<Zone>(), dgb.as<double>() + k0, dnu_cut, 0.0, nullptr, tb.Z.as<double>() + (size_t)k0 * nnu, 0, nullptr);
+                   dzones.as<Zone>(), dranges.as<int4>(), dgb.as<double>() + k0, dnu_cut, 0.0, nullptr, tb.Z.as<double>() + (size_t)k0 * nnu, 0, nullptr);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(s));
     }
@@ -883,6 +885,7 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
     HIPCHK(c.hot.reserve(((size_t)K * maxL + 4) * sizeof(LineHot)));
     HIPCHK(c.cold.reserve((size_t)K * maxL * sizeof(LineCold)));
     HIPCHK(c.sigma.reserve((size_t)K * nnu * sizeof(double)));
+    if (ngas > 0) HIPCHK(c.ranges.reserve((size_t)K * nnu * sizeof(int4)));
     HIPCHK(c.tau.reserve((size_t)nl * nnu * sizeof(double)));
     if (c.want_M) {
         HIPCHK(c.Mup.reserve((size_t)np * nnu * sizeof(double)));
@@ -960,7 +963,7 @@ static int run_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev)
         GasTable &G = ctx->gas[cg.slot];
         launch_gas(s, cg.shape, G, K, c.Tk.as<double>(), c.Pk.as<double>(), cg.Pp.as<double>(), cg.conc.as<double>(),
                    c.hot.as<LineHot>(), c.cold.as<LineCold>(), c.nu.as<double>(), c.nnu, c.ntile, cg.J0.as<int32_t>(),
-                   cg.J1.as<int32_t>(), cg.win.as<WaveWin>(), cg.zones.as<Zone>(), cg.gmax.as<double>(), cg.cut, c.sigma_gray, extra, sig, gi > 0,
+                   cg.J1.as<int32_t>(), cg.win.as<WaveWin>(), cg.zones.as<Zone>(), c.ranges.as<int4>(), cg.gmax.as<double>(), cg.cut, c.sigma_gray, extra, sig, gi > 0,
                    ev ? ev[e] : nullptr, ev ? ev[e + 1] : nullptr);
         if (ev) { e += 2; HIPCHK(hipEventRecord(ev[e++], s)); }
     }

@@ -14,6 +14,7 @@ constexpr double kIsqPi = 0.5641895835477563;   // 1/sqrt(pi)
 constexpr double kPi = 3.14159265358979323846;
 constexpr double kFarS = 1.0e4;
 constexpr double kMidS = 100.0;
+constexpr double kSerS = 1.0e3;   // six-term asymptotic series is good to 2e-15 down to here (k_voigt_far near-zone pass)
 
 // 1/s for s > 0 well inside the normal range: v_rcp_f64 seed + two Newton steps
 __device__ __forceinline__ double rcp_nr(double s)

@@ -203,6 +203,7 @@ __global__ __launch_bounds__(256) void k_zones(const double *__restrict__ nu, in
     const double amax = ((vhi + cut) / kC) * vth / sqrt(mu_min);
     const double dA = 100.0 * amax / kSqLn2 * (1.0 + 1e-6);  // |dnu| >= dA  =>  x^2 >= 1e4 (4-term series good to 1e-14)
     const double dAA = 10.0 * dA;                             // |dnu| >= dAA =>  x^2 >= 1e6 (its u^3 terms < 1e-16)
+    // (inside [N0,N1) the far kernel uses the 6-term series down to s = 1e3, the near kernel takes over below)
     auto lower = [&](double val, int a, int b) { while (a < b) { int m = (a + b) >> 1; if (nul[m] < val) a = m + 1; else b = m; } return a; };
     auto upper = [&](double val, int a, int b) { while (a < b) { int m = (a + b) >> 1; if (nul[m] <= val) a = m + 1; else b = m; } return a; };
     Zone z;
@@ -226,7 +227,9 @@ __global__ __launch_bounds__(256) void k_zones(const double *__restrict__ nu, in
 // constants of the series kept in VGPRs for the whole kernel (gfx950 VALU instructions take one constant-bus operand:
 // the line parameter; a second literal would cost a v_mov per use).  Loaded from memory so they are not rematerialised.
 struct FarK { double k1p5, k3p75, k12, km15, km105, k13p125, k210, km120; };
-__device__ const double kFarTable[8] = {1.5, 3.75, 12.0, -15.0, -105.0, 13.125, 210.0, -120.0};
+__device__ const double kFarTable[19] = {1.5, 3.75, 12.0, -15.0, -105.0, 13.125, 210.0, -120.0,
+                                         59.0625, -787.5, 2835.0, -3780.0, 1680.0,                           // a4*U8 in t
+                                         324.84375, -6496.875, 36382.5, -83160.0, 83160.0, -30240.0};       // a5*U10 in t
 __device__ __forceinline__ FarK load_fark()
 {
     const volatile double *t = kFarTable;
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu
                                                     const LineHot *__restrict__ hot, const WaveWin *__restrict__ win,
                                                     const Zone *__restrict__ zones, int ntile, int nblk, double cut,
                                                     double base, const double *__restrict__ extra,
-                                                    double *__restrict__ sigma, int accumulate)
+                                                    double *__restrict__ sigma, int accumulate, int4 *__restrict__ ranges)
 {
     const int tb = tile_block(nblk);
     const int tile = __builtin_amdgcn_readfirstlane(tb * 4 + (threadIdx.x >> 6));
@@ -315,11 +318,41 @@ __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu
         acc = far_segment<false, 1>(acc, v, hk, a, z.M0, cut, c);
     }
     acc = far_segment<true, 2>(acc, v, hk, z.M0, z.N0, cut, c);
-    for (int j = z.N0; j < z.N1; j++) {
-        const LineHot h = hk[j];
-        const double x = (v - h.nul) * h.p1;
-        const double r = far_term<true, 2>(h, v, cut, c);
-        acc += (__builtin_fma(x, x, h.p2) >= kFarS) ? r : 0.0;
+    // near zone: six-term series where s >= 1e3; the index ranges of this lane's s < 1e3 and s < 100 lines go to
+    // k_voigt_near through `ranges` (relative to N0; empty = {0,0})
+    int bl = 0x3fffffff, bh = -1, cl = 0x3fffffff, ch = -1;
+    if (z.N1 > z.N0) {
+        const volatile double *tb = kFarTable;
+        const double q40 = tb[8], q41 = tb[9], q42 = tb[10], q43 = tb[11], q44 = tb[12];
+        const double q50 = tb[13], q51 = tb[14], q52 = tb[15], q53 = tb[16], q54 = tb[17], q55 = tb[18];
+        for (int j = z.N0; j < z.N1; j++) {
+            const LineHot h = hk[j];
+            const double dv = v - h.nul;
+            const double x = dv * h.p1;
+            const double s = __builtin_fma(x, x, h.p2);
+            const bool in = !(fabs(dv) > cut);
+            const double u = rcp_fast(s);
+            const double t = h.p2 * u;
+            const double p5 = __builtin_fma(__builtin_fma(__builtin_fma(__builtin_fma(__builtin_fma(q55, t, q54), t, q53), t, q52), t, q51), t, q50);
+            const double p4 = __builtin_fma(__builtin_fma(__builtin_fma(__builtin_fma(q44, t, q43), t, q42), t, q41), t, q40);
+            const double p3 = __builtin_fma(__builtin_fma(__builtin_fma(c.km120, t, c.k210), t, c.km105), t, c.k13p125);
+            const double p2 = __builtin_fma(__builtin_fma(c.k12, t, c.km15), t, c.k3p75);
+            const double p1 = __builtin_fma(-2.0, t, c.k1p5);
+            double P = __builtin_fma(u, p5, p4);
+            P = __builtin_fma(u, P, p3);
+            P = __builtin_fma(u, P, p2);
+            P = __builtin_fma(u, P, p1);
+            P = __builtin_fma(u, P, 1.0);
+            acc += (in && s >= kSerS) ? (h.p3 * u) * P : 0.0;
+            if (in && s < kSerS) { bl = min(bl, j); bh = j; }
+            if (in && s < kMidS) { cl = min(cl, j); ch = j; }
+        }
+    }
+    if (i < nnu) {
+        int4 r;
+        r.x = bh >= bl ? bl - z.N0 : 0; r.y = bh >= bl ? bh + 1 - z.N0 : 0;
+        r.z = ch >= cl ? cl - z.N0 : 0; r.w = ch >= cl ? ch + 1 - z.N0 : 0;
+        ranges[(size_t)k * nnu + i] = r;
     }
     acc = far_segment<true, 2>(acc, v, hk, z.N1, z.M1, cut, c);
     if (z.smally) {
@@ -336,15 +369,85 @@ __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu
     }
 }
 
-// K2b: the pairs with s < 1e4.  Every lane finds the index range of its own such lines in the near zone, then walks
-// them: continued fraction for 100 <= s < 1e4, trapezoid + pole correction for s < 100.  Adds into sigma.
+// K2b: the pairs with s < 1e3.  k_voigt_far left every lane the index ranges of its own such lines.  A wave compacts
+// the (lane, line) candidates of its 64 lanes into an LDS queue and evaluates them 64 at a time -- so the expensive forms
+// (continued fraction for 100 <= s < 1e3, trapezoid + pole correction for s < 100) run with full lanes instead of
+// once per "deepest" lane -- then every lane sums its own results in ascending line order (deterministic).
+#define CS_NEAR_Q 768  // queue entries per wave
+template <int TIER>  // 0: 100 <= s < 1e3 (fad_mid), 1: s < 100 (fad_near)
+__device__ __forceinline__ double near_pass(double v, int lo, int hi, int N0, const LineHot *__restrict__ hk,
+                                            const LineCold *__restrict__ ck, double cut, unsigned *qidx, double *qres)
+{
+    const int lane = threadIdx.x & 63;
+    const int cnt = hi - lo;
+    // exclusive prefix sum of the candidate counts over the wave
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    const int off = incl - cnt;
+    const int total = __shfl(incl, 63, 64);
+    double acc = 0.0;
+    if (total == 0) return acc;
+    if (total <= CS_NEAR_Q) {
+        for (int c = 0; c < cnt; c++) qidx[off + c] = ((unsigned)lane << 24) | (unsigned)(lo + c);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        const int ntrip = (total + 63) >> 6;  // wave-uniform: every lane takes part in the shuffles
+        for (int it = 0; it < ntrip; it++) {
+            const int p = it * 64 + lane;
+            double r = 0.0;
+            unsigned e = 0;
+            const bool live = p < total;
+            if (live) e = qidx[p];
+            const int owner = (int)(e >> 24);
+            const double vo = __shfl(v, owner, 64);
+            if (live) {
+                const int j = N0 + (int)(e & 0xffffffu);
+                const LineHot h = hk[j];
+                const double dv = vo - h.nul;
+                const double x = dv * h.p1;
+                const double s = __builtin_fma(x, x, h.p2);
+                const bool mine = TIER == 0 ? (s < kSerS && s >= kMidS) : (s < kMidS);
+                if (!(fabs(dv) > cut) && mine) {
+                    const LineCold c = ck[j];
+                    r = c.A * (TIER == 0 ? fad_mid(fabs(x), c.y) : fad_near(fabs(x), c.y));
+                }
+                qres[p] = r;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        for (int c = 0; c < cnt; c++) acc += qres[off + c];
+        __builtin_amdgcn_wave_barrier();
+    } else {  // more candidates than the queue holds (very dense tables): plain per-lane walk
+        for (int t = 0; __any(t < cnt); t++) {
+            if (t < cnt) {
+                const int j = N0 + lo + t;
+                const LineHot h = hk[j];
+                const double dv = v - h.nul;
+                const double x = dv * h.p1;
+                const double s = __builtin_fma(x, x, h.p2);
+                const bool mine = TIER == 0 ? (s < kSerS && s >= kMidS) : (s < kMidS);
+                if (!(fabs(dv) > cut) && mine) {
+                    const LineCold c = ck[j];
+                    acc += c.A * (TIER == 0 ? fad_mid(fabs(x), c.y) : fad_near(fabs(x), c.y));
+                }
+            }
+        }
+    }
+    return acc;
+}
+
 __global__ __launch_bounds__(256) void k_voigt_near(const double *__restrict__ nu, int64_t nnu, int64_t L,
                                                      const LineHot *__restrict__ hot, const LineCold *__restrict__ cold,
                                                      const Zone *__restrict__ zones, int ntile, int nblk, double cut,
-                                                     double *__restrict__ sigma)
+                                                     double *__restrict__ sigma, const int4 *__restrict__ ranges)
 {
+    __shared__ unsigned qidx_s[4][CS_NEAR_Q];
+    __shared__ double qres_s[4][CS_NEAR_Q];
     const int tb = tile_block(nblk);
-    const int tile = __builtin_amdgcn_readfirstlane(tb * 4 + (threadIdx.x >> 6));
+    const int wv = threadIdx.x >> 6;
+    const int tile = __builtin_amdgcn_readfirstlane(tb * 4 + wv);
     if (tb >= nblk || tile >= ntile) return;
     const int k = blockIdx.y;
     const int64_t i = (int64_t)tile * 64 + (threadIdx.x & 63);
@@ -352,43 +455,10 @@ __global__ __launch_bounds__(256) void k_voigt_near(const double *__restrict__ n
     const LineCold *__restrict__ ck = cold + (size_t)k * L;
     const double v = nu[i < nnu ? i : nnu - 1];
     const Zone z = zones[(size_t)k * ntile + tile];
-    int bl = 0x3fffffff, bh = -1, cl = 0x3fffffff, ch = -1;  // empty ranges: bh - bl < 0 (no overflow when adding t)
-    for (int j = z.N0; j < z.N1; j++) {
-        const LineHot h = hk[j];
-        const double dv = v - h.nul;
-        const double x = dv * h.p1;
-        const double s = __builtin_fma(x, x, h.p2);
-        const bool in = !(fabs(dv) > cut);
-        if (in && s < kFarS) { bl = min(bl, j); bh = j; }
-        if (in && s < kMidS) { cl = min(cl, j); ch = j; }
-    }
-    double acc = 0.0;
-    for (int t = 0; __any(t <= bh - bl); t++) {
-        const int j = bl + t;
-        if (t <= bh - bl) {
-            const LineHot h = hk[j];
-            const double dv = v - h.nul;
-            const double x = dv * h.p1;
-            const double s = __builtin_fma(x, x, h.p2);
-            if (!(fabs(dv) > cut) && s < kFarS && s >= kMidS) {
-                const LineCold c = ck[j];
-                acc = __builtin_fma(c.A, fad_mid(fabs(x), c.y), acc);
-            }
-        }
-    }
-    for (int t = 0; __any(t <= ch - cl); t++) {
-        const int j = cl + t;
-        if (t <= ch - cl) {
-            const LineHot h = hk[j];
-            const double dv = v - h.nul;
-            const double x = dv * h.p1;
-            const double s = __builtin_fma(x, x, h.p2);
-            if (!(fabs(dv) > cut) && s < kMidS) {
-                const LineCold c = ck[j];
-                acc = __builtin_fma(c.A, fad_near(fabs(x), c.y), acc);
-            }
-        }
-    }
+    int4 r = make_int4(0, 0, 0, 0);
+    if (i < nnu) r = ranges[(size_t)k * nnu + i];
+    double acc = near_pass<0>(v, r.x, r.y, z.N0, hk, ck, cut, qidx_s[wv], qres_s[wv]);
+    acc += near_pass<1>(v, r.z, r.w, z.N0, hk, ck, cut, qidx_s[wv], qres_s[wv]);
     if (i < nnu && acc != 0.0) sigma[(size_t)k * nnu + i] += acc;
 }
 
