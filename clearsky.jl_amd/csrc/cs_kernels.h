@@ -183,8 +183,9 @@ __global__ __launch_bounds__(256) void k_linesum(const double *__restrict__ nu, 
 // forms only for those, so the expensive bodies run ~20 and ~4 times per (wave, state) instead of once per line.
 struct WaveWin { int32_t W0, W1, E0, E1; };  // per 64-point tile: window, first line inside every lane's cut-off, one past the last
 // per (state, tile): [M0,N0) and [N1,M1) mid-far lines (1e4 <= x^2 possible < 1e6), [N0,N1) near zone (x^2 < 1e4 possible);
-// smally = 1 when y^2 <= 60 for every line of the window (then the u^2 t, u^2 t^2 terms of the series are < 1e-15)
-struct __attribute__((aligned(16))) Zone { int32_t M0, N0, N1, M1, smally, pad0, pad1, pad2; };
+// [Q0,M0) and [M1,Q1): lines far enough for the 3-term body (s >= 1e6) but not for dropping its y-dependent u^2 terms, which
+// needs 15 y^2/s^3 < 1e-15 (y^2 bounded per window from the largest Lorentz and smallest Doppler width); outside [Q0,Q1): 2 terms + c2
+struct __attribute__((aligned(16))) Zone { int32_t M0, N0, N1, M1, Q0, Q1, pad1, pad2; };
 
 // node-state dependent zone bounds, one thread per (state, tile)
 __global__ __launch_bounds__(256) void k_zones(const double *__restrict__ nu, int64_t nnu, int ntile, int K,
@@ -219,8 +220,17 @@ __global__ __launch_bounds__(256) void k_zones(const double *__restrict__ nu, in
         const double yb = gbound[k] * kSqLn2 / amin;
         y2b = yb * yb;
     }
-    z.smally = y2b <= 60.0;
-    z.pad0 = z.pad1 = z.pad2 = 0;
+    // mode-0 body is exact to 1e-15 where s >= s0 = max(1e6, (1.5e16 y2b)^(1/3))  <=>  |dnu| >= dAA * sqrt(s0/1e6)
+    if (y2b <= 60.0) {
+        z.Q0 = z.M0; z.Q1 = z.M1;
+    } else if (y2b < 1e290) {
+        const double dQ = dAA * sqrt(cbrt(1.5e16 * y2b) * 1e-6);
+        z.Q0 = lower(vlo - dQ, w.W0, z.M0);
+        z.Q1 = upper(vhi + dQ, z.M1, w.W1);
+    } else {
+        z.Q0 = w.W0; z.Q1 = w.W1;
+    }
+    z.pad1 = z.pad2 = 0;
     zones[idx] = z;
 }
 
@@ -307,21 +317,27 @@ __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu
     const double v = nu[i < nnu ? i : nnu - 1];
     const WaveWin w = win[tile];
     const Zone z = zones[(size_t)k * ntile + tile];
-    const int a = min(max(w.E0, w.W0), z.M0), b = max(min(w.E1, w.W1), z.M1);
     const FarK c = load_fark();
     double acc = 0.0;
-    if (z.smally) {
+    {   // left of the wave: [W0,a) edge (cut-off predicate) | [a,Q0) 2-term | [Q0,M0) 3-term      (a <= Q0 <= M0)
+        const int a = min(max(w.E0, w.W0), z.Q0);
         acc = far_segment<true, 0>(acc, v, hk, w.W0, a, cut, c);
-        acc = far_segment<false, 0>(acc, v, hk, a, z.M0, cut, c);
-    } else {
-        acc = far_segment<true, 1>(acc, v, hk, w.W0, a, cut, c);
-        acc = far_segment<false, 1>(acc, v, hk, a, z.M0, cut, c);
+        acc = far_segment<false, 0>(acc, v, hk, a, z.Q0, cut, c);
+        const int a1 = min(max(w.E0, z.Q0), z.M0);
+        acc = far_segment<true, 1>(acc, v, hk, z.Q0, a1, cut, c);
+        acc = far_segment<false, 1>(acc, v, hk, a1, z.M0, cut, c);
     }
+#ifndef CS_EXP_NO_MID
     acc = far_segment<true, 2>(acc, v, hk, z.M0, z.N0, cut, c);
+#endif
     // near zone: six-term series where s >= 1e3; the index ranges of this lane's s < 1e3 and s < 100 lines go to
     // k_voigt_near through `ranges` (relative to N0; empty = {0,0})
     int bl = 0x3fffffff, bh = -1, cl = 0x3fffffff, ch = -1;
+#ifdef CS_EXP_NO_NEARZONE
+    if (false) {
+#else
     if (z.N1 > z.N0) {
+#endif
         const volatile double *tb = kFarTable;
         const double q40 = tb[8], q41 = tb[9], q42 = tb[10], q43 = tb[11], q44 = tb[12];
         const double q50 = tb[13], q51 = tb[14], q52 = tb[15], q53 = tb[16], q54 = tb[17], q55 = tb[18];
@@ -354,13 +370,16 @@ __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu
         r.z = ch >= cl ? cl - z.N0 : 0; r.w = ch >= cl ? ch + 1 - z.N0 : 0;
         ranges[(size_t)k * nnu + i] = r;
     }
+#ifndef CS_EXP_NO_MID
     acc = far_segment<true, 2>(acc, v, hk, z.N1, z.M1, cut, c);
-    if (z.smally) {
-        acc = far_segment<false, 0>(acc, v, hk, z.M1, b, cut, c);
+#endif
+    {   // right of the wave: [M1,Q1) 3-term | [Q1,W1) 2-term, the part beyond E1 with the cut-off predicate
+        const int b1 = max(min(w.E1, z.Q1), z.M1);
+        acc = far_segment<false, 1>(acc, v, hk, z.M1, b1, cut, c);
+        acc = far_segment<true, 1>(acc, v, hk, b1, z.Q1, cut, c);
+        const int b = max(min(w.E1, w.W1), z.Q1);
+        acc = far_segment<false, 0>(acc, v, hk, z.Q1, b, cut, c);
         acc = far_segment<true, 0>(acc, v, hk, b, w.W1, cut, c);
-    } else {
-        acc = far_segment<false, 1>(acc, v, hk, z.M1, b, cut, c);
-        acc = far_segment<true, 1>(acc, v, hk, b, w.W1, cut, c);
     }
     if (i < nnu) {
         const size_t o = (size_t)k * nnu + i;
