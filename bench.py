@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--lines", default=None, help="synthetic | fixture")
     ap.add_argument("--nnu", type=int, default=None)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--precision", default="fp64", help="fp64 (headline) | mixed (fp32 far wings, BASELINE configs[4])")
+    ap.add_argument("--far-s", type=float, default=1e6, help="mixed precision: x^2 threshold of the fp32 region")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL, default) | gloo (rehearsal of N>1 on fewer GPUs)")
     ap.add_argument("--cpu-stride", type=int, default=0, help="cpu_baseline evaluates every n-th wavenumber (0 = size the sample for ~15 s)")
     args = ap.parse_args()
@@ -67,6 +69,7 @@ def main():
     nu, nl = cfg["nu"], cfg["nl"]
     ranges = W.balanced_ranges(nu, cfg["absorbers"], N)
     ctx = cs.Context(dev)
+    ctx.set_precision(args.precision, args.far_s)
     col = cs.Column(cfg["P"], cfg["g"], cfg["T"], cfg["mu"], cfg["fS"], cfg["fa"], *cfg["absorbers"], core=cfg["core"],
                     theta_s=cfg["theta_s"], want_tau=True, want_M=True, nu_range=ranges[rank], ctx=ctx)
     # one explicit torch stream carries the kernels, the D2D copy of the band fluxes and the collective, so they are
@@ -169,7 +172,8 @@ def main():
     if rank == 0:
         out = dict(metric="spectral-points/s (nu x layers), whole-column LBL flux evaluation", value=value,
                    unit="spectral-points/s", n_gpus=N, steps=args.steps, warmup=args.warmup, ms_per_step=ms,
-                   higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f64", data="synthetic",
+                   higher_is_better=True, scaling="strong", vs_baseline=None,
+                   dtype="f64" if args.precision == "fp64" else f"f64 with f32 far wings (x^2 >= {args.far_s:g})", data="synthetic",
                    config=dict(workload=f"{cfg['name']}: {'+'.join(g.formula for g in col.gases)} column, "
                                         f"{len(nu)} wavenumbers x {nl} layers, Voigt, {cfg['lines_kind']} lines "
                                         f"({lines_total} total), Discretized(nstream=5,nlobatto=2)",

@@ -223,6 +223,11 @@ class Context:
     def handle(self):
         return self._h
 
+    def set_precision(self, mode="fp64", far_s: float = 1e6):
+        """"fp64" (default) or "mixed": Voigt far wings with x^2 >= far_s in fp32 (BASELINE configs[4]); far_s >= 1e6 is the
+        knob of the tolerance sweep."""
+        check(lib().cs_set_precision(self._h, {"fp64": 0, "mixed": 1}[mode], float(far_s)))
+
     def slot_of(self, sl: SpectralLines) -> int:
         """Upload `sl` (once) and return its gas slot."""
         key = id(sl)

@@ -145,6 +145,9 @@ struct cs_ctx {
     TableDev tab[CS_MAX_TABLE];
     CiaDev cia[CS_MAX_CIA];
     Column col;
+    int mixed = 0;
+    double far_s = 1e6;
+    DevBuf hot32;
     DevBuf tmpA, tmpB, tmpC;
 };
 
@@ -345,20 +348,25 @@ std::vector<double> gamma_bound(const GasTable &G, int K, const double *T, const
 void launch_gas(hipStream_t s, int shape, const GasTable &G, int kn, const double *Tk, const double *Pk, const double *Ppk,
                 const double *scale, LineHot *hot, LineCold *cold, const double *dnu, int64_t nnu, int ntile256,
                 const int32_t *J0, const int32_t *J1, const WaveWin *win, Zone *zones, int4 *ranges, const double *gbound, double cut, double base,
-                const double *extra, double *sigma, int accumulate, hipEvent_t ev_mid, hipEvent_t ev_far = nullptr)
+                const double *extra, double *sigma, int accumulate, hipEvent_t ev_mid, hipEvent_t ev_far = nullptr,
+                LineF32 *hot32 = nullptr, double far_s = 1e6)
 {
     const int64_t tot = (int64_t)kn * G.L;
     hipLaunchKernelGGL(k_prep, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, shape, G.dev(), kn, Tk, Pk, Ppk, scale,
-                       hot, cold);
+                       hot, cold, shape == SH_VOIGT ? hot32 : nullptr);
     if (shape == SH_VOIGT) {
         const int nt64 = (int)((nnu + 63) / 64);
         hipLaunchKernelGGL(k_zones, dim3((unsigned)(((int64_t)nt64 * kn + 255) / 256)), dim3(256), 0, s, dnu, nnu, nt64, kn,
-                           G.nu.as<double>(), win, Tk, G.mu_min, G.mu_max, cut, gbound, zones);
+                           G.nu.as<double>(), win, Tk, G.mu_min, G.mu_max, cut, gbound, far_s, zones);
         if (ev_mid) (void)hipEventRecord(ev_mid, s);
         const int nblk = (nt64 + 3) / 4;
         const dim3 grid((unsigned)((nblk + 7) / 8 * 8), kn);   // multiple of 8: XCD-aware tile mapping (k_voigt_far)
-        hipLaunchKernelGGL(k_voigt_far, grid, dim3(256), 0, s, dnu, nnu, G.L, hot, win, zones, nt64, nblk, cut, base, extra,
-                           sigma, accumulate, ranges);
+        if (hot32)
+            hipLaunchKernelGGL(k_voigt_far<true>, grid, dim3(256), 0, s, dnu, nnu, G.L, hot, hot32, G.nu.as<double>(), win, zones, nt64, nblk, cut, base,
+                               extra, sigma, accumulate, ranges);
+        else
+            hipLaunchKernelGGL(k_voigt_far<false>, grid, dim3(256), 0, s, dnu, nnu, G.L, hot, (const LineF32 *)nullptr, G.nu.as<double>(), win, zones,
+                               nt64, nblk, cut, base, extra, sigma, accumulate, ranges);
         if (ev_far) (void)hipEventRecord(ev_far, s);
         hipLaunchKernelGGL(k_voigt_near, grid, dim3(256), 0, s, dnu, nnu, G.L, hot, cold, zones, nt64, nblk, cut, sigma, ranges);
     } else {
@@ -457,6 +465,16 @@ int cs_gas_upload(cs_ctx *ctx, int slot, int64_t L, const double *nu, const doub
     return CS_OK;
 }
 
+int cs_set_precision(cs_ctx *ctx, int mode, double far_s)
+{
+    if (!ctx) return fail(CS_EINVAL, "ctx is NULL");
+    if (mode != 0 && mode != 1) return fail(CS_EINVAL, "precision mode must be 0 (fp64) or 1 (fp32 far wings)");
+    if (!(far_s >= 1e6)) return fail(CS_EINVAL, "far_s must be >= 1e6");
+    ctx->mixed = mode;
+    ctx->far_s = far_s;
+    return CS_OK;
+}
+
 int cs_gas_clear(cs_ctx *ctx, int slot)
 {
     if (!ctx || slot < 0 || slot >= CS_MAX_GAS) return fail(CS_EINVAL, "bad slot");
@@ -497,6 +515,11 @@ int cs_shape_batch(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t nnu
     HIPCHK(dsig.reserve((size_t)kc * nnu * sizeof(double)));
     HIPCHK(dzones.reserve((size_t)kc * win.size() * sizeof(Zone)));
     HIPCHK(dgmax.reserve((size_t)K * sizeof(double)));
+    LineF32 *mix32 = nullptr;
+    if (ctx->mixed && shape == SH_VOIGT) {
+        HIPCHK(ctx->hot32.reserve(((size_t)kc * G.L + 4) * sizeof(LineF32)));
+        mix32 = ctx->hot32.as<LineF32>();
+    }
     HIPCHK(dranges.reserve((size_t)kc * nnu * sizeof(int4)));
     {
         std::vector<double> gb = gamma_bound(G, K, T, P, Pp);
@@ -506,7 +529,8 @@ int cs_shape_batch(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t nnu
         const int kn = std::min(kc, K - k0);
         launch_gas(s, shape, G, kn, dT.as<double>() + k0, dP.as<double>() + k0, dPp.as<double>() + k0, nullptr,
                    hot.as<LineHot>(), cold.as<LineCold>(), dnu.as<double>(), nnu, ntile, dJ0.as<int32_t>(), dJ1.as<int32_t>(),
-                   dwin.as<WaveWin>(), dzones.as<Zone>(), dranges.as<int4>(), dgmax.as<double>() + k0, dnu_cut, 0.0, nullptr, dsig.as<double>(), 0, nullptr);
+                   dwin.as<WaveWin>(), dzones.as<Zone>(), dranges.as<int4>(), dgmax.as<double>() + k0, dnu_cut, 0.0, nullptr, dsig.as<double>(), 0, nullptr,
+                   nullptr, mix32, ctx->far_s);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpy2DAsync(sigma + (size_t)k0 * ld_state, ld_state * sizeof(double), dsig.p, nnu * sizeof(double),
                                 nnu * sizeof(double), kn, hipMemcpyDeviceToHost, s));
@@ -563,11 +587,17 @@ int cs_bake(cs_ctx *ctx, int gas_slot, int table_slot, int shape, double dnu_cut
     HIPCHK(cold.reserve((size_t)kc * G.L * sizeof(LineCold)));
     HIPCHK(dzones.reserve((size_t)kc * win.size() * sizeof(Zone)));
     HIPCHK(dranges.reserve((size_t)kc * nnu * sizeof(int4)));
+    LineF32 *mix32 = nullptr;
+    if (ctx->mixed && shape == SH_VOIGT) {
+        HIPCHK(ctx->hot32.reserve(((size_t)kc * G.L + 4) * sizeof(LineF32)));
+        mix32 = ctx->hot32.as<LineF32>();
+    }
     for (int k0 = 0; k0 < M; k0 += kc) {
         const int kn = std::min(kc, M - k0);
         launch_gas(s, shape, G, kn, dT.as<double>() + k0, dP.as<double>() + k0, dPp.as<double>() + k0, nullptr, hot.as<LineHot>(),
                    cold.as<LineCold>(), dnu.as<double>(), nnu, ntile, dJ0.as<int32_t>(), dJ1.as<int32_t>(), dwin.as<WaveWin>(),
-                   dzones.as<Zone>(), dranges.as<int4>(), dgb.as<double>() + k0, dnu_cut, 0.0, nullptr, tb.Z.as<double>() + (size_t)k0 * nnu, 0, nullptr);
+                   dzones.as<Zone>(), dranges.as<int4>(), dgb.as<double>() + k0, dnu_cut, 0.0, nullptr, tb.Z.as<double>() + (size_t)k0 * nnu, 0, nullptr,
+                   nullptr, mix32, ctx->far_s);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(s));
     }
@@ -958,13 +988,19 @@ static int run_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev)
         const int64_t tot = (int64_t)K * c.nnu;
         hipLaunchKernelGGL(k_fill, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, tot, c.sigma_gray, extra, sig);
     }
+    if (ctx->mixed) {
+        size_t maxL = 0;
+        for (auto &g : c.gas) maxL = std::max(maxL, (size_t)ctx->gas[g.slot].L);
+        HIPCHK(ctx->hot32.reserve(((size_t)K * maxL + 4) * sizeof(LineF32)));   // no-op once sized (not capturable the first time)
+    }
     for (int gi = 0; gi < c.ngas; gi++) {
         ColGas &cg = c.gas[gi];
         GasTable &G = ctx->gas[cg.slot];
         launch_gas(s, cg.shape, G, K, c.Tk.as<double>(), c.Pk.as<double>(), cg.Pp.as<double>(), cg.conc.as<double>(),
                    c.hot.as<LineHot>(), c.cold.as<LineCold>(), c.nu.as<double>(), c.nnu, c.ntile, cg.J0.as<int32_t>(),
                    cg.J1.as<int32_t>(), cg.win.as<WaveWin>(), cg.zones.as<Zone>(), c.ranges.as<int4>(), cg.gmax.as<double>(), cg.cut, c.sigma_gray, extra, sig, gi > 0,
-                   ev ? ev[e] : nullptr, ev ? ev[e + 1] : nullptr);
+                   ev ? ev[e] : nullptr, ev ? ev[e + 1] : nullptr,
+                   (ctx->mixed && cg.shape == SH_VOIGT) ? ctx->hot32.as<LineF32>() : nullptr, ctx->far_s);
         if (ev) { e += 2; HIPCHK(hipEventRecord(ev[e++], s)); }
     }
     for (auto &t : c.tab) {  // baked gases: sigma += fC * exp(Phi(T, ln P))

@@ -35,6 +35,11 @@ enum { SH_VOIGT = 0, SH_LORENTZ = 1, SH_DOPPLER = 2, SH_PHCO2 = 3 };
 //   Doppler    : hot = {nul, 1/alpha^2, C*S(T)/(alpha*sqrt(pi)), 0}
 struct __attribute__((aligned(32))) LineHot { double nul, p1, p2, p3; };
 struct __attribute__((aligned(16))) LineCold { double y, A; };
+// mixed-precision variant (BASELINE configs[4]): far-wing record in fp32 -- the line position stays fp64 so that
+// nu - nul is formed exactly; ay carries A*y/sqrt(pi) scaled by 2^100 (line strengths span 1e-38..1e-18)
+struct __attribute__((aligned(16))) LineF32 { float d, y2, ay, c2; };   // 16 B per (node, line); nul comes from the fp64 line table
+constexpr double kMixScale = 1.2676506002282294e30;      // 2^100
+constexpr double kMixUnscale = 7.888609052210118e-31;    // 2^-100
 
 struct GasDev {
     int64_t L;
@@ -63,7 +68,7 @@ __device__ __forceinline__ double cheby_qrefq(double T, int n, const double *__r
 __global__ __launch_bounds__(256) void k_prep(int shape, GasDev g, int K, const double *__restrict__ Tk,
                                                const double *__restrict__ Pk, const double *__restrict__ Ppk,
                                                const double *__restrict__ scale, LineHot *__restrict__ hot,
-                                               LineCold *__restrict__ cold)
+                                               LineCold *__restrict__ cold, LineF32 *__restrict__ hot32)
 {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t total = (int64_t)K * g.L;
@@ -103,6 +108,11 @@ __global__ __launch_bounds__(256) void k_prep(int shape, GasDev g, int K, const 
     }
     hot[idx] = h;
     cold[idx] = c;
+    if (hot32) {
+        LineF32 f;
+        f.d = (float)h.p1; f.y2 = (float)h.p2; f.ay = (float)(h.p3 * kMixScale); f.c2 = (float)(3.75 - 2.0 * h.p2);
+        hot32[idx] = f;
+    }
 }
 
 // line_shapes.jl:467-481 with the two temperature-only factors hoisted
@@ -191,7 +201,7 @@ struct __attribute__((aligned(16))) Zone { int32_t M0, N0, N1, M1, Q0, Q1, pad1,
 __global__ __launch_bounds__(256) void k_zones(const double *__restrict__ nu, int64_t nnu, int ntile, int K,
                                                 const double *__restrict__ nul, const WaveWin *__restrict__ win,
                                                 const double *__restrict__ Tk, double mu_min, double mu_max, double cut,
-                                                const double *__restrict__ gbound, Zone *__restrict__ zones)
+                                                const double *__restrict__ gbound, double far_s, Zone *__restrict__ zones)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= ntile * K) return;
@@ -203,7 +213,7 @@ __global__ __launch_bounds__(256) void k_zones(const double *__restrict__ nu, in
     const double vth = sqrt(2.0 * kRgas * Tk[k]);
     const double amax = ((vhi + cut) / kC) * vth / sqrt(mu_min);
     const double dA = 100.0 * amax / kSqLn2 * (1.0 + 1e-6);  // |dnu| >= dA  =>  x^2 >= 1e4 (4-term series good to 1e-14)
-    const double dAA = 10.0 * dA;                             // |dnu| >= dAA =>  x^2 >= 1e6 (its u^3 terms < 1e-16)
+    const double dAA = dA * sqrt(far_s * 1e-4);               // |dnu| >= dAA =>  x^2 >= far_s (>= 1e6: u^3 terms < 1e-16)
     // (inside [N0,N1) the far kernel uses the 6-term series down to s = 1e3, the near kernel takes over below)
     auto lower = [&](double val, int a, int b) { while (a < b) { int m = (a + b) >> 1; if (nul[m] < val) a = m + 1; else b = m; } return a; };
     auto upper = [&](double val, int a, int b) { while (a < b) { int m = (a + b) >> 1; if (nul[m] <= val) a = m + 1; else b = m; } return a; };
@@ -224,7 +234,7 @@ __global__ __launch_bounds__(256) void k_zones(const double *__restrict__ nu, in
     if (y2b <= 60.0) {
         z.Q0 = z.M0; z.Q1 = z.M1;
     } else if (y2b < 1e290) {
-        const double dQ = dAA * sqrt(cbrt(1.5e16 * y2b) * 1e-6);
+        const double dQ = dA * sqrt(fmax(cbrt(1.5e16 * y2b), far_s) * 1e-4);
         z.Q0 = lower(vlo - dQ, w.W0, z.M0);
         z.Q1 = upper(vhi + dQ, z.M1, w.W1);
     } else {
@@ -288,6 +298,44 @@ __device__ __forceinline__ double far_segment(double acc, double v, const LineHo
     return acc;
 }
 
+// fp32 far-wing body of the mixed-precision variant: 2 fp64 + 8 fp32 VALU instructions per line; partial sums of 4 terms
+// are formed in fp32 and added to the fp64 accumulator.  Relative error of a term ~2e-7.
+template <bool PRED, int MODE>
+__device__ __forceinline__ float far_term32(double nul, const LineF32 h, double v, double cut)
+{
+    const double dvd = v - nul;
+    const float dv = (float)dvd;
+    const float x = dv * h.d;
+    const float s = __builtin_fmaf(x, x, h.y2);
+    const float u = __builtin_amdgcn_rcpf(s);
+    float q = h.c2;
+    if (MODE == 1) {
+        const float t = h.y2 * u;
+        q = __builtin_fmaf(t, __builtin_fmaf(12.0f, t, -15.0f), q);
+    }
+    const float P = __builtin_fmaf(__builtin_fmaf(q, u, 1.5f), u, 1.0f);
+    float r = (h.ay * u) * P;
+    if (PRED) r = (fabs(dvd) > cut) ? 0.0f : r;
+    return r;
+}
+
+template <bool PRED, int MODE>
+__device__ __forceinline__ double far_segment32(double acc, double v, const double *__restrict__ nul, const LineF32 *__restrict__ hk,
+                                                int j0, int j1, double cut)
+{
+    int j = j0;
+    for (; j + 3 < j1; j += 4) {   // 4 lines: one s_load_dwordx8 (positions) + one s_load_dwordx16 (parameters)
+        float part = far_term32<PRED, MODE>(nul[j], hk[j], v, cut);
+        part += far_term32<PRED, MODE>(nul[j + 1], hk[j + 1], v, cut);
+        part += far_term32<PRED, MODE>(nul[j + 2], hk[j + 2], v, cut);
+        part += far_term32<PRED, MODE>(nul[j + 3], hk[j + 3], v, cut);
+        acc = __builtin_fma((double)part, kMixUnscale, acc);
+    }
+    float part = 0.0f;
+    for (; j < j1; j++) part += far_term32<PRED, MODE>(nul[j], hk[j], v, cut);
+    return __builtin_fma((double)part, kMixUnscale, acc);
+}
+
 // blockIdx.x -> block of 4 wave tiles.  Workgroups are dealt round-robin over the 8 XCDs, so block b and b+8 share an
 // L2: give each XCD one contiguous eighth of the spectrum, whose overlapping line windows then stay in that L2.
 // gridDim.x is a multiple of 8 (speed only: any placement is correct).
@@ -302,8 +350,10 @@ __device__ __forceinline__ int tile_block(int nblk)
 // line parameters arrive through scalar loads:
 //   [W0,a) left edge (cut-off predicate) | [a,M0) far | [M0,N0) mid-far | [N0,N1) near zone | [N1,M1) | [M1,b) | [b,W1)
 // In the near zone only the pairs with s >= 1e4 are summed here; the others belong to k_voigt_near.
+template <bool MIXED>
 __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu, int64_t nnu, int64_t L,
-                                                    const LineHot *__restrict__ hot, const WaveWin *__restrict__ win,
+                                                    const LineHot *__restrict__ hot, const LineF32 *__restrict__ hot32,
+                                                    const double *__restrict__ gnul, const WaveWin *__restrict__ win,
                                                     const Zone *__restrict__ zones, int ntile, int nblk, double cut,
                                                     double base, const double *__restrict__ extra,
                                                     double *__restrict__ sigma, int accumulate, int4 *__restrict__ ranges)
@@ -314,12 +364,20 @@ __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu
     const int k = blockIdx.y;
     const int64_t i = (int64_t)tile * 64 + (threadIdx.x & 63);
     const LineHot *__restrict__ hk = hot + (size_t)k * L;
+    const LineF32 *__restrict__ hf = MIXED ? hot32 + (size_t)k * L : nullptr;
     const double v = nu[i < nnu ? i : nnu - 1];
     const WaveWin w = win[tile];
     const Zone z = zones[(size_t)k * ntile + tile];
     const FarK c = load_fark();
     double acc = 0.0;
-    {   // left of the wave: [W0,a) edge (cut-off predicate) | [a,Q0) 2-term | [Q0,M0) 3-term      (a <= Q0 <= M0)
+    if (MIXED) {
+        const int a = min(max(w.E0, w.W0), z.Q0);
+        acc = far_segment32<true, 0>(acc, v, gnul, hf, w.W0, a, cut);
+        acc = far_segment32<false, 0>(acc, v, gnul, hf, a, z.Q0, cut);
+        const int a1 = min(max(w.E0, z.Q0), z.M0);
+        acc = far_segment32<true, 1>(acc, v, gnul, hf, z.Q0, a1, cut);
+        acc = far_segment32<false, 1>(acc, v, gnul, hf, a1, z.M0, cut);
+    } else {   // left of the wave: [W0,a) edge (cut-off predicate) | [a,Q0) 2-term | [Q0,M0) 3-term      (a <= Q0 <= M0)
         const int a = min(max(w.E0, w.W0), z.Q0);
         acc = far_segment<true, 0>(acc, v, hk, w.W0, a, cut, c);
         acc = far_segment<false, 0>(acc, v, hk, a, z.Q0, cut, c);
@@ -373,7 +431,14 @@ __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu
 #ifndef CS_EXP_NO_MID
     acc = far_segment<true, 2>(acc, v, hk, z.N1, z.M1, cut, c);
 #endif
-    {   // right of the wave: [M1,Q1) 3-term | [Q1,W1) 2-term, the part beyond E1 with the cut-off predicate
+    if (MIXED) {
+        const int b1 = max(min(w.E1, z.Q1), z.M1);
+        acc = far_segment32<false, 1>(acc, v, gnul, hf, z.M1, b1, cut);
+        acc = far_segment32<true, 1>(acc, v, gnul, hf, b1, z.Q1, cut);
+        const int b = max(min(w.E1, w.W1), z.Q1);
+        acc = far_segment32<false, 0>(acc, v, gnul, hf, z.Q1, b, cut);
+        acc = far_segment32<true, 0>(acc, v, gnul, hf, b, w.W1, cut);
+    } else {   // right of the wave: [M1,Q1) 3-term | [Q1,W1) 2-term, the part beyond E1 with the cut-off predicate
         const int b1 = max(min(w.E1, z.Q1), z.M1);
         acc = far_segment<false, 1>(acc, v, hk, z.M1, b1, cut, c);
         acc = far_segment<true, 1>(acc, v, hk, b1, z.Q1, cut, c);

@@ -67,6 +67,16 @@ int cs_gas_upload(cs_ctx *ctx, int slot, int64_t L, const double *nu, const doub
 int cs_gas_clear(cs_ctx *ctx, int slot);
 
 /*
+ * Arithmetic of the Voigt far wings (BASELINE configs[4], "fp32 mixed-precision variant with tolerance sweep"):
+ *   mode 0 (default): fp64 everywhere;
+ *   mode 1: (nu, line) pairs with x^2 >= far_s (far_s >= 1e6) are evaluated in fp32 (nu - nul is still formed in fp64, partial
+ *           sums of 4 terms, fp64 accumulation); everything nearer stays fp64.  far_s is the knob of the tolerance sweep
+ *           (1e6: ~90 % of the pairs in fp32; larger: fewer).  Cross-sections then agree with mode 0 to ~1e-7.
+ * Applies to every later cs_shape_batch / cs_bake / cs_column_run of the context.
+ */
+int cs_set_precision(cs_ctx *ctx, int mode, double far_s);
+
+/*
  * B1: batched in-place line shape.  For every state k:  sigma[k*ld_state + i] = shape(nu[i]; T[k], P[k], Pp[k]).
  * Replaces: shape!(sigma, nu, sl, T, P, Pp, dnu_cut) -- voigt!/lorentz!/doppler!/PHCO2!, line_shapes.jl:412-424,
  * :313-324, :200-211, :527-540 -- as invoked by bake, gases.jl:126 (K = nT*nP states in one launch instead of

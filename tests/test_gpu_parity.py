@@ -277,3 +277,34 @@ def test_update_state_matches_fresh_setup(cs, lines, ctx):
     a = col.fetch()
     b = cs.fluxes(P, 9.8, T2, 0.029, 0.0, 0.0, gas, ctx=ctx)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_mixed_precision_variant(cs, O, lines):
+    """BASELINE configs[4]: fp32 far wings.  Cross-sections within 1e-6 of the fp64 path and of the oracle (north-star
+    tolerance), OLR within 1e-5 W/m^2; widening the fp64 region (far_s) tightens the agreement; fp64 mode is untouched."""
+    from clearsky_jl_amd import workloads as W
+    ctx = cs.Context(0)
+    cfg = W.config("C2", nnu=4000, nl=20)
+    def run():
+        col = cs.Column(cfg["P"], cfg["g"], cfg["T"], cfg["mu"], 0.0, 0.0, *cfg["absorbers"], core=cfg["core"], ctx=ctx)
+        col.run()
+        F = col.fetch()
+        return col, col.sigma_nodes(), F
+    col, s64, F64 = run()
+    ctx.set_precision("mixed", 1e6)
+    _, s32, F32 = run()
+    ctx.set_precision("mixed", 1e8)
+    _, s32b, F32b = run()
+    ctx.set_precision("fp64")
+    _, s64b, F64b = run()
+    assert np.array_equal(s64, s64b) and np.array_equal(F64[0], F64b[0])
+    m = s64 > 0
+    e1, e2 = np.max(np.abs(s32[m] / s64[m] - 1)), np.max(np.abs(s32b[m] / s64[m] - 1))
+    assert 0 < e1 < 1e-6 and e2 <= e1
+    assert abs(F32[0][0] - F64[0][0]) < 1e-5 and abs(F32b[0][0] - F64[0][0]) <= abs(F32[0][0] - F64[0][0]) + 1e-9
+    r = O.fluxes_discretized(cfg["nu"], cfg["P"], cfg["g"], 2, col.Tn, col.mun, col.Tlev, [g.sl for g in col.gases], ["voigt"],
+                             [25.0], col.conc, want_sigma=True)
+    assert np.max(np.abs(s32[m] / r["sigma"][m] - 1)) < 1e-6
+    with pytest.raises(cs.ClearSkyHIPError):
+        ctx.set_precision("mixed", 1e3)
+    ctx.close()
