@@ -174,7 +174,7 @@ def main():
                    unit="spectral-points/s", n_gpus=N, steps=args.steps, warmup=args.warmup, ms_per_step=ms,
                    higher_is_better=True, scaling="strong", vs_baseline=None,
                    dtype="f64" if args.precision == "fp64" else f"f64 with f32 far wings (x^2 >= {args.far_s:g})", data="synthetic",
-                   config=dict(workload=f"{cfg['name']}: {'+'.join(g.formula for g in col.gases)} column, "
+                   config=dict(workload=f"{cfg['name']}: {'+'.join(g.formula for g in col.gases)}{' + CIA' if col.U.cia else ''} column, "
                                         f"{len(nu)} wavenumbers x {nl} layers, Voigt, {cfg['lines_kind']} lines "
                                         f"({lines_total} total), Discretized(nstream=5,nlobatto=2)",
                                nnu=len(nu), layers=nl, lines=lines_total, parallelism=f"nu-shard x{N}"),

@@ -4,7 +4,8 @@ import os
 import numpy as np
 
 from . import constants as K
-from .core import DirectGas, Discretized, GrayGas, pressuregrid, psatH2O
+from .cia import CIATables
+from .core import DirectGas, Discretized, GrayGas, ozonelayer, pressuregrid, psatH2O
 from .hitran import SpectralLines
 
 _HITRAN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "hitran")
@@ -47,6 +48,11 @@ def config(name: str, nnu=None, nl=None, lines_kind=None):
     elif name == "C3":
         nnu, nl, lines_kind = nnu or 100_000, nl or 60, lines_kind or "synthetic"
         gases = ["H2O", "CO2"]
+    elif name == "C5":
+        # H2O+CO2+CH4+O3 with CIA continuum, 5e5 wavenumbers x 100 layers: reference fixtures for H2O/CO2/CH4, a seeded
+        # synthetic O3 table (the container holds no O3 file) and the two CIA files of test/HITRAN
+        nnu, nl, lines_kind = nnu or 500_000, nl or 100, lines_kind or "fixture"
+        gases = ["H2O", "CO2", "CH4", "O3"]
     else:
         raise ValueError(name)
     nu = np.linspace(1.0, 2500.0, nnu)
@@ -54,8 +60,12 @@ def config(name: str, nnu=None, nl=None, lines_kind=None):
     T = earth_temperature(P)
     absorbers = []
     for gname in gases:
-        fC = fC_h2o if gname == "H2O" else 400e-6
-        absorbers.append(DirectGas(lines(lines_kind, gname), fC, nu))
+        fC = {"H2O": fC_h2o, "CO2": 400e-6, "CH4": 1.8e-6, "O3": lambda T, P_: ozonelayer(P_)}[gname]
+        kind = "synthetic" if gname == "O3" else lines_kind
+        absorbers.append(DirectGas(lines(kind, gname), fC, nu))
+    if name == "C5":
+        absorbers.append(CIATables(fixture("CO2-CO2_2018.cia")))
+        absorbers.append(CIATables(fixture("CO2-CH4_2018.cia")))
     return dict(name=name, nu=nu, P=P, g=9.8, T=T, mu=0.029, fS=0.0, fa=0.0, absorbers=absorbers,
                 core=Discretized(5, 2), theta_s=0.841, lines_kind=lines_kind, nl=nl)
 

@@ -279,6 +279,29 @@ def test_update_state_matches_fresh_setup(cs, lines, ctx):
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
 
 
+def test_c5_reduced_vs_oracle(cs, O):
+    """BASELINE configs[4] physics at reduced size (4 gases incl. synthetic O3 + both CIA pairs, 100 layers, 3000 wavenumbers):
+    fp64 outputs vs the oracle fed with the numpy CIA restatement."""
+    from clearsky_jl_amd import workloads as W
+    ctx = cs.Context(0)
+    cfg = W.config("C5", nnu=3000)
+    col = cs.Column(cfg["P"], cfg["g"], cfg["T"], cfg["mu"], 0.0, 0.0, *cfg["absorbers"], core=cfg["core"], ctx=ctx)
+    col.run()
+    F = cs.FluxPack(col.np, col.nnu)
+    F.Fup[:], F.Fdn[:] = col.fetch(F.tau, F.Mup, F.Mdn)
+    F.Fnet[:] = F.Fup - F.Fdn
+    assert len(col.gases) == 4 and len(col.U.cia) == 2 and col.K == 101
+    d = [cs.readcia(W.fixture(f)) for f in ("CO2-CO2_2018.cia", "CO2-CH4_2018.cia")]
+    extra = np.zeros((col.K, col.nnu))
+    for k in range(col.K):
+        for ci, x in enumerate(col.U.cia):
+            extra[k] += O.cia_sigma(d[ci], cfg["nu"], col.Tk[k], col.Pk[k], col.cia_P1[ci, k], col.cia_P2[ci, k])
+    r = O.fluxes_discretized(cfg["nu"], cfg["P"], cfg["g"], 2, col.Tn, col.mun, col.Tlev, [g.sl for g in col.gases], ["voigt"] * 4,
+                             [25.0] * 4, col.conc, sigma_extra=extra)
+    _column_vs(cs, r, F)
+    ctx.close()
+
+
 def test_mixed_precision_variant(cs, O, lines):
     """BASELINE configs[4]: fp32 far wings.  Cross-sections within 1e-6 of the fp64 path and of the oracle (north-star
     tolerance), OLR within 1e-5 W/m^2; widening the fp64 region (far_s) tightens the agreement; fp64 mode is untouched."""
