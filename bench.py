@@ -122,8 +122,10 @@ def main():
     K = col.K
     lines_total = sum(len(g.sl.nu) for g in col.gases)
     # k_voigt_far (one launch per gas).  Algorithmic HBM bytes per launch: the 32-B record of every
-    # (node, line) read once + sigma written (8 B per (nu, node)) + sigma re-read when a later gas accumulates + nu.
-    far_bytes = [32 * K * len(g.sl.nu) + 8 * col.nnu * K * (2 if gi > 0 else 1) + 8 * col.nnu for gi, g in enumerate(col.gases)]
+    # (node, line) read once + sigma written (8 B per (nu, node)) + sigma re-read when a later gas accumulates
+    # + the 16-B near-line index ranges handed to k_voigt_near per (nu, node) + nu.
+    far_bytes = [32 * K * len(g.sl.nu) + 8 * col.nnu * K * (2 if gi > 0 else 1) + 16 * col.nnu * K + 8 * col.nnu
+                 for gi, g in enumerate(col.gases)]
     far_ms = prof["far"] / max(ngas, 1)
     alg = float(np.mean(far_bytes)) if far_bytes else 0.0
     achieved = alg / (far_ms * 1e-3) / 1e9 if far_ms > 0 else 0.0
