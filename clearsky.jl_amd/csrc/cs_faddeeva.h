@@ -1,6 +1,7 @@
 // cs_faddeeva.h -- Re w(x+iy) for gfx950, fp64.  Replaces Faddeyeva985.faddeyeva(x,y) at its only call site,
 // fvoigt (reference src/absorption/line_shapes.jl:366-378, call :375).  Three regions in s = x^2+y^2:
-//   s >= 1e4 : 4-term real asymptotic series (the branch 99% of (nu,line) pairs take; 20 fp64 VALU ops)
+//   s >= 1e4 : 4-term real asymptotic series (the branch 99% of (nu,line) pairs take; k_voigt_far runs 2-, 3- and 6-term
+//              cuts of the same series where they are exact to 1e-15)
 //   s >= 100 : 10-term Laplace continued fraction as the rational  z*PA(z^2)/PB(z^2)
 //   s <  100 : trapezoid rule, h = 1/2, on the integer or half-shifted grid + pole correction when y < 2*pi
 // Max relative error ~1e-14 against 40-digit mpmath (tools/faddeeva_proto.py); the reference's own Faddeeva
@@ -32,11 +33,7 @@ __device__ __forceinline__ double rcp_nr(double s)
 // step.  s beyond the f32 range gives a zero seed and a zero term (the true term is < 1e-38 of the line strength).
 __device__ __forceinline__ double rcp_fast(double s)
 {
-#ifdef CS_RCP_F64
-    double r = __builtin_amdgcn_rcp(s);
-#else
     double r = (double)__builtin_amdgcn_rcpf((float)s);
-#endif
     double e = __builtin_fma(-s, r, 1.0);
     return __builtin_fma(r, e, r);
 }

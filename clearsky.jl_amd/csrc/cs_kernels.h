@@ -385,17 +385,11 @@ __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu
         acc = far_segment<true, 1>(acc, v, hk, z.Q0, a1, cut, c);
         acc = far_segment<false, 1>(acc, v, hk, a1, z.M0, cut, c);
     }
-#ifndef CS_EXP_NO_MID
     acc = far_segment<true, 2>(acc, v, hk, z.M0, z.N0, cut, c);
-#endif
     // near zone: six-term series where s >= 1e3; the index ranges of this lane's s < 1e3 and s < 100 lines go to
     // k_voigt_near through `ranges` (relative to N0; empty = {0,0})
     int bl = 0x3fffffff, bh = -1, cl = 0x3fffffff, ch = -1;
-#ifdef CS_EXP_NO_NEARZONE
-    if (false) {
-#else
     if (z.N1 > z.N0) {
-#endif
         const volatile double *tb = kFarTable;
         const double q40 = tb[8], q41 = tb[9], q42 = tb[10], q43 = tb[11], q44 = tb[12];
         const double q50 = tb[13], q51 = tb[14], q52 = tb[15], q53 = tb[16], q54 = tb[17], q55 = tb[18];
@@ -428,9 +422,7 @@ __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu
         r.z = ch >= cl ? cl - z.N0 : 0; r.w = ch >= cl ? ch + 1 - z.N0 : 0;
         ranges[(size_t)k * nnu + i] = r;
     }
-#ifndef CS_EXP_NO_MID
     acc = far_segment<true, 2>(acc, v, hk, z.N1, z.M1, cut, c);
-#endif
     if (MIXED) {
         const int b1 = max(min(w.E1, z.Q1), z.M1);
         acc = far_segment32<false, 1>(acc, v, gnul, hf, z.M1, b1, cut);

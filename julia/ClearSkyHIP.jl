@@ -190,3 +190,19 @@ end
 export HIPDiscretized, DirectGas, hipvoigt!, hiplorentz!, hipdoppler!, hipPHCO2!, hipbake!
 
 end # module
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Addendum (same status: source only).  Baked gases and CIA through the resident-column entry points:
+#
+#   cs_bake(ctx, gas_slot, table_slot, shape, Δνcut, nν, ν, nT, Ω.T, nP, Ω.P, conc[nT,nP], lnσ_out_or_NULL)
+#       replaces bake + OpacityTable (gases.jl:97-145, 75-82); the ln σ tables stay in HBM.  A `HIPGas <: AbstractGas`
+#       wrapping (table_slot, Ω, fC, ν) then plays the role of `Gas` (gases.jl:205-249):
+#         (g::HIPGas)(i, T, P) = g.fC(T,P) * rawσ via cs_table_eval(ctx, slot, T, P, i-1, 1, out)      # gases.jl:278
+#   cs_cia_begin / cs_cia_band upload a CIATables object (collision_induced_absorption.jl:145-235): one call per Φ
+#       (BilinearInterpolator grid: ν = Φ.G.x, T = Φ.G.y, ln k = Φ.G.Z) and per ϕ (single-temperature range, nt = 1).
+#   monochromaticfluxes!(…, core::HIPDiscretized, …) with such members uses, instead of cs_fluxes_discretized:
+#       cs_column_setup(…) ; cs_column_set_tables(ctx, ntab, slots, conc_tab[ntab,K]) ;
+#       cs_column_set_cia(ctx, ncia, slots, flags, P1[ncia,K], P2[ncia,K]) ; cs_column_run ; cs_column_fetch(τ, M⁺, M⁻, F⁺, F⁻)
+#   with conc_tab[t,k] = fC_t(T_k,P_k) and P1/P2 = P_k*concentration(g₁/g₂, T_k, P_k) (cia…jl:378-382), all evaluated on
+#   the Julia side at the node states (T_k, P_k) built in the method above.
+#   cs_set_precision(ctx, 1, 1e6) selects the fp32 far-wing variant (BASELINE configs[4]).
