@@ -7,7 +7,13 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "../../include/clearsky_hip.h"
 #include "cs_kernels.h"
@@ -1152,6 +1158,95 @@ int cs_fluxes_discretized(cs_ctx *ctx, int64_t nnu, const double *nu, int np, co
     if (rc) return rc;
     if ((rc = cs_column_run(ctx, nullptr))) return rc;
     return cs_column_fetch(ctx, tau, Mup, Mdn, Fup, Fdn);
+}
+
+namespace {
+struct MappedFile {
+    const char *p = nullptr;
+    size_t len = 0;
+    int fd = -1;
+    ~MappedFile()
+    {
+        if (p) munmap((void *)p, len);
+        if (fd >= 0) close(fd);
+    }
+    int open_ro(const char *fn)
+    {
+        fd = ::open(fn, O_RDONLY);
+        if (fd < 0) return fail(CS_EINVAL, "cannot open %s", fn);
+        struct stat st;
+        if (fstat(fd, &st) != 0 || st.st_size == 0) return fail(CS_EINVAL, "cannot stat %s (or empty file)", fn);
+        len = (size_t)st.st_size;
+        void *m = mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) return fail(CS_EINVAL, "cannot map %s", fn);
+        p = (const char *)m;
+        return CS_OK;
+    }
+};
+
+// record length incl. line terminator: 160 characters + "\n" or "\r\n"
+int par_layout(const MappedFile &f, size_t &stride, int64_t &n)
+{
+    const char *nl = (const char *)memchr(f.p, '\n', f.len);
+    stride = nl ? (size_t)(nl - f.p) + 1 : f.len;
+    const size_t body = (stride >= 2 && f.p[stride - 2] == '\r') ? stride - 2 : (nl ? stride - 1 : stride);
+    if (body != 160) return fail(CS_EINVAL, "expected 160-character HITRAN records, found %zu", body);
+    n = (int64_t)((f.len + (nl ? 0 : 1)) / stride);
+    if ((size_t)n * stride < f.len && f.len - (size_t)n * stride >= 160) n++;  // last record without a terminator
+    return CS_OK;
+}
+
+double field(const char *s, int a, int b)   // columns a..b (1-based, inclusive), like parse(Float64, line[a:b])
+{
+    char buf[32];
+    const int w = b - a + 1;
+    memcpy(buf, s + a - 1, w);
+    buf[w] = 0;
+    return strtod(buf, nullptr);
+}
+}  // namespace
+
+int cs_par_count(const char *filename, int64_t *n)
+{
+    if (!filename || !n) return fail(CS_EINVAL, "bad arguments");
+    MappedFile f;
+    int rc = f.open_ro(filename);
+    if (rc) return rc;
+    size_t stride;
+    return par_layout(f, stride, *n);
+}
+
+int cs_par_parse(const char *filename, int64_t n, int16_t *M, char *I, double *nu, double *S, double *A, double *gamma_a,
+                 double *gamma_s, double *Epp, double *na, double *delta_a)
+{
+    if (!filename) return fail(CS_EINVAL, "bad arguments");
+    MappedFile f;
+    int rc = f.open_ro(filename);
+    if (rc) return rc;
+    size_t stride;
+    int64_t cnt;
+    if ((rc = par_layout(f, stride, cnt))) return rc;
+    if (cnt != n) return fail(CS_EINVAL, "file holds %lld records, caller expects %lld", (long long)cnt, (long long)n);
+    const int nth = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::thread::hardware_concurrency(), 32, n / 20000}));
+    std::vector<std::thread> th;
+    for (int t = 0; t < nth; t++)
+        th.emplace_back([&, t]() {
+            for (int64_t i = n * t / nth; i < n * (t + 1) / nth; i++) {
+                const char *r = f.p + (size_t)i * stride;   // columns: par.jl:131-140
+                M[i] = (int16_t)field(r, 1, 2);
+                I[i] = r[2];
+                nu[i] = field(r, 4, 15);
+                S[i] = field(r, 16, 25);
+                A[i] = field(r, 26, 35);
+                gamma_a[i] = field(r, 36, 40);
+                gamma_s[i] = field(r, 41, 45);
+                Epp[i] = field(r, 46, 55);
+                na[i] = field(r, 56, 59);
+                delta_a[i] = field(r, 60, 67);
+            }
+        });
+    for (auto &x : th) x.join();
+    return CS_OK;
 }
 
 int cs_streamnodes(int n, double *m, double *W)

@@ -67,7 +67,7 @@ _FIELDS = ("M", "I", "nu", "S", "A", "gamma_a", "gamma_s", "Epp", "na", "delta_a
 
 
 def readpar(filename: str, numin: float = 0.0, numax: float = np.inf, Scut: float = 0.0, I: Sequence = (),
-            maxlines: int = -1) -> dict:
+            maxlines: int = -1, native: bool = True) -> dict:
     """Read a HITRAN 160-column .par file (par.jl:91-193; columns :131-149).
 
     Filters (nu range, intensity cut, isotopologues, strongest `maxlines`) and the final stable sort by wavenumber
@@ -76,6 +76,9 @@ def readpar(filename: str, numin: float = 0.0, numax: float = np.inf, Scut: floa
     """
     if not filename.endswith(".par"):
         raise AssertionError("expected file with .par extension, downloaded from https://hitran.org/lbl/")
+    par = _readpar_native(filename) if native else None    # cs_par_parse: mmap + threads (include/clearsky_hip.h)
+    if par is not None:
+        return _filter_sort(par, len(par["nu"]), numin, numax, Scut, I, maxlines)
     with open(filename, "rb") as f:
         raw = f.read().split(b"\n")
     raw = [ln.rstrip(b"\r") for ln in raw if len(ln.strip()) > 0]
@@ -93,6 +96,31 @@ def readpar(filename: str, numin: float = 0.0, numax: float = np.inf, Scut: floa
         par["Epp"][i] = float(ln[45:55])
         par["na"][i] = float(ln[55:59])
         par["delta_a"][i] = float(ln[59:67])
+    return _filter_sort(par, N, numin, numax, Scut, I, maxlines)
+
+
+def _readpar_native(filename):
+    """Parsing loop in the native library (cs_par_parse: mmap + threads); None when the library is not built."""
+    import ctypes as C
+    from . import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        return None
+    L = _lib.lib()
+    n = C.c_int64()
+    _lib.check(L.cs_par_count(filename.encode(), C.byref(n)))
+    N = n.value
+    par = dict(M=np.zeros(N, np.int16), I=np.zeros(N, "S1"), nu=np.zeros(N), S=np.zeros(N), A=np.zeros(N),
+               gamma_a=np.zeros(N), gamma_s=np.zeros(N), Epp=np.zeros(N), na=np.zeros(N), delta_a=np.zeros(N))
+    d = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    _lib.check(L.cs_par_parse(filename.encode(), N, par["M"].ctypes.data_as(C.POINTER(C.c_int16)),
+                              par["I"].ctypes.data_as(C.c_char_p), d(par["nu"]), d(par["S"]), d(par["A"]), d(par["gamma_a"]),
+                              d(par["gamma_s"]), d(par["Epp"]), d(par["na"]), d(par["delta_a"])))
+    par["I"] = par["I"].astype("U1")
+    return par
+
+
+def _filter_sort(par, N, numin, numax, Scut, I, maxlines):
+    """par.jl:153-191: masks, strongest-N selection, stable sort by wavenumber"""
     mask = (par["nu"] >= numin) & (par["nu"] <= numax) & (par["S"] >= Scut)
     if len(I) > 0:
         keep = set(I)

@@ -178,6 +178,18 @@ int cs_column_counts(cs_ctx *ctx, int64_t *pair_evals, int64_t *lines_in_range);
 int cs_column_update_state(cs_ctx *ctx, const double *T_nodes, const double *mu_nodes, const double *T_levels,
                            const double *conc, const double *conc_tab);
 
+/*
+ * Native HITRAN .par ingestion (host only, no GPU needed).  Replaces the parsing loop of readpar (hitran/par.jl:127-152;
+ * 160-column layout :131-149) with a memory-mapped, multi-threaded fixed-width parser.  Filters (nu range, intensity cut,
+ * isotopologue selection, strongest-N) and the final stable sort stay with the caller, as in par.jl:153-191.
+ *   cs_par_count : number of records in the file
+ *   cs_par_parse : fills the caller's arrays of length n (= cs_par_count): M (molecule number), I (isotopologue character),
+ *                  nu, S, A, gamma_a, gamma_s, Epp, na, delta_a
+ */
+int cs_par_count(const char *filename, int64_t *n);
+int cs_par_parse(const char *filename, int64_t n, int16_t *M, char *I, double *nu, double *S, double *A, double *gamma_a,
+                 double *gamma_s, double *Epp, double *na, double *delta_a);
+
 /* Scalar helpers exported for tests of the host logic (same formulas the kernels use). */
 int cs_streamnodes(int n, double *m, double *W);    /* core/shared.jl:4-21 */
 int cs_lobattonodes(int n, double *x, double *w);   /* core/discretized.jl:2-9 */

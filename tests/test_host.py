@@ -75,6 +75,19 @@ def test_readpar_filters(cs):
         cs.readpar("foo.txt")
 
 
+@pytest.mark.parametrize("name", ["CO2", "H2O", "CH4"])
+def test_native_par_parser_matches_python(cs, name):
+    """cs_par_parse (mmap + threads) against the pure-Python restatement of readpar's parsing loop (par.jl:127-152)."""
+    f = os.path.join(HITRAN, name + ".par")
+    a, b = cs.readpar(f, native=True), cs.readpar(f, native=False)
+    assert set(a) == set(b)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    n = ctypes.c_int64()
+    assert cs.lib().cs_par_count(f.encode(), ctypes.byref(n)) == 0 and n.value == len(a["nu"])
+    assert cs.lib().cs_par_count(b"/nonexistent.par", ctypes.byref(n)) != 0
+
+
 def test_first_line_fields(cs):
     p = cs.readpar(os.path.join(HITRAN, "CO2.par"))
     j = int(np.argmin(np.abs(p["nu"] - 0.757206)))
