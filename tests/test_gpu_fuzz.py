@@ -1,0 +1,100 @@
+"""Randomised GPU-vs-oracle parity on awkward inputs: non-uniform / tiny / gappy wavenumber grids, duplicated and very dense
+lines (the near-line queue overflows into its fallback), light molecules and hot gas (near zone = whole window), tiny and
+huge cut-offs, zero and very high pressure.  Same tolerances as test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def _table(cs, rng, M, L, lo, hi, dense=None, dup=False):
+    nu = np.sort(rng.uniform(lo, hi, L))
+    if dense is not None:                      # a clump of lines inside ~1 cm^-1
+        c0 = rng.uniform(lo, hi)
+        nu[: dense] = c0 + rng.uniform(0, 1.0, dense)
+        nu = np.sort(nu)
+    if dup:
+        nu[1::7] = nu[0::7][: len(nu[1::7])]
+        nu = np.sort(nu)
+    niso = len(cs.MOLPARAM[M].I)
+    iso = rng.integers(1, min(niso, 3) + 1, L).astype(np.int16)
+    par = dict(M=np.full(L, M, np.int16), I=iso, nu=nu, S=10.0 ** rng.uniform(-27, -19, L), gamma_a=rng.uniform(0.01, 0.12, L),
+               gamma_s=rng.uniform(0.02, 0.5, L), Epp=rng.uniform(0, 4000, L), na=rng.uniform(0.3, 0.9, L))
+    return cs.SpectralLines(par)
+
+
+def _grid(rng, kind, lo, hi, n):
+    if kind == "uniform":
+        return np.linspace(lo, hi, n)
+    if kind == "log":
+        return np.unique(np.exp(np.linspace(np.log(max(lo, 1e-3)), np.log(hi), n)))
+    if kind == "random":
+        return np.unique(np.sort(rng.uniform(lo, hi, n)))
+    # clustered with gaps
+    a = np.concatenate([rng.normal(c, 0.05 * (hi - lo) / 10, n // 4) for c in rng.uniform(lo, hi, 4)])
+    return np.unique(np.clip(np.sort(a), lo, hi))
+
+
+CASES = [
+    # (molecule, L, line range, grid kind, grid range, nnu, cut, dense, dup, states)
+    (2, 3000, (500, 900), "uniform", (550, 850), 1000, 25.0, None, False, [(250, 1e4, 4.0), (180, 30.0, 0.0)]),
+    (1, 2000, (1, 300), "log", (0.5, 280), 700, 25.0, None, True, [(296, 101325.0, 1e3), (300, 0.0, 0.0)]),
+    (2, 4000, (600, 700), "random", (590, 710), 513, 25.0, 1500, False, [(220, 50.0, 0.01), (260, 5e3, 50.0)]),
+    (45, 500, (300, 4000), "clustered", (200, 4200), 900, 25.0, None, False, [(1000, 1e5, 1e5), (25, 1e3, 10.0)]),   # H2: light, hot
+    (2, 1500, (2000, 2400), "uniform", (2100, 2300), 65, 0.05, None, False, [(250, 1e4, 4.0)]),                      # tiny cut-off
+    (2, 1500, (100, 3000), "uniform", (1000, 2000), 129, 600.0, None, False, [(250, 3e5, 3e5)]),                     # huge cut-off, 3 bar
+    (6, 800, (1200, 1400), "uniform", (1299.9, 1300.1), 64, 25.0, 300, True, [(200, 1.0, 0.0), (320, 2e4, 1.0)]),  # 2e-4 cm^-1 spacing
+    (2, 50, (660, 670), "uniform", (667.0, 667.0001), 2, 25.0, None, False, [(250, 1e3, 1.0)]),
+    (2, 50, (660, 670), "uniform", (667.3, 667.3), 1, 25.0, None, False, [(250, 1e3, 1.0)]),
+]
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_shape_batch_fuzz(cs, O, case):
+    M, L, (llo, lhi), kind, (glo, ghi), n, cut, dense, dup, states = CASES[case]
+    rng = np.random.default_rng(100 + case)
+    sl = _table(cs, rng, M, L, llo, lhi, dense, dup)
+    nu = _grid(rng, kind, glo, ghi, n) if n > 1 else np.array([glo])
+    T, P, Pp = map(list, zip(*states))
+    ctx = cs.Context(0)
+    for shape in ("voigt", "lorentz", "doppler"):
+        sg = cs.shape_batch(sl, shape, nu, T, P, Pp, cut, ctx)
+        for k in range(len(T)):
+            so = O.shape_bang(shape, nu, sl, T[k], P[k], Pp[k], cut)
+            assert np.array_equal(sg[k] == 0, so == 0), (shape, k)
+            tol = 1e-11 if shape != "doppler" else 1e-9      # exp(-x^2) at x^2 ~ 700 amplifies an ulp of x^2 by 700
+            assert relerr(sg[k], so, floor=1e-280) < tol, (shape, k, relerr(sg[k], so, floor=1e-280))
+    ctx.close()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_column_fuzz(cs, O, seed):
+    rng = np.random.default_rng(500 + seed)
+    n = int(rng.integers(100, 1500))
+    nu = _grid(rng, ["uniform", "log", "random", "clustered"][seed], 50.0, 2500.0, n)
+    g1 = cs.DirectGas(_table(cs, rng, 2, 2500, 1, 2600, dense=400 if seed == 2 else None), float(rng.uniform(1e-5, 0.3)), nu)
+    g2 = cs.DirectGas(_table(cs, rng, 1, 1500, 1, 2600), lambda T, P: min(0.05, 1e-3 * (P / 1e5) ** 2 * (T / 250) ** 4), nu)
+    npl = int(rng.integers(3, 30))
+    P = cs.pressuregrid(float(10 ** rng.uniform(-2, 1)), float(10 ** rng.uniform(4, 5.5)), npl)
+    T = np.sort(rng.uniform(150, 400, npl))
+    nlob, ns = int(rng.integers(2, 6)), int(rng.integers(1, 9))
+    ctx = cs.Context(0)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        col = cs.Column(P, float(rng.uniform(3, 25)), T, float(rng.uniform(0.002, 0.05)), float(rng.uniform(0, 5)), float(rng.uniform(0, 1)),
+                        g1, g2, core=cs.Discretized(ns, nlob), theta_s=float(rng.uniform(0, 1.4)), ctx=ctx)
+    col.run()
+    F = cs.FluxPack(npl, len(nu))
+    F.Fup[:], F.Fdn[:] = col.fetch(F.tau, F.Mup, F.Mdn)
+    r = O.fluxes_discretized(nu, P, col.g, nlob, col.Tn, col.mun, col.Tlev, [g1.sl, g2.sl], ["voigt"] * 2, [25.0] * 2, col.conc,
+                             S_toa=col.S_toa, albedo=col.albedo, theta_s=col.theta_s, nstream=ns, want_sigma=True)
+    assert relerr(col.sigma_nodes(), r["sigma"], floor=1e-280) < 1e-11
+    assert relerr(F.tau, r["tau"]) < 1e-11
+    sm = max(r["Mup"].max(), r["Mdn"].max())
+    assert np.max(np.abs(F.Mup - r["Mup"])) < 1e-11 * sm and np.max(np.abs(F.Mdn - r["Mdn"])) < 1e-11 * sm
+    fm = max(np.abs(r["Fup"]).max(), np.abs(r["Fdn"]).max())
+    assert np.max(np.abs(F.Fup - r["Fup"])) < 1e-11 * fm and np.max(np.abs(F.Fdn - r["Fdn"])) < 1e-11 * fm
+    ctx.close()
