@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--precision", default="fp64", help="fp64 (headline) | mixed (fp32 far wings, BASELINE configs[4])")
     ap.add_argument("--far-s", type=float, default=1e6, help="mixed precision: x^2 threshold of the fp32 region")
+    ap.add_argument("--emulate-shard", default=None, help="R/N: time only shard R of an N-way split on this one GPU (rehearsal)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL, default) | gloo (rehearsal of N>1 on fewer GPUs)")
     ap.add_argument("--cpu-stride", type=int, default=0, help="cpu_baseline evaluates every n-th wavenumber (0 = size the sample for ~15 s)")
     args = ap.parse_args()
@@ -68,6 +69,9 @@ def main():
     cfg = W.config(args.config, nnu=args.nnu, lines_kind=args.lines)
     nu, nl = cfg["nu"], cfg["nl"]
     ranges = W.balanced_ranges(nu, cfg["absorbers"], N)
+    if args.emulate_shard:
+        r_, n_ = map(int, args.emulate_shard.split("/"))
+        ranges = [W.balanced_ranges(nu, cfg["absorbers"], n_)[r_]]
     ctx = cs.Context(dev)
     ctx.set_precision(args.precision, args.far_s)
     col = cs.Column(cfg["P"], cfg["g"], cfg["T"], cfg["mu"], cfg["fS"], cfg["fa"], *cfg["absorbers"], core=cfg["core"],

@@ -123,13 +123,13 @@ struct ColGas {
     double cut = 25.0;
     DevBuf conc, Pp, J0, J1;  // [K], [K], [ntile], [ntile]
     DevBuf win, zones, gmax;  // [ntile64] WaveWin, [K][ntile64] Zone, [K] max Lorentz width (Voigt fast path)
-    int64_t pairs_per_state = 0, lines_in_range = 0;
+    int64_t pairs_per_state = 0, lines_in_range = 0, jlo = 0, jhi = 0;
 };
 
 struct Column {
     bool ready = false;
     int64_t nnu = 0;
-    int np = 0, nl = 0, nlob = 0, K = 0, nstream = 0, ngas = 0, ntile = 0;
+    int np = 0, nl = 0, nlob = 0, K = 0, nstream = 0, ngas = 0, ntile = 0, rt_bs = 256, rt_nblk = 0;
     bool want_tau = false, want_M = false, has_extra = false, has_S = false, has_alb = false;
     double g = 0, sigma_gray = 0, theta_s = 0;
     RtParams rt;
@@ -255,19 +255,19 @@ void launch_linesum_shape(int shape, dim3 grid, hipStream_t s, const double *nu,
 }
 
 template <int NS>
-void launch_rt_ns(int nblk, size_t shmem, hipStream_t s, const RtParams &p, const double *nu, const double *wts,
+void launch_rt_ns(int nblk, int bs, size_t shmem, hipStream_t s, const RtParams &p, const double *nu, const double *wts,
                   int64_t nnu, const double *sigma, const double *muk, const double *P, const double *Tlev,
                   const double *S, const double *alb, double *tau, double *Mup, double *Mdn, double *partial)
 {
-    hipLaunchKernelGGL(k_rt<NS>, dim3(nblk), dim3(256), shmem, s, p, nu, wts, nnu, sigma, muk, P, Tlev, S, alb, tau, Mup,
+    hipLaunchKernelGGL(k_rt<NS>, dim3(nblk), dim3(bs), shmem, s, p, nu, wts, nnu, sigma, muk, P, Tlev, S, alb, tau, Mup,
                        Mdn, partial);
 }
 
-void launch_rt(int ns, int nblk, size_t shmem, hipStream_t s, const RtParams &p, const double *nu, const double *wts,
+void launch_rt(int ns, int nblk, int bs, size_t shmem, hipStream_t s, const RtParams &p, const double *nu, const double *wts,
                int64_t nnu, const double *sigma, const double *muk, const double *P, const double *Tlev,
                const double *S, const double *alb, double *tau, double *Mup, double *Mdn, double *partial)
 {
-#define CS_RT_CASE(N) case N: launch_rt_ns<N>(nblk, shmem, s, p, nu, wts, nnu, sigma, muk, P, Tlev, S, alb, tau, Mup, Mdn, partial); break;
+#define CS_RT_CASE(N) case N: launch_rt_ns<N>(nblk, bs, shmem, s, p, nu, wts, nnu, sigma, muk, P, Tlev, S, alb, tau, Mup, Mdn, partial); break;
     switch (ns) {
         CS_RT_CASE(1) CS_RT_CASE(2) CS_RT_CASE(3) CS_RT_CASE(4) CS_RT_CASE(5) CS_RT_CASE(6) CS_RT_CASE(7) CS_RT_CASE(8)
         CS_RT_CASE(9) CS_RT_CASE(10) CS_RT_CASE(11) CS_RT_CASE(12) CS_RT_CASE(13) CS_RT_CASE(14) CS_RT_CASE(15) CS_RT_CASE(16)
@@ -351,14 +351,17 @@ std::vector<double> gamma_bound(const GasTable &G, int K, const double *T, const
 }
 
 // K1 + K2 for one gas on `s`: parameters for `kn` states, then the line sum into sigma ([kn][nnu])
-void launch_gas(hipStream_t s, int shape, const GasTable &G, int kn, const double *Tk, const double *Pk, const double *Ppk,
+void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, int64_t jrange1, int kn, const double *Tk, const double *Pk, const double *Ppk,
                 const double *scale, LineHot *hot, LineCold *cold, const double *dnu, int64_t nnu, int ntile256,
                 const int32_t *J0, const int32_t *J1, const WaveWin *win, Zone *zones, int4 *ranges, const double *gbound, double cut, double base,
                 const double *extra, double *sigma, int accumulate, hipEvent_t ev_mid, hipEvent_t ev_far = nullptr,
                 LineF32 *hot32 = nullptr, double far_s = 1e6)
 {
-    const int64_t tot = (int64_t)kn * G.L;
-    hipLaunchKernelGGL(k_prep, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, shape, G.dev(), kn, Tk, Pk, Ppk, scale,
+    // only the lines some window can reach (windows are sorted: first tile's start .. last tile's end)
+    const int64_t jlo = jrange0, jhi = std::max(jrange1, jrange0);
+    const int64_t tot = (int64_t)kn * (jhi - jlo);
+    if (tot > 0)
+        hipLaunchKernelGGL(k_prep, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, shape, G.dev(), jlo, jhi, kn, Tk, Pk, Ppk, scale,
                        hot, cold, shape == SH_VOIGT ? hot32 : nullptr);
     if (shape == SH_VOIGT) {
         const int nt64 = (int)((nnu + 63) / 64);
@@ -366,13 +369,20 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int kn, const doubl
                            G.nu.as<double>(), win, Tk, G.mu_min, G.mu_max, cut, gbound, far_s, zones);
         if (ev_mid) (void)hipEventRecord(ev_mid, s);
         const int nblk = (nt64 + 3) / 4;
-        const dim3 grid((unsigned)((nblk + 7) / 8 * 8), kn);   // multiple of 8: XCD-aware tile mapping (k_voigt_far)
-        if (hot32)
-            hipLaunchKernelGGL(k_voigt_far<true>, grid, dim3(256), 0, s, dnu, nnu, G.L, hot, hot32, G.nu.as<double>(), win, zones, nt64, nblk, cut, base,
-                               extra, sigma, accumulate, ranges);
-        else
-            hipLaunchKernelGGL(k_voigt_far<false>, grid, dim3(256), 0, s, dnu, nnu, G.L, hot, (const LineF32 *)nullptr, G.nu.as<double>(), win, zones,
-                               nt64, nblk, cut, base, extra, sigma, accumulate, ranges);
+        const dim3 grid((unsigned)((nblk + 7) / 8 * 8), kn);   // multiple of 8: XCD-aware tile mapping (tile_block)
+        // waves per tile: enough waves to fill 256 CUs x 32 wave slots about 4 times over
+        const int64_t nwave = (int64_t)nt64 * kn;
+        const int split = nwave >= 32768 ? 1 : (nwave >= 16384 ? 2 : 4);
+        const int nblk_s = (nt64 * split + 3) / 4;
+        const dim3 grid_s((unsigned)((nblk_s + 7) / 8 * 8), kn);
+#define CS_FAR_LAUNCH(MIX, SP) hipLaunchKernelGGL((k_voigt_far<MIX, SP>), grid_s, dim3(256), 0, s, dnu, nnu, G.L, hot, hot32, G.nu.as<double>(), \
+                                                  win, zones, nt64, nblk_s, cut, base, extra, sigma, accumulate, ranges)
+        if (hot32) {
+            if (split == 1) CS_FAR_LAUNCH(true, 1); else if (split == 2) CS_FAR_LAUNCH(true, 2); else CS_FAR_LAUNCH(true, 4);
+        } else {
+            if (split == 1) CS_FAR_LAUNCH(false, 1); else if (split == 2) CS_FAR_LAUNCH(false, 2); else CS_FAR_LAUNCH(false, 4);
+        }
+#undef CS_FAR_LAUNCH
         if (ev_far) (void)hipEventRecord(ev_far, s);
         hipLaunchKernelGGL(k_voigt_near, grid, dim3(256), 0, s, dnu, nnu, G.L, hot, cold, zones, nt64, nblk, cut, sigma, ranges);
     } else {
@@ -533,7 +543,7 @@ int cs_shape_batch(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t nnu
     }
     for (int k0 = 0; k0 < K; k0 += kc) {
         const int kn = std::min(kc, K - k0);
-        launch_gas(s, shape, G, kn, dT.as<double>() + k0, dP.as<double>() + k0, dPp.as<double>() + k0, nullptr,
+        launch_gas(s, shape, G, J0.front(), J1.back(), kn, dT.as<double>() + k0, dP.as<double>() + k0, dPp.as<double>() + k0, nullptr,
                    hot.as<LineHot>(), cold.as<LineCold>(), dnu.as<double>(), nnu, ntile, dJ0.as<int32_t>(), dJ1.as<int32_t>(),
                    dwin.as<WaveWin>(), dzones.as<Zone>(), dranges.as<int4>(), dgmax.as<double>() + k0, dnu_cut, 0.0, nullptr, dsig.as<double>(), 0, nullptr,
                    nullptr, mix32, ctx->far_s);
@@ -600,7 +610,7 @@ int cs_bake(cs_ctx *ctx, int gas_slot, int table_slot, int shape, double dnu_cut
     }
     for (int k0 = 0; k0 < M; k0 += kc) {
         const int kn = std::min(kc, M - k0);
-        launch_gas(s, shape, G, kn, dT.as<double>() + k0, dP.as<double>() + k0, dPp.as<double>() + k0, nullptr, hot.as<LineHot>(),
+        launch_gas(s, shape, G, J0.front(), J1.back(), kn, dT.as<double>() + k0, dP.as<double>() + k0, dPp.as<double>() + k0, nullptr, hot.as<LineHot>(),
                    cold.as<LineCold>(), dnu.as<double>(), nnu, ntile, dJ0.as<int32_t>(), dJ1.as<int32_t>(), dwin.as<WaveWin>(),
                    dzones.as<Zone>(), dranges.as<int4>(), dgb.as<double>() + k0, dnu_cut, 0.0, nullptr, tb.Z.as<double>() + (size_t)k0 * nnu, 0, nullptr,
                    nullptr, mix32, ctx->far_s);
@@ -850,6 +860,8 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
     hipStream_t s = ctx->stream;
     c.nnu = nnu; c.np = np; c.nl = np - 1; c.nlob = nlobatto; c.K = (np - 1) * (nlobatto - 1) + 1;
     c.nstream = nstream; c.ngas = ngas; c.ntile = (int)((nnu + 255) / 256);
+    c.rt_bs = nnu >= 65536 ? 256 : 64;   // small grids: one wave per block so that k_rt still covers all 256 CUs
+    c.rt_nblk = (int)((nnu + c.rt_bs - 1) / c.rt_bs);
     c.want_tau = want_tau != 0; c.want_M = want_M != 0;
     c.g = g; c.sigma_gray = sigma_gray; c.theta_s = theta_s;
     const int K = c.K, nl = c.nl;
@@ -909,6 +921,8 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
         included_range(G.h_nu, nu[0], nu[nnu - 1], cg.cut, false, g0, g1);
         std::vector<int32_t> J0, J1;
         tile_windows(G.h_nu, g0, g1, nu, nnu, cg.cut, J0, J1, cg.pairs_per_state, cg.lines_in_range);
+        cg.jlo = J0.front();
+        cg.jhi = J1.back();
         std::vector<WaveWin> win;
         wave_windows(G.h_nu, g0, g1, nu, nnu, cg.cut, win);
         if ((rc = upload(cg.J0, J0.data(), J0.size(), s)) || (rc = upload(cg.J1, J1.data(), J1.size(), s)) ||
@@ -927,7 +941,7 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
         HIPCHK(c.Mup.reserve((size_t)np * nnu * sizeof(double)));
         HIPCHK(c.Mdn.reserve((size_t)np * nnu * sizeof(double)));
     }
-    HIPCHK(c.partial.reserve((size_t)c.ntile * 2 * np * sizeof(double)));
+    HIPCHK(c.partial.reserve((size_t)c.rt_nblk * 2 * np * sizeof(double)));
     HIPCHK(c.F.reserve((size_t)2 * np * sizeof(double)));
     HIPCHK(hipStreamSynchronize(s));
     c.ready = true;  // state upload below needs the sizes
@@ -1002,7 +1016,7 @@ static int run_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev)
     for (int gi = 0; gi < c.ngas; gi++) {
         ColGas &cg = c.gas[gi];
         GasTable &G = ctx->gas[cg.slot];
-        launch_gas(s, cg.shape, G, K, c.Tk.as<double>(), c.Pk.as<double>(), cg.Pp.as<double>(), cg.conc.as<double>(),
+        launch_gas(s, cg.shape, G, cg.jlo, cg.jhi, K, c.Tk.as<double>(), c.Pk.as<double>(), cg.Pp.as<double>(), cg.conc.as<double>(),
                    c.hot.as<LineHot>(), c.cold.as<LineCold>(), c.nu.as<double>(), c.nnu, c.ntile, cg.J0.as<int32_t>(),
                    cg.J1.as<int32_t>(), cg.win.as<WaveWin>(), cg.zones.as<Zone>(), c.ranges.as<int4>(), cg.gmax.as<double>(), cg.cut, c.sigma_gray, extra, sig, gi > 0,
                    ev ? ev[e] : nullptr, ev ? ev[e + 1] : nullptr,
@@ -1021,12 +1035,12 @@ static int run_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev)
     for (auto &cc : c.cia)  // CIA pairs
         hipLaunchKernelGGL(k_cia, dim3((unsigned)c.ntile), dim3(256), 0, s, cc.nband, cc.bands.as<CiaBand>(), cc.st.as<CiaState>(),
                            c.nu.as<double>(), c.nnu, K, cc.rho1.as<double>(), cc.rho2.as<double>(), cc.rhoa.as<double>(), sig);
-    launch_rt(c.nstream, c.ntile, (size_t)2 * c.np * 4 * sizeof(double), s, c.rt, c.nu.as<double>(), c.wts.as<double>(),
+    launch_rt(c.nstream, c.rt_nblk, c.rt_bs, (size_t)2 * c.np * (c.rt_bs / 64) * sizeof(double), s, c.rt, c.nu.as<double>(), c.wts.as<double>(),
               c.nnu, sig, c.muk.as<double>(), c.P.as<double>(), c.Tlev.as<double>(),
               c.has_S ? c.S_toa.as<double>() : nullptr, c.has_alb ? c.albedo.as<double>() : nullptr, c.tau.as<double>(),
               c.want_M ? c.Mup.as<double>() : nullptr, c.want_M ? c.Mdn.as<double>() : nullptr, c.partial.as<double>());
     if (ev) HIPCHK(hipEventRecord(ev[e++], s));
-    hipLaunchKernelGGL(k_freduce, dim3(2 * c.np), dim3(256), 0, s, c.partial.as<double>(), c.ntile, 2 * c.np,
+    hipLaunchKernelGGL(k_freduce, dim3(2 * c.np), dim3(256), 0, s, c.partial.as<double>(), c.rt_nblk, 2 * c.np,
                        c.F.as<double>());
     if (ev) HIPCHK(hipEventRecord(ev[e++], s));
     HIPCHK(hipGetLastError());

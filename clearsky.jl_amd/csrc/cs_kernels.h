@@ -64,17 +64,19 @@ __device__ __forceinline__ double cheby_qrefq(double T, int n, const double *__r
     return 1.0 / y;
 }
 
-// K1: one thread per (state k, line j); j fastest so the SoA line table is read coalesced.
-__global__ __launch_bounds__(256) void k_prep(int shape, GasDev g, int K, const double *__restrict__ Tk,
+// K1: one thread per (state k, line j), j in [jlo, jhi) = the lines some window of this wavenumber grid can reach (a nu-shard
+// of a multi-GPU run needs only its part of the table); j fastest so the SoA line table is read coalesced.
+__global__ __launch_bounds__(256) void k_prep(int shape, GasDev g, int64_t jlo, int64_t jhi, int K, const double *__restrict__ Tk,
                                                const double *__restrict__ Pk, const double *__restrict__ Ppk,
                                                const double *__restrict__ scale, LineHot *__restrict__ hot,
                                                LineCold *__restrict__ cold, LineF32 *__restrict__ hot32)
 {
+    const int64_t nj = jhi - jlo;
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t total = (int64_t)K * g.L;
-    if (idx >= total) return;
-    int k = (int)(idx / g.L);
-    int64_t j = idx - (int64_t)k * g.L;
+    if (idx >= (int64_t)K * nj) return;
+    int k = (int)(idx / nj);
+    int64_t j = jlo + (idx - (int64_t)k * nj);
+    idx = (int64_t)k * g.L + j;   // records are addressed by the line's index in the full table
     double T = Tk[k], P = Pk[k], Pp = Ppk[k], C = scale ? scale[k] : 1.0;
     double nul = g.nu[j];
     // scaleintensity, line_shapes.jl:107-123
@@ -350,7 +352,7 @@ __device__ __forceinline__ int tile_block(int nblk)
 // line parameters arrive through scalar loads:
 //   [W0,a) left edge (cut-off predicate) | [a,M0) far | [M0,N0) mid-far | [N0,N1) near zone | [N1,M1) | [M1,b) | [b,W1)
 // In the near zone only the pairs with s >= 1e4 are summed here; the others belong to k_voigt_near.
-template <bool MIXED>
+template <bool MIXED, int S>
 __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu, int64_t nnu, int64_t L,
                                                     const LineHot *__restrict__ hot, const LineF32 *__restrict__ hot32,
                                                     const double *__restrict__ gnul, const WaveWin *__restrict__ win,
@@ -358,62 +360,123 @@ __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu
                                                     double base, const double *__restrict__ extra,
                                                     double *__restrict__ sigma, int accumulate, int4 *__restrict__ ranges)
 {
+    // S = 1: one wave per tile.  S = 2, 4: the S waves of a tile split its window of lines into S parts of equal estimated
+    // cost and add their partial sums through LDS -- S times more, S times shorter waves, for grids too small to fill the
+    // chip otherwise (a nu-shard of a multi-GPU run, bake on a short grid).
+    __shared__ double acc_sh[S > 1 ? 256 : 1];
+    __shared__ int4 rng_sh[S > 1 ? 256 : 1];
     const int tb = tile_block(nblk);
-    const int tile = __builtin_amdgcn_readfirstlane(tb * 4 + (threadIdx.x >> 6));
-    if (tb >= nblk || tile >= ntile) return;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave-uniform by construction:
+    const int tile = tb * (4 / S) + wv / S;                                                      // tell the compiler, so that the
+    const int part = wv % S;                                                                     // line records stay scalar loads
+    const bool work = tb < nblk && tile < ntile;
+    if (S == 1 && !work) return;
     const int k = blockIdx.y;
-    const int64_t i = (int64_t)tile * 64 + (threadIdx.x & 63);
-    const LineHot *__restrict__ hk = hot + (size_t)k * L;
-    const LineF32 *__restrict__ hf = MIXED ? hot32 + (size_t)k * L : nullptr;
-    const double v = nu[i < nnu ? i : nnu - 1];
-    const WaveWin w = win[tile];
-    const Zone z = zones[(size_t)k * ntile + tile];
-    const FarK c = load_fark();
+    const int64_t i = (int64_t)tile * 64 + lane;
     double acc = 0.0;
-    if (MIXED) {
-        const int a = min(max(w.E0, w.W0), z.Q0);
-        acc = far_segment32<true, 0>(acc, v, gnul, hf, w.W0, a, cut);
-        acc = far_segment32<false, 0>(acc, v, gnul, hf, a, z.Q0, cut);
-        const int a1 = min(max(w.E0, z.Q0), z.M0);
-        acc = far_segment32<true, 1>(acc, v, gnul, hf, z.Q0, a1, cut);
-        acc = far_segment32<false, 1>(acc, v, gnul, hf, a1, z.M0, cut);
-    } else {   // left of the wave: [W0,a) edge (cut-off predicate) | [a,Q0) 2-term | [Q0,M0) 3-term      (a <= Q0 <= M0)
-        const int a = min(max(w.E0, w.W0), z.Q0);
-        acc = far_segment<true, 0>(acc, v, hk, w.W0, a, cut, c);
-        acc = far_segment<false, 0>(acc, v, hk, a, z.Q0, cut, c);
-        const int a1 = min(max(w.E0, z.Q0), z.M0);
-        acc = far_segment<true, 1>(acc, v, hk, z.Q0, a1, cut, c);
-        acc = far_segment<false, 1>(acc, v, hk, a1, z.M0, cut, c);
-    }
-    acc = far_segment<true, 2>(acc, v, hk, z.M0, z.N0, cut, c);
-    // near zone: six-term series where s >= 1e3; the index ranges of this lane's s < 1e3 and s < 100 lines go to
-    // k_voigt_near through `ranges` (relative to N0; empty = {0,0})
     int bl = 0x3fffffff, bh = -1, cl = 0x3fffffff, ch = -1;
-    if (z.N1 > z.N0) {
-        const volatile double *tb = kFarTable;
-        const double q40 = tb[8], q41 = tb[9], q42 = tb[10], q43 = tb[11], q44 = tb[12];
-        const double q50 = tb[13], q51 = tb[14], q52 = tb[15], q53 = tb[16], q54 = tb[17], q55 = tb[18];
-        for (int j = z.N0; j < z.N1; j++) {
-            const LineHot h = hk[j];
-            const double dv = v - h.nul;
-            const double x = dv * h.p1;
-            const double s = __builtin_fma(x, x, h.p2);
-            const bool in = !(fabs(dv) > cut);
-            const double u = rcp_fast(s);
-            const double t = h.p2 * u;
-            const double p5 = __builtin_fma(__builtin_fma(__builtin_fma(__builtin_fma(__builtin_fma(q55, t, q54), t, q53), t, q52), t, q51), t, q50);
-            const double p4 = __builtin_fma(__builtin_fma(__builtin_fma(__builtin_fma(q44, t, q43), t, q42), t, q41), t, q40);
-            const double p3 = __builtin_fma(__builtin_fma(__builtin_fma(c.km120, t, c.k210), t, c.km105), t, c.k13p125);
-            const double p2 = __builtin_fma(__builtin_fma(c.k12, t, c.km15), t, c.k3p75);
-            const double p1 = __builtin_fma(-2.0, t, c.k1p5);
-            double P = __builtin_fma(u, p5, p4);
-            P = __builtin_fma(u, P, p3);
-            P = __builtin_fma(u, P, p2);
-            P = __builtin_fma(u, P, p1);
-            P = __builtin_fma(u, P, 1.0);
-            acc += (in && s >= kSerS) ? (h.p3 * u) * P : 0.0;
-            if (in && s < kSerS) { bl = min(bl, j); bh = j; }
-            if (in && s < kMidS) { cl = min(cl, j); ch = j; }
+    Zone z = {};
+    if (work) {
+        const LineHot *__restrict__ hk = hot + (size_t)k * L;
+        const LineF32 *__restrict__ hf = MIXED ? hot32 + (size_t)k * L : nullptr;
+        const double v = nu[i < nnu ? i : nnu - 1];
+        const WaveWin w = win[tile];
+        z = zones[(size_t)k * ntile + tile];
+        const FarK c = load_fark();
+        // this wave's share [p0, p1) of the window
+        int p0 = w.W0, p1 = w.W1;
+        if (S > 1) {
+            // piecewise-constant cost per line: 14 (far), 20 (4-term), 36 (near zone)
+            const int b5[6] = {w.W0, z.M0, z.N0, z.N1, z.M1, w.W1};
+            const int c5[5] = {14, 20, 36, 20, 14};
+            int total = 0;
+            for (int q = 0; q < 5; q++) total += (b5[q + 1] - b5[q]) * c5[q];
+            auto cut_at = [&](int target) {
+                int accu = 0;
+                for (int q = 0; q < 5; q++) {
+                    const int seg = (b5[q + 1] - b5[q]) * c5[q];
+                    if (accu + seg >= target) return b5[q] + (target - accu) / c5[q];
+                    accu += seg;
+                }
+                return w.W1;
+            };
+            p0 = part == 0 ? w.W0 : cut_at((int)((long long)total * part / S));
+            p1 = part == S - 1 ? w.W1 : cut_at((int)((long long)total * (part + 1) / S));
+        }
+#define LO(x) max((x), p0)
+#define HI(x) min((x), p1)
+        {   // left of the wave: [W0,a) edge (cut-off predicate) | [a,Q0) 2-term | [Q0,a1) | [a1,M0) 3-term   (a <= Q0 <= a1 <= M0)
+            const int a = min(max(w.E0, w.W0), z.Q0), a1 = min(max(w.E0, z.Q0), z.M0);
+            if (MIXED) {
+                acc = far_segment32<true, 0>(acc, v, gnul, hf, LO(w.W0), HI(a), cut);
+                acc = far_segment32<false, 0>(acc, v, gnul, hf, LO(a), HI(z.Q0), cut);
+                acc = far_segment32<true, 1>(acc, v, gnul, hf, LO(z.Q0), HI(a1), cut);
+                acc = far_segment32<false, 1>(acc, v, gnul, hf, LO(a1), HI(z.M0), cut);
+            } else {
+                acc = far_segment<true, 0>(acc, v, hk, LO(w.W0), HI(a), cut, c);
+                acc = far_segment<false, 0>(acc, v, hk, LO(a), HI(z.Q0), cut, c);
+                acc = far_segment<true, 1>(acc, v, hk, LO(z.Q0), HI(a1), cut, c);
+                acc = far_segment<false, 1>(acc, v, hk, LO(a1), HI(z.M0), cut, c);
+            }
+        }
+        acc = far_segment<true, 2>(acc, v, hk, LO(z.M0), HI(z.N0), cut, c);
+        // near zone: six-term series where s >= 1e3; the index ranges of this lane's s < 1e3 and s < 100 lines go to
+        // k_voigt_near through `ranges` (relative to N0; empty = {0,0})
+        if (HI(z.N1) > LO(z.N0)) {
+            const volatile double *tb2 = kFarTable;
+            const double q40 = tb2[8], q41 = tb2[9], q42 = tb2[10], q43 = tb2[11], q44 = tb2[12];
+            const double q50 = tb2[13], q51 = tb2[14], q52 = tb2[15], q53 = tb2[16], q54 = tb2[17], q55 = tb2[18];
+            for (int j = LO(z.N0); j < HI(z.N1); j++) {
+                const LineHot h = hk[j];
+                const double dv = v - h.nul;
+                const double x = dv * h.p1;
+                const double s = __builtin_fma(x, x, h.p2);
+                const bool in = !(fabs(dv) > cut);
+                const double u = rcp_fast(s);
+                const double t = h.p2 * u;
+                const double p5 = __builtin_fma(__builtin_fma(__builtin_fma(__builtin_fma(__builtin_fma(q55, t, q54), t, q53), t, q52), t, q51), t, q50);
+                const double p4 = __builtin_fma(__builtin_fma(__builtin_fma(__builtin_fma(q44, t, q43), t, q42), t, q41), t, q40);
+                const double p3 = __builtin_fma(__builtin_fma(__builtin_fma(c.km120, t, c.k210), t, c.km105), t, c.k13p125);
+                const double p2 = __builtin_fma(__builtin_fma(c.k12, t, c.km15), t, c.k3p75);
+                const double p1v = __builtin_fma(-2.0, t, c.k1p5);
+                double P = __builtin_fma(u, p5, p4);
+                P = __builtin_fma(u, P, p3);
+                P = __builtin_fma(u, P, p2);
+                P = __builtin_fma(u, P, p1v);
+                P = __builtin_fma(u, P, 1.0);
+                acc += (in && s >= kSerS) ? (h.p3 * u) * P : 0.0;
+                if (in && s < kSerS) { bl = min(bl, j); bh = j; }
+                if (in && s < kMidS) { cl = min(cl, j); ch = j; }
+            }
+        }
+        acc = far_segment<true, 2>(acc, v, hk, LO(z.N1), HI(z.M1), cut, c);
+        {   // right of the wave: [M1,b1) | [b1,Q1) 3-term | [Q1,b) | [b,W1) 2-term, beyond E1 with the cut-off predicate
+            const int b1 = max(min(w.E1, z.Q1), z.M1), bq = max(min(w.E1, w.W1), z.Q1);
+            if (MIXED) {
+                acc = far_segment32<false, 1>(acc, v, gnul, hf, LO(z.M1), HI(b1), cut);
+                acc = far_segment32<true, 1>(acc, v, gnul, hf, LO(b1), HI(z.Q1), cut);
+                acc = far_segment32<false, 0>(acc, v, gnul, hf, LO(z.Q1), HI(bq), cut);
+                acc = far_segment32<true, 0>(acc, v, gnul, hf, LO(bq), HI(w.W1), cut);
+            } else {
+                acc = far_segment<false, 1>(acc, v, hk, LO(z.M1), HI(b1), cut, c);
+                acc = far_segment<true, 1>(acc, v, hk, LO(b1), HI(z.Q1), cut, c);
+                acc = far_segment<false, 0>(acc, v, hk, LO(z.Q1), HI(bq), cut, c);
+                acc = far_segment<true, 0>(acc, v, hk, LO(bq), HI(w.W1), cut, c);
+            }
+        }
+#undef LO
+#undef HI
+    }
+    if (S > 1) {   // add the parts in part order (deterministic) and merge the index ranges
+        acc_sh[threadIdx.x] = acc;
+        rng_sh[threadIdx.x] = make_int4(bl, bh, cl, ch);
+        __syncthreads();
+        if (part != 0 || !work) return;
+        for (int q = 1; q < S; q++) {
+            const int o = threadIdx.x + 64 * q;
+            acc += acc_sh[o];
+            const int4 r = rng_sh[o];
+            bl = min(bl, r.x); bh = max(bh, r.y); cl = min(cl, r.z); ch = max(ch, r.w);
         }
     }
     if (i < nnu) {
@@ -421,24 +484,6 @@ __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu
         r.x = bh >= bl ? bl - z.N0 : 0; r.y = bh >= bl ? bh + 1 - z.N0 : 0;
         r.z = ch >= cl ? cl - z.N0 : 0; r.w = ch >= cl ? ch + 1 - z.N0 : 0;
         ranges[(size_t)k * nnu + i] = r;
-    }
-    acc = far_segment<true, 2>(acc, v, hk, z.N1, z.M1, cut, c);
-    if (MIXED) {
-        const int b1 = max(min(w.E1, z.Q1), z.M1);
-        acc = far_segment32<false, 1>(acc, v, gnul, hf, z.M1, b1, cut);
-        acc = far_segment32<true, 1>(acc, v, gnul, hf, b1, z.Q1, cut);
-        const int b = max(min(w.E1, w.W1), z.Q1);
-        acc = far_segment32<false, 0>(acc, v, gnul, hf, z.Q1, b, cut);
-        acc = far_segment32<true, 0>(acc, v, gnul, hf, b, w.W1, cut);
-    } else {   // right of the wave: [M1,Q1) 3-term | [Q1,W1) 2-term, the part beyond E1 with the cut-off predicate
-        const int b1 = max(min(w.E1, z.Q1), z.M1);
-        acc = far_segment<false, 1>(acc, v, hk, z.M1, b1, cut, c);
-        acc = far_segment<true, 1>(acc, v, hk, b1, z.Q1, cut, c);
-        const int b = max(min(w.E1, w.W1), z.Q1);
-        acc = far_segment<false, 0>(acc, v, hk, z.Q1, b, cut, c);
-        acc = far_segment<true, 0>(acc, v, hk, b, w.W1, cut, c);
-    }
-    if (i < nnu) {
         const size_t o = (size_t)k * nnu + i;
         const double prev = accumulate ? sigma[o] : (base + (extra ? extra[o] : 0.0));
         sigma[o] = prev + acc;
@@ -584,8 +629,9 @@ __global__ __launch_bounds__(256) void k_rt(RtParams p, const double *__restrict
                                              double *__restrict__ Mup, double *__restrict__ Mdn,
                                              double *__restrict__ partial)
 {
-    extern __shared__ double red[];  // [2*np][4 waves]
-    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    extern __shared__ double red[];  // [2*np][waves per block]
+    const int nw = blockDim.x >> 6;  // 4 waves per block for big grids, 1 for small ones (more blocks than CUs)
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = j < nnu;
     const int64_t jj = live ? j : nnu - 1;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -605,7 +651,7 @@ __global__ __launch_bounds__(256) void k_rt(RtParams p, const double *__restrict
     double Bprev = planck(v, Tlev[0]);
     {
         double r = wave_sum(w * Md);
-        if (lane == 0) red[(np + 0) * 4 + wv] = r;
+        if (lane == 0) red[(np + 0) * nw + wv] = r;
         if (Mdn && live) Mdn[j] = Md;
     }
     for (int i = 0; i < nl; i++) {
@@ -635,7 +681,7 @@ __global__ __launch_bounds__(256) void k_rt(RtParams p, const double *__restrict
         Md += Ms;
         Bprev = Bnext;
         double r = wave_sum(w * Md);
-        if (lane == 0) red[(np + i + 1) * 4 + wv] = r;
+        if (lane == 0) red[(np + i + 1) * nw + wv] = r;
         if (Mdn && live) Mdn[(size_t)(i + 1) * nnu + j] = Md;
     }
     // surface: Lambertian reflection + Planck emission, discretized.jl:309-310
@@ -643,7 +689,7 @@ __global__ __launch_bounds__(256) void k_rt(RtParams p, const double *__restrict
     double Mu = Is * kPi;
     {
         double r = wave_sum(w * Mu);
-        if (lane == 0) red[(np - 1) * 4 + wv] = r;
+        if (lane == 0) red[(np - 1) * nw + wv] = r;
         if (Mup && live) Mup[(size_t)(np - 1) * nnu + j] = Mu;
     }
 #pragma unroll
@@ -663,13 +709,15 @@ __global__ __launch_bounds__(256) void k_rt(RtParams p, const double *__restrict
         }
         Bhi = Blo;
         double r = wave_sum(w * Mu);
-        if (lane == 0) red[i * 4 + wv] = r;
+        if (lane == 0) red[i * nw + wv] = r;
         if (Mup && live) Mup[(size_t)i * nnu + j] = Mu;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < 2 * np; e += 256) {
-        const double *q = red + e * 4;
-        partial[(size_t)blockIdx.x * 2 * np + e] = ((q[0] + q[1]) + q[2]) + q[3];
+    for (int e = threadIdx.x; e < 2 * np; e += blockDim.x) {
+        const double *q = red + e * nw;
+        double t = q[0];
+        for (int x = 1; x < nw; x++) t += q[x];
+        partial[(size_t)blockIdx.x * 2 * np + e] = t;
     }
 }
 
