@@ -749,6 +749,37 @@ class Column:
                                            dptr(self.conc_tab.ravel(order="F").copy()) if self.conc_tab.size else None))
         self._set_cia()
 
+    def run_batch(self, Ts, mus=None):
+        """Band fluxes of B temperature profiles on this column's grid in one device batch (the np+1 perturbed profiles of
+        jacobian!, or the profiles of an RCM loop: radiative_convective.jl:109-171).  Ts: [B, np] level temperatures (or a
+        list of callables fT(P)); mus: None (keep the molar mass), a number, or per-profile profiles.  Returns (Fup, Fdn) of
+        shape [B, np].  Only line-by-line gases (and the gray term) may be members."""
+        self._ensure_resident()
+        B = len(Ts)
+        nlob = self.core.nlobatto
+        nn = nlob * self.nl
+        Tn_all, mun_all = np.zeros((B, nn)), np.zeros((B, nn))
+        Tlev_all = np.zeros((B, self.np))
+        conc_all = np.zeros((B, max(len(self.gases), 1) * self.K))
+        for b in range(B):
+            fT = formprofile(self.P, Ts[b])
+            mu_b = mus if (mus is None or np.ndim(mus) == 0) else mus[b]
+            fmu = formprofile(self.P, mu_b) if mu_b is not None else (lambda *a: self.muk[0])
+            Tn, mun = lobattoevaluations(self.P, fT, fmu, nlob)
+            Tk = nodevalues(Tn, nlob)
+            Tn_all[b], mun_all[b] = Tn.ravel(order="F"), mun.ravel(order="F")
+            Tlev_all[b] = [fT(p) for p in self.P]
+            cc = np.zeros((len(self.gases), self.K), order="F")
+            for gi, g_ in enumerate(self.gases):
+                for k in range(self.K):
+                    cc[gi, k] = g_.fC(Tk[k], self.Pk[k])
+            if len(self.gases):
+                conc_all[b] = cc.ravel(order="F")
+        Fup, Fdn = np.zeros((B, self.np)), np.zeros((B, self.np))
+        check(lib().cs_column_batch(self.ctx.handle, B, dptr(Tn_all), dptr(mun_all), dptr(Tlev_all), dptr(conc_all), dptr(Fup),
+                                    dptr(Fdn)))
+        return Fup, Fdn
+
     # -- execution -------------------------------------------------------------------------------------------------
     def run(self, stream: int = 0):
         """Enqueue one evaluation (asynchronous).  `stream` is a raw hipStream_t (e.g. torch's cuda_stream) or 0."""

@@ -263,6 +263,26 @@ void launch_rt_ns(int nblk, int bs, size_t shmem, hipStream_t s, const RtParams 
                        Mdn, partial);
 }
 
+template <int NS>
+void launch_rt_batch_ns(int nblk, int B, int bs, size_t shmem, hipStream_t s, const RtParams &p, const double *nu, const double *wts,
+                        int64_t nnu, const double *sigma, const double *muk, const double *P, const double *Tlev, const double *S,
+                        const double *alb, double *tau, double *Mup, double *Mdn, double *partial)
+{
+    hipLaunchKernelGGL(k_rt<NS>, dim3(nblk, B), dim3(bs), shmem, s, p, nu, wts, nnu, sigma, muk, P, Tlev, S, alb, tau, Mup, Mdn, partial);
+}
+
+void launch_rt_batch(int ns, int nblk, int B, int bs, size_t shmem, hipStream_t s, const RtParams &p, const double *nu,
+                     const double *wts, int64_t nnu, const double *sigma, const double *muk, const double *P, const double *Tlev,
+                     const double *S, const double *alb, double *tau, double *Mup, double *Mdn, double *partial)
+{
+#define CS_RT_CASE(N) case N: launch_rt_batch_ns<N>(nblk, B, bs, shmem, s, p, nu, wts, nnu, sigma, muk, P, Tlev, S, alb, tau, Mup, Mdn, partial); break;
+    switch (ns) {
+        CS_RT_CASE(1) CS_RT_CASE(2) CS_RT_CASE(3) CS_RT_CASE(4) CS_RT_CASE(5) CS_RT_CASE(6) CS_RT_CASE(7) CS_RT_CASE(8)
+        CS_RT_CASE(9) CS_RT_CASE(10) CS_RT_CASE(11) CS_RT_CASE(12) CS_RT_CASE(13) CS_RT_CASE(14) CS_RT_CASE(15) CS_RT_CASE(16)
+    }
+#undef CS_RT_CASE
+}
+
 void launch_rt(int ns, int nblk, int bs, size_t shmem, hipStream_t s, const RtParams &p, const double *nu, const double *wts,
                int64_t nnu, const double *sigma, const double *muk, const double *P, const double *Tlev,
                const double *S, const double *alb, double *tau, double *Mup, double *Mdn, double *partial)
@@ -991,6 +1011,101 @@ int cs_column_update_state(cs_ctx *ctx, const double *T_nodes, const double *mu_
     if (!c.tab.empty()) {
         if (!conc_tab) return fail(CS_EINVAL, "the resident column has opacity tables: conc_tab is required");
         if ((rc = upload_tables(ctx, conc_tab))) return rc;
+    }
+    return CS_OK;
+}
+
+int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_nodes, const double *T_levels,
+                    const double *conc, double *Fup, double *Fdn)
+{
+    if (!ctx || !ctx->col.ready) return fail(CS_ESTATE, "cs_column_setup has not been called");
+    Column &c = ctx->col;
+    if (B < 1) return fail(CS_EINVAL, "empty batch");
+    if (!c.tab.empty() || !c.cia.empty()) return fail(CS_EINVAL, "opacity tables and CIA pairs are not supported in batch mode");
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const int K = c.K, nl = c.nl, nlob = c.nlob, np = c.np;
+    const int64_t BK = (int64_t)B * K;
+    const size_t nn = (size_t)nlob * nl;
+    std::vector<double> Tk(BK), muk(BK), Pk(BK);
+    for (int b = 0; b < B; b++) {
+        const double *Tn = T_nodes + b * nn, *mn = mu_nodes + b * nn;
+        double *t = Tk.data() + (size_t)b * K, *m = muk.data() + (size_t)b * K;
+        t[0] = Tn[0];
+        m[0] = mn[0];
+        for (int i = 0; i < nl; i++)
+            for (int n = 1; n < nlob; n++) {
+                t[i * (nlob - 1) + n] = Tn[n + (size_t)nlob * i];
+                m[i * (nlob - 1) + n] = mn[n + (size_t)nlob * i];
+            }
+        std::copy(c.h_Pk.begin(), c.h_Pk.end(), Pk.begin() + (size_t)b * K);
+    }
+    int rc;
+    for (int gi = 0; gi < c.ngas; gi++)
+        if ((rc = check_gas_states(ctx->gas[c.gas[gi].slot], (int)BK, Tk.data()))) return rc;
+    DevBuf dTk, dPk, dmuk, dTlev, dsig, dtau, dpart, dF, dranges, dconc, dPp, dgb, dzones, hot, cold;
+    if ((rc = upload(dTk, Tk.data(), BK, s)) || (rc = upload(dPk, Pk.data(), BK, s)) || (rc = upload(dmuk, muk.data(), BK, s)) ||
+        (rc = upload(dTlev, T_levels, (size_t)B * np, s)))
+        return rc;
+    HIPCHK(dsig.reserve((size_t)BK * c.nnu * sizeof(double)));
+    HIPCHK(dtau.reserve((size_t)B * nl * c.nnu * sizeof(double)));
+    HIPCHK(dpart.reserve((size_t)B * c.rt_nblk * 2 * np * sizeof(double)));
+    HIPCHK(dF.reserve((size_t)B * 2 * np * sizeof(double)));
+    const double *extra = c.has_extra ? c.extra.as<double>() : nullptr;
+    if (extra) return fail(CS_EINVAL, "host-evaluated sigma(nu,T,P) terms are not supported in batch mode");
+    if (c.ngas == 0) {
+        const int64_t tot = BK * c.nnu;
+        hipLaunchKernelGGL(k_fill, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, tot, c.sigma_gray, (const double *)nullptr,
+                           dsig.as<double>());
+    }
+    size_t maxL = 0;
+    for (auto &g : c.gas) maxL = std::max(maxL, (size_t)ctx->gas[g.slot].L);
+    const size_t per_state = maxL * (sizeof(LineHot) + sizeof(LineCold) + (ctx->mixed ? sizeof(LineF32) : 0)) + (size_t)c.nnu * sizeof(int4);
+    const int kc = (int)std::max<size_t>(1, std::min<size_t>((size_t)BK, ((size_t)8 << 30) / std::max<size_t>(per_state, 1)));
+    if (c.ngas > 0) {
+        HIPCHK(hot.reserve(((size_t)kc * maxL + 4) * sizeof(LineHot)));
+        HIPCHK(cold.reserve((size_t)kc * maxL * sizeof(LineCold)));
+        HIPCHK(dranges.reserve((size_t)kc * c.nnu * sizeof(int4)));
+        if (ctx->mixed) HIPCHK(ctx->hot32.reserve(((size_t)kc * maxL + 4) * sizeof(LineF32)));
+    }
+    std::vector<double> cc(BK), pp(BK);
+    for (int gi = 0; gi < c.ngas; gi++) {
+        ColGas &cg = c.gas[gi];
+        GasTable &G = ctx->gas[cg.slot];
+        for (int b = 0; b < B; b++)
+            for (int k = 0; k < K; k++) {
+                const double v = conc[(size_t)b * c.ngas * K + gi + (size_t)c.ngas * k];
+                if (!(v >= 0 && v <= 1)) return fail(CS_EINVAL, "gas molar concentrations must be in [0,1], not %g", v);
+                cc[(size_t)b * K + k] = v;
+                pp[(size_t)b * K + k] = v * c.h_Pk[k];
+            }
+        std::vector<double> gb = gamma_bound(G, (int)BK, Tk.data(), Pk.data(), pp.data());
+        const size_t nt64 = (size_t)((c.nnu + 63) / 64);
+        if ((rc = upload(dconc, cc.data(), BK, s)) || (rc = upload(dPp, pp.data(), BK, s)) || (rc = upload(dgb, gb.data(), BK, s))) return rc;
+        HIPCHK(dzones.reserve((size_t)kc * nt64 * sizeof(Zone)));
+        for (int64_t k0 = 0; k0 < BK; k0 += kc) {
+            const int kn = (int)std::min<int64_t>(kc, BK - k0);
+            launch_gas(s, cg.shape, G, cg.jlo, cg.jhi, kn, dTk.as<double>() + k0, dPk.as<double>() + k0, dPp.as<double>() + k0,
+                       dconc.as<double>() + k0, hot.as<LineHot>(), cold.as<LineCold>(), c.nu.as<double>(), c.nnu, c.ntile,
+                       cg.J0.as<int32_t>(), cg.J1.as<int32_t>(), cg.win.as<WaveWin>(), dzones.as<Zone>(), dranges.as<int4>(),
+                       dgb.as<double>() + k0, cg.cut, c.sigma_gray, nullptr, dsig.as<double>() + (size_t)k0 * c.nnu, gi > 0, nullptr,
+                       nullptr, (ctx->mixed && cg.shape == SH_VOIGT) ? ctx->hot32.as<LineF32>() : nullptr, ctx->far_s);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipStreamSynchronize(s));   // cc/pp/gb host buffers are reused by the next gas
+    }
+    launch_rt_batch(c.nstream, c.rt_nblk, B, c.rt_bs, (size_t)2 * np * (c.rt_bs / 64) * sizeof(double), s, c.rt, c.nu.as<double>(),
+                    c.wts.as<double>(), c.nnu, dsig.as<double>(), dmuk.as<double>(), c.P.as<double>(), dTlev.as<double>(),
+                    c.has_S ? c.S_toa.as<double>() : nullptr, c.has_alb ? c.albedo.as<double>() : nullptr, dtau.as<double>(), nullptr,
+                    nullptr, dpart.as<double>());
+    hipLaunchKernelGGL(k_freduce, dim3(2 * np, B), dim3(256), 0, s, dpart.as<double>(), c.rt_nblk, 2 * np, dF.as<double>());
+    HIPCHK(hipGetLastError());
+    std::vector<double> F((size_t)B * 2 * np);
+    HIPCHK(hipMemcpyAsync(F.data(), dF.p, F.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (int b = 0; b < B; b++) {
+        std::copy(F.begin() + (size_t)b * 2 * np, F.begin() + (size_t)b * 2 * np + np, Fup + (size_t)b * np);
+        std::copy(F.begin() + (size_t)b * 2 * np + np, F.begin() + (size_t)(b + 1) * 2 * np, Fdn + (size_t)b * np);
     }
     return CS_OK;
 }

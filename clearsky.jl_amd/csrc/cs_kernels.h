@@ -631,6 +631,14 @@ __global__ __launch_bounds__(256) void k_rt(RtParams p, const double *__restrict
 {
     extern __shared__ double red[];  // [2*np][waves per block]
     const int nw = blockDim.x >> 6;  // 4 waves per block for big grids, 1 for small ones (more blocks than CUs)
+    {   // blockIdx.y = column of a batch (cs_column_batch): same grid, pressures and stream rule, its own node states
+        const size_t b = blockIdx.y;
+        sigma += b * (size_t)p.K * nnu;
+        muk += b * p.K;
+        Tlev += b * p.np;
+        tau += b * (size_t)(p.np - 1) * nnu;
+        partial += b * (size_t)gridDim.x * 2 * p.np;
+    }
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = j < nnu;
     const int64_t jj = live ? j : nnu - 1;
@@ -726,6 +734,8 @@ __global__ __launch_bounds__(256) void k_freduce(const double *__restrict__ part
 {
     __shared__ double sh[256];
     const int e = blockIdx.x;
+    partial += (size_t)blockIdx.y * nblk * n2;   // column of a batch
+    F += (size_t)blockIdx.y * n2;
     double s = 0.0;
     for (int b = threadIdx.x; b < nblk; b += 256) s += partial[(size_t)b * n2 + e];
     sh[threadIdx.x] = s;

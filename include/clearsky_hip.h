@@ -190,6 +190,17 @@ int cs_par_count(const char *filename, int64_t *n);
 int cs_par_parse(const char *filename, int64_t n, int16_t *M, char *I, double *nu, double *S, double *A, double *gamma_a,
                  double *gamma_s, double *Epp, double *na, double *delta_a);
 
+/*
+ * B thermal states of the resident column in one go: the np+1 perturbed profiles of jacobian! or the successive profiles of
+ * an RCM step loop (radiative_convective.jl:109-171).  Line sums for all B*K node states go through K1/K2 as one batch
+ * (chunked to bound the workspace), then one k_rt launch solves the B columns side by side.  Gas members must be
+ * line-by-line gases (plus the gray / host-evaluated terms of the setup); tables and CIA pairs are not batched.
+ *   T_nodes, mu_nodes : [B][nlobatto*(np-1)]   T_levels : [B][np]   conc : [B][ngas*K]  (each column laid out as in
+ *   cs_column_update_state);  outputs Fup, Fdn : [B][np] on the host.  The resident column's own state is left untouched.
+ */
+int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_nodes, const double *T_levels,
+                    const double *conc, double *Fup, double *Fdn);
+
 /* Scalar helpers exported for tests of the host logic (same formulas the kernels use). */
 int cs_streamnodes(int n, double *m, double *W);    /* core/shared.jl:4-21 */
 int cs_lobattonodes(int n, double *x, double *w);   /* core/discretized.jl:2-9 */

@@ -331,3 +331,30 @@ def test_mixed_precision_variant(cs, O, lines):
     with pytest.raises(cs.ClearSkyHIPError):
         ctx.set_precision("mixed", 1e3)
     ctx.close()
+
+
+def test_batched_columns_match_sequential(cs, lines):
+    """cs_column_batch (the np+1 perturbed profiles of jacobian!, radiative_convective.jl:154-171): one device batch == the same
+    profiles evaluated one after the other on the resident column (summation grouping may differ: 1e-13)."""
+    from clearsky_jl_amd import workloads as W
+    ctx = cs.Context(0)
+    nu = np.linspace(400.0, 1100.0, 3000)
+    P = cs.pressuregrid(5.0, 1e5, 16)
+    T0 = W.earth_temperature(P)
+    g1 = cs.DirectGas(lines("CO2"), 400e-6, nu)
+    g2 = cs.DirectGas(lines("H2O"), W.fC_h2o, nu)
+    col = cs.Column(P, 9.8, T0, 0.029, 0.0, 0.0, g1, g2, cs.GrayGas(1e-27, nu), core=cs.Discretized(5, 3), want_tau=False, want_M=False,
+                    ctx=ctx)
+    Ts = [T0] + [T0 + 0.5 * (np.arange(len(P)) == i) for i in range(len(P))]      # jacobian!: one level perturbed at a time
+    Fu, Fd = col.run_batch(Ts, 0.029)
+    assert Fu.shape == (len(P) + 1, len(P))
+    for b in (0, 1, 7, len(P)):
+        col.update(Ts[b], 0.029)
+        col.run()
+        a = col.fetch()
+        assert np.max(np.abs(Fu[b] - a[0])) < 1e-13 * a[0].max() and np.max(np.abs(Fd[b] - a[1])) < 1e-13 * a[0].max()
+    J = (Fu[1:] - Fd[1:] - (Fu[0] - Fd[0])) / 0.5                                   # dFnet/dT: finite and not all zero
+    assert np.all(np.isfinite(J)) and np.abs(J).max() > 0
+    with pytest.raises(cs.ClearSkyHIPError):
+        col.run_batch([np.full(len(P), 2000.0)])                                    # T outside [25, 1000]
+    ctx.close()
