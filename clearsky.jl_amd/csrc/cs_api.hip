@@ -545,7 +545,7 @@ int cs_shape_batch(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t nnu
         return rc;
     // bound the workspace: process the states in chunks
     const size_t per_state = (size_t)G.L * (sizeof(LineHot) + sizeof(LineCold)) + (size_t)nnu * (sizeof(double) + sizeof(int4));
-    int kc = (int)std::max<size_t>(1, std::min<size_t>((size_t)K, ((size_t)4 << 30) / per_state));
+    int kc = (int)std::max<size_t>(1, std::min<size_t>({(size_t)K, ((size_t)4 << 30) / per_state, (size_t)65535}));   // gridDim.y limit
     HIPCHK(hot.reserve(((size_t)kc * G.L + 4) * sizeof(LineHot)));
     HIPCHK(cold.reserve((size_t)kc * G.L * sizeof(LineCold)));
     HIPCHK(dsig.reserve((size_t)kc * nnu * sizeof(double)));
@@ -618,7 +618,7 @@ int cs_bake(cs_ctx *ctx, int gas_slot, int table_slot, int shape, double dnu_cut
         return rc;
     HIPCHK(tb.Z.reserve((size_t)M * nnu * sizeof(double)));
     const size_t per_state = (size_t)G.L * (sizeof(LineHot) + sizeof(LineCold)) + (size_t)nnu * sizeof(int4);
-    const int kc = (int)std::max<size_t>(1, std::min<size_t>((size_t)M, ((size_t)4 << 30) / per_state));
+    const int kc = (int)std::max<size_t>(1, std::min<size_t>({(size_t)M, ((size_t)4 << 30) / per_state, (size_t)65535}));
     HIPCHK(hot.reserve(((size_t)kc * G.L + 4) * sizeof(LineHot)));
     HIPCHK(cold.reserve((size_t)kc * G.L * sizeof(LineCold)));
     HIPCHK(dzones.reserve((size_t)kc * win.size() * sizeof(Zone)));
@@ -872,6 +872,7 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
     if (ngas < 0 || ngas > CS_MAX_GAS) return fail(CS_EINVAL, "ngas out of range");
     if (!(theta_s >= 0 && theta_s < M_PI / 2)) return fail(CS_EINVAL, "azimuth angle theta must be in [0,pi/2)");
     if (!(g > 0)) return fail(CS_EINVAL, "g must be positive");
+    if ((int64_t)(np - 1) * (nlobatto - 1) + 1 > 65535) return fail(CS_EINVAL, "too many node states for one launch (65535)");
     int rc;
     if ((rc = check_ascending(nu, nnu))) return rc;
     for (int i = 1; i < np; i++)
@@ -1061,7 +1062,7 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
     size_t maxL = 0;
     for (auto &g : c.gas) maxL = std::max(maxL, (size_t)ctx->gas[g.slot].L);
     const size_t per_state = maxL * (sizeof(LineHot) + sizeof(LineCold) + (ctx->mixed ? sizeof(LineF32) : 0)) + (size_t)c.nnu * sizeof(int4);
-    const int kc = (int)std::max<size_t>(1, std::min<size_t>((size_t)BK, ((size_t)8 << 30) / std::max<size_t>(per_state, 1)));
+    const int kc = (int)std::max<size_t>(1, std::min<size_t>({(size_t)BK, ((size_t)8 << 30) / std::max<size_t>(per_state, 1), (size_t)65535}));
     if (c.ngas > 0) {
         HIPCHK(hot.reserve(((size_t)kc * maxL + 4) * sizeof(LineHot)));
         HIPCHK(cold.reserve((size_t)kc * maxL * sizeof(LineCold)));
