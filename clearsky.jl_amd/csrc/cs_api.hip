@@ -1021,7 +1021,7 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
 {
     if (!ctx || !ctx->col.ready) return fail(CS_ESTATE, "cs_column_setup has not been called");
     Column &c = ctx->col;
-    if (B < 1) return fail(CS_EINVAL, "empty batch");
+    if (B < 1 || B > 65535) return fail(CS_EINVAL, "batch size must be in [1, 65535]");
     if (!c.tab.empty() || !c.cia.empty()) return fail(CS_EINVAL, "opacity tables and CIA pairs are not supported in batch mode");
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;

@@ -358,3 +358,25 @@ def test_batched_columns_match_sequential(cs, lines):
     with pytest.raises(cs.ClearSkyHIPError):
         col.run_batch([np.full(len(P), 2000.0)])                                    # T outside [25, 1000]
     ctx.close()
+
+
+def test_dense_table_large_grid_sparse_parity(cs, O):
+    """4e5 lines x 2e5 wavenumbers x 31 levels (2e11 line evaluations, windows of ~16 000 lines, the near-line queue spills into
+    its fallback): 48 random columns against the oracle, and bitwise repeatability."""
+    ctx = cs.Context(0)
+    sl = cs.SpectralLines.synthetic(2, 400_000, 4242, numin=200.0, numax=1450.0)
+    nu = np.linspace(300.0, 1300.0, 200_000)
+    P = cs.pressuregrid(1.0, 1e5, 31)
+    T = np.linspace(210.0, 295.0, 31)
+    gas = cs.DirectGas(sl, 3e-4, nu)
+    col = cs.Column(P, 9.8, T, 0.029, 0.0, 0.0, gas, want_M=False, ctx=ctx)
+    col.run()
+    tau = np.zeros((col.nl, col.nnu), order="F")
+    F1 = col.fetch(tau)
+    col.run()
+    F2 = col.fetch()
+    assert np.array_equal(F1[0], F2[0]) and np.all(np.isfinite(tau))
+    idx = np.sort(np.random.default_rng(5).choice(col.nnu, 48, replace=False))
+    r = O.fluxes_discretized(nu[idx], P, 9.8, 2, col.Tn, col.mun, col.Tlev, [sl], ["voigt"], [25.0], col.conc)
+    assert relerr(tau[:, idx], r["tau"]) < 1e-11
+    ctx.close()
