@@ -887,7 +887,6 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
     c.g = g; c.sigma_gray = sigma_gray; c.theta_s = theta_s;
     const int K = c.K, nl = c.nl;
     // quadrature rules
-    double x[CS_MAX_STREAM], w[CS_MAX_STREAM];
     RtParams &rt = c.rt;
     memset(&rt, 0, sizeof rt);
     rt.np = np; rt.nlobatto = nlobatto; rt.K = K; rt.nstream = nstream;
@@ -896,7 +895,6 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
     c.h_xs.assign(nlobatto, 0.0);
     cs_lobattonodes(nlobatto, c.h_xs.data(), rt.ws);
     cs_streamnodes(nstream, rt.m, rt.W);
-    (void)x; (void)w;
     // node states: k = i*(nlobatto-1) + n   (discretized.jl:150,162,169)
     c.h_P.assign(P, P + np);
     c.h_nu.assign(nu, nu + nnu);

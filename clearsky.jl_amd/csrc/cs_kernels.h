@@ -662,6 +662,7 @@ __global__ __launch_bounds__(256) void k_rt(RtParams p, const double *__restrict
         if (lane == 0) red[(np + 0) * nw + wv] = r;
         if (Mdn && live) Mdn[j] = Md;
     }
+    double sg_next = sigma[(size_t)(nlob - 1) * nnu + jj];   // end node of layer 0; later layers are fetched one layer ahead
     for (int i = 0; i < nl; i++) {
         const double dP = P[i + 1] - P[i];
         double ti = (dP * p.ws[0]) * b1;
@@ -670,7 +671,9 @@ __global__ __launch_bounds__(256) void k_rt(RtParams p, const double *__restrict
             ti += (dP * p.ws[n]) * (p.C * (sigma[(size_t)k * nnu + jj] / muk[k]));
         }
         const int ke = (i + 1) * (nlob - 1);
-        const double bn = p.C * (sigma[(size_t)ke * nnu + jj] / muk[ke]);
+        const double sg = sg_next;
+        if (i + 1 < nl) sg_next = sigma[(size_t)(ke + nlob - 1) * nnu + jj];   // in flight during this layer's exp/divide chain
+        const double bn = p.C * (sg / muk[ke]);
         ti += (dP * p.ws[nlob - 1]) * bn;
         b1 = bn;
         const double t = ti > 1e-6 ? ti : 1e-6;  // floor, discretized.jl:147,174
@@ -703,8 +706,10 @@ __global__ __launch_bounds__(256) void k_rt(RtParams p, const double *__restrict
 #pragma unroll
     for (int k = 0; k < NS; k++) I[k] = Is;
     double Bhi = Bprev;  // B at level i+1
+    double t_next = live ? tau[(size_t)(nl - 1) * nnu + j] : 1.0;
     for (int i = nl - 1; i >= 0; i--) {
-        const double t = live ? tau[(size_t)i * nnu + j] : 1.0;
+        const double t = t_next;
+        if (i > 0) t_next = live ? tau[(size_t)(i - 1) * nnu + j] : 1.0;   // one layer ahead
         const double Blo = planck(v, Tlev[i]);
         Mu = 0.0;
 #pragma unroll
