@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--nnu", type=int, default=None)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--precision", default="fp64", help="fp64 (headline) | mixed (fp32 far wings, BASELINE configs[4])")
+    ap.add_argument("--no-interp", action="store_true", help="evaluate every (nu, line) pair (no far-wing interpolation)")
     ap.add_argument("--far-s", type=float, default=1e6, help="mixed precision: x^2 threshold of the fp32 region")
     ap.add_argument("--emulate-shard", default=None, help="R/N: time only shard R of an N-way split on this one GPU (rehearsal)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL, default) | gloo (rehearsal of N>1 on fewer GPUs)")
@@ -74,6 +75,7 @@ def main():
         ranges = [W.balanced_ranges(nu, cfg["absorbers"], n_)[r_]]
     ctx = cs.Context(dev)
     ctx.set_precision(args.precision, args.far_s)
+    ctx.set_interp(not args.no_interp)
     col = cs.Column(cfg["P"], cfg["g"], cfg["T"], cfg["mu"], cfg["fS"], cfg["fa"], *cfg["absorbers"], core=cfg["core"],
                     theta_s=cfg["theta_s"], want_tau=True, want_M=True, nu_range=ranges[rank], ctx=ctx)
     # one explicit torch stream carries the kernels, the D2D copy of the band fluxes and the collective, so they are

@@ -228,6 +228,10 @@ class Context:
         knob of the tolerance sweep."""
         check(lib().cs_set_precision(self._h, {"fp64": 0, "mixed": 1}[mode], float(far_s)))
 
+    def set_interp(self, on: bool = True):
+        """Far wings by Chebyshev interpolation over 256-point intervals (default on); off = every (nu, line) pair."""
+        check(lib().cs_set_interp(self._h, int(bool(on))))
+
     def slot_of(self, sl: SpectralLines) -> int:
         """Upload `sl` (once) and return its gas slot."""
         key = id(sl)

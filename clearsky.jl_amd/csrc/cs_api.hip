@@ -123,6 +123,7 @@ struct ColGas {
     double cut = 25.0;
     DevBuf conc, Pp, J0, J1;  // [K], [K], [ntile], [ntile]
     DevBuf win, zones, gmax;  // [ntile64] WaveWin, [K][ntile64] Zone, [K] max Lorentz width (Voigt fast path)
+    DevBuf iwin, izones;      // [nI] WaveWin, [K][nI] IZone (interpolated far wings; empty = off)
     int64_t pairs_per_state = 0, lines_in_range = 0, jlo = 0, jhi = 0;
 };
 
@@ -140,6 +141,8 @@ struct Column {
     std::vector<double> h_Tk;
     DevBuf nu, wts, P, Pk, Tk, muk, Tlev, extra, S_toa, albedo;
     DevBuf hot, cold, sigma, tau, Mup, Mdn, partial, F, stage, ranges;
+    int nI = 0;                // interpolation intervals of the nu grid (0 = off)
+    DevBuf cheb_nodes, cheb_C;
 };
 
 }  // namespace
@@ -152,6 +155,7 @@ struct cs_ctx {
     CiaDev cia[CS_MAX_CIA];
     Column col;
     int mixed = 0;
+    int interp = 1;   // far wings by Chebyshev interpolation over 256-point intervals (k_voigt_cheb)
     double far_s = 1e6;
     DevBuf hot32;
     DevBuf tmpA, tmpB, tmpC;
@@ -338,13 +342,13 @@ int64_t count_pairs(const std::vector<double> &nul, const double *nu, int64_t nn
 
 // per-64-point windows of the Voigt fast path: [W0,W1) superset window, [E0,E1) lines inside every lane's cut-off
 void wave_windows(const std::vector<double> &nul, int64_t g0, int64_t g1, const double *nu, int64_t nnu, double cut,
-                  std::vector<WaveWin> &win)
+                  std::vector<WaveWin> &win, int span = 64)
 {
-    const int nt = (int)((nnu + 63) / 64);
+    const int nt = (int)((nnu + span - 1) / span);
     win.resize(nt);
     auto b = nul.begin() + g0, e = nul.begin() + g1;
     for (int t = 0; t < nt; t++) {
-        const int64_t i0 = (int64_t)t * 64, i1 = std::min<int64_t>(nnu, i0 + 64) - 1;
+        const int64_t i0 = (int64_t)t * span, i1 = std::min<int64_t>(nnu, i0 + span) - 1;
         const double vlo = nu[i0], vhi = nu[i1];
         const double tol = 1e-9 * (std::fabs(vhi) + cut + 1.0);
         WaveWin w;
@@ -370,12 +374,36 @@ std::vector<double> gamma_bound(const GasTable &G, int K, const double *T, const
     return g;
 }
 
+// far wings by interpolation (k_voigt_cheb): per-grid nodes and matrices, per-gas interval windows and zones; nI = 0: off
+struct Interp {
+    int nI = 0;
+    const double *nodes = nullptr, *Cm = nullptr;
+    const WaveWin *iwin = nullptr;
+    IZone *iz = nullptr;
+};
+
+// the grid part of Interp: nodes [nI][64] and interpolation matrices [nI][64][256]
+struct ChebGrid {
+    int nI = 0;
+    DevBuf nodes, Cm;
+    int build(const double *dnu, int64_t nnu, hipStream_t s) { return build_into(nI, nodes, Cm, dnu, nnu, s); }
+    static int build_into(int &nI, DevBuf &nodes, DevBuf &Cm, const double *dnu, int64_t nnu, hipStream_t s)
+    {
+        nI = (int)((nnu + CS_ITV - 1) / CS_ITV);
+        HIPCHK(nodes.reserve((size_t)nI * CS_NC * sizeof(double)));
+        HIPCHK(Cm.reserve((size_t)nI * CS_NC * CS_ITV * sizeof(double)));
+        hipLaunchKernelGGL(k_cheb_setup, dim3(nI), dim3(256), 0, s, dnu, nnu, nI, nodes.as<double>(), Cm.as<double>());
+        HIPCHK(hipGetLastError());
+        return CS_OK;
+    }
+};
+
 // K1 + K2 for one gas on `s`: parameters for `kn` states, then the line sum into sigma ([kn][nnu])
 void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, int64_t jrange1, int kn, const double *Tk, const double *Pk, const double *Ppk,
                 const double *scale, LineHot *hot, LineCold *cold, const double *dnu, int64_t nnu, int ntile256,
                 const int32_t *J0, const int32_t *J1, const WaveWin *win, Zone *zones, int4 *ranges, const double *gbound, double cut, double base,
                 const double *extra, double *sigma, int accumulate, hipEvent_t ev_mid, hipEvent_t ev_far = nullptr,
-                LineF32 *hot32 = nullptr, double far_s = 1e6)
+                LineF32 *hot32 = nullptr, double far_s = 1e6, Interp itp = Interp())
 {
     // only the lines some window can reach (windows are sorted: first tile's start .. last tile's end)
     const int64_t jlo = jrange0, jhi = std::max(jrange1, jrange0);
@@ -387,7 +415,23 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
         const int nt64 = (int)((nnu + 63) / 64);
         hipLaunchKernelGGL(k_zones, dim3((unsigned)(((int64_t)nt64 * kn + 255) / 256)), dim3(256), 0, s, dnu, nnu, nt64, kn,
                            G.nu.as<double>(), win, Tk, G.mu_min, G.mu_max, cut, gbound, far_s, zones);
+        const IZone *iz = nullptr;
+        if (itp.nI > 0) {
+            iz = itp.iz;
+            hipLaunchKernelGGL(k_izones, dim3((unsigned)(((int64_t)itp.nI * kn + 255) / 256)), dim3(256), 0, s, dnu, nnu, itp.nI, kn,
+                               G.nu.as<double>(), itp.iwin, Tk, G.mu_min, G.mu_max, cut, gbound, far_s, itp.iz);
+        }
         if (ev_mid) (void)hipEventRecord(ev_mid, s);
+        if (iz) {   // sigma = base + extra + interpolated far wings; the per-point kernels add the rest
+            const dim3 gridc((unsigned)((kn + 3) / 4), (unsigned)itp.nI);
+            if (hot32)
+                hipLaunchKernelGGL((k_voigt_cheb<true>), gridc, dim3(256), 0, s, itp.nodes, itp.Cm, nnu, G.L, hot, hot32, G.nu.as<double>(), iz,
+                                   itp.nI, kn, cut, base, extra, sigma, accumulate);
+            else
+                hipLaunchKernelGGL((k_voigt_cheb<false>), gridc, dim3(256), 0, s, itp.nodes, itp.Cm, nnu, G.L, hot, hot32, G.nu.as<double>(), iz,
+                                   itp.nI, kn, cut, base, extra, sigma, accumulate);
+            accumulate = 1;
+        }
         const int nblk = (nt64 + 3) / 4;
         const dim3 grid((unsigned)((nblk + 7) / 8 * 8), kn);   // multiple of 8: XCD-aware tile mapping (tile_block)
         // waves per tile: enough waves to fill 256 CUs x 32 wave slots about 4 times over
@@ -396,7 +440,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
         const int nblk_s = (nt64 * split + 3) / 4;
         const dim3 grid_s((unsigned)((nblk_s + 7) / 8 * 8), kn);
 #define CS_FAR_LAUNCH(MIX, SP) hipLaunchKernelGGL((k_voigt_far<MIX, SP>), grid_s, dim3(256), 0, s, dnu, nnu, G.L, hot, hot32, G.nu.as<double>(), \
-                                                  win, zones, nt64, nblk_s, cut, base, extra, sigma, accumulate, ranges)
+                                                  win, zones, nt64, nblk_s, cut, base, extra, sigma, accumulate, ranges, iz, itp.nI)
         if (hot32) {
             if (split == 1) CS_FAR_LAUNCH(true, 1); else if (split == 2) CS_FAR_LAUNCH(true, 2); else CS_FAR_LAUNCH(true, 4);
         } else {
@@ -511,6 +555,13 @@ int cs_set_precision(cs_ctx *ctx, int mode, double far_s)
     return CS_OK;
 }
 
+int cs_set_interp(cs_ctx *ctx, int on)
+{
+    if (!ctx) return fail(CS_EINVAL, "ctx is NULL");
+    ctx->interp = on ? 1 : 0;
+    return CS_OK;
+}
+
 int cs_gas_clear(cs_ctx *ctx, int slot)
 {
     if (!ctx || slot < 0 || slot >= CS_MAX_GAS) return fail(CS_EINVAL, "bad slot");
@@ -561,12 +612,23 @@ int cs_shape_batch(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t nnu
         std::vector<double> gb = gamma_bound(G, K, T, P, Pp);
         if ((rc = upload(dgmax, gb.data(), K, s))) return rc;
     }
+    ChebGrid cheb;
+    DevBuf diwin, dizones;
+    Interp itp;
+    if (ctx->interp && shape == SH_VOIGT) {
+        std::vector<WaveWin> iwin;
+        wave_windows(G.h_nu, g0, g1, nu, nnu, dnu_cut, iwin, CS_ITV);
+        if ((rc = cheb.build(dnu.as<double>(), nnu, s)) || (rc = upload(diwin, iwin.data(), iwin.size(), s))) return rc;
+        HIPCHK(dizones.reserve((size_t)kc * cheb.nI * sizeof(IZone)));
+        itp.nI = cheb.nI; itp.nodes = cheb.nodes.as<double>(); itp.Cm = cheb.Cm.as<double>();
+        itp.iwin = diwin.as<WaveWin>(); itp.iz = dizones.as<IZone>();
+    }
     for (int k0 = 0; k0 < K; k0 += kc) {
         const int kn = std::min(kc, K - k0);
         launch_gas(s, shape, G, J0.front(), J1.back(), kn, dT.as<double>() + k0, dP.as<double>() + k0, dPp.as<double>() + k0, nullptr,
                    hot.as<LineHot>(), cold.as<LineCold>(), dnu.as<double>(), nnu, ntile, dJ0.as<int32_t>(), dJ1.as<int32_t>(),
                    dwin.as<WaveWin>(), dzones.as<Zone>(), dranges.as<int4>(), dgmax.as<double>() + k0, dnu_cut, 0.0, nullptr, dsig.as<double>(), 0, nullptr,
-                   nullptr, mix32, ctx->far_s);
+                   nullptr, mix32, ctx->far_s, itp);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpy2DAsync(sigma + (size_t)k0 * ld_state, ld_state * sizeof(double), dsig.p, nnu * sizeof(double),
                                 nnu * sizeof(double), kn, hipMemcpyDeviceToHost, s));
@@ -628,12 +690,23 @@ int cs_bake(cs_ctx *ctx, int gas_slot, int table_slot, int shape, double dnu_cut
         HIPCHK(ctx->hot32.reserve(((size_t)kc * G.L + 4) * sizeof(LineF32)));
         mix32 = ctx->hot32.as<LineF32>();
     }
+    ChebGrid cheb;
+    DevBuf diwin, dizones;
+    Interp itp;
+    if (ctx->interp && shape == SH_VOIGT) {
+        std::vector<WaveWin> iwin;
+        wave_windows(G.h_nu, g0, g1, nu, nnu, dnu_cut, iwin, CS_ITV);
+        if ((rc = cheb.build(dnu.as<double>(), nnu, s)) || (rc = upload(diwin, iwin.data(), iwin.size(), s))) return rc;
+        HIPCHK(dizones.reserve((size_t)kc * cheb.nI * sizeof(IZone)));
+        itp.nI = cheb.nI; itp.nodes = cheb.nodes.as<double>(); itp.Cm = cheb.Cm.as<double>();
+        itp.iwin = diwin.as<WaveWin>(); itp.iz = dizones.as<IZone>();
+    }
     for (int k0 = 0; k0 < M; k0 += kc) {
         const int kn = std::min(kc, M - k0);
         launch_gas(s, shape, G, J0.front(), J1.back(), kn, dT.as<double>() + k0, dP.as<double>() + k0, dPp.as<double>() + k0, nullptr, hot.as<LineHot>(),
                    cold.as<LineCold>(), dnu.as<double>(), nnu, ntile, dJ0.as<int32_t>(), dJ1.as<int32_t>(), dwin.as<WaveWin>(),
                    dzones.as<Zone>(), dranges.as<int4>(), dgb.as<double>() + k0, dnu_cut, 0.0, nullptr, tb.Z.as<double>() + (size_t)k0 * nnu, 0, nullptr,
-                   nullptr, mix32, ctx->far_s);
+                   nullptr, mix32, ctx->far_s, itp);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(s));
     }
@@ -926,6 +999,7 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
     // gases: tile windows and workspace
     c.gas.clear();
     c.gas.resize(ngas);
+    c.nI = 0;
     size_t maxL = 0;
     for (int gi = 0; gi < ngas; gi++) {
         ColGas &cg = c.gas[gi];
@@ -949,6 +1023,13 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
             return rc;
         HIPCHK(cg.zones.reserve((size_t)c.K * win.size() * sizeof(Zone)));
         HIPCHK(cg.gmax.reserve((size_t)c.K * sizeof(double)));
+        if (ctx->interp && cg.shape == SH_VOIGT) {
+            if (c.nI == 0 && (rc = ChebGrid::build_into(c.nI, c.cheb_nodes, c.cheb_C, c.nu.as<double>(), nnu, s))) return rc;
+            std::vector<WaveWin> iwin;
+            wave_windows(G.h_nu, g0, g1, nu, nnu, cg.cut, iwin, CS_ITV);
+            if ((rc = upload(cg.iwin, iwin.data(), iwin.size(), s))) return rc;
+            HIPCHK(cg.izones.reserve((size_t)c.K * c.nI * sizeof(IZone)));
+        }
         maxL = std::max(maxL, (size_t)G.L);
     }
     HIPCHK(c.hot.reserve(((size_t)K * maxL + 4) * sizeof(LineHot)));
@@ -1042,7 +1123,7 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
     int rc;
     for (int gi = 0; gi < c.ngas; gi++)
         if ((rc = check_gas_states(ctx->gas[c.gas[gi].slot], (int)BK, Tk.data()))) return rc;
-    DevBuf dTk, dPk, dmuk, dTlev, dsig, dtau, dpart, dF, dranges, dconc, dPp, dgb, dzones, hot, cold;
+    DevBuf dTk, dPk, dmuk, dTlev, dsig, dtau, dpart, dF, dranges, dconc, dPp, dgb, dzones, dizones, hot, cold;
     if ((rc = upload(dTk, Tk.data(), BK, s)) || (rc = upload(dPk, Pk.data(), BK, s)) || (rc = upload(dmuk, muk.data(), BK, s)) ||
         (rc = upload(dTlev, T_levels, (size_t)B * np, s)))
         return rc;
@@ -1082,13 +1163,19 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
         const size_t nt64 = (size_t)((c.nnu + 63) / 64);
         if ((rc = upload(dconc, cc.data(), BK, s)) || (rc = upload(dPp, pp.data(), BK, s)) || (rc = upload(dgb, gb.data(), BK, s))) return rc;
         HIPCHK(dzones.reserve((size_t)kc * nt64 * sizeof(Zone)));
+        Interp itp;
+        if (cg.iwin.p && c.nI > 0) {
+            HIPCHK(dizones.reserve((size_t)kc * c.nI * sizeof(IZone)));
+            itp.nI = c.nI; itp.nodes = c.cheb_nodes.as<double>(); itp.Cm = c.cheb_C.as<double>();
+            itp.iwin = cg.iwin.as<WaveWin>(); itp.iz = dizones.as<IZone>();
+        }
         for (int64_t k0 = 0; k0 < BK; k0 += kc) {
             const int kn = (int)std::min<int64_t>(kc, BK - k0);
             launch_gas(s, cg.shape, G, cg.jlo, cg.jhi, kn, dTk.as<double>() + k0, dPk.as<double>() + k0, dPp.as<double>() + k0,
                        dconc.as<double>() + k0, hot.as<LineHot>(), cold.as<LineCold>(), c.nu.as<double>(), c.nnu, c.ntile,
                        cg.J0.as<int32_t>(), cg.J1.as<int32_t>(), cg.win.as<WaveWin>(), dzones.as<Zone>(), dranges.as<int4>(),
                        dgb.as<double>() + k0, cg.cut, c.sigma_gray, nullptr, dsig.as<double>() + (size_t)k0 * c.nnu, gi > 0, nullptr,
-                       nullptr, (ctx->mixed && cg.shape == SH_VOIGT) ? ctx->hot32.as<LineF32>() : nullptr, ctx->far_s);
+                       nullptr, (ctx->mixed && cg.shape == SH_VOIGT) ? ctx->hot32.as<LineF32>() : nullptr, ctx->far_s, itp);
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipStreamSynchronize(s));   // cc/pp/gb host buffers are reused by the next gas
@@ -1130,11 +1217,16 @@ static int run_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev)
     for (int gi = 0; gi < c.ngas; gi++) {
         ColGas &cg = c.gas[gi];
         GasTable &G = ctx->gas[cg.slot];
+        Interp itp;
+        if (cg.iwin.p && c.nI > 0) {
+            itp.nI = c.nI; itp.nodes = c.cheb_nodes.as<double>(); itp.Cm = c.cheb_C.as<double>();
+            itp.iwin = cg.iwin.as<WaveWin>(); itp.iz = cg.izones.as<IZone>();
+        }
         launch_gas(s, cg.shape, G, cg.jlo, cg.jhi, K, c.Tk.as<double>(), c.Pk.as<double>(), cg.Pp.as<double>(), cg.conc.as<double>(),
                    c.hot.as<LineHot>(), c.cold.as<LineCold>(), c.nu.as<double>(), c.nnu, c.ntile, cg.J0.as<int32_t>(),
                    cg.J1.as<int32_t>(), cg.win.as<WaveWin>(), cg.zones.as<Zone>(), c.ranges.as<int4>(), cg.gmax.as<double>(), cg.cut, c.sigma_gray, extra, sig, gi > 0,
                    ev ? ev[e] : nullptr, ev ? ev[e + 1] : nullptr,
-                   (ctx->mixed && cg.shape == SH_VOIGT) ? ctx->hot32.as<LineF32>() : nullptr, ctx->far_s);
+                   (ctx->mixed && cg.shape == SH_VOIGT) ? ctx->hot32.as<LineF32>() : nullptr, ctx->far_s, itp);
         if (ev) { e += 2; HIPCHK(hipEventRecord(ev[e++], s)); }
     }
     for (auto &t : c.tab) {  // baked gases: sigma += fC * exp(Phi(T, ln P))

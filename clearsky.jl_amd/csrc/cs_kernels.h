@@ -347,6 +347,168 @@ __device__ __forceinline__ int tile_block(int nblk)
     return (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
 }
 
+// ---- K2c: far wings by spectral interpolation ---------------------------------------------------------------------------
+// A line whose centre lies D >= 0.3 h beyond an interval of half-width h contributes a function of nu that is analytic inside
+// a Bernstein ellipse of parameter rho >= 2.1 around the interval (its poles sit at nul +- i*gamma): the Chebyshev interpolant
+// through CS_NC = 64 extrema reproduces it to rounding (error ~ rho^-63 < 1e-18; 1.2e-15 measured, tools/cheb_proto.py).
+// So the sum over all such lines of an interval of CS_ITV = 256 wavenumbers is evaluated at 64 nodes instead of 256 points
+// and interpolated (a 256x64 matrix per interval) -- 4x fewer line evaluations for ~2/3 of the pairs.  Only lines inside
+// the cut-off of EVERY point of the interval qualify (the cut-off makes the others discontinuous in nu); lines nearer than
+// max(dA, 0.3 h) and the cut-off edges stay with the per-point kernels.
+#define CS_ITV 256
+#define CS_NC 64
+constexpr double kChebMargin = 0.3;
+// per (state, interval): interpolated lines = [E0,Z0) U [Z1,E1), cut into the 2-/3-/4-term zones of the far body
+struct __attribute__((aligned(32))) IZone { int32_t E0, Q0, M0, Z0, Z1, M1, Q1, E1; };
+
+// nodes[T][m] = centre + h cos(pi m/63) and C[T][m][i] = l_m(nu_i): Lagrange basis of the extrema, barycentric form
+__global__ __launch_bounds__(256) void k_cheb_setup(const double *__restrict__ nu, int64_t nnu, int nI, double *__restrict__ nodes,
+                                                     double *__restrict__ Cm)
+{
+    const int T = blockIdx.x;
+    const int64_t i0 = (int64_t)T * CS_ITV, i1 = (i0 + CS_ITV - 1 < nnu ? i0 + CS_ITV - 1 : nnu - 1);
+    const double vlo = nu[i0], vhi = nu[i1];
+    const double cen = 0.5 * (vlo + vhi), h = 0.5 * (vhi - vlo);
+    __shared__ double xm[CS_NC];
+    if (threadIdx.x < CS_NC) {
+        const double x = cen + h * cos(kPi * threadIdx.x / (CS_NC - 1));
+        xm[threadIdx.x] = x;
+        nodes[(size_t)T * CS_NC + threadIdx.x] = x;
+    }
+    __syncthreads();
+    const int64_t i = i0 + threadIdx.x;
+    const double v = nu[i < nnu ? i : nnu - 1];
+    double den = 0.0;
+    int hit = -1;
+    for (int m = 0; m < CS_NC; m++) {
+        const double d = v - xm[m];
+        if (d == 0.0) hit = m;
+        const double w = ((m & 1) ? -1.0 : 1.0) * ((m == 0 || m == CS_NC - 1) ? 0.5 : 1.0);
+        den += (d == 0.0) ? 0.0 : w / d;
+    }
+    for (int m = 0; m < CS_NC; m++) {
+        const double d = v - xm[m];
+        const double w = ((m & 1) ? -1.0 : 1.0) * ((m == 0 || m == CS_NC - 1) ? 0.5 : 1.0);
+        double c = (hit >= 0) ? (m == hit ? 1.0 : 0.0) : (w / d) / den;
+        if (!(h > 0.0)) c = 0.0;  // degenerate interval: nothing is interpolated there (k_izones leaves its set empty)
+        Cm[((size_t)T * CS_NC + m) * CS_ITV + threadIdx.x] = c;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_izones(const double *__restrict__ nu, int64_t nnu, int nI, int K,
+                                                 const double *__restrict__ nul, const WaveWin *__restrict__ iwin,
+                                                 const double *__restrict__ Tk, double mu_min, double mu_max, double cut,
+                                                 const double *__restrict__ gbound, double far_s, IZone *__restrict__ iz)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nI * K) return;
+    const int k = idx / nI, T = idx - k * nI;
+    const int64_t i0 = (int64_t)T * CS_ITV, i1 = (i0 + CS_ITV - 1 < nnu ? i0 + CS_ITV - 1 : nnu - 1);
+    const double vlo = nu[i0], vhi = nu[i1];
+    const WaveWin w = iwin[T];   // E0..E1: lines inside the cut-off of every point of the interval
+    IZone z;
+    z.E0 = w.E0; z.E1 = w.E1;
+    const double h = 0.5 * (vhi - vlo);
+    if (!(h > 0.0) || w.E1 <= w.E0) {  // nothing to interpolate
+        z.Q0 = z.M0 = z.Z0 = w.E0;
+        z.Z1 = z.M1 = z.Q1 = z.E1 = w.E0;
+        z.E1 = w.E0;
+        iz[idx] = z;
+        return;
+    }
+    const double vth = sqrt(2.0 * kRgas * Tk[k]);
+    const double amax = ((vhi + cut) / kC) * vth / sqrt(mu_min);
+    const double dA = 100.0 * amax / kSqLn2 * (1.0 + 1e-6);
+    const double dAA = dA * sqrt(far_s * 1e-4);
+    const double dZ = fmax(dA, kChebMargin * h);
+    auto lower = [&](double val, int a, int b) { while (a < b) { int m = (a + b) >> 1; if (nul[m] < val) a = m + 1; else b = m; } return a; };
+    auto upper = [&](double val, int a, int b) { while (a < b) { int m = (a + b) >> 1; if (nul[m] <= val) a = m + 1; else b = m; } return a; };
+    z.Z0 = lower(vlo - dZ, w.E0, w.E1);
+    z.Z1 = upper(vhi + dZ, z.Z0, w.E1);
+    z.M0 = lower(vlo - dAA, w.E0, z.Z0);
+    z.M1 = upper(vhi + dAA, z.Z1, w.E1);
+    const double vmin = vlo - cut;
+    double y2b = 1e300;
+    if (vmin > 0.0) {
+        const double amin = (fmax(vmin, nul[w.E0]) / kC) * vth / sqrt(mu_max);
+        const double yb = gbound[k] * kSqLn2 / amin;
+        y2b = yb * yb;
+    }
+    if (y2b <= 60.0) {
+        z.Q0 = z.M0; z.Q1 = z.M1;
+    } else if (y2b < 1e290) {
+        const double dQ = dA * sqrt(fmax(cbrt(1.5e16 * y2b), far_s) * 1e-4);
+        z.Q0 = lower(vlo - dQ, w.E0, z.M0);
+        z.Q1 = upper(vhi + dQ, z.M1, w.E1);
+    } else {
+        z.Q0 = w.E0; z.Q1 = w.E1;
+    }
+    iz[idx] = z;
+}
+
+// one wave = the 64 Chebyshev nodes of one interval x one node state: far-wing sums at the nodes, then the interval's 256
+// cross-sections as C * F (4 outputs per lane).  The 4 waves of a block and the blocks next to it share the interval (its
+// 128 KB of C stay in L2); blockIdx.y = interval.
+template <bool MIXED>
+__global__ __launch_bounds__(256) void k_voigt_cheb(const double *__restrict__ nodes, const double *__restrict__ Cm, int64_t nnu,
+                                                     int64_t L, const LineHot *__restrict__ hot, const LineF32 *__restrict__ hot32,
+                                                     const double *__restrict__ gnul, const IZone *__restrict__ iz, int nI, int K,
+                                                     double cut, double base, const double *__restrict__ extra,
+                                                     double *__restrict__ sigma, int accumulate)
+{
+    __shared__ double Fsh[4][CS_NC];
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int T = blockIdx.y;
+    const int k = blockIdx.x * 4 + wv;
+    if (k >= K) return;
+    const LineHot *__restrict__ hk = hot + (size_t)k * L;
+    const LineF32 *__restrict__ hf = MIXED ? hot32 + (size_t)k * L : nullptr;
+    const double v = nodes[(size_t)T * CS_NC + lane];
+    const IZone z = iz[(size_t)k * nI + T];
+    const FarK c = load_fark();
+    double acc = 0.0;
+    if (MIXED) {
+        acc = far_segment32<false, 0>(acc, v, gnul, hf, z.E0, z.Q0, cut);
+        acc = far_segment32<false, 1>(acc, v, gnul, hf, z.Q0, z.M0, cut);
+    } else {
+        acc = far_segment<false, 0>(acc, v, hk, z.E0, z.Q0, cut, c);
+        acc = far_segment<false, 1>(acc, v, hk, z.Q0, z.M0, cut, c);
+    }
+    acc = far_segment<false, 2>(acc, v, hk, z.M0, z.Z0, cut, c);
+    acc = far_segment<false, 2>(acc, v, hk, z.Z1, z.M1, cut, c);
+    if (MIXED) {
+        acc = far_segment32<false, 1>(acc, v, gnul, hf, z.M1, z.Q1, cut);
+        acc = far_segment32<false, 0>(acc, v, gnul, hf, z.Q1, z.E1, cut);
+    } else {
+        acc = far_segment<false, 1>(acc, v, hk, z.M1, z.Q1, cut, c);
+        acc = far_segment<false, 0>(acc, v, hk, z.Q1, z.E1, cut, c);
+    }
+    Fsh[wv][lane] = acc;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const double *__restrict__ Ct = Cm + (size_t)T * CS_NC * CS_ITV;
+    double o0 = 0.0, o1 = 0.0, o2 = 0.0, o3 = 0.0;
+#pragma unroll 4
+    for (int m = 0; m < CS_NC; m++) {
+        const double f = Fsh[wv][m];
+        const double *cr = Ct + (size_t)m * CS_ITV + lane;
+        o0 = __builtin_fma(cr[0], f, o0);
+        o1 = __builtin_fma(cr[64], f, o1);
+        o2 = __builtin_fma(cr[128], f, o2);
+        o3 = __builtin_fma(cr[192], f, o3);
+    }
+    const double outv[4] = {o0, o1, o2, o3};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int64_t i = (int64_t)T * CS_ITV + lane + 64 * q;
+        if (i < nnu) {
+            const size_t o = (size_t)k * nnu + i;
+            const double prev = accumulate ? sigma[o] : (base + (extra ? extra[o] : 0.0));
+            sigma[o] = prev + outv[q];
+        }
+    }
+}
+
 // K2a: far wings.  One wave = 64 consecutive wavenumbers x one node state; its window of lines [W0,W1) (sorted by nul)
 // is cut into wave-uniform segments so that ~90 % of the (nu, line) pairs run a 13-16 instruction branch-free body whose
 // line parameters arrive through scalar loads:
@@ -358,8 +520,10 @@ __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu
                                                     const double *__restrict__ gnul, const WaveWin *__restrict__ win,
                                                     const Zone *__restrict__ zones, int ntile, int nblk, double cut,
                                                     double base, const double *__restrict__ extra,
-                                                    double *__restrict__ sigma, int accumulate, int4 *__restrict__ ranges)
+                                                    double *__restrict__ sigma, int accumulate, int4 *__restrict__ ranges,
+                                                    const IZone *__restrict__ iz, int nI)
 {
+    // iz != NULL: the lines [E0,Z0) U [Z1,E1) of the tile's parent interval were summed by k_voigt_cheb -- skip them here.
     // S = 1: one wave per tile.  S = 2, 4: the S waves of a tile split its window of lines into S parts of equal estimated
     // cost and add their partial sums through LDS -- S times more, S times shorter waves, for grids too small to fill the
     // chip otherwise (a nu-shard of a multi-GPU run, bake on a short grid).
@@ -383,26 +547,37 @@ __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu
         const WaveWin w = win[tile];
         z = zones[(size_t)k * ntile + tile];
         const FarK c = load_fark();
-        // this wave's share [p0, p1) of the window
-        int p0 = w.W0, p1 = w.W1;
+        // lines already covered by the interpolated sum: [sa0,sa1) and [sb0,sb1) (empty when interpolation is off)
+        int sa0 = z.M0, sa1 = z.M0, sb0 = z.M1, sb1 = z.M1;
+        if (iz) {
+            const IZone zi = iz[(size_t)k * nI + (tile >> 2)];
+            sa0 = min(max(zi.E0, w.W0), z.N0); sa1 = min(max(zi.Z0, sa0), z.N0);
+            sb0 = max(min(zi.Z1, w.W1), z.N1); sb1 = max(min(zi.E1, w.W1), sb0);
+        }
+        // this wave's share [q0, q1) of the window
+        int q0 = w.W0, q1 = w.W1;
         if (S > 1) {
-            // piecewise-constant cost per line: 14 (far), 20 (4-term), 36 (near zone)
-            const int b5[6] = {w.W0, z.M0, z.N0, z.N1, z.M1, w.W1};
-            const int c5[5] = {14, 20, 36, 20, 14};
+            // piecewise-constant cost per line: 14 (far), 0 (skipped), 20 (4-term), 36 (near zone)
+            const int b8[8] = {w.W0, sa0, sa1, z.N0, z.N1, sb0, sb1, w.W1};
+            const int c7[7] = {14, 0, 20, 36, 20, 0, 14};
             int total = 0;
-            for (int q = 0; q < 5; q++) total += (b5[q + 1] - b5[q]) * c5[q];
+            for (int q = 0; q < 7; q++) total += (b8[q + 1] - b8[q]) * c7[q];
             auto cut_at = [&](int target) {
                 int accu = 0;
-                for (int q = 0; q < 5; q++) {
-                    const int seg = (b5[q + 1] - b5[q]) * c5[q];
-                    if (accu + seg >= target) return b5[q] + (target - accu) / c5[q];
+                for (int q = 0; q < 7; q++) {
+                    const int seg = (b8[q + 1] - b8[q]) * c7[q];
+                    if (c7[q] > 0 && accu + seg >= target) return b8[q] + (target - accu) / c7[q];
                     accu += seg;
                 }
                 return w.W1;
             };
-            p0 = part == 0 ? w.W0 : cut_at((int)((long long)total * part / S));
-            p1 = part == S - 1 ? w.W1 : cut_at((int)((long long)total * (part + 1) / S));
+            q0 = part == 0 ? w.W0 : cut_at((int)((long long)total * part / S));
+            q1 = part == S - 1 ? w.W1 : cut_at((int)((long long)total * (part + 1) / S));
         }
+        const int cw_lo[3] = {w.W0, sa1, sb1}, cw_hi[3] = {sa0, sb0, w.W1};
+        for (int cw = 0; cw < 3; cw++) {
+        const int p0 = max(q0, cw_lo[cw]), p1 = min(q1, cw_hi[cw]);
+        if (p0 >= p1) continue;
 #define LO(x) max((x), p0)
 #define HI(x) min((x), p1)
         {   // left of the wave: [W0,a) edge (cut-off predicate) | [a,Q0) 2-term | [Q0,a1) | [a1,M0) 3-term   (a <= Q0 <= a1 <= M0)
@@ -466,6 +641,7 @@ __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu
         }
 #undef LO
 #undef HI
+        }  // clip windows
     }
     if (S > 1) {   // add the parts in part order (deterministic) and merge the index ranges
         acc_sh[threadIdx.x] = acc;

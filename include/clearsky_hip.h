@@ -77,6 +77,15 @@ int cs_gas_clear(cs_ctx *ctx, int slot);
 int cs_set_precision(cs_ctx *ctx, int mode, double far_s);
 
 /*
+ * Far wings by spectral interpolation (on by default).  The reference evaluates every (nu, line) pair of surf!
+ * (line_shapes.jl:56-96); with `on`, lines further than max(100 Doppler widths, 0.3 x the half-width of a 256-point
+ * interval) from the interval -- and inside the cut-off of all its points -- are summed at 64 Chebyshev nodes of the interval
+ * and interpolated, which reproduces the pointwise sum to ~1e-15.  on = 0: every pair is evaluated.
+ * Applies to every later cs_shape_batch / cs_bake / cs_column_setup of the context.
+ */
+int cs_set_interp(cs_ctx *ctx, int on);
+
+/*
  * B1: batched in-place line shape.  For every state k:  sigma[k*ld_state + i] = shape(nu[i]; T[k], P[k], Pp[k]).
  * Replaces: shape!(sigma, nu, sl, T, P, Pp, dnu_cut) -- voigt!/lorentz!/doppler!/PHCO2!, line_shapes.jl:412-424,
  * :313-324, :200-211, :527-540 -- as invoked by bake, gases.jl:126 (K = nT*nP states in one launch instead of

@@ -1,0 +1,31 @@
+#!/bin/bash
+# Profiling recipe (run on the GPU box from the repo root):  tools/profile.sh <tag> [bench.py args...]
+#   pass 1: rocprofv3 --kernel-trace --stats           -> gpurun_out/prof_<tag>/stats/*kernel_stats.csv
+#   pass 2, 3: --pmc FETCH_SIZE / --pmc WRITE_SIZE      -> gpurun_out/prof_<tag>/{fetch,write}/*counter_collection.csv
+# (counters in their own passes, the program directly after `--`; summaries are copied into profiles/ by hand)
+set -e
+tag=$1; shift
+root=${GRAFT_REPO_ROOT:-$PWD}
+out=$root/gpurun_out/prof_$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $root/bench.py --steps 10 --warmup 2 --no-cpu "$@" > $out/stats.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu "$@" > $out/fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu "$@" > $out/write.log 2>&1
+python3 - "$out" <<'PY'
+import csv, glob, sys, collections
+out = sys.argv[1]
+for f in glob.glob(out + "/stats/**/*kernel_stats.csv", recursive=True):
+    print(open(f).read())
+for name in ("fetch", "write"):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for f in glob.glob(f"{out}/{name}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            a = agg[r["Kernel_Name"].split("(")[0]]
+            a[0] += 1; a[1] += float(r["Counter_Value"])
+    with open(f"{out}/pmc_{name}_summary.csv", "w") as fo:
+        fo.write("kernel,launches,avg_KB_per_launch\n")
+        for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            fo.write(f"{k},{n},{v / n:.1f}\n")
+    print(open(f"{out}/pmc_{name}_summary.csv").read())
+PY
