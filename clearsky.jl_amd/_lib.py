@@ -57,6 +57,8 @@ SIGNATURES = {
     "cs_column_fetch": (C.c_int, [_vp, _dp, _dp, _dp, _dp, _dp]),
     "cs_column_sigma_fetch": (C.c_int, [_vp, _dp]),
     "cs_column_counts": (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "cs_column_work": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
+    "cs_interp_plan": (C.c_int, [C.c_int64, _dp, C.c_double, _ip]),
     "cs_column_batch": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp]),
     "cs_column_update_state": (C.c_int, [_vp, _dp, _dp, _dp, _dp, _dp]),
     "cs_par_count": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64)]),

@@ -196,6 +196,16 @@ def nodevalues(X, nlobatto):
 # device context
 
 
+def interp_plan(nu, cut=25.0):
+    """Interval sizes the far-wing interpolation uses on grid `nu` with cut-off `cut` ([] = every pair evaluated directly)."""
+    nu = np.ascontiguousarray(nu, dtype=np.float64)
+    out = (C.c_int * 5)()
+    n = lib().cs_interp_plan(nu.size, nu.ctypes.data_as(C.POINTER(C.c_double)), float(cut), out)
+    if n < 0:
+        check(n)
+    return [out[i] for i in range(n)]
+
+
 class Context:
     """One HIP context (cs_ctx) = one device + stream + resident gas tables.  Not re-entrant."""
 
@@ -813,6 +823,13 @@ class Column:
         a, b = C.c_int64(), C.c_int64()
         check(lib().cs_column_counts(self.ctx.handle, C.byref(a), C.byref(b)))
         return dict(pair_evals=a.value, lines_in_range=b.value)
+
+    def work(self):
+        """Evaluations the last run issued for its Voigt gases: per-point, at interpolation nodes; levels in use."""
+        self._ensure_resident()
+        out = (C.c_int64 * 4)()
+        check(lib().cs_column_work(self.ctx.handle, out))
+        return dict(direct_evals=out[0], node_evals=out[1], levels=out[2], intervals=out[3])
 
     def fetch(self, tau=None, Mup=None, Mdn=None):
         """Copy results to host.  Returns (Fup, Fdn); fills the optional Fortran-order matrices in place."""

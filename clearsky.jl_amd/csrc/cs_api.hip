@@ -118,12 +118,22 @@ struct ColCia {
     int nband = 0;
 };
 
+// interpolated far wings: interval levels of a nu grid (descending interval size; intervals of all levels form one list)
+struct ChebGrid {
+    int nlev = 0, nItot = 0;
+    int itv[CS_MAX_LEVEL] = {}, nI[CS_MAX_LEVEL] = {}, ioff[CS_MAX_LEVEL] = {};
+    DevBuf nodes;               // [nItot][64]
+    DevBuf Cm[CS_MAX_LEVEL];    // [nI][64][itv]
+    DevBuf F;                   // [nItot][64][Kpad] node sums of the gas being processed
+};
+struct GasInterp { int nlev = 0; DevBuf iwin[CS_MAX_LEVEL], iz; };   // per gas on that grid: windows per level, zones [K][nItot]
+
 struct ColGas {
     int slot = 0, shape = 0;
     double cut = 25.0;
     DevBuf conc, Pp, J0, J1;  // [K], [K], [ntile], [ntile]
     DevBuf win, zones, gmax;  // [ntile64] WaveWin, [K][ntile64] Zone, [K] max Lorentz width (Voigt fast path)
-    DevBuf iwin, izones;      // [nI] WaveWin, [K][nI] IZone (interpolated far wings; empty = off)
+    GasInterp itp;            // interpolated far wings (nlev = 0: off)
     int64_t pairs_per_state = 0, lines_in_range = 0, jlo = 0, jhi = 0;
 };
 
@@ -141,8 +151,7 @@ struct Column {
     std::vector<double> h_Tk;
     DevBuf nu, wts, P, Pk, Tk, muk, Tlev, extra, S_toa, albedo;
     DevBuf hot, cold, sigma, tau, Mup, Mdn, partial, F, stage, ranges;
-    int nI = 0;                // interpolation intervals of the nu grid (0 = off)
-    DevBuf cheb_nodes, cheb_C;
+    ChebGrid cheb;             // interpolation levels of the nu grid (nlev = 0: off)
 };
 
 }  // namespace
@@ -374,29 +383,92 @@ std::vector<double> gamma_bound(const GasTable &G, int K, const double *T, const
     return g;
 }
 
-// far wings by interpolation (k_voigt_cheb): per-grid nodes and matrices, per-gas interval windows and zones; nI = 0: off
+// far wings by interpolation (k_cheb_nodes + k_cheb_apply), view handed to launch_gas; nlev = 0: off
 struct Interp {
-    int nI = 0;
-    const double *nodes = nullptr, *Cm = nullptr;
-    const WaveWin *iwin = nullptr;
+    int nlev = 0, nItot = 0, Kpad = 0;
+    int itv[CS_MAX_LEVEL], nI[CS_MAX_LEVEL], ioff[CS_MAX_LEVEL];
+    const double *nodes = nullptr, *Cm[CS_MAX_LEVEL];
+    const WaveWin *iwin[CS_MAX_LEVEL];
     IZone *iz = nullptr;
+    double *F = nullptr;
 };
 
-// the grid part of Interp: nodes [nI][64] and interpolation matrices [nI][64][256]
-struct ChebGrid {
-    int nI = 0;
-    DevBuf nodes, Cm;
-    int build(const double *dnu, int64_t nnu, hipStream_t s) { return build_into(nI, nodes, Cm, dnu, nnu, s); }
-    static int build_into(int &nI, DevBuf &nodes, DevBuf &Cm, const double *dnu, int64_t nnu, hipStream_t s)
-    {
-        nI = (int)((nnu + CS_ITV - 1) / CS_ITV);
-        HIPCHK(nodes.reserve((size_t)nI * CS_NC * sizeof(double)));
-        HIPCHK(Cm.reserve((size_t)nI * CS_NC * CS_ITV * sizeof(double)));
-        hipLaunchKernelGGL(k_cheb_setup, dim3(nI), dim3(256), 0, s, dnu, nnu, nI, nodes.as<double>(), Cm.as<double>());
-        HIPCHK(hipGetLastError());
-        return CS_OK;
+// interval sizes worth using on this grid: an interval of width W leaves lines over (2 cut - 2.3 W) to interpolate
+int choose_levels(const double *nu, int64_t nnu, double cut, int *itv)
+{
+    int n = 0;
+    if (nnu < 128) return 0;
+    const double dnu = (nu[nnu - 1] - nu[0]) / (double)(nnu - 1);
+    int szmax = 2048, szmin = 128;   // debugging knobs: restrict the interval sizes
+    if (const char *e = getenv("CLEARSKY_INTERP_MAX")) szmax = atoi(e);
+    if (const char *e = getenv("CLEARSKY_INTERP_MIN")) szmin = atoi(e);
+    for (int sz = 2048; sz >= 128 && n < CS_MAX_LEVEL; sz >>= 1)
+        if (sz <= szmax && sz >= szmin && 2.3 * sz * dnu <= 1.5 * cut && sz / 2 <= nnu &&
+            sz * dnu > 1e-8 * std::fabs(nu[nnu - 1]))   // (nodes 1e-3 of an interval apart must stay distinct doubles)
+            itv[n++] = sz;
+    return n;
+}
+
+// the grid part: nodes [nItot][64] and interpolation matrices [nI][64][itv] per level
+int cheb_build(ChebGrid &g, const double *h_nu, const double *dnu, int64_t nnu, double cut, hipStream_t s)
+{
+    g.nlev = choose_levels(h_nu, nnu, cut, g.itv);
+    g.nItot = 0;
+    for (int l = 0; l < g.nlev; l++) {
+        g.nI[l] = (int)((nnu + g.itv[l] - 1) / g.itv[l]);
+        g.ioff[l] = g.nItot;
+        g.nItot += g.nI[l];
     }
-};
+    if (g.nlev == 0) return CS_OK;
+    HIPCHK(g.nodes.reserve((size_t)g.nItot * CS_NC * sizeof(double)));
+    for (int l = 0; l < g.nlev; l++) {
+        HIPCHK(g.Cm[l].reserve((size_t)g.nI[l] * CS_NC * g.itv[l] * sizeof(double)));
+        hipLaunchKernelGGL(k_cheb_setup, dim3(g.nI[l]), dim3(256), 0, s, dnu, nnu, g.itv[l], g.nI[l],
+                           g.nodes.as<double>() + (size_t)g.ioff[l] * CS_NC, g.Cm[l].as<double>());
+        HIPCHK(hipGetLastError());
+    }
+    return CS_OK;
+}
+
+int cheb_kpad(int K) { return (K + CS_KPAD - 1) / CS_KPAD * CS_KPAD; }
+
+// the gas part: per-level interval windows (uploaded) and zone workspace for K states; F workspace of the grid
+int gas_interp_build(GasInterp &gi, ChebGrid &g, const std::vector<double> &nul, int64_t g0, int64_t g1,
+                     const double *nu, int64_t nnu, double cut, int K, hipStream_t s)
+{
+    int rc;
+    gi.nlev = g.nlev;
+    if (g.nlev == 0) return CS_OK;
+    for (int l = 0; l < g.nlev; l++) {
+        std::vector<WaveWin> iwin;
+        wave_windows(nul, g0, g1, nu, nnu, cut, iwin, g.itv[l]);
+        if ((rc = upload(gi.iwin[l], iwin.data(), iwin.size(), s))) return rc;
+        HIPCHK(hipStreamSynchronize(s));   // iwin is a local
+    }
+    HIPCHK(gi.iz.reserve((size_t)K * g.nItot * sizeof(IZone)));
+    if (g.F.bytes < (size_t)g.nItot * CS_NC * cheb_kpad(K) * sizeof(double)) {
+        HIPCHK(g.F.reserve((size_t)g.nItot * CS_NC * cheb_kpad(K) * sizeof(double)));
+        HIPCHK(hipMemsetAsync(g.F.p, 0, g.F.bytes, s));   // padding states stay finite
+    }
+    return CS_OK;
+}
+
+Interp interp_view(const ChebGrid &g, const GasInterp &gi, int K, IZone *iz_override = nullptr)
+{
+    Interp v;
+    v.nlev = gi.nlev;
+    v.nItot = g.nItot;
+    v.Kpad = cheb_kpad(K);
+    v.nodes = g.nodes.as<double>();
+    v.iz = iz_override ? iz_override : gi.iz.as<IZone>();
+    v.F = g.F.as<double>();
+    for (int l = 0; l < gi.nlev; l++) {
+        v.itv[l] = g.itv[l]; v.nI[l] = g.nI[l]; v.ioff[l] = g.ioff[l];
+        v.Cm[l] = g.Cm[l].as<double>();
+        v.iwin[l] = gi.iwin[l].as<WaveWin>();
+    }
+    return v;
+}
 
 // K1 + K2 for one gas on `s`: parameters for `kn` states, then the line sum into sigma ([kn][nnu])
 void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, int64_t jrange1, int kn, const double *Tk, const double *Pk, const double *Ppk,
@@ -416,21 +488,37 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
         hipLaunchKernelGGL(k_zones, dim3((unsigned)(((int64_t)nt64 * kn + 255) / 256)), dim3(256), 0, s, dnu, nnu, nt64, kn,
                            G.nu.as<double>(), win, Tk, G.mu_min, G.mu_max, cut, gbound, far_s, zones);
         const IZone *iz = nullptr;
-        if (itp.nI > 0) {
-            iz = itp.iz;
-            hipLaunchKernelGGL(k_izones, dim3((unsigned)(((int64_t)itp.nI * kn + 255) / 256)), dim3(256), 0, s, dnu, nnu, itp.nI, kn,
-                               G.nu.as<double>(), itp.iwin, Tk, G.mu_min, G.mu_max, cut, gbound, far_s, itp.iz);
+        int ishift = 0;
+        for (int l = 0; l < itp.nlev; l++) {
+            int pshift = 0;
+            if (l > 0) for (int r = itp.itv[l - 1] / itp.itv[l]; r > 1; r >>= 1) pshift++;
+            hipLaunchKernelGGL(k_izones, dim3((unsigned)(((int64_t)itp.nI[l] * kn + 255) / 256)), dim3(256), 0, s, dnu, nnu, itp.itv[l],
+                               itp.nI[l], kn, G.nu.as<double>(), itp.iwin[l], Tk, G.mu_min, G.mu_max, cut, gbound, far_s,
+                               l > 0 ? itp.ioff[l - 1] : -1, pshift, itp.ioff[l], itp.nItot, itp.iz);
         }
         if (ev_mid) (void)hipEventRecord(ev_mid, s);
-        if (iz) {   // sigma = base + extra + interpolated far wings; the per-point kernels add the rest
-            const dim3 gridc((unsigned)((kn + 3) / 4), (unsigned)itp.nI);
+        if (itp.nlev > 0) {   // sigma = base + extra + interpolated far wings; the per-point kernels add the rest
+            const dim3 gridn((unsigned)((kn + 3) / 4), (unsigned)itp.nItot);
             if (hot32)
-                hipLaunchKernelGGL((k_voigt_cheb<true>), gridc, dim3(256), 0, s, itp.nodes, itp.Cm, nnu, G.L, hot, hot32, G.nu.as<double>(), iz,
-                                   itp.nI, kn, cut, base, extra, sigma, accumulate);
+                hipLaunchKernelGGL((k_cheb_nodes<true>), gridn, dim3(256), 0, s, itp.nodes, G.L, hot, hot32, G.nu.as<double>(), itp.iz,
+                                   itp.nItot, kn, itp.Kpad, cut, itp.F);
             else
-                hipLaunchKernelGGL((k_voigt_cheb<false>), gridc, dim3(256), 0, s, itp.nodes, itp.Cm, nnu, G.L, hot, hot32, G.nu.as<double>(), iz,
-                                   itp.nI, kn, cut, base, extra, sigma, accumulate);
+                hipLaunchKernelGGL((k_cheb_nodes<false>), gridn, dim3(256), 0, s, itp.nodes, G.L, hot, hot32, G.nu.as<double>(), itp.iz,
+                                   itp.nItot, kn, itp.Kpad, cut, itp.F);
+            ChebApply A;
+            A.nlev = itp.nlev;
+            for (int l = 0; l < itp.nlev; l++) {
+                A.shift[l] = 0;
+                for (int r = itp.itv[l] / 64; r > 1; r >>= 1) A.shift[l]++;
+                A.ioff[l] = itp.ioff[l];
+                A.Cm[l] = itp.Cm[l];
+            }
+            hipLaunchKernelGGL(k_cheb_apply, dim3((unsigned)((nt64 + 3) / 4), (unsigned)((kn + CS_KPAD - 1) / CS_KPAD)), dim3(256), 0, s, A,
+                               itp.F, itp.Kpad, nnu, nt64, kn, base, extra, sigma, accumulate);
             accumulate = 1;
+            const int low = itp.nlev - 1;
+            iz = itp.iz + itp.ioff[low];
+            ishift = A.shift[low];
         }
         const int nblk = (nt64 + 3) / 4;
         const dim3 grid((unsigned)((nblk + 7) / 8 * 8), kn);   // multiple of 8: XCD-aware tile mapping (tile_block)
@@ -440,7 +528,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
         const int nblk_s = (nt64 * split + 3) / 4;
         const dim3 grid_s((unsigned)((nblk_s + 7) / 8 * 8), kn);
 #define CS_FAR_LAUNCH(MIX, SP) hipLaunchKernelGGL((k_voigt_far<MIX, SP>), grid_s, dim3(256), 0, s, dnu, nnu, G.L, hot, hot32, G.nu.as<double>(), \
-                                                  win, zones, nt64, nblk_s, cut, base, extra, sigma, accumulate, ranges, iz, itp.nI)
+                                                  win, zones, nt64, nblk_s, cut, base, extra, sigma, accumulate, ranges, iz, itp.nItot, ishift)
         if (hot32) {
             if (split == 1) CS_FAR_LAUNCH(true, 1); else if (split == 2) CS_FAR_LAUNCH(true, 2); else CS_FAR_LAUNCH(true, 4);
         } else {
@@ -613,15 +701,13 @@ int cs_shape_batch(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t nnu
         if ((rc = upload(dgmax, gb.data(), K, s))) return rc;
     }
     ChebGrid cheb;
-    DevBuf diwin, dizones;
+    GasInterp ginterp;
     Interp itp;
     if (ctx->interp && shape == SH_VOIGT) {
-        std::vector<WaveWin> iwin;
-        wave_windows(G.h_nu, g0, g1, nu, nnu, dnu_cut, iwin, CS_ITV);
-        if ((rc = cheb.build(dnu.as<double>(), nnu, s)) || (rc = upload(diwin, iwin.data(), iwin.size(), s))) return rc;
-        HIPCHK(dizones.reserve((size_t)kc * cheb.nI * sizeof(IZone)));
-        itp.nI = cheb.nI; itp.nodes = cheb.nodes.as<double>(); itp.Cm = cheb.Cm.as<double>();
-        itp.iwin = diwin.as<WaveWin>(); itp.iz = dizones.as<IZone>();
+        if ((rc = cheb_build(cheb, nu, dnu.as<double>(), nnu, dnu_cut, s)) ||
+            (rc = gas_interp_build(ginterp, cheb, G.h_nu, g0, g1, nu, nnu, dnu_cut, kc, s)))
+            return rc;
+        itp = interp_view(cheb, ginterp, kc);
     }
     for (int k0 = 0; k0 < K; k0 += kc) {
         const int kn = std::min(kc, K - k0);
@@ -691,15 +777,13 @@ int cs_bake(cs_ctx *ctx, int gas_slot, int table_slot, int shape, double dnu_cut
         mix32 = ctx->hot32.as<LineF32>();
     }
     ChebGrid cheb;
-    DevBuf diwin, dizones;
+    GasInterp ginterp;
     Interp itp;
     if (ctx->interp && shape == SH_VOIGT) {
-        std::vector<WaveWin> iwin;
-        wave_windows(G.h_nu, g0, g1, nu, nnu, dnu_cut, iwin, CS_ITV);
-        if ((rc = cheb.build(dnu.as<double>(), nnu, s)) || (rc = upload(diwin, iwin.data(), iwin.size(), s))) return rc;
-        HIPCHK(dizones.reserve((size_t)kc * cheb.nI * sizeof(IZone)));
-        itp.nI = cheb.nI; itp.nodes = cheb.nodes.as<double>(); itp.Cm = cheb.Cm.as<double>();
-        itp.iwin = diwin.as<WaveWin>(); itp.iz = dizones.as<IZone>();
+        if ((rc = cheb_build(cheb, nu, dnu.as<double>(), nnu, dnu_cut, s)) ||
+            (rc = gas_interp_build(ginterp, cheb, G.h_nu, g0, g1, nu, nnu, dnu_cut, kc, s)))
+            return rc;
+        itp = interp_view(cheb, ginterp, kc);
     }
     for (int k0 = 0; k0 < M; k0 += kc) {
         const int kn = std::min(kc, M - k0);
@@ -999,7 +1083,16 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
     // gases: tile windows and workspace
     c.gas.clear();
     c.gas.resize(ngas);
-    c.nI = 0;
+    c.cheb.nlev = 0;
+    if (ctx->interp) {   // interval sizes from the narrowest Voigt cut-off of the column
+        double cmin = 0.0;
+        for (int gi = 0; gi < ngas; gi++)
+            if ((shapes ? shapes[gi] : CS_SHAPE_VOIGT) == SH_VOIGT) {
+                const double cu = dnu_cuts ? dnu_cuts[gi] : 25.0;
+                cmin = cmin > 0.0 ? std::min(cmin, cu) : cu;
+            }
+        if (cmin > 0.0 && (rc = cheb_build(c.cheb, nu, c.nu.as<double>(), nnu, cmin, s))) return rc;
+    }
     size_t maxL = 0;
     for (int gi = 0; gi < ngas; gi++) {
         ColGas &cg = c.gas[gi];
@@ -1023,13 +1116,9 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
             return rc;
         HIPCHK(cg.zones.reserve((size_t)c.K * win.size() * sizeof(Zone)));
         HIPCHK(cg.gmax.reserve((size_t)c.K * sizeof(double)));
-        if (ctx->interp && cg.shape == SH_VOIGT) {
-            if (c.nI == 0 && (rc = ChebGrid::build_into(c.nI, c.cheb_nodes, c.cheb_C, c.nu.as<double>(), nnu, s))) return rc;
-            std::vector<WaveWin> iwin;
-            wave_windows(G.h_nu, g0, g1, nu, nnu, cg.cut, iwin, CS_ITV);
-            if ((rc = upload(cg.iwin, iwin.data(), iwin.size(), s))) return rc;
-            HIPCHK(cg.izones.reserve((size_t)c.K * c.nI * sizeof(IZone)));
-        }
+        if (c.cheb.nlev > 0 && cg.shape == SH_VOIGT &&
+            (rc = gas_interp_build(cg.itp, c.cheb, G.h_nu, g0, g1, nu, nnu, cg.cut, c.K, s)))
+            return rc;
         maxL = std::max(maxL, (size_t)G.L);
     }
     HIPCHK(c.hot.reserve(((size_t)K * maxL + 4) * sizeof(LineHot)));
@@ -1123,7 +1212,7 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
     int rc;
     for (int gi = 0; gi < c.ngas; gi++)
         if ((rc = check_gas_states(ctx->gas[c.gas[gi].slot], (int)BK, Tk.data()))) return rc;
-    DevBuf dTk, dPk, dmuk, dTlev, dsig, dtau, dpart, dF, dranges, dconc, dPp, dgb, dzones, dizones, hot, cold;
+    DevBuf dTk, dPk, dmuk, dTlev, dsig, dtau, dpart, dF, dranges, dconc, dPp, dgb, dzones, dizones, dF2, hot, cold;
     if ((rc = upload(dTk, Tk.data(), BK, s)) || (rc = upload(dPk, Pk.data(), BK, s)) || (rc = upload(dmuk, muk.data(), BK, s)) ||
         (rc = upload(dTlev, T_levels, (size_t)B * np, s)))
         return rc;
@@ -1164,10 +1253,15 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
         if ((rc = upload(dconc, cc.data(), BK, s)) || (rc = upload(dPp, pp.data(), BK, s)) || (rc = upload(dgb, gb.data(), BK, s))) return rc;
         HIPCHK(dzones.reserve((size_t)kc * nt64 * sizeof(Zone)));
         Interp itp;
-        if (cg.iwin.p && c.nI > 0) {
-            HIPCHK(dizones.reserve((size_t)kc * c.nI * sizeof(IZone)));
-            itp.nI = c.nI; itp.nodes = c.cheb_nodes.as<double>(); itp.Cm = c.cheb_C.as<double>();
-            itp.iwin = cg.iwin.as<WaveWin>(); itp.iz = dizones.as<IZone>();
+        if (cg.itp.nlev > 0) {
+            HIPCHK(dizones.reserve((size_t)kc * c.cheb.nItot * sizeof(IZone)));
+            const size_t fb = (size_t)c.cheb.nItot * CS_NC * cheb_kpad(kc) * sizeof(double);
+            if (dF2.bytes < fb) {
+                HIPCHK(dF2.reserve(fb));
+                HIPCHK(hipMemsetAsync(dF2.p, 0, dF2.bytes, s));
+            }
+            itp = interp_view(c.cheb, cg.itp, kc, dizones.as<IZone>());
+            itp.F = dF2.as<double>();
         }
         for (int64_t k0 = 0; k0 < BK; k0 += kc) {
             const int kn = (int)std::min<int64_t>(kc, BK - k0);
@@ -1217,11 +1311,7 @@ static int run_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev)
     for (int gi = 0; gi < c.ngas; gi++) {
         ColGas &cg = c.gas[gi];
         GasTable &G = ctx->gas[cg.slot];
-        Interp itp;
-        if (cg.iwin.p && c.nI > 0) {
-            itp.nI = c.nI; itp.nodes = c.cheb_nodes.as<double>(); itp.Cm = c.cheb_C.as<double>();
-            itp.iwin = cg.iwin.as<WaveWin>(); itp.iz = cg.izones.as<IZone>();
-        }
+        const Interp itp = cg.itp.nlev > 0 ? interp_view(c.cheb, cg.itp, K) : Interp();
         launch_gas(s, cg.shape, G, cg.jlo, cg.jhi, K, c.Tk.as<double>(), c.Pk.as<double>(), cg.Pp.as<double>(), cg.conc.as<double>(),
                    c.hot.as<LineHot>(), c.cold.as<LineCold>(), c.nu.as<double>(), c.nnu, c.ntile, cg.J0.as<int32_t>(),
                    cg.J1.as<int32_t>(), cg.win.as<WaveWin>(), cg.zones.as<Zone>(), c.ranges.as<int4>(), cg.gmax.as<double>(), cg.cut, c.sigma_gray, extra, sig, gi > 0,
@@ -1363,6 +1453,57 @@ int cs_column_counts(cs_ctx *ctx, int64_t *pair_evals, int64_t *lines_in_range)
     }
     if (pair_evals) *pair_evals = p;
     if (lines_in_range) *lines_in_range = l;
+    return CS_OK;
+}
+
+int cs_interp_plan(int64_t nnu, const double *nu, double dnu_cut, int *interval_sizes)
+{
+    if (!nu || nnu < 1 || !interval_sizes) return fail(CS_EINVAL, "bad arguments");
+    return choose_levels(nu, nnu, dnu_cut, interval_sizes);
+}
+
+int cs_column_work(cs_ctx *ctx, int64_t *out)
+{
+    if (!ctx || !ctx->col.ready || !out) return fail(CS_ESTATE, "no resident column");
+    Column &c = ctx->col;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipDeviceSynchronize());
+    const int K = c.K;
+    const int nt64 = (int)((c.nnu + 63) / 64);
+    int64_t direct = 0, nodes = 0;
+    for (auto &g : c.gas) {
+        if (g.shape != SH_VOIGT) continue;
+        std::vector<WaveWin> win(nt64);
+        std::vector<Zone> zn((size_t)K * nt64);
+        HIPCHK(hipMemcpy(win.data(), g.win.p, win.size() * sizeof(WaveWin), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(zn.data(), g.zones.p, zn.size() * sizeof(Zone), hipMemcpyDeviceToHost));
+        std::vector<IZone> iz;
+        const int nlev = g.itp.nlev, nItot = c.cheb.nItot;
+        if (nlev > 0) {
+            iz.resize((size_t)K * nItot);
+            HIPCHK(hipMemcpy(iz.data(), g.itp.iz.p, iz.size() * sizeof(IZone), hipMemcpyDeviceToHost));
+            for (const IZone &z : iz) nodes += (int64_t)CS_NC * ((z.P0 - z.E0) + (z.Z0 - z.P1) + (z.P2 - z.Z1) + (z.E1 - z.P3));
+        }
+        int ishift = 0;
+        if (nlev > 0) for (int r = c.cheb.itv[nlev - 1] / 64; r > 1; r >>= 1) ishift++;
+        for (int k = 0; k < K; k++)
+            for (int t = 0; t < nt64; t++) {
+                const WaveWin &w = win[t];
+                const Zone &z = zn[(size_t)k * nt64 + t];
+                int64_t n = w.W1 - w.W0;
+                if (nlev > 0) {   // same clamps as k_voigt_far
+                    const IZone &zi = iz[(size_t)k * nItot + c.cheb.ioff[nlev - 1] + (t >> ishift)];
+                    const int sa0 = std::min(std::max(zi.E0, w.W0), z.N0), sa1 = std::min(std::max(zi.Z0, sa0), z.N0);
+                    const int sb0 = std::max(std::min(zi.Z1, w.W1), z.N1), sb1 = std::max(std::min(zi.E1, w.W1), sb0);
+                    n -= (sa1 - sa0) + (sb1 - sb0);
+                }
+                direct += 64 * n;
+            }
+    }
+    out[0] = direct;
+    out[1] = nodes;
+    out[2] = c.cheb.nlev;
+    out[3] = c.cheb.nItot;
     return CS_OK;
 }
 

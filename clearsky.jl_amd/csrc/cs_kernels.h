@@ -270,7 +270,11 @@ __device__ __forceinline__ double far_term(const LineHot &h, double v, double cu
     const double dv = v - h.nul;
     const double x = dv * h.p1;
     const double s = __builtin_fma(x, x, h.p2);
+#ifdef CS_EXP_RCP_NR
+    const double u = rcp_nr(s);
+#else
     const double u = rcp_fast(s);
+#endif
     double P;
     if (MODE == 2) {
         const double t = h.p2 * u;
@@ -297,6 +301,15 @@ __device__ __forceinline__ double far_segment(double acc, double v, const LineHo
 {
 #pragma unroll 4
     for (int j = j0; j < j1; j++) acc += far_term<PRED, MODE>(hk[j], v, cut, c);
+    return acc;
+}
+// the same lines from j1-1 down to j0 (lines right of nu: farthest = smallest terms first)
+template <bool PRED, int MODE>
+__device__ __forceinline__ double far_segment_rev(double acc, double v, const LineHot *__restrict__ hk, int j0, int j1, double cut,
+                                                  const FarK &c)
+{
+#pragma unroll 4
+    for (int j = j1 - 1; j >= j0; j--) acc += far_term<PRED, MODE>(hk[j], v, cut, c);
     return acc;
 }
 
@@ -337,6 +350,22 @@ __device__ __forceinline__ double far_segment32(double acc, double v, const doub
     for (; j < j1; j++) part += far_term32<PRED, MODE>(nul[j], hk[j], v, cut);
     return __builtin_fma((double)part, kMixUnscale, acc);
 }
+template <bool PRED, int MODE>
+__device__ __forceinline__ double far_segment32_rev(double acc, double v, const double *__restrict__ nul, const LineF32 *__restrict__ hk,
+                                                    int j0, int j1, double cut)
+{
+    int j = j1 - 4;
+    for (; j >= j0; j -= 4) {
+        float part = far_term32<PRED, MODE>(nul[j + 3], hk[j + 3], v, cut);
+        part += far_term32<PRED, MODE>(nul[j + 2], hk[j + 2], v, cut);
+        part += far_term32<PRED, MODE>(nul[j + 1], hk[j + 1], v, cut);
+        part += far_term32<PRED, MODE>(nul[j], hk[j], v, cut);
+        acc = __builtin_fma((double)part, kMixUnscale, acc);
+    }
+    float part = 0.0f;
+    for (j += 3; j >= j0; j--) part += far_term32<PRED, MODE>(nul[j], hk[j], v, cut);
+    return __builtin_fma((double)part, kMixUnscale, acc);
+}
 
 // blockIdx.x -> block of 4 wave tiles.  Workgroups are dealt round-robin over the 8 XCDs, so block b and b+8 share an
 // L2: give each XCD one contiguous eighth of the spectrum, whose overlapping line windows then stay in that L2.
@@ -351,71 +380,85 @@ __device__ __forceinline__ int tile_block(int nblk)
 // A line whose centre lies D >= 0.3 h beyond an interval of half-width h contributes a function of nu that is analytic inside
 // a Bernstein ellipse of parameter rho >= 2.1 around the interval (its poles sit at nul +- i*gamma): the Chebyshev interpolant
 // through CS_NC = 64 extrema reproduces it to rounding (error ~ rho^-63 < 1e-18; 1.2e-15 measured, tools/cheb_proto.py).
-// So the sum over all such lines of an interval of CS_ITV = 256 wavenumbers is evaluated at 64 nodes instead of 256 points
-// and interpolated (a 256x64 matrix per interval) -- 4x fewer line evaluations for ~2/3 of the pairs.  Only lines inside
-// the cut-off of EVERY point of the interval qualify (the cut-off makes the others discontinuous in nu); lines nearer than
-// max(dA, 0.3 h) and the cut-off edges stay with the per-point kernels.
-#define CS_ITV 256
+// So the sum over all such lines of an interval of N = 128 .. 2048 wavenumbers is evaluated at 64 nodes instead of N points
+// and interpolated (an N x 64 matrix per interval) -- N/64 times fewer line evaluations.  Only lines inside the cut-off of
+// EVERY point of the interval qualify (the cut-off makes the others discontinuous in nu); lines nearer than
+// max(dA, 0.3 h) and the cut-off edges are left to the next smaller interval size, and finally to the per-point kernels.
 #define CS_NC 64
+#define CS_MAX_LEVEL 5
 constexpr double kChebMargin = 0.3;
-// per (state, interval): interpolated lines = [E0,Z0) U [Z1,E1), cut into the 2-/3-/4-term zones of the far body
-struct __attribute__((aligned(32))) IZone { int32_t E0, Q0, M0, Z0, Z1, M1, Q1, E1; };
+// per (state, interval): own set = [E0,Z0) U [Z1,E1), cut into the 2-/3-/4-term zones of the far body; [P0,P1) and [P2,P3)
+// is the part of it the parent interval (next level up) has already summed.
+struct __attribute__((aligned(16))) IZone { int32_t E0, Q0, M0, Z0, Z1, M1, Q1, E1, P0, P1, P2, P3; };
 
 // nodes[T][m] = centre + h cos(pi m/63) and C[T][m][i] = l_m(nu_i): Lagrange basis of the extrema, barycentric form
-__global__ __launch_bounds__(256) void k_cheb_setup(const double *__restrict__ nu, int64_t nnu, int nI, double *__restrict__ nodes,
-                                                     double *__restrict__ Cm)
+__global__ __launch_bounds__(256) void k_cheb_setup(const double *__restrict__ nu, int64_t nnu, int itv, int nI,
+                                                     double *__restrict__ nodes, double *__restrict__ Cm)
 {
     const int T = blockIdx.x;
-    const int64_t i0 = (int64_t)T * CS_ITV, i1 = (i0 + CS_ITV - 1 < nnu ? i0 + CS_ITV - 1 : nnu - 1);
+    const int64_t i0 = (int64_t)T * itv, i1 = (i0 + itv - 1 < nnu ? i0 + itv - 1 : nnu - 1);
     const double vlo = nu[i0], vhi = nu[i1];
     const double cen = 0.5 * (vlo + vhi), h = 0.5 * (vhi - vlo);
-    __shared__ double xm[CS_NC];
+    __shared__ double xm[CS_NC], wm[CS_NC];
     if (threadIdx.x < CS_NC) {
         const double x = cen + h * cos(kPi * threadIdx.x / (CS_NC - 1));
         xm[threadIdx.x] = x;
         nodes[(size_t)T * CS_NC + threadIdx.x] = x;
     }
     __syncthreads();
-    const int64_t i = i0 + threadIdx.x;
-    const double v = nu[i < nnu ? i : nnu - 1];
-    double den = 0.0;
-    int hit = -1;
-    for (int m = 0; m < CS_NC; m++) {
-        const double d = v - xm[m];
-        if (d == 0.0) hit = m;
-        const double w = ((m & 1) ? -1.0 : 1.0) * ((m == 0 || m == CS_NC - 1) ? 0.5 : 1.0);
-        den += (d == 0.0) ? 0.0 : w / d;
+    // barycentric weights of the nodes AS ROUNDED: w_m = 1 / prod_{j != m} (x_m - x_j).  The closed form (-1)^m {1/2,1,..,1,1/2}
+    // belongs to the exact extrema; nodes near nu ~ 1e3 are rounded by ~1e-13 / h of the interval, and the mismatch shows up
+    // as a 1e-13..1e-12 error of the interpolant (tools/cheb_proto.py).  Differences of nodes are exact in fp64.
+    if (threadIdx.x < CS_NC) {
+        double prod = 1.0;
+        const double x = xm[threadIdx.x], ih = h > 0.0 ? 1.0 / h : 1.0;
+        for (int j = 0; j < CS_NC; j++)
+            if (j != threadIdx.x) prod *= 2.0 * (x - xm[j]) * ih;   // factor 2: keeps the product near 1e2 instead of 1e-17
+        wm[threadIdx.x] = 1.0 / prod;
     }
-    for (int m = 0; m < CS_NC; m++) {
-        const double d = v - xm[m];
-        const double w = ((m & 1) ? -1.0 : 1.0) * ((m == 0 || m == CS_NC - 1) ? 0.5 : 1.0);
-        double c = (hit >= 0) ? (m == hit ? 1.0 : 0.0) : (w / d) / den;
-        if (!(h > 0.0)) c = 0.0;  // degenerate interval: nothing is interpolated there (k_izones leaves its set empty)
-        Cm[((size_t)T * CS_NC + m) * CS_ITV + threadIdx.x] = c;
+    __syncthreads();
+    for (int p = threadIdx.x; p < itv; p += blockDim.x) {
+        const int64_t i = i0 + p;
+        const double v = nu[i < nnu ? i : nnu - 1];
+        double den = 0.0;
+        int hit = -1;
+        for (int m = 0; m < CS_NC; m++) {
+            const double d = v - xm[m];
+            if (d == 0.0) hit = m;
+            den += (d == 0.0) ? 0.0 : wm[m] / d;
+        }
+        for (int m = 0; m < CS_NC; m++) {
+            const double d = v - xm[m];
+            const double c = (hit >= 0) ? (m == hit ? 1.0 : 0.0) : (wm[m] / d) / den;   // (one-point interval: all nodes coincide, hit = 63)
+            Cm[((size_t)T * CS_NC + m) * itv + p] = c;
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void k_izones(const double *__restrict__ nu, int64_t nnu, int nI, int K,
+// parent interval = T >> pshift of the level that starts at poff
+__global__ __launch_bounds__(256) void k_izones(const double *__restrict__ nu, int64_t nnu, int itv, int nI, int K,
                                                  const double *__restrict__ nul, const WaveWin *__restrict__ iwin,
                                                  const double *__restrict__ Tk, double mu_min, double mu_max, double cut,
-                                                 const double *__restrict__ gbound, double far_s, IZone *__restrict__ iz)
+                                                 const double *__restrict__ gbound, double far_s, int poff, int pshift,
+                                                 int ioff, int nItot, IZone *__restrict__ izall)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= nI * K) return;
-    const int k = idx / nI, T = idx - k * nI;
-    const int64_t i0 = (int64_t)T * CS_ITV, i1 = (i0 + CS_ITV - 1 < nnu ? i0 + CS_ITV - 1 : nnu - 1);
+    // zones of all levels live in one array [K][nItot]; this level starts at ioff, its parent level at poff (-1: none)
+    const int idx0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx0 >= nI * K) return;
+    const int k = idx0 / nI, T = idx0 - k * nI;
+    IZone *__restrict__ iz = izall;
+    const size_t idx = (size_t)k * nItot + ioff + T;
+    const int64_t i0 = (int64_t)T * itv, i1 = (i0 + itv - 1 < nnu ? i0 + itv - 1 : nnu - 1);
     const double vlo = nu[i0], vhi = nu[i1];
     const WaveWin w = iwin[T];   // E0..E1: lines inside the cut-off of every point of the interval
     IZone z;
-    z.E0 = w.E0; z.E1 = w.E1;
     const double h = 0.5 * (vhi - vlo);
-    if (!(h > 0.0) || w.E1 <= w.E0) {  // nothing to interpolate
-        z.Q0 = z.M0 = z.Z0 = w.E0;
-        z.Z1 = z.M1 = z.Q1 = z.E1 = w.E0;
-        z.E1 = w.E0;
+    if (w.E1 <= w.E0) {  // nothing to interpolate (then the parent has nothing either: the sets are nested)
+        z.E0 = z.Q0 = z.M0 = z.Z0 = z.Z1 = z.M1 = z.Q1 = z.E1 = z.P0 = z.P1 = z.P2 = z.P3 = w.E0;
         iz[idx] = z;
         return;
     }
+    z.E0 = w.E0; z.E1 = w.E1;
     const double vth = sqrt(2.0 * kRgas * Tk[k]);
     const double amax = ((vhi + cut) / kC) * vth / sqrt(mu_min);
     const double dA = 100.0 * amax / kSqLn2 * (1.0 + 1e-6);
@@ -443,20 +486,26 @@ __global__ __launch_bounds__(256) void k_izones(const double *__restrict__ nu, i
     } else {
         z.Q0 = w.E0; z.Q1 = w.E1;
     }
+    // the parent's own set is nested in this one ([E0,E1) grows and [Z0,Z1) shrinks with the interval); clamp it anyway
+    z.P0 = z.P1 = z.E0;
+    z.P2 = z.P3 = z.E1;
+    if (poff >= 0) {
+        const IZone q = izall[(size_t)k * nItot + poff + (T >> pshift)];
+        if (q.Z0 > q.E0) { z.P0 = min(max(q.E0, z.E0), z.Z0); z.P1 = min(max(q.Z0, z.P0), z.Z0); }
+        if (q.E1 > q.Z1) { z.P2 = min(max(q.Z1, z.Z1), z.E1); z.P3 = min(max(q.E1, z.P2), z.E1); }
+    }
     iz[idx] = z;
 }
 
-// one wave = the 64 Chebyshev nodes of one interval x one node state: far-wing sums at the nodes, then the interval's 256
-// cross-sections as C * F (4 outputs per lane).  The 4 waves of a block and the blocks next to it share the interval (its
-// 128 KB of C stay in L2); blockIdx.y = interval.
+// one wave = the 64 Chebyshev nodes of one interval x one node state: far-wing sums at the nodes -> F[interval][node][state].
+// All levels run in one launch: blockIdx.y walks the concatenated interval list (largest intervals, i.e. longest waves, first).
+#define CS_KPAD 16   // F rows are padded to a multiple of 16 states (k_cheb_apply reads 16 at a time with scalar loads)
 template <bool MIXED>
-__global__ __launch_bounds__(256) void k_voigt_cheb(const double *__restrict__ nodes, const double *__restrict__ Cm, int64_t nnu,
-                                                     int64_t L, const LineHot *__restrict__ hot, const LineF32 *__restrict__ hot32,
-                                                     const double *__restrict__ gnul, const IZone *__restrict__ iz, int nI, int K,
-                                                     double cut, double base, const double *__restrict__ extra,
-                                                     double *__restrict__ sigma, int accumulate)
+__global__ __launch_bounds__(256) void k_cheb_nodes(const double *__restrict__ nodes, int64_t L, const LineHot *__restrict__ hot,
+                                                     const LineF32 *__restrict__ hot32, const double *__restrict__ gnul,
+                                                     const IZone *__restrict__ iz, int nItot, int K, int Kpad, double cut,
+                                                     double *__restrict__ F)
 {
-    __shared__ double Fsh[4][CS_NC];
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int T = blockIdx.y;
     const int k = blockIdx.x * 4 + wv;
@@ -464,47 +513,86 @@ __global__ __launch_bounds__(256) void k_voigt_cheb(const double *__restrict__ n
     const LineHot *__restrict__ hk = hot + (size_t)k * L;
     const LineF32 *__restrict__ hf = MIXED ? hot32 + (size_t)k * L : nullptr;
     const double v = nodes[(size_t)T * CS_NC + lane];
-    const IZone z = iz[(size_t)k * nI + T];
+    const IZone z = iz[(size_t)k * nItot + T];
     const FarK c = load_fark();
-    double acc = 0.0;
-    if (MIXED) {
-        acc = far_segment32<false, 0>(acc, v, gnul, hf, z.E0, z.Q0, cut);
-        acc = far_segment32<false, 1>(acc, v, gnul, hf, z.Q0, z.M0, cut);
-    } else {
-        acc = far_segment<false, 0>(acc, v, hk, z.E0, z.Q0, cut, c);
-        acc = far_segment<false, 1>(acc, v, hk, z.Q0, z.M0, cut, c);
+    // own set minus the parent's: [E0,P0) U [P1,Z0) left of the interval, [Z1,P2) U [P3,E1) right of it.  Both sides are summed
+    // from the far end towards the interval (increasing terms): the rounding error of a node sum then stays a few ulp of the
+    // sum itself, which the interpolation amplifies by up to (2.3/0.3)^2 at the far end of the interval.
+    double accL = 0.0, accR = 0.0;
+    for (int cw = 0; cw < 2; cw++) {
+        const int p0 = cw == 0 ? z.E0 : z.P1, p1 = cw == 0 ? z.P0 : z.Z0;
+        if (p0 >= p1) continue;
+#define LO(x) max((x), p0)
+#define HI(x) min((x), p1)
+        if (MIXED) {
+            accL = far_segment32<false, 0>(accL, v, gnul, hf, LO(z.E0), HI(z.Q0), cut);
+            accL = far_segment32<false, 1>(accL, v, gnul, hf, LO(z.Q0), HI(z.M0), cut);
+        } else {
+            accL = far_segment<false, 0>(accL, v, hk, LO(z.E0), HI(z.Q0), cut, c);
+            accL = far_segment<false, 1>(accL, v, hk, LO(z.Q0), HI(z.M0), cut, c);
+        }
+        accL = far_segment<false, 2>(accL, v, hk, LO(z.M0), HI(z.Z0), cut, c);
     }
-    acc = far_segment<false, 2>(acc, v, hk, z.M0, z.Z0, cut, c);
-    acc = far_segment<false, 2>(acc, v, hk, z.Z1, z.M1, cut, c);
-    if (MIXED) {
-        acc = far_segment32<false, 1>(acc, v, gnul, hf, z.M1, z.Q1, cut);
-        acc = far_segment32<false, 0>(acc, v, gnul, hf, z.Q1, z.E1, cut);
-    } else {
-        acc = far_segment<false, 1>(acc, v, hk, z.M1, z.Q1, cut, c);
-        acc = far_segment<false, 0>(acc, v, hk, z.Q1, z.E1, cut, c);
+    for (int cw = 0; cw < 2; cw++) {
+        const int p0 = cw == 0 ? z.P3 : z.Z1, p1 = cw == 0 ? z.E1 : z.P2;
+        if (p0 >= p1) continue;
+        if (MIXED) {
+            accR = far_segment32_rev<false, 0>(accR, v, gnul, hf, LO(z.Q1), HI(z.E1), cut);
+            accR = far_segment32_rev<false, 1>(accR, v, gnul, hf, LO(z.M1), HI(z.Q1), cut);
+        } else {
+            accR = far_segment_rev<false, 0>(accR, v, hk, LO(z.Q1), HI(z.E1), cut, c);
+            accR = far_segment_rev<false, 1>(accR, v, hk, LO(z.M1), HI(z.Q1), cut, c);
+        }
+        accR = far_segment_rev<false, 2>(accR, v, hk, LO(z.Z1), HI(z.M1), cut, c);
+#undef LO
+#undef HI
     }
-    Fsh[wv][lane] = acc;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    const double *__restrict__ Ct = Cm + (size_t)T * CS_NC * CS_ITV;
-    double o0 = 0.0, o1 = 0.0, o2 = 0.0, o3 = 0.0;
-#pragma unroll 4
-    for (int m = 0; m < CS_NC; m++) {
-        const double f = Fsh[wv][m];
-        const double *cr = Ct + (size_t)m * CS_ITV + lane;
-        o0 = __builtin_fma(cr[0], f, o0);
-        o1 = __builtin_fma(cr[64], f, o1);
-        o2 = __builtin_fma(cr[128], f, o2);
-        o3 = __builtin_fma(cr[192], f, o3);
-    }
-    const double outv[4] = {o0, o1, o2, o3};
+    const double acc = accL + accR;
+    F[((size_t)T * CS_NC + lane) * Kpad + k] = acc;
+}
+
+// sigma[k][i] (+)= sum over levels of  C_l[T_l][:, i] . F[T_l][:, k]  -- the interpolation as a small matrix product.
+// One wave = one 64-point tile x 16 states: a column of C is loaded once and used for 16 states whose F values arrive as
+// wave-uniform scalar operands.
+struct ChebApply {
+    int nlev;
+    int shift[CS_MAX_LEVEL];   // log2(interval size / 64)
+    int ioff[CS_MAX_LEVEL];    // offset of the level in the concatenated interval list
+    const double *Cm[CS_MAX_LEVEL];
+};
+__global__ __launch_bounds__(256) void k_cheb_apply(ChebApply A, const double *__restrict__ F, int Kpad, int64_t nnu, int ntile,
+                                                     int K, double base, const double *__restrict__ extra,
+                                                     double *__restrict__ sigma, int accumulate)
+{
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + wv;
+    if (tile >= ntile) return;
+    const int k0 = blockIdx.y * CS_KPAD;
+    double acc[CS_KPAD];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int64_t i = (int64_t)T * CS_ITV + lane + 64 * q;
-        if (i < nnu) {
-            const size_t o = (size_t)k * nnu + i;
+    for (int q = 0; q < CS_KPAD; q++) acc[q] = 0.0;
+    for (int l = 0; l < A.nlev; l++) {
+        const int sh = A.shift[l];
+        const int T = tile >> sh, sub = tile & ((1 << sh) - 1);
+        const size_t itv = (size_t)64 << sh;
+        const double *__restrict__ Cp = A.Cm[l] + (size_t)T * CS_NC * itv + (size_t)sub * 64 + lane;
+        const double *__restrict__ Fp = F + (size_t)(A.ioff[l] + T) * CS_NC * Kpad + k0;
+#pragma unroll 2
+        for (int m = 0; m < CS_NC; m++) {
+            const double cv = Cp[(size_t)m * itv];
+            const double *__restrict__ fr = Fp + (size_t)m * Kpad;
+#pragma unroll
+            for (int q = 0; q < CS_KPAD; q++) acc[q] = __builtin_fma(cv, fr[q], acc[q]);
+        }
+    }
+    const int64_t i = (int64_t)tile * 64 + lane;
+    if (i >= nnu) return;
+#pragma unroll
+    for (int q = 0; q < CS_KPAD; q++) {
+        if (k0 + q < K) {
+            const size_t o = (size_t)(k0 + q) * nnu + i;
             const double prev = accumulate ? sigma[o] : (base + (extra ? extra[o] : 0.0));
-            sigma[o] = prev + outv[q];
+            sigma[o] = prev + acc[q];
         }
     }
 }
@@ -521,9 +609,10 @@ __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu
                                                     const Zone *__restrict__ zones, int ntile, int nblk, double cut,
                                                     double base, const double *__restrict__ extra,
                                                     double *__restrict__ sigma, int accumulate, int4 *__restrict__ ranges,
-                                                    const IZone *__restrict__ iz, int nI)
+                                                    const IZone *__restrict__ iz, int nI, int ishift)
 {
-    // iz != NULL: the lines [E0,Z0) U [Z1,E1) of the tile's parent interval were summed by k_voigt_cheb -- skip them here.
+    // iz != NULL: the lines [E0,Z0) U [Z1,E1) of the tile's parent interval (tile >> ishift, smallest interval size) were
+    // summed by k_voigt_cheb -- skip them here.
     // S = 1: one wave per tile.  S = 2, 4: the S waves of a tile split its window of lines into S parts of equal estimated
     // cost and add their partial sums through LDS -- S times more, S times shorter waves, for grids too small to fill the
     // chip otherwise (a nu-shard of a multi-GPU run, bake on a short grid).
@@ -550,7 +639,7 @@ __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu
         // lines already covered by the interpolated sum: [sa0,sa1) and [sb0,sb1) (empty when interpolation is off)
         int sa0 = z.M0, sa1 = z.M0, sb0 = z.M1, sb1 = z.M1;
         if (iz) {
-            const IZone zi = iz[(size_t)k * nI + (tile >> 2)];
+            const IZone zi = iz[(size_t)k * nI + (tile >> ishift)];
             sa0 = min(max(zi.E0, w.W0), z.N0); sa1 = min(max(zi.Z0, sa0), z.N0);
             sb0 = max(min(zi.Z1, w.W1), z.N1); sb1 = max(min(zi.E1, w.W1), sb0);
         }

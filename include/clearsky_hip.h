@@ -183,6 +183,13 @@ int cs_column_flux_to(cs_ctx *ctx, double *dst_device, void *stream);
 int cs_column_fetch(cs_ctx *ctx, double *tau, double *Mup, double *Mdn, double *Fup, double *Fdn);
 int cs_column_sigma_fetch(cs_ctx *ctx, double *sigma);
 int cs_column_counts(cs_ctx *ctx, int64_t *pair_evals, int64_t *lines_in_range);
+/* line-shape evaluations the last cs_column_run actually issued for its Voigt gases (measurement hook): out[0] = per-point
+ * evaluations of k_voigt_far/k_voigt_near (64 lanes x lines per wave), out[1] = node evaluations of k_cheb_nodes,
+ * out[2] = interpolation levels in use, out[3] = intervals over all levels.  cs_column_counts is the reference's count. */
+int cs_column_work(cs_ctx *ctx, int64_t *out);
+/* interval sizes (descending, <= 5, each 128..2048 points) cs_set_interp(on) would use for this grid and cut-off; returns
+ * their number (0: the grid is too coarse for the cut-off -- every pair is evaluated directly) */
+int cs_interp_plan(int64_t nnu, const double *nu, double dnu_cut, int *interval_sizes);
 /* update only the temperature-dependent inputs of a resident column (RCM stepping, radiative_convective.jl:109-144) */
 int cs_column_update_state(cs_ctx *ctx, const double *T_nodes, const double *mu_nodes, const double *T_levels,
                            const double *conc, const double *conc_tab);

@@ -1,0 +1,122 @@
+"""GPU parity of the interpolated far wings (k_cheb_nodes + k_cheb_apply).
+
+The interpolation replaces per-point evaluations of surf! (line_shapes.jl:56-96) by sums at Chebyshev nodes; these tests
+pin it (a) against the oracle, which evaluates every pair, and (b) against the same device path with interpolation off,
+on grids chosen so that 1..5 interval levels are active, intervals are ragged, the cut-off is narrow or wide.
+Tolerance: 1e-11 vs the oracle (the repo-wide cross-section tolerance), 5e-14 on/off (interpolation error proper;
+1.3e-14 observed with five levels stacked).
+"""
+import numpy as np
+import pytest
+
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+
+STATES = [(220.0, 50.0, 0.02), (296.0, 101325.0, 40.53), (260.0, 3e3, 30.0), (190.0, 2.0, 0.0)]
+
+
+@pytest.fixture(scope="module")
+def ctx_on(cs):
+    c = cs.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def ctx_off(cs):
+    c = cs.Context(0)
+    c.set_interp(False)
+    yield c
+    c.close()
+
+
+def test_plan():
+    import clearsky_jl_amd as cs
+    assert cs.interp_plan(np.linspace(1, 2500, 100000), 25.0) == [512, 256, 128]      # the bench grid: 3 levels
+    assert cs.interp_plan(np.linspace(1, 2500, 5003), 25.0) == []                      # coarse grid: all direct
+    assert cs.interp_plan(np.linspace(600, 700, 100000), 25.0) == [2048, 1024, 512, 256, 128]
+    assert cs.interp_plan(np.linspace(600, 700, 100), 25.0) == []                      # fewer than 128 points
+
+
+GRIDS = {
+    # name: (nu, cut, expected number of levels)
+    "fine-5-levels": (np.linspace(640.0, 700.0, 60001), 25.0, 5),
+    "bench-spacing": (np.linspace(600.0, 760.0, 6401), 25.0, 3),
+    "ragged-1-point-tail": (np.linspace(660.0, 680.0, 4 * 2048 + 1), 25.0, 5),
+    "ragged-short": (np.linspace(666.0, 669.0, 1153), 25.0, 5),
+    "narrow-cut": (np.linspace(2300.0, 2380.0, 40000), 3.0, 3),
+    "wide-cut": (np.linspace(500.0, 900.0, 8000), 120.0, 4),
+    "nonuniform": (np.sort(np.concatenate([600.0 + 160.0 * np.random.default_rng(5).random(9000) ** 2, [600.0, 760.0]])), 25.0, None),
+}
+
+
+@pytest.mark.parametrize("name", list(GRIDS))
+def test_shape_batch_interp_vs_oracle_and_direct(cs, O, lines, ctx_on, ctx_off, name):
+    nu, cut, nlev = GRIDS[name]
+    if nlev is not None:
+        assert len(cs.interp_plan(nu, cut)) == nlev
+    sl = lines("CO2")
+    T, P, Pp = map(list, zip(*STATES))
+    on = cs.shape_batch(sl, "voigt", nu, T, P, Pp, cut, ctx_on)
+    off = cs.shape_batch(sl, "voigt", nu, T, P, Pp, cut, ctx_off)
+    assert np.array_equal(on == 0, off == 0)
+    assert relerr(on, off, floor=1e-250) < 5e-14
+    for k in (0, 1, 3):
+        so = O.shape_bang("voigt", nu, sl, T[k], P[k], Pp[k], cut)
+        assert np.array_equal(on[k] == 0, so == 0)
+        assert relerr(on[k], so, floor=1e-250) < 1e-11
+
+
+def test_dense_synthetic_lines(cs, O, ctx_on, ctx_off):
+    """Line density of the bench workload (40 lines per cm^-1), strong/weak lines side by side."""
+    sl = cs.SpectralLines.synthetic(1, 20000, seed=9, numin=400.0, numax=900.0)
+    nu = np.linspace(600.0, 700.0, 20000)
+    T, P, Pp = [250.0, 288.0], [1e4, 1e5], [100.0, 1e3]
+    on = cs.shape_batch(sl, "voigt", nu, T, P, Pp, 25.0, ctx_on)
+    off = cs.shape_batch(sl, "voigt", nu, T, P, Pp, 25.0, ctx_off)
+    assert relerr(on, off, floor=1e-250) < 5e-14
+    idx = np.sort(np.random.default_rng(2).choice(nu.size, 400, replace=False))
+    for k in range(2):
+        assert relerr(on[k][idx], O.shape_bang("voigt", nu[idx], sl, T[k], P[k], Pp[k], 25.0), floor=1e-250) < 1e-11
+
+
+def test_column_interp_on_off(cs, lines):
+    """Whole column (two gases, accumulation across gases, batch path): on/off agree to rounding; the work counters show
+    that interpolation really ran."""
+    nu = np.linspace(580.0, 780.0, 20000)
+    P = cs.pressuregrid(10.0, 1e5, 21)
+    T = cs.AtmosphericProfile(P, np.linspace(200.0, 290.0, 21))
+    res = {}
+    for on in (True, False):
+        c = cs.Context(0)
+        c.set_interp(on)
+        gases = [cs.DirectGas(lines("CO2"), 400e-6, nu), cs.DirectGas(lines("H2O"), 5e-3, nu)]
+        col = cs.Column(P, 9.8, T, 0.029, 0.0, 0.0, *gases, core=cs.Discretized(4, 3), want_tau=True, want_M=True, ctx=c)
+        col.run()
+        F = cs.FluxPack(col.np, col.nnu)
+        F.Fup[:], F.Fdn[:] = col.fetch(F.tau, F.Mup, F.Mdn)
+        w = col.work()
+        B = col.run_batch([T, cs.AtmosphericProfile(P, np.linspace(205.0, 288.0, 21))])
+        res[on] = (F, w, B)
+        c.close()
+    Fon, won, Bon = res[True]
+    Foff, woff, Boff = res[False]
+    assert won["levels"] >= 3 and won["node_evals"] > 0 and woff["levels"] == 0 and woff["node_evals"] == 0
+    assert won["direct_evals"] + won["node_evals"] < 0.6 * woff["direct_evals"]
+    assert relerr(Fon.tau, Foff.tau) < 5e-14
+    sm = Foff.Mup.max()
+    assert np.max(np.abs(Fon.Mup - Foff.Mup)) < 1e-12 * sm and np.max(np.abs(Fon.Mdn - Foff.Mdn)) < 1e-12 * sm   # exp(-tau), tau ~ 1e2
+    assert relerr(Fon.Fup, Foff.Fup) < 1e-13
+    for a, b in zip(Bon, Boff):
+        assert relerr(np.asarray(a), np.asarray(b), floor=1e-9) < 1e-13
+    assert relerr(np.asarray(Bon[0])[0], Fon.Fup) < 1e-13      # batch member 0 = the resident state
+
+
+def test_bake_with_interp(cs, O, lines, ctx_on, ctx_off):
+    nu = np.linspace(640.0, 700.0, 6000)
+    Om = cs.AtmosphericDomain((180.0, 320.0), 4, (10.0, 1e5), 5)
+    gon = cs.Gas(lines("CO2"), 400e-6, nu, Om, ctx=ctx_on, keep_host_tables=True)
+    goff = cs.Gas(lines("CO2"), 400e-6, nu, Om, ctx=ctx_off, keep_host_tables=True)
+    a, b = np.asarray(gon.lnsigma), np.asarray(goff.lnsigma)
+    assert np.max(np.abs(a - b)) < 5e-14       # ln sigma: absolute = relative in sigma
