@@ -127,10 +127,12 @@ def main():
     ngas = len(col.gases)
     K = col.K
     lines_total = sum(len(g.sl.nu) for g in col.gases)
-    # k_voigt_far (one launch per gas).  Algorithmic HBM bytes per launch: the 32-B record of every
-    # (node, line) read once + sigma written (8 B per (nu, node)) + sigma re-read when a later gas accumulates
-    # + the 16-B near-line index ranges handed to k_voigt_near per (nu, node) + nu.
-    far_bytes = [32 * K * len(g.sl.nu) + 8 * col.nnu * K * (2 if gi > 0 else 1) + 16 * col.nnu * K + 8 * col.nnu
+    # k_voigt_far (one launch per gas), the longest kernel.  Algorithmic HBM bytes per launch: the 32-B
+    # record of every (node, line) read once + sigma written (8 B per (nu, node)) + sigma re-read when it accumulates (a later
+    # gas, or onto the interpolated far wings) + the 16-B near-line index ranges handed to k_voigt_near per (nu, node) + nu.
+    work = col.work()
+    interp_on = work["levels"] > 0
+    far_bytes = [32 * K * len(g.sl.nu) + 8 * col.nnu * K * (2 if (gi > 0 or interp_on) else 1) + 16 * col.nnu * K + 8 * col.nnu
                  for gi, g in enumerate(col.gases)]
     far_ms = prof["far"] / max(ngas, 1)
     alg = float(np.mean(far_bytes)) if far_bytes else 0.0
@@ -138,21 +140,26 @@ def main():
     traffic = None
     try:   # PMC traffic is collected offline (rocprofv3 --pmc, separate passes) for this exact workload: profiles/
         pm = json.load(open(os.path.join(_ROOT, "profiles", "r01_pmc_traffic.json")))
-        if args.config == "C3" and args.nnu is None and args.lines is None and N == 1:
+        if args.config == "C3" and args.nnu is None and args.lines is None and N == 1 and interp_on and args.precision == "fp64":
             kk = pm["kernels"]["k_voigt_far"]
             traffic = (kk["FETCH_SIZE_KB"] + kk["WRITE_SIZE_KB"]) * 1024.0
     except Exception:
         traffic = None
-    flops = cnt["pair_evals"] * FLOPS_PER_PAIR
-    line_ms = prof["far"] + prof["near"]
+    # fp64 VALU view of the three line kernels: evaluations actually issued (per-point ones count all 64 lanes of a wave, node
+    # ones 64 nodes per (interval, line)) x 24 flops, over their time.  `reference_pair_evals` is what surf! evaluates.
+    evals = work["direct_evals"] + work["node_evals"]
+    flops = evals * FLOPS_PER_PAIR
+    line_ms = prof["nodes"] + prof["far"] + prof["near"]
     roofline = dict(bound="hbm", kernel="k_voigt_far", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=achieved / HBM_PEAK_GBS, traffic=traffic, launches_per_step=ngas, avg_launch_ms=far_ms,
                     algorithmic_bytes_per_launch=alg,
                     note="elementwise fp64 accumulate over (nu,line) pairs: VALU-bound by construction, see valu_fp64",
                     valu_fp64=dict(achieved=flops / (line_ms * 1e-3) / 1e12 if line_ms > 0 else 0.0, peak=FP64_VALU_PEAK_TFLOPS,
                                    unit="TFLOP/s", frac=flops / (line_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS if line_ms > 0 else 0.0,
-                                   pair_evals=cnt["pair_evals"], flops_per_pair=FLOPS_PER_PAIR),
-                    kernel_ms=prof)
+                                   evals_issued=evals, direct_evals=work["direct_evals"], node_evals=work["node_evals"],
+                                   reference_pair_evals=cnt["pair_evals"], flops_per_eval=FLOPS_PER_PAIR,
+                                   kernels="k_cheb_nodes + k_voigt_far + k_voigt_near"),
+                    interp_levels=work["levels"], kernel_ms=prof)
 
     cpu = None
     if rank == 0 and N == 1 and not args.no_cpu:

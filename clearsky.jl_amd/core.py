@@ -804,11 +804,12 @@ class Column:
         check(lib().cs_column_sync(self.ctx.handle))
 
     def profile(self, reps: int = 3, stream: int = 0):
-        """HIP-event time per kernel class, ms per evaluation: dict(prep, far, near, rt, reduce), summed over gases."""
-        ms = np.zeros(5)
+        """HIP-event time per kernel class, ms per evaluation, summed over gases: dict(prep, nodes, apply, far, near, rt,
+        reduce) = k_prep+k_zones+k_izones, k_cheb_nodes, k_cheb_apply, k_voigt_far (or k_linesum), k_voigt_near, k_rt, k_freduce."""
+        ms = np.zeros(7)
         self._ensure_resident()
         check(lib().cs_column_profile(self.ctx.handle, C.c_void_p(stream) if stream else None, reps, dptr(ms)))
-        return dict(prep=ms[0], far=ms[1], near=ms[2], rt=ms[3], reduce=ms[4])
+        return dict(prep=ms[0], nodes=ms[1], apply=ms[2], far=ms[3], near=ms[4], rt=ms[5], reduce=ms[6])
 
     def flux_ptr(self) -> int:
         p = C.c_void_p()

@@ -474,7 +474,7 @@ Interp interp_view(const ChebGrid &g, const GasInterp &gi, int K, IZone *iz_over
 void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, int64_t jrange1, int kn, const double *Tk, const double *Pk, const double *Ppk,
                 const double *scale, LineHot *hot, LineCold *cold, const double *dnu, int64_t nnu, int ntile256,
                 const int32_t *J0, const int32_t *J1, const WaveWin *win, Zone *zones, int4 *ranges, const double *gbound, double cut, double base,
-                const double *extra, double *sigma, int accumulate, hipEvent_t ev_mid, hipEvent_t ev_far = nullptr,
+                const double *extra, double *sigma, int accumulate, hipEvent_t *evg,   // NULL or 4 events: after K1, nodes, apply, far
                 LineF32 *hot32 = nullptr, double far_s = 1e6, Interp itp = Interp())
 {
     // only the lines some window can reach (windows are sorted: first tile's start .. last tile's end)
@@ -496,7 +496,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
                                itp.nI[l], kn, G.nu.as<double>(), itp.iwin[l], Tk, G.mu_min, G.mu_max, cut, gbound, far_s,
                                l > 0 ? itp.ioff[l - 1] : -1, pshift, itp.ioff[l], itp.nItot, itp.iz);
         }
-        if (ev_mid) (void)hipEventRecord(ev_mid, s);
+        if (evg) (void)hipEventRecord(evg[0], s);
         if (itp.nlev > 0) {   // sigma = base + extra + interpolated far wings; the per-point kernels add the rest
             const dim3 gridn((unsigned)((kn + 3) / 4), (unsigned)itp.nItot);
             if (hot32)
@@ -505,6 +505,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
             else
                 hipLaunchKernelGGL((k_cheb_nodes<false>), gridn, dim3(256), 0, s, itp.nodes, G.L, hot, hot32, G.nu.as<double>(), itp.iz,
                                    itp.nItot, kn, itp.Kpad, cut, itp.F);
+            if (evg) (void)hipEventRecord(evg[1], s);
             ChebApply A;
             A.nlev = itp.nlev;
             for (int l = 0; l < itp.nlev; l++) {
@@ -519,6 +520,10 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
             const int low = itp.nlev - 1;
             iz = itp.iz + itp.ioff[low];
             ishift = A.shift[low];
+            if (evg) (void)hipEventRecord(evg[2], s);
+        } else if (evg) {
+            (void)hipEventRecord(evg[1], s);
+            (void)hipEventRecord(evg[2], s);
         }
         const int nblk = (nt64 + 3) / 4;
         const dim3 grid((unsigned)((nblk + 7) / 8 * 8), kn);   // multiple of 8: XCD-aware tile mapping (tile_block)
@@ -535,13 +540,14 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
             if (split == 1) CS_FAR_LAUNCH(false, 1); else if (split == 2) CS_FAR_LAUNCH(false, 2); else CS_FAR_LAUNCH(false, 4);
         }
 #undef CS_FAR_LAUNCH
-        if (ev_far) (void)hipEventRecord(ev_far, s);
-        hipLaunchKernelGGL(k_voigt_near, grid, dim3(256), 0, s, dnu, nnu, G.L, hot, cold, zones, nt64, nblk, cut, sigma, ranges);
+        if (evg) (void)hipEventRecord(evg[3], s);
+        hipLaunchKernelGGL(k_voigt_near<0>, grid, dim3(256), 0, s, dnu, nnu, G.L, hot, cold, zones, nt64, nblk, cut, sigma, ranges);
+        hipLaunchKernelGGL(k_voigt_near<1>, grid, dim3(256), 0, s, dnu, nnu, G.L, hot, cold, zones, nt64, nblk, cut, sigma, ranges);
     } else {
-        if (ev_mid) (void)hipEventRecord(ev_mid, s);
+        if (evg) { (void)hipEventRecord(evg[0], s); (void)hipEventRecord(evg[1], s); (void)hipEventRecord(evg[2], s); }
         launch_linesum_shape(shape, dim3(ntile256, kn), s, dnu, nnu, G.L, hot, cold, J0, J1, cut, Tk, base, extra, sigma,
                              accumulate);
-        if (ev_far) (void)hipEventRecord(ev_far, s);
+        if (evg) (void)hipEventRecord(evg[3], s);
     }
 }
 
@@ -714,7 +720,7 @@ int cs_shape_batch(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t nnu
         launch_gas(s, shape, G, J0.front(), J1.back(), kn, dT.as<double>() + k0, dP.as<double>() + k0, dPp.as<double>() + k0, nullptr,
                    hot.as<LineHot>(), cold.as<LineCold>(), dnu.as<double>(), nnu, ntile, dJ0.as<int32_t>(), dJ1.as<int32_t>(),
                    dwin.as<WaveWin>(), dzones.as<Zone>(), dranges.as<int4>(), dgmax.as<double>() + k0, dnu_cut, 0.0, nullptr, dsig.as<double>(), 0, nullptr,
-                   nullptr, mix32, ctx->far_s, itp);
+                   mix32, ctx->far_s, itp);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpy2DAsync(sigma + (size_t)k0 * ld_state, ld_state * sizeof(double), dsig.p, nnu * sizeof(double),
                                 nnu * sizeof(double), kn, hipMemcpyDeviceToHost, s));
@@ -790,7 +796,7 @@ int cs_bake(cs_ctx *ctx, int gas_slot, int table_slot, int shape, double dnu_cut
         launch_gas(s, shape, G, J0.front(), J1.back(), kn, dT.as<double>() + k0, dP.as<double>() + k0, dPp.as<double>() + k0, nullptr, hot.as<LineHot>(),
                    cold.as<LineCold>(), dnu.as<double>(), nnu, ntile, dJ0.as<int32_t>(), dJ1.as<int32_t>(), dwin.as<WaveWin>(),
                    dzones.as<Zone>(), dranges.as<int4>(), dgb.as<double>() + k0, dnu_cut, 0.0, nullptr, tb.Z.as<double>() + (size_t)k0 * nnu, 0, nullptr,
-                   nullptr, mix32, ctx->far_s, itp);
+                   mix32, ctx->far_s, itp);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(s));
     }
@@ -1269,7 +1275,7 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
                        dconc.as<double>() + k0, hot.as<LineHot>(), cold.as<LineCold>(), c.nu.as<double>(), c.nnu, c.ntile,
                        cg.J0.as<int32_t>(), cg.J1.as<int32_t>(), cg.win.as<WaveWin>(), dzones.as<Zone>(), dranges.as<int4>(),
                        dgb.as<double>() + k0, cg.cut, c.sigma_gray, nullptr, dsig.as<double>() + (size_t)k0 * c.nnu, gi > 0, nullptr,
-                       nullptr, (ctx->mixed && cg.shape == SH_VOIGT) ? ctx->hot32.as<LineF32>() : nullptr, ctx->far_s, itp);
+                       (ctx->mixed && cg.shape == SH_VOIGT) ? ctx->hot32.as<LineF32>() : nullptr, ctx->far_s, itp);
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipStreamSynchronize(s));   // cc/pp/gb host buffers are reused by the next gas
@@ -1290,7 +1296,7 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
     return CS_OK;
 }
 
-// enqueue one evaluation; when ev != NULL an event is recorded between the kernel classes (ev must hold 3*ngas+3)
+// enqueue one evaluation; when ev != NULL an event is recorded between the kernel classes (ev must hold 5*ngas+3)
 static int run_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev)
 {
     Column &c = ctx->col;
@@ -1315,9 +1321,9 @@ static int run_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev)
         launch_gas(s, cg.shape, G, cg.jlo, cg.jhi, K, c.Tk.as<double>(), c.Pk.as<double>(), cg.Pp.as<double>(), cg.conc.as<double>(),
                    c.hot.as<LineHot>(), c.cold.as<LineCold>(), c.nu.as<double>(), c.nnu, c.ntile, cg.J0.as<int32_t>(),
                    cg.J1.as<int32_t>(), cg.win.as<WaveWin>(), cg.zones.as<Zone>(), c.ranges.as<int4>(), cg.gmax.as<double>(), cg.cut, c.sigma_gray, extra, sig, gi > 0,
-                   ev ? ev[e] : nullptr, ev ? ev[e + 1] : nullptr,
+                   ev ? ev + e : nullptr,
                    (ctx->mixed && cg.shape == SH_VOIGT) ? ctx->hot32.as<LineF32>() : nullptr, ctx->far_s, itp);
-        if (ev) { e += 2; HIPCHK(hipEventRecord(ev[e++], s)); }
+        if (ev) { e += 4; HIPCHK(hipEventRecord(ev[e++], s)); }
     }
     for (auto &t : c.tab) {  // baked gases: sigma += fC * exp(Phi(T, ln P))
         TableDev &tb = ctx->tab[t.slot];
@@ -1356,26 +1362,23 @@ int cs_column_profile(cs_ctx *ctx, void *stream, int reps, double *ms)
     Column &c = ctx->col;
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     HIPCHK(hipSetDevice(ctx->device));
-    const int nev = 3 * c.ngas + 3;
+    const int nev = 5 * c.ngas + 3;
     std::vector<hipEvent_t> ev(nev);
     for (auto &e : ev) HIPCHK(hipEventCreate(&e));
-    for (int i = 0; i < 5; i++) ms[i] = 0.0;
+    for (int i = 0; i < 7; i++) ms[i] = 0.0;
     int rc = CS_OK;
     for (int r = 0; r < reps && rc == CS_OK; r++) {
         rc = run_impl(ctx, s, ev.data());
         if (rc) break;
         if (hipStreamSynchronize(s) != hipSuccess) { rc = fail(CS_EHIP, "hipStreamSynchronize failed"); break; }
         float t;
-        for (int gi = 0; gi < c.ngas; gi++) {
-            (void)hipEventElapsedTime(&t, ev[3 * gi], ev[3 * gi + 1]); ms[0] += t;
-            (void)hipEventElapsedTime(&t, ev[3 * gi + 1], ev[3 * gi + 2]); ms[1] += t;
-            (void)hipEventElapsedTime(&t, ev[3 * gi + 2], ev[3 * gi + 3]); ms[2] += t;
-        }
-        (void)hipEventElapsedTime(&t, ev[3 * c.ngas], ev[3 * c.ngas + 1]); ms[3] += t;
-        (void)hipEventElapsedTime(&t, ev[3 * c.ngas + 1], ev[3 * c.ngas + 2]); ms[4] += t;
+        for (int gi = 0; gi < c.ngas; gi++)
+            for (int q = 0; q < 5; q++) { (void)hipEventElapsedTime(&t, ev[5 * gi + q], ev[5 * gi + q + 1]); ms[q] += t; }
+        (void)hipEventElapsedTime(&t, ev[5 * c.ngas], ev[5 * c.ngas + 1]); ms[5] += t;
+        (void)hipEventElapsedTime(&t, ev[5 * c.ngas + 1], ev[5 * c.ngas + 2]); ms[6] += t;
     }
     for (auto &e : ev) (void)hipEventDestroy(e);
-    for (int i = 0; i < 5; i++) ms[i] /= reps;
+    for (int i = 0; i < 7; i++) ms[i] /= reps;
     return rc;
 }
 

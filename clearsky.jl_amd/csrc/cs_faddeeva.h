@@ -92,11 +92,11 @@ __device__ __forceinline__ double fad_near(double x, double y)
         double q = 4.0 * x;
         q -= 2.0 * rint(0.5 * q);
         double sph, cph;
-        sincos(kPi * q, &sph, &cph);
+        sincospi(q, &sph, &cph);
         double dr = __builtin_fma(sgn, cph, g), di = -sgn * sph;
         double em = exp(y2 - x * x);
         double sa, ca;
-        sincos(2.0 * x * y, &sa, &ca);
+        sincospi((2.0 / kPi) * x * y, &sa, &ca);   // |2xy| < 126: the phase error of the scaled argument stays below 1e-14
         // Re[(ca - i sa)/(dr + i di)] = (ca*dr - sa*di)/|d|^2
         res += 2.0 * g * em * (ca * dr - sa * di) * rcp_nr(__builtin_fma(dr, dr, di * di));
     }

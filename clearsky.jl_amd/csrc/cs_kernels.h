@@ -745,10 +745,12 @@ __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu
         }
     }
     if (i < nnu) {
-        int4 r;
-        r.x = bh >= bl ? bl - z.N0 : 0; r.y = bh >= bl ? bh + 1 - z.N0 : 0;
-        r.z = ch >= cl ? cl - z.N0 : 0; r.w = ch >= cl ? ch + 1 - z.N0 : 0;
-        ranges[(size_t)k * nnu + i] = r;
+        int2 r0, r1;   // two planes of int2 inside the int4 workspace (k_voigt_near<0>, <1>)
+        r0.x = bh >= bl ? bl - z.N0 : 0; r0.y = bh >= bl ? bh + 1 - z.N0 : 0;
+        r1.x = ch >= cl ? cl - z.N0 : 0; r1.y = ch >= cl ? ch + 1 - z.N0 : 0;
+        int2 *__restrict__ rp = reinterpret_cast<int2 *>(ranges);
+        rp[(size_t)k * nnu + i] = r0;
+        rp[((size_t)gridDim.y + k) * nnu + i] = r1;
         const size_t o = (size_t)k * nnu + i;
         const double prev = accumulate ? sigma[o] : (base + (extra ? extra[o] : 0.0));
         sigma[o] = prev + acc;
@@ -759,7 +761,7 @@ __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu
 // the (lane, line) candidates of its 64 lanes into an LDS queue and evaluates them 64 at a time -- so the expensive forms
 // (continued fraction for 100 <= s < 1e3, trapezoid + pole correction for s < 100) run with full lanes instead of
 // once per "deepest" lane -- then every lane sums its own results in ascending line order (deterministic).
-#define CS_NEAR_Q 768  // queue entries per wave
+#define CS_NEAR_Q 256  // queue entries per wave; longer candidate lists go through the queue in windows
 template <int TIER>  // 0: 100 <= s < 1e3 (fad_mid), 1: s < 100 (fad_near)
 __device__ __forceinline__ double near_pass(double v, int lo, int hi, int N0, const LineHot *__restrict__ hk,
                                             const LineCold *__restrict__ ck, double cut, unsigned *qidx, double *qres)
@@ -773,57 +775,49 @@ __device__ __forceinline__ double near_pass(double v, int lo, int hi, int N0, co
     const int off = incl - cnt;
     const int total = __shfl(incl, 63, 64);
     double acc = 0.0;
-    if (total == 0) return acc;
-    if (total <= CS_NEAR_Q) {
-        for (int c = 0; c < cnt; c++) qidx[off + c] = ((unsigned)lane << 24) | (unsigned)(lo + c);
+    for (int base = 0; base < total; base += CS_NEAR_Q) {   // wave-uniform
+        // this lane's candidates that fall into the window [base, base + Q)
+        const int c0 = max(base - off, 0), c1 = min(base + CS_NEAR_Q - off, cnt);
+        for (int c = c0; c < c1; c++) qidx[off + c - base] = ((unsigned)lane << 24) | (unsigned)(lo + c);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
-        const int ntrip = (total + 63) >> 6;  // wave-uniform: every lane takes part in the shuffles
+        const int nwin = min(total - base, CS_NEAR_Q);
+        const int ntrip = (nwin + 63) >> 6;  // wave-uniform: every lane takes part in the shuffles
+        // the line records of trip it+1 are fetched while trip it is evaluated (a wave is a chain of dependent gathers otherwise)
+        LineHot hn = {};
+        LineCold cn = {};
+        unsigned en = 0;
+        if (lane < nwin) { en = qidx[lane]; const int j = N0 + (int)(en & 0xffffffu); hn = hk[j]; cn = ck[j]; }
         for (int it = 0; it < ntrip; it++) {
             const int p = it * 64 + lane;
-            double r = 0.0;
-            unsigned e = 0;
-            const bool live = p < total;
-            if (live) e = qidx[p];
+            const bool live = p < nwin;
+            const LineHot h = hn;
+            const LineCold c = cn;
+            const unsigned e = en;
+            if (p + 64 < nwin) { en = qidx[p + 64]; const int j = N0 + (int)(en & 0xffffffu); hn = hk[j]; cn = ck[j]; }
             const int owner = (int)(e >> 24);
             const double vo = __shfl(v, owner, 64);
             if (live) {
-                const int j = N0 + (int)(e & 0xffffffu);
-                const LineHot h = hk[j];
+                double r = 0.0;
                 const double dv = vo - h.nul;
                 const double x = dv * h.p1;
                 const double s = __builtin_fma(x, x, h.p2);
                 const bool mine = TIER == 0 ? (s < kSerS && s >= kMidS) : (s < kMidS);
-                if (!(fabs(dv) > cut) && mine) {
-                    const LineCold c = ck[j];
-                    r = c.A * (TIER == 0 ? fad_mid(fabs(x), c.y) : fad_near(fabs(x), c.y));
-                }
+                if (!(fabs(dv) > cut) && mine) r = c.A * (TIER == 0 ? fad_mid(fabs(x), c.y) : fad_near(fabs(x), c.y));
                 qres[p] = r;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
-        for (int c = 0; c < cnt; c++) acc += qres[off + c];
+        for (int c = c0; c < c1; c++) acc += qres[off + c - base];   // ascending line order per lane: deterministic
         __builtin_amdgcn_wave_barrier();
-    } else {  // more candidates than the queue holds (very dense tables): plain per-lane walk
-        for (int t = 0; __any(t < cnt); t++) {
-            if (t < cnt) {
-                const int j = N0 + lo + t;
-                const LineHot h = hk[j];
-                const double dv = v - h.nul;
-                const double x = dv * h.p1;
-                const double s = __builtin_fma(x, x, h.p2);
-                const bool mine = TIER == 0 ? (s < kSerS && s >= kMidS) : (s < kMidS);
-                if (!(fabs(dv) > cut) && mine) {
-                    const LineCold c = ck[j];
-                    acc += c.A * (TIER == 0 ? fad_mid(fabs(x), c.y) : fad_near(fabs(x), c.y));
-                }
-            }
-        }
     }
     return acc;
 }
 
+// one launch per tier: the tier-0 kernel is light (continued fraction, few registers, many waves in flight), the tier-1 kernel
+// carries the trapezoid + pole correction (exp, sincos: 127 VGPRs)
+template <int TIER>
 __global__ __launch_bounds__(256) void k_voigt_near(const double *__restrict__ nu, int64_t nnu, int64_t L,
                                                      const LineHot *__restrict__ hot, const LineCold *__restrict__ cold,
                                                      const Zone *__restrict__ zones, int ntile, int nblk, double cut,
@@ -841,10 +835,11 @@ __global__ __launch_bounds__(256) void k_voigt_near(const double *__restrict__ n
     const LineCold *__restrict__ ck = cold + (size_t)k * L;
     const double v = nu[i < nnu ? i : nnu - 1];
     const Zone z = zones[(size_t)k * ntile + tile];
-    int4 r = make_int4(0, 0, 0, 0);
-    if (i < nnu) r = ranges[(size_t)k * nnu + i];
-    double acc = near_pass<0>(v, r.x, r.y, z.N0, hk, ck, cut, qidx_s[wv], qres_s[wv]);
-    acc += near_pass<1>(v, r.z, r.w, z.N0, hk, ck, cut, qidx_s[wv], qres_s[wv]);
+    // two planes of int2 inside the int4 workspace: tier 0 ranges, then tier 1 ranges, [gridDim.y][nnu] each
+    const int2 *__restrict__ rp = reinterpret_cast<const int2 *>(ranges) + (size_t)TIER * gridDim.y * nnu;
+    int2 r = make_int2(0, 0);
+    if (i < nnu) r = rp[(size_t)k * nnu + i];
+    const double acc = near_pass<TIER>(v, r.x, r.y, z.N0, hk, ck, cut, qidx_s[wv], qres_s[wv]);
     if (i < nnu && acc != 0.0) sigma[(size_t)k * nnu + i] += acc;
 }
 

@@ -174,8 +174,9 @@ int cs_column_set_tables(cs_ctx *ctx, int ntab, const int *table_slots, const do
 int cs_column_set_cia(cs_ctx *ctx, int ncia, const int *cia_slots, const int *flags, const double *P1, const double *P2);
 int cs_column_run(cs_ctx *ctx, void *stream);
 int cs_column_sync(cs_ctx *ctx);
-/* run `reps` evaluations with HIP events between the kernel classes on `stream`; ms[5] = average milliseconds per
- * evaluation spent in {k_prep+k_zones, k_voigt_far (or k_linesum), k_voigt_near, k_rt, k_freduce}, summed over gases */
+/* run `reps` evaluations with HIP events between the kernel classes on `stream`; ms[7] = average milliseconds per
+ * evaluation spent in {k_prep+k_zones+k_izones, k_cheb_nodes, k_cheb_apply, k_voigt_far (or k_linesum), k_voigt_near, k_rt,
+ * k_freduce}, summed over gases */
 int cs_column_profile(cs_ctx *ctx, void *stream, int reps, double *ms);
 int cs_column_flux_ptr(cs_ctx *ctx, double **dF);
 /* asynchronously copy the [2*np] band fluxes (Fup then Fdn) into caller-owned DEVICE memory on `stream` */
