@@ -124,9 +124,9 @@ struct ChebGrid {
     int itv[CS_MAX_LEVEL] = {}, nI[CS_MAX_LEVEL] = {}, ioff[CS_MAX_LEVEL] = {};
     DevBuf nodes;               // [nItot][64]
     DevBuf Cm[CS_MAX_LEVEL];    // [nI][64][itv]
-    DevBuf F;                   // [nItot][64][Kpad] node sums of the gas being processed
 };
-struct GasInterp { int nlev = 0; DevBuf iwin[CS_MAX_LEVEL], iz; };   // per gas on that grid: windows per level, zones [K][nItot]
+// per gas on that grid: windows per level, zones [K][nItot], node sums F [nItot][64][Kpad]
+struct GasInterp { int nlev = 0; DevBuf iwin[CS_MAX_LEVEL], iz, F; };
 
 struct ColGas {
     int slot = 0, shape = 0;
@@ -446,9 +446,9 @@ int gas_interp_build(GasInterp &gi, ChebGrid &g, const std::vector<double> &nul,
         HIPCHK(hipStreamSynchronize(s));   // iwin is a local
     }
     HIPCHK(gi.iz.reserve((size_t)K * g.nItot * sizeof(IZone)));
-    if (g.F.bytes < (size_t)g.nItot * CS_NC * cheb_kpad(K) * sizeof(double)) {
-        HIPCHK(g.F.reserve((size_t)g.nItot * CS_NC * cheb_kpad(K) * sizeof(double)));
-        HIPCHK(hipMemsetAsync(g.F.p, 0, g.F.bytes, s));   // padding states stay finite
+    if (gi.F.bytes < (size_t)g.nItot * CS_NC * cheb_kpad(K) * sizeof(double)) {
+        HIPCHK(gi.F.reserve((size_t)g.nItot * CS_NC * cheb_kpad(K) * sizeof(double)));
+        HIPCHK(hipMemsetAsync(gi.F.p, 0, gi.F.bytes, s));   // padding states stay finite
     }
     return CS_OK;
 }
@@ -461,7 +461,7 @@ Interp interp_view(const ChebGrid &g, const GasInterp &gi, int K, IZone *iz_over
     v.Kpad = cheb_kpad(K);
     v.nodes = g.nodes.as<double>();
     v.iz = iz_override ? iz_override : gi.iz.as<IZone>();
-    v.F = g.F.as<double>();
+    v.F = gi.F.as<double>();
     for (int l = 0; l < gi.nlev; l++) {
         v.itv[l] = g.itv[l]; v.nI[l] = g.nI[l]; v.ioff[l] = g.ioff[l];
         v.Cm[l] = g.Cm[l].as<double>();
@@ -470,12 +470,20 @@ Interp interp_view(const ChebGrid &g, const GasInterp &gi, int K, IZone *iz_over
     return v;
 }
 
+void launch_apply(hipStream_t s, const ChebApply &A, int Kpad, int64_t nnu, int kn, double base, const double *extra, double *sigma,
+                  int accumulate)
+{
+    const int nt64 = (int)((nnu + 63) / 64);
+    hipLaunchKernelGGL(k_cheb_apply, dim3((unsigned)(((nt64 + 3) / 4 + 7) / 8 * 8) * (unsigned)((kn + CS_KPAD - 1) / CS_KPAD)), dim3(256), 0, s, A,
+                       Kpad, nnu, nt64, kn, base, extra, sigma, accumulate);
+}
+
 // K1 + K2 for one gas on `s`: parameters for `kn` states, then the line sum into sigma ([kn][nnu])
 void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, int64_t jrange1, int kn, const double *Tk, const double *Pk, const double *Ppk,
                 const double *scale, LineHot *hot, LineCold *cold, const double *dnu, int64_t nnu, int ntile256,
                 const int32_t *J0, const int32_t *J1, const WaveWin *win, Zone *zones, int4 *ranges, const double *gbound, double cut, double base,
-                const double *extra, double *sigma, int accumulate, hipEvent_t *evg,   // NULL or 4 events: after K1, nodes, apply, far
-                LineF32 *hot32 = nullptr, double far_s = 1e6, Interp itp = Interp())
+                const double *extra, double *sigma, int accumulate, hipEvent_t *evg,   // NULL or 3 events: after K1, nodes, far
+                LineF32 *hot32 = nullptr, double far_s = 1e6, Interp itp = Interp(), ChebApply *defer = nullptr)
 {
     // only the lines some window can reach (windows are sorted: first tile's start .. last tile's end)
     const int64_t jlo = jrange0, jhi = std::max(jrange1, jrange0);
@@ -506,7 +514,9 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
                 hipLaunchKernelGGL((k_cheb_nodes<false>), gridn, dim3(256), 0, s, itp.nodes, G.L, hot, hot32, G.nu.as<double>(), itp.iz,
                                    itp.nItot, kn, itp.Kpad, cut, itp.F);
             if (evg) (void)hipEventRecord(evg[1], s);
-            ChebApply A;
+            ChebApply A0;
+            ChebApply &A = defer ? *defer : A0;
+            if (!defer) A.ngas = 0;
             A.nlev = itp.nlev;
             for (int l = 0; l < itp.nlev; l++) {
                 A.shift[l] = 0;
@@ -514,16 +524,16 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
                 A.ioff[l] = itp.ioff[l];
                 A.Cm[l] = itp.Cm[l];
             }
-            hipLaunchKernelGGL(k_cheb_apply, dim3((unsigned)((nt64 + 3) / 4), (unsigned)((kn + CS_KPAD - 1) / CS_KPAD)), dim3(256), 0, s, A,
-                               itp.F, itp.Kpad, nnu, nt64, kn, base, extra, sigma, accumulate);
-            accumulate = 1;
+            A.F[A.ngas++] = itp.F;
+            if (!defer) {   // sigma = base + extra + interpolated far wings now; the per-point kernels add the rest
+                launch_apply(s, A, itp.Kpad, nnu, kn, base, extra, sigma, accumulate);
+                accumulate = 1;
+            }               // (deferred: the caller applies the node sums of all its gases in one launch, after the last gas)
             const int low = itp.nlev - 1;
             iz = itp.iz + itp.ioff[low];
             ishift = A.shift[low];
-            if (evg) (void)hipEventRecord(evg[2], s);
         } else if (evg) {
             (void)hipEventRecord(evg[1], s);
-            (void)hipEventRecord(evg[2], s);
         }
         const int nblk = (nt64 + 3) / 4;
         const dim3 grid((unsigned)((nblk + 7) / 8 * 8), kn);   // multiple of 8: XCD-aware tile mapping (tile_block)
@@ -540,14 +550,14 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
             if (split == 1) CS_FAR_LAUNCH(false, 1); else if (split == 2) CS_FAR_LAUNCH(false, 2); else CS_FAR_LAUNCH(false, 4);
         }
 #undef CS_FAR_LAUNCH
-        if (evg) (void)hipEventRecord(evg[3], s);
+        if (evg) (void)hipEventRecord(evg[2], s);
         hipLaunchKernelGGL(k_voigt_near<0>, grid, dim3(256), 0, s, dnu, nnu, G.L, hot, cold, zones, nt64, nblk, cut, sigma, ranges);
         hipLaunchKernelGGL(k_voigt_near<1>, grid, dim3(256), 0, s, dnu, nnu, G.L, hot, cold, zones, nt64, nblk, cut, sigma, ranges);
     } else {
-        if (evg) { (void)hipEventRecord(evg[0], s); (void)hipEventRecord(evg[1], s); (void)hipEventRecord(evg[2], s); }
+        if (evg) { (void)hipEventRecord(evg[0], s); (void)hipEventRecord(evg[1], s); }
         launch_linesum_shape(shape, dim3(ntile256, kn), s, dnu, nnu, G.L, hot, cold, J0, J1, cut, Tk, base, extra, sigma,
                              accumulate);
-        if (evg) (void)hipEventRecord(evg[3], s);
+        if (evg) (void)hipEventRecord(evg[2], s);
     }
 }
 
@@ -1296,7 +1306,7 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
     return CS_OK;
 }
 
-// enqueue one evaluation; when ev != NULL an event is recorded between the kernel classes (ev must hold 5*ngas+3)
+// enqueue one evaluation; when ev != NULL an event is recorded between the kernel classes (ev must hold 4*ngas+4)
 static int run_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev)
 {
     Column &c = ctx->col;
@@ -1314,6 +1324,8 @@ static int run_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev)
         for (auto &g : c.gas) maxL = std::max(maxL, (size_t)ctx->gas[g.slot].L);
         HIPCHK(ctx->hot32.reserve(((size_t)K * maxL + 4) * sizeof(LineF32)));   // no-op once sized (not capturable the first time)
     }
+    ChebApply apply;
+    apply.ngas = 0;
     for (int gi = 0; gi < c.ngas; gi++) {
         ColGas &cg = c.gas[gi];
         GasTable &G = ctx->gas[cg.slot];
@@ -1322,9 +1334,11 @@ static int run_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev)
                    c.hot.as<LineHot>(), c.cold.as<LineCold>(), c.nu.as<double>(), c.nnu, c.ntile, cg.J0.as<int32_t>(),
                    cg.J1.as<int32_t>(), cg.win.as<WaveWin>(), cg.zones.as<Zone>(), c.ranges.as<int4>(), cg.gmax.as<double>(), cg.cut, c.sigma_gray, extra, sig, gi > 0,
                    ev ? ev + e : nullptr,
-                   (ctx->mixed && cg.shape == SH_VOIGT) ? ctx->hot32.as<LineF32>() : nullptr, ctx->far_s, itp);
-        if (ev) { e += 4; HIPCHK(hipEventRecord(ev[e++], s)); }
+                   (ctx->mixed && cg.shape == SH_VOIGT) ? ctx->hot32.as<LineF32>() : nullptr, ctx->far_s, itp, &apply);
+        if (ev) { e += 3; HIPCHK(hipEventRecord(ev[e++], s)); }
     }
+    // interpolated far wings of all gases: sigma += sum_gas sum_level C F  (one pass over C and sigma)
+    if (apply.ngas > 0) launch_apply(s, apply, cheb_kpad(K), c.nnu, K, 0.0, nullptr, sig, 1);
     for (auto &t : c.tab) {  // baked gases: sigma += fC * exp(Phi(T, ln P))
         TableDev &tb = ctx->tab[t.slot];
         const int M = tb.nT * tb.nP;
@@ -1337,6 +1351,7 @@ static int run_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev)
     for (auto &cc : c.cia)  // CIA pairs
         hipLaunchKernelGGL(k_cia, dim3((unsigned)c.ntile), dim3(256), 0, s, cc.nband, cc.bands.as<CiaBand>(), cc.st.as<CiaState>(),
                            c.nu.as<double>(), c.nnu, K, cc.rho1.as<double>(), cc.rho2.as<double>(), cc.rhoa.as<double>(), sig);
+    if (ev) HIPCHK(hipEventRecord(ev[e++], s));
     launch_rt(c.nstream, c.rt_nblk, c.rt_bs, (size_t)2 * c.np * (c.rt_bs / 64) * sizeof(double), s, c.rt, c.nu.as<double>(), c.wts.as<double>(),
               c.nnu, sig, c.muk.as<double>(), c.P.as<double>(), c.Tlev.as<double>(),
               c.has_S ? c.S_toa.as<double>() : nullptr, c.has_alb ? c.albedo.as<double>() : nullptr, c.tau.as<double>(),
@@ -1362,7 +1377,7 @@ int cs_column_profile(cs_ctx *ctx, void *stream, int reps, double *ms)
     Column &c = ctx->col;
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     HIPCHK(hipSetDevice(ctx->device));
-    const int nev = 5 * c.ngas + 3;
+    const int nev = 4 * c.ngas + 4;
     std::vector<hipEvent_t> ev(nev);
     for (auto &e : ev) HIPCHK(hipEventCreate(&e));
     for (int i = 0; i < 7; i++) ms[i] = 0.0;
@@ -1372,10 +1387,13 @@ int cs_column_profile(cs_ctx *ctx, void *stream, int reps, double *ms)
         if (rc) break;
         if (hipStreamSynchronize(s) != hipSuccess) { rc = fail(CS_EHIP, "hipStreamSynchronize failed"); break; }
         float t;
+        const int slot[4] = {0, 1, 3, 4};   // per gas: K1, nodes, far, near
         for (int gi = 0; gi < c.ngas; gi++)
-            for (int q = 0; q < 5; q++) { (void)hipEventElapsedTime(&t, ev[5 * gi + q], ev[5 * gi + q + 1]); ms[q] += t; }
-        (void)hipEventElapsedTime(&t, ev[5 * c.ngas], ev[5 * c.ngas + 1]); ms[5] += t;
-        (void)hipEventElapsedTime(&t, ev[5 * c.ngas + 1], ev[5 * c.ngas + 2]); ms[6] += t;
+            for (int q = 0; q < 4; q++) { (void)hipEventElapsedTime(&t, ev[4 * gi + q], ev[4 * gi + q + 1]); ms[slot[q]] += t; }
+        const int b = 4 * c.ngas;
+        (void)hipEventElapsedTime(&t, ev[b], ev[b + 1]); ms[2] += t;       // apply (+ baked tables, CIA)
+        (void)hipEventElapsedTime(&t, ev[b + 1], ev[b + 2]); ms[5] += t;   // rt
+        (void)hipEventElapsedTime(&t, ev[b + 2], ev[b + 3]); ms[6] += t;   // reduce
     }
     for (auto &e : ev) (void)hipEventDestroy(e);
     for (int i = 0; i < 7; i++) ms[i] /= reps;

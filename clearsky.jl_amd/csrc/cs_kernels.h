@@ -555,34 +555,42 @@ __global__ __launch_bounds__(256) void k_cheb_nodes(const double *__restrict__ n
 // One wave = one 64-point tile x 16 states: a column of C is loaded once and used for 16 states whose F values arrive as
 // wave-uniform scalar operands.
 struct ChebApply {
-    int nlev;
+    int nlev, ngas;
     int shift[CS_MAX_LEVEL];   // log2(interval size / 64)
     int ioff[CS_MAX_LEVEL];    // offset of the level in the concatenated interval list
     const double *Cm[CS_MAX_LEVEL];
+    const double *F[16];       // node sums of up to CS_MAX_GAS gases: C is read once for all of them
 };
-__global__ __launch_bounds__(256) void k_cheb_apply(ChebApply A, const double *__restrict__ F, int Kpad, int64_t nnu, int ntile,
+__global__ __launch_bounds__(256) void k_cheb_apply(ChebApply A, int Kpad, int64_t nnu, int ntile,
                                                      int K, double base, const double *__restrict__ extra,
                                                      double *__restrict__ sigma, int accumulate)
 {
+    // 1-D grid.  Workgroups are dealt round-robin over the 8 XCDs (private L2 each): all state groups of a tile block go to
+    // the same XCD, back to back, so its column block of C is fetched from HBM once.  Grid = 8 * ceil(ntb/8) * nsg blocks.
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * 4 + wv;
+    const int nsg = (K + CS_KPAD - 1) / CS_KPAD;
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int tile = ((q / nsg) * 8 + xcd) * 4 + wv;
     if (tile >= ntile) return;
-    const int k0 = blockIdx.y * CS_KPAD;
+    const int k0 = (q % nsg) * CS_KPAD;
     double acc[CS_KPAD];
 #pragma unroll
     for (int q = 0; q < CS_KPAD; q++) acc[q] = 0.0;
-    for (int l = 0; l < A.nlev; l++) {
-        const int sh = A.shift[l];
-        const int T = tile >> sh, sub = tile & ((1 << sh) - 1);
-        const size_t itv = (size_t)64 << sh;
-        const double *__restrict__ Cp = A.Cm[l] + (size_t)T * CS_NC * itv + (size_t)sub * 64 + lane;
-        const double *__restrict__ Fp = F + (size_t)(A.ioff[l] + T) * CS_NC * Kpad + k0;
-#pragma unroll 2
-        for (int m = 0; m < CS_NC; m++) {
-            const double cv = Cp[(size_t)m * itv];
-            const double *__restrict__ fr = Fp + (size_t)m * Kpad;
+    for (int g = 0; g < A.ngas; g++) {   // gas outermost: the column block of C comes from L2 again, sigma is touched once
+        const double *__restrict__ Fg = A.F[g];
+        for (int l = 0; l < A.nlev; l++) {
+            const int sh = A.shift[l];
+            const int T = tile >> sh, sub = tile & ((1 << sh) - 1);
+            const size_t itv = (size_t)64 << sh;
+            const double *__restrict__ Cp = A.Cm[l] + (size_t)T * CS_NC * itv + (size_t)sub * 64 + lane;
+            const double *__restrict__ Fp = Fg + (size_t)(A.ioff[l] + T) * CS_NC * Kpad + k0;
+#pragma unroll 4
+            for (int m = 0; m < CS_NC; m++) {
+                const double cv = Cp[(size_t)m * itv];
+                const double *__restrict__ fr = Fp + (size_t)m * Kpad;
 #pragma unroll
-            for (int q = 0; q < CS_KPAD; q++) acc[q] = __builtin_fma(cv, fr[q], acc[q]);
+                for (int q = 0; q < CS_KPAD; q++) acc[q] = __builtin_fma(cv, fr[q], acc[q]);
+            }
         }
     }
     const int64_t i = (int64_t)tile * 64 + lane;
