@@ -270,11 +270,7 @@ __device__ __forceinline__ double far_term(const LineHot &h, double v, double cu
     const double dv = v - h.nul;
     const double x = dv * h.p1;
     const double s = __builtin_fma(x, x, h.p2);
-#ifdef CS_EXP_RCP_NR
-    const double u = rcp_nr(s);
-#else
     const double u = rcp_fast(s);
-#endif
     double P;
     if (MODE == 2) {
         const double t = h.p2 * u;

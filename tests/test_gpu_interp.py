@@ -106,7 +106,7 @@ def test_column_interp_on_off(cs, lines):
     assert won["direct_evals"] + won["node_evals"] < 0.6 * woff["direct_evals"]
     assert relerr(Fon.tau, Foff.tau) < 5e-14
     sm = Foff.Mup.max()
-    assert np.max(np.abs(Fon.Mup - Foff.Mup)) < 1e-12 * sm and np.max(np.abs(Fon.Mdn - Foff.Mdn)) < 1e-12 * sm   # exp(-tau), tau ~ 1e2
+    assert np.max(np.abs(Fon.Mup - Foff.Mup)) < 3e-12 * sm and np.max(np.abs(Fon.Mdn - Foff.Mdn)) < 3e-12 * sm   # exp(-tau), tau ~ 1e2
     assert relerr(Fon.Fup, Foff.Fup) < 1e-13
     for a, b in zip(Bon, Boff):
         assert relerr(np.asarray(a), np.asarray(b), floor=1e-9) < 1e-13
