@@ -497,12 +497,13 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
                            G.nu.as<double>(), win, Tk, G.mu_min, G.mu_max, cut, gbound, far_s, zones);
         const IZone *iz = nullptr;
         int ishift = 0;
-        for (int l = 0; l < itp.nlev; l++) {
-            int pshift = 0;
-            if (l > 0) for (int r = itp.itv[l - 1] / itp.itv[l]; r > 1; r >>= 1) pshift++;
-            hipLaunchKernelGGL(k_izones, dim3((unsigned)(((int64_t)itp.nI[l] * kn + 255) / 256)), dim3(256), 0, s, dnu, nnu, itp.itv[l],
-                               itp.nI[l], kn, G.nu.as<double>(), itp.iwin[l], Tk, G.mu_min, G.mu_max, cut, gbound, far_s,
-                               l > 0 ? itp.ioff[l - 1] : -1, pshift, itp.ioff[l], itp.nItot, itp.iz);
+        if (itp.nlev > 0) {
+            IzParams P;
+            P.nlev = itp.nlev;
+            P.nItot = itp.nItot;
+            for (int l = 0; l < itp.nlev; l++) { P.itv[l] = itp.itv[l]; P.nI[l] = itp.nI[l]; P.ioff[l] = itp.ioff[l]; P.iwin[l] = itp.iwin[l]; }
+            hipLaunchKernelGGL(k_izones, dim3((unsigned)(((int64_t)itp.nItot * kn + 255) / 256)), dim3(256), 0, s, P, dnu, nnu, kn,
+                               G.nu.as<double>(), Tk, G.mu_min, G.mu_max, cut, gbound, far_s, itp.iz);
         }
         if (evg) (void)hipEventRecord(evg[0], s);
         if (itp.nlev > 0) {   // sigma = base + extra + interpolated far wings; the per-point kernels add the rest

@@ -431,45 +431,65 @@ __global__ __launch_bounds__(256) void k_cheb_setup(const double *__restrict__ n
     }
 }
 
-// parent interval = T >> pshift of the level that starts at poff
-__global__ __launch_bounds__(256) void k_izones(const double *__restrict__ nu, int64_t nnu, int itv, int nI, int K,
-                                                 const double *__restrict__ nul, const WaveWin *__restrict__ iwin,
-                                                 const double *__restrict__ Tk, double mu_min, double mu_max, double cut,
-                                                 const double *__restrict__ gbound, double far_s, int poff, int pshift,
-                                                 int ioff, int nItot, IZone *__restrict__ izall)
+// zones of the interpolation intervals, all levels in one launch.  A thread owns one (state, interval); the four bounds it
+// needs from its parent interval (next larger size) are recomputed rather than read, so there is no order between levels.
+struct IzParams {
+    int nlev, nItot;
+    int itv[CS_MAX_LEVEL], nI[CS_MAX_LEVEL], ioff[CS_MAX_LEVEL];
+    const WaveWin *iwin[CS_MAX_LEVEL];
+};
+// E0, Z0, Z1, E1 of (level l, interval T, state with thermal speed vth); false if the set is empty
+__device__ __forceinline__ bool izone_outer(const IzParams &P, int l, int T, const double *__restrict__ nu, int64_t nnu,
+                                            const double *__restrict__ nul, double vth, double mu_min, double cut, double &vlo,
+                                            double &vhi, double &dA, int &E0, int &Z0, int &Z1, int &E1)
 {
-    // zones of all levels live in one array [K][nItot]; this level starts at ioff, its parent level at poff (-1: none)
-    const int idx0 = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx0 >= nI * K) return;
-    const int k = idx0 / nI, T = idx0 - k * nI;
-    IZone *__restrict__ iz = izall;
-    const size_t idx = (size_t)k * nItot + ioff + T;
+    const int itv = P.itv[l];
     const int64_t i0 = (int64_t)T * itv, i1 = (i0 + itv - 1 < nnu ? i0 + itv - 1 : nnu - 1);
-    const double vlo = nu[i0], vhi = nu[i1];
-    const WaveWin w = iwin[T];   // E0..E1: lines inside the cut-off of every point of the interval
-    IZone z;
+    vlo = nu[i0];
+    vhi = nu[i1];
+    const WaveWin w = P.iwin[l][T];   // E0..E1: lines inside the cut-off of every point of the interval
+    E0 = w.E0; E1 = w.E1;
+    if (w.E1 <= w.E0) { E0 = Z0 = Z1 = E1 = w.E0; return false; }   // (then the parent has nothing either: the sets are nested)
     const double h = 0.5 * (vhi - vlo);
-    if (w.E1 <= w.E0) {  // nothing to interpolate (then the parent has nothing either: the sets are nested)
-        z.E0 = z.Q0 = z.M0 = z.Z0 = z.Z1 = z.M1 = z.Q1 = z.E1 = z.P0 = z.P1 = z.P2 = z.P3 = w.E0;
-        iz[idx] = z;
-        return;
-    }
-    z.E0 = w.E0; z.E1 = w.E1;
-    const double vth = sqrt(2.0 * kRgas * Tk[k]);
     const double amax = ((vhi + cut) / kC) * vth / sqrt(mu_min);
-    const double dA = 100.0 * amax / kSqLn2 * (1.0 + 1e-6);
-    const double dAA = dA * sqrt(far_s * 1e-4);
+    dA = 100.0 * amax / kSqLn2 * (1.0 + 1e-6);
     const double dZ = fmax(dA, kChebMargin * h);
     auto lower = [&](double val, int a, int b) { while (a < b) { int m = (a + b) >> 1; if (nul[m] < val) a = m + 1; else b = m; } return a; };
     auto upper = [&](double val, int a, int b) { while (a < b) { int m = (a + b) >> 1; if (nul[m] <= val) a = m + 1; else b = m; } return a; };
-    z.Z0 = lower(vlo - dZ, w.E0, w.E1);
-    z.Z1 = upper(vhi + dZ, z.Z0, w.E1);
-    z.M0 = lower(vlo - dAA, w.E0, z.Z0);
-    z.M1 = upper(vhi + dAA, z.Z1, w.E1);
+    Z0 = lower(vlo - dZ, w.E0, w.E1);
+    Z1 = upper(vhi + dZ, Z0, w.E1);
+    return true;
+}
+__global__ __launch_bounds__(256) void k_izones(IzParams P, const double *__restrict__ nu, int64_t nnu, int K,
+                                                 const double *__restrict__ nul, const double *__restrict__ Tk, double mu_min,
+                                                 double mu_max, double cut, const double *__restrict__ gbound, double far_s,
+                                                 IZone *__restrict__ iz)
+{
+    // zones of all levels live in one array [K][nItot]; level l starts at ioff[l]
+    const int idx0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx0 >= P.nItot * K) return;
+    const int k = idx0 / P.nItot, q = idx0 - k * P.nItot;
+    int l = 0;
+    while (l + 1 < P.nlev && q >= P.ioff[l + 1]) l++;
+    const int T = q - P.ioff[l];
+    const size_t idx = (size_t)k * P.nItot + q;
+    const double vth = sqrt(2.0 * kRgas * Tk[k]);
+    double vlo, vhi, dA;
+    IZone z;
+    if (!izone_outer(P, l, T, nu, nnu, nul, vth, mu_min, cut, vlo, vhi, dA, z.E0, z.Z0, z.Z1, z.E1)) {
+        z.Q0 = z.M0 = z.M1 = z.Q1 = z.P0 = z.P1 = z.P2 = z.P3 = z.E0;
+        iz[idx] = z;
+        return;
+    }
+    const double dAA = dA * sqrt(far_s * 1e-4);
+    auto lower = [&](double val, int a, int b) { while (a < b) { int m = (a + b) >> 1; if (nul[m] < val) a = m + 1; else b = m; } return a; };
+    auto upper = [&](double val, int a, int b) { while (a < b) { int m = (a + b) >> 1; if (nul[m] <= val) a = m + 1; else b = m; } return a; };
+    z.M0 = lower(vlo - dAA, z.E0, z.Z0);
+    z.M1 = upper(vhi + dAA, z.Z1, z.E1);
     const double vmin = vlo - cut;
     double y2b = 1e300;
     if (vmin > 0.0) {
-        const double amin = (fmax(vmin, nul[w.E0]) / kC) * vth / sqrt(mu_max);
+        const double amin = (fmax(vmin, nul[z.E0]) / kC) * vth / sqrt(mu_max);
         const double yb = gbound[k] * kSqLn2 / amin;
         y2b = yb * yb;
     }
@@ -477,18 +497,23 @@ __global__ __launch_bounds__(256) void k_izones(const double *__restrict__ nu, i
         z.Q0 = z.M0; z.Q1 = z.M1;
     } else if (y2b < 1e290) {
         const double dQ = dA * sqrt(fmax(cbrt(1.5e16 * y2b), far_s) * 1e-4);
-        z.Q0 = lower(vlo - dQ, w.E0, z.M0);
-        z.Q1 = upper(vhi + dQ, z.M1, w.E1);
+        z.Q0 = lower(vlo - dQ, z.E0, z.M0);
+        z.Q1 = upper(vhi + dQ, z.M1, z.E1);
     } else {
-        z.Q0 = w.E0; z.Q1 = w.E1;
+        z.Q0 = z.E0; z.Q1 = z.E1;
     }
     // the parent's own set is nested in this one ([E0,E1) grows and [Z0,Z1) shrinks with the interval); clamp it anyway
     z.P0 = z.P1 = z.E0;
     z.P2 = z.P3 = z.E1;
-    if (poff >= 0) {
-        const IZone q = izall[(size_t)k * nItot + poff + (T >> pshift)];
-        if (q.Z0 > q.E0) { z.P0 = min(max(q.E0, z.E0), z.Z0); z.P1 = min(max(q.Z0, z.P0), z.Z0); }
-        if (q.E1 > q.Z1) { z.P2 = min(max(q.Z1, z.Z1), z.E1); z.P3 = min(max(q.E1, z.P2), z.E1); }
+    if (l > 0) {
+        int pshift = 0;
+        for (int r = P.itv[l - 1] / P.itv[l]; r > 1; r >>= 1) pshift++;
+        double pvlo, pvhi, pdA;
+        int qE0, qZ0, qZ1, qE1;
+        if (izone_outer(P, l - 1, T >> pshift, nu, nnu, nul, vth, mu_min, cut, pvlo, pvhi, pdA, qE0, qZ0, qZ1, qE1)) {
+            if (qZ0 > qE0) { z.P0 = min(max(qE0, z.E0), z.Z0); z.P1 = min(max(qZ0, z.P0), z.Z0); }
+            if (qE1 > qZ1) { z.P2 = min(max(qZ1, z.Z1), z.E1); z.P3 = min(max(qE1, z.P2), z.E1); }
+        }
     }
     iz[idx] = z;
 }

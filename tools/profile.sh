@@ -26,6 +26,6 @@ for name in ("fetch", "write"):
     with open(f"{out}/pmc_{name}_summary.csv", "w") as fo:
         fo.write("kernel,launches,avg_KB_per_launch\n")
         for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-            fo.write(f"{k},{n},{v / n:.1f}\n")
+            fo.write(f"\"{k}\",{n},{v / n:.1f}\n")
     print(open(f"{out}/pmc_{name}_summary.csv").read())
 PY
