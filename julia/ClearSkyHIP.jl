@@ -206,3 +206,5 @@ end # module
 #   with conc_tab[t,k] = fC_t(T_k,P_k) and P1/P2 = P_k*concentration(g₁/g₂, T_k, P_k) (cia…jl:378-382), all evaluated on
 #   the Julia side at the node states (T_k, P_k) built in the method above.
 #   cs_set_precision(ctx, 1, 1e6) selects the fp32 far-wing variant (BASELINE configs[4]).
+#   cs_set_interp(ctx, 0) switches the far-wing interpolation off (every (nu, line) pair evaluated, as surf! does); it is on
+#   by default and exact to rounding (DESIGN.md section 3, K2c).
