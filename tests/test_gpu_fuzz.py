@@ -98,3 +98,78 @@ def test_column_fuzz(cs, O, seed):
     fm = max(np.abs(r["Fup"]).max(), np.abs(r["Fdn"]).max())
     assert np.max(np.abs(F.Fup - r["Fup"])) < 1e-11 * fm and np.max(np.abs(F.Fdn - r["Fdn"])) < 1e-11 * fm
     ctx.close()
+
+
+# ---- interpolated far wings (K2c): the same device path with and without interpolation on random fine grids --------------
+
+@pytest.mark.parametrize("seed", range(16))
+def test_interp_fuzz(cs, O, seed):
+    """Random grid kind / size / spacing / cut-off / molecule / states; interpolation on vs off (every pair evaluated) at
+    2e-13, and vs the oracle at 1e-11 on a subset of the points."""
+    rng = np.random.default_rng(9000 + seed)
+    cut = float(rng.choice([1.0, 5.0, 25.0, 25.0, 60.0]))
+    nlev_target = int(rng.integers(1, 6))
+    n = int(rng.integers(130, 9000))
+    # spacing so that the interval of 128 * 2^(nlev_target-1) points is the largest one that fits 2.3 W <= 1.5 cut
+    dnu = 1.5 * cut / 2.3 / (128 * 2 ** (nlev_target - 1)) * float(rng.uniform(0.55, 0.95))
+    c0 = float(rng.uniform(300, 2500))
+    span = dnu * (n - 1)
+    kind = ["uniform", "random", "log", "jitter"][seed % 4]
+    if kind == "uniform":
+        nu = c0 + dnu * np.arange(n)
+    elif kind == "random":
+        nu = np.unique(c0 + np.sort(rng.uniform(0, span, n)))
+    elif kind == "log":
+        nu = np.unique(c0 * np.exp(np.linspace(0, np.log1p(span / c0), n)))
+    else:
+        nu = c0 + dnu * (np.arange(n) + rng.uniform(-0.4, 0.4, n))
+    M = int(rng.choice([1, 2, 2, 6, 45]))
+    L = int(rng.integers(200, 6000))
+    sl = _table(cs, rng, M, L, c0 - 2 * cut - 5, c0 + span + 2 * cut + 5, dense=int(L // 4) if seed % 5 == 0 else None, dup=seed % 7 == 0)
+    K = int(rng.integers(1, 40))
+    T = rng.uniform(25, 1000, K) if M != 45 else rng.uniform(100, 1000, K)
+    P = 10 ** rng.uniform(-1, 5.5, K)
+    P[rng.random(K) < 0.1] = 0.0
+    Pp = P * rng.uniform(0, 1, K)
+    on, off = cs.Context(0), cs.Context(0)
+    off.set_interp(False)
+    a = cs.shape_batch(sl, "voigt", nu, list(T), list(P), list(Pp), cut, on)
+    b = cs.shape_batch(sl, "voigt", nu, list(T), list(P), list(Pp), cut, off)
+    assert np.array_equal(a == 0, b == 0)
+    assert relerr(a, b, floor=1e-280) < 2e-13, (seed, kind, cs.interp_plan(nu, cut), relerr(a, b, floor=1e-280))
+    idx = np.sort(rng.choice(len(nu), min(len(nu), 300), replace=False))
+    for k in rng.choice(K, min(K, 3), replace=False):
+        so = O.shape_bang("voigt", nu, sl, T[k], P[k], Pp[k], cut)[idx] if len(nu) <= 3000 else None
+        if so is not None:
+            assert relerr(a[k][idx], so, floor=1e-280) < 1e-11
+    on.close(); off.close()
+
+
+def test_interp_column_mixed_gases(cs, O):
+    """Two Voigt gases with different cut-offs (levels follow the narrower one), a Lorentz gas in between, gray term, stellar
+    beam: on vs off and vs the oracle."""
+    rng = np.random.default_rng(77)
+    nu = np.linspace(900.0, 1100.0, 12001)
+    g1 = cs.DirectGas(_table(cs, rng, 2, 3000, 800, 1200), 3e-4, nu, dnu_cut=25.0)
+    g2 = cs.DirectGas(_table(cs, rng, 1, 2000, 800, 1200), 2e-3, nu, dnu_cut=8.0)
+    g3 = cs.DirectGas(_table(cs, rng, 6, 500, 800, 1200), 1e-5, nu, shape="lorentz", dnu_cut=25.0)
+    P = cs.pressuregrid(5.0, 1e5, 12)
+    T = np.linspace(210.0, 295.0, 12)
+    out = {}
+    for flag in (True, False):
+        ctx = cs.Context(0)
+        ctx.set_interp(flag)
+        col = cs.Column(P, 9.8, T, 0.029, 1.0, 0.1, g1, g3, g2, cs.GrayGas(1e-27, nu), core=cs.Discretized(4, 3), theta_s=0.5, ctx=ctx)
+        col.run()
+        F = cs.FluxPack(len(P), len(nu))
+        F.Fup[:], F.Fdn[:] = col.fetch(F.tau, F.Mup, F.Mdn)
+        out[flag] = (F, col.sigma_nodes(), col.work(), col)
+    Fon, son, won, col = out[True]
+    Foff, soff, woff, _ = out[False]
+    assert won["levels"] >= 2 and woff["levels"] == 0
+    assert relerr(son, soff) < 2e-13 and relerr(Fon.tau, Foff.tau) < 2e-13
+    idx = np.sort(rng.choice(len(nu), 200, replace=False))
+    r = O.fluxes_discretized(nu[idx], P, col.g, 3, col.Tn, col.mun, col.Tlev, [g1.sl, g3.sl, g2.sl], ["voigt", "lorentz", "voigt"],
+                             [25.0, 25.0, 8.0], col.conc, S_toa=col.S_toa[idx], albedo=col.albedo[idx], theta_s=0.5, nstream=4,
+                             sigma_gray=1e-27)
+    assert relerr(Fon.tau[:, idx], r["tau"]) < 1e-11
