@@ -172,3 +172,17 @@ def test_missing_library_fails_loudly(cs, monkeypatch, tmp_path):
     monkeypatch.setattr(lib_mod, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(cs.ClearSkyHIPError, match="no CPU fallback"):
         lib_mod.lib()
+
+
+def test_interp_plan_host_logic(cs):
+    """cs_interp_plan is pure host code (no GPU call): interval sizes follow 2.3 N dnu <= 1.5 cut, descending, <= 5 levels."""
+    for nu, cut, want in ((np.linspace(1, 2500, 100000), 25.0, [512, 256, 128]),      # the bench grid
+                          (np.linspace(1, 2500, 5003), 25.0, []),                      # coarse: every pair evaluated directly
+                          (np.linspace(600, 700, 100000), 25.0, [2048, 1024, 512, 256, 128]),
+                          (np.linspace(600, 700, 100000), 0.5, [256, 128]),
+                          (np.linspace(600, 700, 100), 25.0, []),                      # fewer than 128 points
+                          (np.array([667.0]), 25.0, [])):
+        got = cs.interp_plan(nu, cut)
+        assert got == want, (len(nu), cut, got)
+        dnu = (nu[-1] - nu[0]) / max(len(nu) - 1, 1)
+        assert all(2.3 * n * dnu <= 1.5 * cut for n in got) and got == sorted(got, reverse=True)
