@@ -507,7 +507,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
         }
         if (evg) (void)hipEventRecord(evg[0], s);
         if (itp.nlev > 0) {   // sigma = base + extra + interpolated far wings; the per-point kernels add the rest
-            const dim3 gridn((unsigned)((kn + 3) / 4), (unsigned)itp.nItot);
+            const dim3 gridn((unsigned)((kn + 3) / 4) * (unsigned)itp.nItot);
             if (hot32)
                 hipLaunchKernelGGL((k_cheb_nodes<true>), gridn, dim3(256), 0, s, itp.nodes, G.L, hot, hot32, G.nu.as<double>(), itp.iz,
                                    itp.nItot, kn, itp.Kpad, cut, itp.F);

@@ -519,7 +519,7 @@ __global__ __launch_bounds__(256) void k_izones(IzParams P, const double *__rest
 }
 
 // one wave = the 64 Chebyshev nodes of one interval x one node state: far-wing sums at the nodes -> F[interval][node][state].
-// All levels run in one launch: blockIdx.y walks the concatenated interval list (largest intervals, i.e. longest waves, first).
+// All levels run in one launch over the concatenated interval list (largest intervals, i.e. longest waves, first).
 #define CS_KPAD 16   // F rows are padded to a multiple of 16 states (k_cheb_apply reads 16 at a time with scalar loads)
 template <bool MIXED>
 __global__ __launch_bounds__(256) void k_cheb_nodes(const double *__restrict__ nodes, int64_t L, const LineHot *__restrict__ hot,
@@ -527,9 +527,11 @@ __global__ __launch_bounds__(256) void k_cheb_nodes(const double *__restrict__ n
                                                      const IZone *__restrict__ iz, int nItot, int K, int Kpad, double cut,
                                                      double *__restrict__ F)
 {
+    // 1-D grid (an interval list can exceed the 65535 limit of gridDim.y): block = interval * nsb + state block, state fastest
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int T = blockIdx.y;
-    const int k = blockIdx.x * 4 + wv;
+    const int nsb = (K + 3) >> 2;
+    const int T = (int)(blockIdx.x / nsb);
+    const int k = (int)(blockIdx.x % nsb) * 4 + wv;
     if (k >= K) return;
     const LineHot *__restrict__ hk = hot + (size_t)k * L;
     const LineF32 *__restrict__ hf = MIXED ? hot32 + (size_t)k * L : nullptr;

@@ -120,3 +120,13 @@ def test_bake_with_interp(cs, O, lines, ctx_on, ctx_off):
     goff = cs.Gas(lines("CO2"), 400e-6, nu, Om, ctx=ctx_off, keep_host_tables=True)
     a, b = np.asarray(gon.lnsigma), np.asarray(goff.lnsigma)
     assert np.max(np.abs(a - b)) < 5e-14       # ln sigma: absolute = relative in sigma
+
+
+def test_more_than_65535_intervals(cs, lines, ctx_on, ctx_off):
+    """5e6 wavenumbers, five levels: 75 000 intervals in the node kernel's (1-D) grid; on vs off."""
+    nu = np.linspace(640.0, 700.0, 5_000_000)
+    assert len(cs.interp_plan(nu, 25.0)) == 5
+    sl = lines("CO2")
+    on = cs.shape_batch(sl, "voigt", nu, [250.0], [2e4], [8.0], 25.0, ctx_on)
+    off = cs.shape_batch(sl, "voigt", nu, [250.0], [2e4], [8.0], 25.0, ctx_off)
+    assert relerr(on, off, floor=1e-250) < 5e-14
