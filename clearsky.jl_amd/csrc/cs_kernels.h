@@ -979,7 +979,7 @@ __global__ __launch_bounds__(256) void k_rt(RtParams p, const double *__restrict
             I[k] = I[k] * tr + Be;
             Md += p.W[k] * I[k];
         }
-        Ms *= exp(-t / c);
+        if (S_toa) Ms *= exp(-t / c);   // (wave-uniform; without a stellar beam Ms stays 0)
         Md += Ms;
         Bprev = Bnext;
         double r = wave_sum(w * Md);
