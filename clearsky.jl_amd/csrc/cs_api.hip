@@ -552,8 +552,10 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
         }
 #undef CS_FAR_LAUNCH
         if (evg) (void)hipEventRecord(evg[2], s);
-        hipLaunchKernelGGL(k_voigt_near<0>, grid, dim3(256), 0, s, dnu, nnu, G.L, hot, cold, zones, nt64, nblk, cut, sigma, ranges);
-        hipLaunchKernelGGL(k_voigt_near<1>, grid, dim3(256), 0, s, dnu, nnu, G.L, hot, cold, zones, nt64, nblk, cut, sigma, ranges);
+        const int ngrp = (nt64 + CS_NEAR_R - 1) / CS_NEAR_R;   // near kernels: one wave = CS_NEAR_R consecutive tiles
+        const dim3 gridq((unsigned)((ngrp + 3) / 4), kn);
+        hipLaunchKernelGGL(k_voigt_near<0>, gridq, dim3(256), 0, s, dnu, nnu, G.L, hot, cold, zones, nt64, ngrp, cut, sigma, ranges);
+        hipLaunchKernelGGL(k_voigt_near<1>, gridq, dim3(256), 0, s, dnu, nnu, G.L, hot, cold, zones, nt64, ngrp, cut, sigma, ranges);
     } else {
         if (evg) { (void)hipEventRecord(evg[0], s); (void)hipEventRecord(evg[1], s); }
         launch_linesum_shape(shape, dim3(ntile256, kn), s, dnu, nnu, G.L, hot, cold, J0, J1, cut, Tk, base, extra, sigma,

@@ -793,41 +793,57 @@ __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu
 // (continued fraction for 100 <= s < 1e3, trapezoid + pole correction for s < 100) run with full lanes instead of
 // once per "deepest" lane -- then every lane sums its own results in ascending line order (deterministic).
 #define CS_NEAR_Q 256  // queue entries per wave; longer candidate lists go through the queue in windows
+#define CS_NEAR_R 1    // consecutive 64-point tiles per wave (2 and 4 fill the 64-wide trips better but measured slower: 0.47-0.58 vs 0.45 ms)
+// candidates of lane l: for r = 0..R-1 the lines [lo[r], hi[r]) (absolute indices) against wavenumber (tile0 + r) * 64 + l
 template <int TIER>  // 0: 100 <= s < 1e3 (fad_mid), 1: s < 100 (fad_near)
-__device__ __forceinline__ double near_pass(double v, int lo, int hi, int N0, const LineHot *__restrict__ hk,
-                                            const LineCold *__restrict__ ck, double cut, unsigned *qidx, double *qres)
+__device__ __forceinline__ void near_pass(const double *__restrict__ nu, int64_t nnu, int tile0, const int (&lo)[CS_NEAR_R],
+                                          const int (&hi)[CS_NEAR_R], double (&acc)[CS_NEAR_R], const LineHot *__restrict__ hk,
+                                          const LineCold *__restrict__ ck, double cut, unsigned *qidx, double *qres)
 {
     const int lane = threadIdx.x & 63;
-    const int cnt = hi - lo;
+    int cnt = 0, pre[CS_NEAR_R + 1];
+#pragma unroll
+    for (int r = 0; r < CS_NEAR_R; r++) { pre[r] = cnt; cnt += hi[r] - lo[r]; }
+    pre[CS_NEAR_R] = cnt;
     // exclusive prefix sum of the candidate counts over the wave
     int incl = cnt;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
     const int off = incl - cnt;
     const int total = __shfl(incl, 63, 64);
-    double acc = 0.0;
     for (int base = 0; base < total; base += CS_NEAR_Q) {   // wave-uniform
-        // this lane's candidates that fall into the window [base, base + Q)
-        const int c0 = max(base - off, 0), c1 = min(base + CS_NEAR_Q - off, cnt);
-        for (int c = c0; c < c1; c++) qidx[off + c - base] = ((unsigned)lane << 24) | (unsigned)(lo + c);
+        // this lane's candidates that fall into the window [base, base + Q): entry = lane | sub-tile | line
+#pragma unroll
+        for (int r = 0; r < CS_NEAR_R; r++) {
+            const int o = off + pre[r] - base;   // queue position of this sub-tile's first candidate
+            const int c0 = max(-o, 0), c1 = min(CS_NEAR_Q - o, hi[r] - lo[r]);
+            for (int c = c0; c < c1; c++) qidx[o + c] = ((unsigned)lane << 26) | ((unsigned)r << 24) | (unsigned)(lo[r] + c);
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         const int nwin = min(total - base, CS_NEAR_Q);
-        const int ntrip = (nwin + 63) >> 6;  // wave-uniform: every lane takes part in the shuffles
+        const int ntrip = (nwin + 63) >> 6;
         // the line records of trip it+1 are fetched while trip it is evaluated (a wave is a chain of dependent gathers otherwise)
         LineHot hn = {};
         LineCold cn = {};
         unsigned en = 0;
-        if (lane < nwin) { en = qidx[lane]; const int j = N0 + (int)(en & 0xffffffu); hn = hk[j]; cn = ck[j]; }
+        double vn = 0.0;
+        auto fetch = [&](int p) {
+            en = qidx[p];
+            const int j = (int)(en & 0xffffffu);
+            hn = hk[j];
+            cn = ck[j];
+            const int64_t i = (int64_t)(tile0 + (int)((en >> 24) & 3u)) * 64 + (int)(en >> 26);
+            vn = nu[i < nnu ? i : nnu - 1];
+        };
+        if (lane < nwin) fetch(lane);
         for (int it = 0; it < ntrip; it++) {
             const int p = it * 64 + lane;
             const bool live = p < nwin;
             const LineHot h = hn;
             const LineCold c = cn;
-            const unsigned e = en;
-            if (p + 64 < nwin) { en = qidx[p + 64]; const int j = N0 + (int)(en & 0xffffffu); hn = hk[j]; cn = ck[j]; }
-            const int owner = (int)(e >> 24);
-            const double vo = __shfl(v, owner, 64);
+            const double vo = vn;
+            if (p + 64 < nwin) fetch(p + 64);
             if (live) {
                 double r = 0.0;
                 const double dv = vo - h.nul;
@@ -840,38 +856,56 @@ __device__ __forceinline__ double near_pass(double v, int lo, int hi, int N0, co
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
-        for (int c = c0; c < c1; c++) acc += qres[off + c - base];   // ascending line order per lane: deterministic
+#pragma unroll
+        for (int r = 0; r < CS_NEAR_R; r++) {   // ascending line order per (lane, sub-tile): deterministic
+            const int o = off + pre[r] - base;
+            const int c0 = max(-o, 0), c1 = min(CS_NEAR_Q - o, hi[r] - lo[r]);
+            for (int c = c0; c < c1; c++) acc[r] += qres[o + c];
+        }
         __builtin_amdgcn_wave_barrier();
     }
-    return acc;
 }
 
 // one launch per tier: the tier-0 kernel is light (continued fraction, few registers, many waves in flight), the tier-1 kernel
-// carries the trapezoid + pole correction (exp, sincos: 127 VGPRs)
+// carries the trapezoid + pole correction (exp, sincospi: ~160 VGPRs).  One wave = CS_NEAR_R consecutive tiles x one state.
 template <int TIER>
 __global__ __launch_bounds__(256) void k_voigt_near(const double *__restrict__ nu, int64_t nnu, int64_t L,
                                                      const LineHot *__restrict__ hot, const LineCold *__restrict__ cold,
-                                                     const Zone *__restrict__ zones, int ntile, int nblk, double cut,
+                                                     const Zone *__restrict__ zones, int ntile, int ngrp, double cut,
                                                      double *__restrict__ sigma, const int4 *__restrict__ ranges)
 {
     __shared__ unsigned qidx_s[4][CS_NEAR_Q];
     __shared__ double qres_s[4][CS_NEAR_Q];
-    const int tb = tile_block(nblk);
-    const int wv = threadIdx.x >> 6;
-    const int tile = __builtin_amdgcn_readfirstlane(tb * 4 + wv);
-    if (tb >= nblk || tile >= ntile) return;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int grp = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wv);   // group of CS_NEAR_R tiles
+    if (grp >= ngrp) return;
+    const int tile0 = grp * CS_NEAR_R;
     const int k = blockIdx.y;
-    const int64_t i = (int64_t)tile * 64 + (threadIdx.x & 63);
     const LineHot *__restrict__ hk = hot + (size_t)k * L;
     const LineCold *__restrict__ ck = cold + (size_t)k * L;
-    const double v = nu[i < nnu ? i : nnu - 1];
-    const Zone z = zones[(size_t)k * ntile + tile];
     // two planes of int2 inside the int4 workspace: tier 0 ranges, then tier 1 ranges, [gridDim.y][nnu] each
-    const int2 *__restrict__ rp = reinterpret_cast<const int2 *>(ranges) + (size_t)TIER * gridDim.y * nnu;
-    int2 r = make_int2(0, 0);
-    if (i < nnu) r = rp[(size_t)k * nnu + i];
-    const double acc = near_pass<TIER>(v, r.x, r.y, z.N0, hk, ck, cut, qidx_s[wv], qres_s[wv]);
-    if (i < nnu && acc != 0.0) sigma[(size_t)k * nnu + i] += acc;
+    const int2 *__restrict__ rp = reinterpret_cast<const int2 *>(ranges) + (size_t)TIER * gridDim.y * nnu + (size_t)k * nnu;
+    int lo[CS_NEAR_R], hi[CS_NEAR_R];
+    double acc[CS_NEAR_R];
+#pragma unroll
+    for (int r = 0; r < CS_NEAR_R; r++) {
+        const int tile = tile0 + r;
+        const int64_t i = (int64_t)tile * 64 + lane;
+        lo[r] = hi[r] = 0;
+        acc[r] = 0.0;
+        if (tile < ntile && i < nnu) {
+            const int2 q = rp[i];
+            const int N0 = zones[(size_t)k * ntile + tile].N0;
+            lo[r] = N0 + q.x;
+            hi[r] = N0 + q.y;
+        }
+    }
+    near_pass<TIER>(nu, nnu, tile0, lo, hi, acc, hk, ck, cut, qidx_s[wv], qres_s[wv]);
+#pragma unroll
+    for (int r = 0; r < CS_NEAR_R; r++) {
+        const int64_t i = (int64_t)(tile0 + r) * 64 + lane;
+        if (tile0 + r < ntile && i < nnu && acc[r] != 0.0) sigma[(size_t)k * nnu + i] += acc[r];
+    }
 }
 
 // radiation.jl:48-54
