@@ -1071,6 +1071,7 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
     c.h_xs.assign(nlobatto, 0.0);
     cs_lobattonodes(nlobatto, c.h_xs.data(), rt.ws);
     cs_streamnodes(nstream, rt.m, rt.W);
+    for (int k = 0; k < nstream; k++) rt.im[k] = 1.0 / rt.m[k];
     // node states: k = i*(nlobatto-1) + n   (discretized.jl:150,162,169)
     c.h_P.assign(P, P + np);
     c.h_nu.assign(nu, nu + nnu);

@@ -8,6 +8,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <rocprim/warp/warp_reduce.hpp>
+#include <rocprim/warp/warp_scan.hpp>
 #include "cs_faddeeva.h"
 
 namespace csdev {
@@ -805,12 +807,15 @@ __device__ __forceinline__ void near_pass(const double *__restrict__ nu, int64_t
 #pragma unroll
     for (int r = 0; r < CS_NEAR_R; r++) { pre[r] = cnt; cnt += hi[r] - lo[r]; }
     pre[CS_NEAR_R] = cnt;
-    // exclusive prefix sum of the candidate counts over the wave
-    int incl = cnt;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    // exclusive prefix sum of the candidate counts over the wave (rocPRIM: DPP row shifts + broadcasts, no LDS round trips)
+    int incl;
+    {
+        using scan_t = rocprim::warp_scan<int, 64>;
+        typename scan_t::storage_type st;
+        scan_t().inclusive_scan(cnt, incl, st);
+    }
     const int off = incl - cnt;
-    const int total = __shfl(incl, 63, 64);
+    const int total = __builtin_amdgcn_readlane(incl, 63);
     for (int base = 0; base < total; base += CS_NEAR_Q) {   // wave-uniform
         // this lane's candidates that fall into the window [base, base + Q): entry = lane | sub-tile | line
 #pragma unroll
@@ -922,6 +927,11 @@ __device__ __forceinline__ double layerplanck(double B1, double B2, double tau, 
 {
     return B2 * (1.0 - t) - (B1 - B2) * t + (1.0 - t) * (B1 - B2) / tau;
 }
+// the same with 1/tau handed in: k_rt forms 1/(t m_k) as (1/t)(1/m_k), one division per layer instead of one per stream
+__device__ __forceinline__ double layerplanck_inv(double B1, double B2, double itau, double t)
+{
+    return B2 * (1.0 - t) - (B1 - B2) * t + ((1.0 - t) * (B1 - B2)) * itau;
+}
 
 struct RtParams {
     int np, nlobatto, K, nstream;
@@ -930,13 +940,18 @@ struct RtParams {
     double ws[16];   // Lobatto weights on [0,1]
     double m[16];    // 1/cos(theta_k)
     double W[16];    // stream weights
+    double im[16];   // cos(theta_k) = 1/m
 };
 
+// sum over the wave, valid in lane 0 (rocPRIM: DPP row shifts instead of six LDS-routed shuffles -- k_rt does this twice per
+// level inside a chain of dependent work)
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
+    using red_t = rocprim::warp_reduce<double, 64>;
+    typename red_t::storage_type st;
+    double r;
+    red_t().reduce(v, r, st);
+    return r;
 }
 
 // K3: one lane per wavenumber.  Pass 1 walks TOA -> surface: layer optical depths from the node cross-sections
@@ -1005,11 +1020,12 @@ __global__ __launch_bounds__(256) void k_rt(RtParams p, const double *__restrict
         if (live) tau[(size_t)i * nnu + j] = t;
         const double Bnext = planck(v, Tlev[i + 1]);
         Md = 0.0;
+        const double it = 1.0 / t;
 #pragma unroll
         for (int k = 0; k < NS; k++) {
             const double tk = t * p.m[k];
             const double tr = exp(-tk);
-            const double Be = layerplanck(Bprev, Bnext, tk, tr);
+            const double Be = layerplanck_inv(Bprev, Bnext, it * p.im[k], tr);
             I[k] = I[k] * tr + Be;
             Md += p.W[k] * I[k];
         }
@@ -1037,11 +1053,12 @@ __global__ __launch_bounds__(256) void k_rt(RtParams p, const double *__restrict
         if (i > 0) t_next = live ? tau[(size_t)(i - 1) * nnu + j] : 1.0;   // one layer ahead
         const double Blo = planck(v, Tlev[i]);
         Mu = 0.0;
+        const double it = 1.0 / t;
 #pragma unroll
         for (int k = 0; k < NS; k++) {
             const double tk = t * p.m[k];
             const double tr = exp(-tk);
-            const double Be = layerplanck(Bhi, Blo, tk, tr);
+            const double Be = layerplanck_inv(Bhi, Blo, it * p.im[k], tr);
             I[k] = I[k] * tr + Be;
             Mu += p.W[k] * I[k];
         }
