@@ -872,9 +872,10 @@ __device__ __forceinline__ void near_pass(const double *__restrict__ nu, int64_t
 }
 
 // one launch per tier: the tier-0 kernel is light (continued fraction, few registers, many waves in flight), the tier-1 kernel
-// carries the trapezoid + pole correction (exp, sincospi: ~160 VGPRs).  One wave = CS_NEAR_R consecutive tiles x one state.
+// carries the trapezoid + pole correction (exp, sincospi).  One wave = CS_NEAR_R consecutive tiles x one state.  The register
+// allocator would give tier 1 161 VGPRs (3 waves per SIMD); capped at 96 (5 waves) it still does not spill and runs 12 % faster.
 template <int TIER>
-__global__ __launch_bounds__(256) void k_voigt_near(const double *__restrict__ nu, int64_t nnu, int64_t L,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_voigt_near(const double *__restrict__ nu, int64_t nnu, int64_t L,
                                                      const LineHot *__restrict__ hot, const LineCold *__restrict__ cold,
                                                      const Zone *__restrict__ zones, int ntile, int ngrp, double cut,
                                                      double *__restrict__ sigma, const int4 *__restrict__ ranges)
