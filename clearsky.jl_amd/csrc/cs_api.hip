@@ -78,7 +78,7 @@ struct GasTable {
     std::vector<double> h_nu;
     std::vector<int16_t> h_iso;
     std::vector<int32_t> h_ncheb;
-    DevBuf nu, S, ga, gs, Epp, na, mu, iso, ncheb, cheb;
+    DevBuf nu, S, ga, gs, Epp, na, mu, iso, ncheb, cheb, sref;
     GasDev dev() const
     {
         GasDev g;
@@ -86,6 +86,7 @@ struct GasTable {
         g.nu = nu.as<double>(); g.S = S.as<double>(); g.ga = ga.as<double>(); g.gs = gs.as<double>();
         g.Epp = Epp.as<double>(); g.na = na.as<double>(); g.mu = mu.as<double>();
         g.iso = iso.as<int16_t>(); g.ncheb = ncheb.as<int32_t>(); g.cheb = cheb.as<double>();
+        g.sref = sref.as<double>();
         return g;
     }
 };
@@ -641,7 +642,10 @@ int cs_gas_upload(cs_ctx *ctx, int slot, int64_t L, const double *nu, const doub
     G.na_min = *std::min_element(na, na + L);
     G.na_max = *std::max_element(na, na + L);
     if (!(G.mu_min > 0)) return fail(CS_EINVAL, "isotopologue molar masses must be positive");
+    std::vector<double> sref(L);   // scaleintensity, line_shapes.jl:107-123: the denominator at Tref does not depend on the state
+    for (int64_t j = 0; j < L; j++) sref[j] = S[j] / (std::exp(-kC2 * Epp[j] / kTref) * (1.0 - std::exp(-kC2 * nu[j] / kTref)));
     int rc;
+    if ((rc = upload(G.sref, sref.data(), L, s))) return rc;
     if ((rc = upload(G.nu, nu, L, s)) || (rc = upload(G.S, S, L, s)) || (rc = upload(G.ga, gamma_a, L, s)) ||
         (rc = upload(G.gs, gamma_s, L, s)) || (rc = upload(G.Epp, Epp, L, s)) || (rc = upload(G.na, na, L, s)) ||
         (rc = upload(G.mu, mu_iso, L, s)) || (rc = upload(G.iso, iso, L, s)) || (rc = upload(G.ncheb, ncheb, niso, s)) ||
