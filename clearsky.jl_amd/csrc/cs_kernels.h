@@ -723,6 +723,7 @@ __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu
             const volatile double *tb2 = kFarTable;
             const double q40 = tb2[8], q41 = tb2[9], q42 = tb2[10], q43 = tb2[11], q44 = tb2[12];
             const double q50 = tb2[13], q51 = tb2[14], q52 = tb2[15], q53 = tb2[16], q54 = tb2[17], q55 = tb2[18];
+#pragma unroll 4
             for (int j = LO(z.N0); j < HI(z.N1); j++) {
                 const LineHot h = hk[j];
                 const double dv = v - h.nul;
