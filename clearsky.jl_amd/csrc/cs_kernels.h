@@ -609,7 +609,7 @@ __global__ __launch_bounds__(256) void k_cheb_apply(ChebApply A, int Kpad, int64
             const size_t itv = (size_t)64 << sh;
             const double *__restrict__ Cp = A.Cm[l] + (size_t)T * CS_NC * itv + (size_t)sub * 64 + lane;
             const double *__restrict__ Fp = Fg + (size_t)(A.ioff[l] + T) * CS_NC * Kpad + k0;
-#pragma unroll 2
+#pragma unroll 4   // (2 is 10 % faster on the bench workload but 20-40 % slower on nu-shards and on five levels x four gases)
             for (int m = 0; m < CS_NC; m++) {
                 const double cv = Cp[(size_t)m * itv];
                 const double *__restrict__ fr = Fp + (size_t)m * Kpad;
