@@ -127,7 +127,7 @@ struct ChebGrid {
     DevBuf Cm[CS_MAX_LEVEL];    // [nI][64][itv]
 };
 // per gas on that grid: windows per level, zones [K][nItot], node sums F [nItot][64][Kpad]
-struct GasInterp { int nlev = 0; DevBuf iwin[CS_MAX_LEVEL], iz, F; };
+struct GasInterp { int nlev = 0, l0 = 0; DevBuf iwin[CS_MAX_LEVEL], iz, F; };   // levels l0 .. nlev-1 of the grid are in use
 
 struct ColGas {
     int slot = 0, shape = 0;
@@ -386,7 +386,7 @@ std::vector<double> gamma_bound(const GasTable &G, int K, const double *T, const
 
 // far wings by interpolation (k_cheb_nodes + k_cheb_apply), view handed to launch_gas; nlev = 0: off
 struct Interp {
-    int nlev = 0, nItot = 0, Kpad = 0;
+    int nlev = 0, nItot = 0, Kpad = 0, l0 = 0;
     int itv[CS_MAX_LEVEL], nI[CS_MAX_LEVEL], ioff[CS_MAX_LEVEL];
     const double *nodes = nullptr, *Cm[CS_MAX_LEVEL];
     const WaveWin *iwin[CS_MAX_LEVEL];
@@ -434,12 +434,44 @@ int cheb_build(ChebGrid &g, const double *h_nu, const double *dnu, int64_t nnu, 
 int cheb_kpad(int K) { return (K + CS_KPAD - 1) / CS_KPAD * CS_KPAD; }
 
 // the gas part: per-level interval windows (uploaded) and zone workspace for K states; F workspace of the grid
+// First level worth using for a gas with `lambda` lines per cm^-1 (work per (nu, state) in line evaluations): a level costs
+// ~4.4 evaluations in k_cheb_apply whatever the table, and saves (lines of its set) x (1/r_next - 1/r), r = interval size / 64.
+int choose_l0(const ChebGrid &g, const double *nu, int64_t nnu, double cut, double lambda)
+{
+    const double dnu = (nu[nnu - 1] - nu[0]) / (double)std::max<int64_t>(nnu - 1, 1);
+    int best = g.nlev;
+    double bestc = 1e300;
+    for (int l0 = 0; l0 <= g.nlev; l0++) {
+        double c = 0.0;
+        if (l0 == g.nlev) {
+            c = 1.05 * 2.0 * cut * lambda;   // every pair evaluated directly
+        } else {
+            const double Wtop = g.itv[l0] * dnu;
+            c += std::max(2.0 * cut - 2.3 * Wtop, 0.0) * lambda * 64.0 / g.itv[l0];
+            for (int l = l0 + 1; l < g.nlev; l++) c += 2.3 * (g.itv[l - 1] - g.itv[l]) * dnu * lambda * 64.0 / g.itv[l];
+            c += (2.3 * g.itv[g.nlev - 1] + 64.0) * dnu * lambda * 1.4;   // left to the per-point kernels
+            c += 4.4 * (g.nlev - l0);
+        }
+        if (c < bestc) { bestc = c; best = l0; }
+    }
+    return best;
+}
+
 int gas_interp_build(GasInterp &gi, ChebGrid &g, const std::vector<double> &nul, int64_t g0, int64_t g1,
                      const double *nu, int64_t nnu, double cut, int K, hipStream_t s)
 {
     int rc;
     gi.nlev = g.nlev;
+    gi.l0 = 0;
     if (g.nlev == 0) return CS_OK;
+    {
+        const double span = nu[nnu - 1] - nu[0] + 2.0 * cut;
+        const auto b = std::lower_bound(nul.begin() + g0, nul.begin() + g1, nu[0] - cut);
+        const auto e = std::upper_bound(nul.begin() + g0, nul.begin() + g1, nu[nnu - 1] + cut);
+        gi.l0 = choose_l0(g, nu, nnu, cut, (double)(e - b) / span);
+        if (const char *env = getenv("CLEARSKY_INTERP_L0")) gi.l0 = std::min(std::max(atoi(env), 0), g.nlev);
+        if (gi.l0 >= g.nlev) { gi.nlev = 0; gi.l0 = 0; return CS_OK; }   // too few lines: every pair directly
+    }
     for (int l = 0; l < g.nlev; l++) {
         std::vector<WaveWin> iwin;
         wave_windows(nul, g0, g1, nu, nnu, cut, iwin, g.itv[l]);
@@ -458,6 +490,7 @@ Interp interp_view(const ChebGrid &g, const GasInterp &gi, int K, IZone *iz_over
 {
     Interp v;
     v.nlev = gi.nlev;
+    v.l0 = gi.l0;
     v.nItot = g.nItot;
     v.Kpad = cheb_kpad(K);
     v.nodes = g.nodes.as<double>();
@@ -502,19 +535,21 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
             IzParams P;
             P.nlev = itp.nlev;
             P.nItot = itp.nItot;
+            P.l0 = itp.l0;
             for (int l = 0; l < itp.nlev; l++) { P.itv[l] = itp.itv[l]; P.nI[l] = itp.nI[l]; P.ioff[l] = itp.ioff[l]; P.iwin[l] = itp.iwin[l]; }
-            hipLaunchKernelGGL(k_izones, dim3((unsigned)(((int64_t)itp.nItot * kn + 255) / 256)), dim3(256), 0, s, P, dnu, nnu, kn,
+            hipLaunchKernelGGL(k_izones, dim3((unsigned)(((int64_t)(itp.nItot - itp.ioff[itp.l0]) * kn + 255) / 256)), dim3(256), 0, s, P, dnu, nnu, kn,
                                G.nu.as<double>(), Tk, G.mu_min, G.mu_max, cut, gbound, far_s, itp.iz);
         }
         if (evg) (void)hipEventRecord(evg[0], s);
         if (itp.nlev > 0) {   // sigma = base + extra + interpolated far wings; the per-point kernels add the rest
-            const dim3 gridn((unsigned)((kn + 3) / 4) * (unsigned)itp.nItot);
+            const int q0 = itp.ioff[itp.l0];
+            const dim3 gridn((unsigned)((kn + 3) / 4) * (unsigned)(itp.nItot - q0));
             if (hot32)
                 hipLaunchKernelGGL((k_cheb_nodes<true>), gridn, dim3(256), 0, s, itp.nodes, G.L, hot, hot32, G.nu.as<double>(), itp.iz,
-                                   itp.nItot, kn, itp.Kpad, cut, itp.F);
+                                   itp.nItot, q0, kn, itp.Kpad, cut, itp.F);
             else
                 hipLaunchKernelGGL((k_cheb_nodes<false>), gridn, dim3(256), 0, s, itp.nodes, G.L, hot, hot32, G.nu.as<double>(), itp.iz,
-                                   itp.nItot, kn, itp.Kpad, cut, itp.F);
+                                   itp.nItot, q0, kn, itp.Kpad, cut, itp.F);
             if (evg) (void)hipEventRecord(evg[1], s);
             ChebApply A0;
             ChebApply &A = defer ? *defer : A0;
@@ -526,6 +561,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
                 A.ioff[l] = itp.ioff[l];
                 A.Cm[l] = itp.Cm[l];
             }
+            A.l0[A.ngas] = itp.l0;
             A.F[A.ngas++] = itp.F;
             if (!defer) {   // sigma = base + extra + interpolated far wings now; the per-point kernels add the rest
                 launch_apply(s, A, itp.Kpad, nnu, kn, base, extra, sigma, accumulate);
@@ -1511,7 +1547,12 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
         if (nlev > 0) {
             iz.resize((size_t)K * nItot);
             HIPCHK(hipMemcpy(iz.data(), g.itp.iz.p, iz.size() * sizeof(IZone), hipMemcpyDeviceToHost));
-            for (const IZone &z : iz) nodes += (int64_t)CS_NC * ((z.P0 - z.E0) + (z.Z0 - z.P1) + (z.P2 - z.Z1) + (z.E1 - z.P3));
+            const int q0 = c.cheb.ioff[g.itp.l0];
+            for (int k = 0; k < K; k++)
+                for (int q = q0; q < nItot; q++) {
+                    const IZone &z = iz[(size_t)k * nItot + q];
+                    nodes += (int64_t)CS_NC * ((z.P0 - z.E0) + (z.Z0 - z.P1) + (z.P2 - z.Z1) + (z.E1 - z.P3));
+                }
         }
         int ishift = 0;
         if (nlev > 0) for (int r = c.cheb.itv[nlev - 1] / 64; r > 1; r >>= 1) ishift++;

@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256) void k_cheb_setup(const double *__restrict__ n
 // zones of the interpolation intervals, all levels in one launch.  A thread owns one (state, interval); the four bounds it
 // needs from its parent interval (next larger size) are recomputed rather than read, so there is no order between levels.
 struct IzParams {
-    int nlev, nItot;
+    int nlev, nItot, l0;   // levels l0 .. nlev-1 are in use for this gas (a sparse line table skips the largest intervals)
     int itv[CS_MAX_LEVEL], nI[CS_MAX_LEVEL], ioff[CS_MAX_LEVEL];
     const WaveWin *iwin[CS_MAX_LEVEL];
 };
@@ -469,9 +469,10 @@ __global__ __launch_bounds__(256) void k_izones(IzParams P, const double *__rest
 {
     // zones of all levels live in one array [K][nItot]; level l starts at ioff[l]
     const int idx0 = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx0 >= P.nItot * K) return;
-    const int k = idx0 / P.nItot, q = idx0 - k * P.nItot;
-    int l = 0;
+    const int q0 = P.ioff[P.l0], nq = P.nItot - q0;
+    if (idx0 >= nq * K) return;
+    const int k = idx0 / nq, q = q0 + (idx0 - k * nq);
+    int l = P.l0;
     while (l + 1 < P.nlev && q >= P.ioff[l + 1]) l++;
     const int T = q - P.ioff[l];
     const size_t idx = (size_t)k * P.nItot + q;
@@ -507,7 +508,7 @@ __global__ __launch_bounds__(256) void k_izones(IzParams P, const double *__rest
     // the parent's own set is nested in this one ([E0,E1) grows and [Z0,Z1) shrinks with the interval); clamp it anyway
     z.P0 = z.P1 = z.E0;
     z.P2 = z.P3 = z.E1;
-    if (l > 0) {
+    if (l > P.l0) {
         int pshift = 0;
         for (int r = P.itv[l - 1] / P.itv[l]; r > 1; r >>= 1) pshift++;
         double pvlo, pvhi, pdA;
@@ -526,13 +527,14 @@ __global__ __launch_bounds__(256) void k_izones(IzParams P, const double *__rest
 template <bool MIXED>
 __global__ __launch_bounds__(256) void k_cheb_nodes(const double *__restrict__ nodes, int64_t L, const LineHot *__restrict__ hot,
                                                      const LineF32 *__restrict__ hot32, const double *__restrict__ gnul,
-                                                     const IZone *__restrict__ iz, int nItot, int K, int Kpad, double cut,
+                                                     const IZone *__restrict__ iz, int nItot, int q0, int K, int Kpad, double cut,
                                                      double *__restrict__ F)
 {
-    // 1-D grid (an interval list can exceed the 65535 limit of gridDim.y): block = interval * nsb + state block, state fastest
+    // 1-D grid (an interval list can exceed the 65535 limit of gridDim.y): block = interval * nsb + state block, state fastest;
+    // intervals q0 .. nItot-1 (the levels this gas uses)
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int nsb = (K + 3) >> 2;
-    const int T = (int)(blockIdx.x / nsb);
+    const int T = q0 + (int)(blockIdx.x / nsb);
     const int k = (int)(blockIdx.x % nsb) * 4 + wv;
     if (k >= K) return;
     const LineHot *__restrict__ hk = hot + (size_t)k * L;
@@ -585,6 +587,7 @@ struct ChebApply {
     int ioff[CS_MAX_LEVEL];    // offset of the level in the concatenated interval list
     const double *Cm[CS_MAX_LEVEL];
     const double *F[16];       // node sums of up to CS_MAX_GAS gases: C is read once for all of them
+    int l0[16];                // first level each gas uses
 };
 __global__ __launch_bounds__(256) void k_cheb_apply(ChebApply A, int Kpad, int64_t nnu, int ntile,
                                                      int K, double base, const double *__restrict__ extra,
@@ -603,7 +606,7 @@ __global__ __launch_bounds__(256) void k_cheb_apply(ChebApply A, int Kpad, int64
     for (int q = 0; q < CS_KPAD; q++) acc[q] = 0.0;
     for (int g = 0; g < A.ngas; g++) {   // gas outermost: the column block of C comes from L2 again, sigma is touched once
         const double *__restrict__ Fg = A.F[g];
-        for (int l = 0; l < A.nlev; l++) {
+        for (int l = A.l0[g]; l < A.nlev; l++) {
             const int sh = A.shift[l];
             const int T = tile >> sh, sub = tile & ((1 << sh) - 1);
             const size_t itv = (size_t)64 << sh;
