@@ -130,3 +130,35 @@ def test_more_than_65535_intervals(cs, lines, ctx_on, ctx_off):
     on = cs.shape_batch(sl, "voigt", nu, [250.0], [2e4], [8.0], 25.0, ctx_on)
     off = cs.shape_batch(sl, "voigt", nu, [250.0], [2e4], [8.0], 25.0, ctx_off)
     assert relerr(on, off, floor=1e-250) < 5e-14
+
+
+def test_first_level_choice(cs, lines, monkeypatch):
+    """A gas may skip the largest interval sizes (choose_l0, by line density).  Forcing every possible first level -- including
+    "none" -- gives the same cross-sections; the automatic choice drops levels for the sparse H2O fixture on a fine grid."""
+    nu = np.linspace(1500.0, 1560.0, 30001)          # 0.002 cm^-1: five levels on the grid
+    assert len(cs.interp_plan(nu, 25.0)) == 5
+    P = cs.pressuregrid(10.0, 1e5, 9)
+    T = np.linspace(210.0, 290.0, 9)
+    ref = None
+    for l0 in (None, 0, 1, 3, 4, 5):
+        if l0 is None:
+            monkeypatch.delenv("CLEARSKY_INTERP_L0", raising=False)
+        else:
+            monkeypatch.setenv("CLEARSKY_INTERP_L0", str(l0))
+        ctx = cs.Context(0)
+        col = cs.Column(P, 9.8, T, 0.029, 0.0, 0.0, cs.DirectGas(lines("H2O"), 5e-3, nu), cs.DirectGas(lines("CH4"), 2e-6, nu),
+                        core=cs.Discretized(3, 2), ctx=ctx)
+        col.run()
+        sig, w = col.sigma_nodes(), col.work()
+        ctx.close()
+        if l0 == 5:
+            assert w["node_evals"] == 0                # no level left: every pair evaluated directly
+        if l0 == 0:
+            full = w["node_evals"]
+        if l0 is None:
+            auto = w["node_evals"]
+        if ref is None:
+            ref = sig
+        else:
+            assert relerr(sig, ref, floor=1e-250) < 5e-14, l0
+    assert auto > full > 0          # the sparse tables skip the largest intervals: more node evaluations, fewer matrix passes
