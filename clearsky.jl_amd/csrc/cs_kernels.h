@@ -654,7 +654,9 @@ __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu
     // chip otherwise (a nu-shard of a multi-GPU run, bake on a short grid).
     __shared__ double acc_sh[S > 1 ? 256 : 1];
     __shared__ int4 rng_sh[S > 1 ? 256 : 1];
-    const int tb = tile_block(nblk);
+    // XCD-aware order only without interpolation: then a tile's window spans +-25 cm^-1 of lines and neighbours share them in L2;
+    // with the far wings interpolated the window is a few cm^-1 and the plain order is 3 % faster
+    const int tb = iz ? (int)blockIdx.x : tile_block(nblk);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave-uniform by construction:
     const int tile = tb * (4 / S) + wv / S;                                                      // tell the compiler, so that the
     const int part = wv % S;                                                                     // line records stay scalar loads
