@@ -508,7 +508,13 @@ void launch_apply(hipStream_t s, const ChebApply &A, int Kpad, int64_t nnu, int 
                   int accumulate)
 {
     const int nt64 = (int)((nnu + 63) / 64);
-    hipLaunchKernelGGL(k_cheb_apply, dim3((unsigned)(((nt64 + 3) / 4 + 7) / 8 * 8) * (unsigned)((kn + CS_KPAD - 1) / CS_KPAD)), dim3(256), 0, s, A,
+    const int nsg = (kn + CS_KPAD - 1) / CS_KPAD;
+    if ((int64_t)nt64 * nsg <= 1200) {   // small grid: four waves per (tile, state group), 16 nodes each (0.076 -> 0.040 ms at 784; a tie at 1564, slower beyond)
+        hipLaunchKernelGGL(k_cheb_apply_split, dim3((unsigned)(nt64 * nsg)), dim3(256), 0, s, A, Kpad, nnu, nt64, kn, base, extra, sigma,
+                           accumulate);
+        return;
+    }
+    hipLaunchKernelGGL(k_cheb_apply, dim3((unsigned)(((nt64 + 3) / 4 + 7) / 8 * 8) * (unsigned)nsg), dim3(256), 0, s, A,
                        Kpad, nnu, nt64, kn, base, extra, sigma, accumulate);
 }
 

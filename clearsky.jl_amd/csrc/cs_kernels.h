@@ -633,6 +633,56 @@ __global__ __launch_bounds__(256) void k_cheb_apply(ChebApply A, int Kpad, int64
     }
 }
 
+// The same for small grids (a nu-shard): the four waves of a block share ONE tile x 16 states and take 16 of the 64 nodes
+// each, then add their partial sums through LDS in wave order -- a few hundred tiles would otherwise mean a few hundred
+// waves, each a serial chain of levels x gases x 64 loads.
+__global__ __launch_bounds__(256) void k_cheb_apply_split(ChebApply A, int Kpad, int64_t nnu, int ntile, int K, double base,
+                                                           const double *__restrict__ extra, double *__restrict__ sigma,
+                                                           int accumulate)
+{
+    __shared__ double part[3][CS_KPAD][64];
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int nsg = (K + CS_KPAD - 1) / CS_KPAD;
+    const int tile = (int)(blockIdx.x / nsg);
+    const int k0 = (int)(blockIdx.x % nsg) * CS_KPAD;
+    double acc[CS_KPAD];
+#pragma unroll
+    for (int q = 0; q < CS_KPAD; q++) acc[q] = 0.0;
+    for (int g = 0; g < A.ngas; g++) {
+        const double *__restrict__ Fg = A.F[g];
+        for (int l = A.l0[g]; l < A.nlev; l++) {
+            const int sh = A.shift[l];
+            const int T = tile >> sh, sub = tile & ((1 << sh) - 1);
+            const size_t itv = (size_t)64 << sh;
+            const double *__restrict__ Cp = A.Cm[l] + (size_t)T * CS_NC * itv + (size_t)sub * 64 + lane;
+            const double *__restrict__ Fp = Fg + (size_t)(A.ioff[l] + T) * CS_NC * Kpad + k0;
+#pragma unroll 4
+            for (int m = 16 * wv; m < 16 * wv + 16; m++) {
+                const double cv = Cp[(size_t)m * itv];
+                const double *__restrict__ fr = Fp + (size_t)m * Kpad;
+#pragma unroll
+                for (int q = 0; q < CS_KPAD; q++) acc[q] = __builtin_fma(cv, fr[q], acc[q]);
+            }
+        }
+    }
+    if (wv > 0) {
+#pragma unroll
+        for (int q = 0; q < CS_KPAD; q++) part[wv - 1][q][lane] = acc[q];
+    }
+    __syncthreads();
+    if (wv > 0) return;
+    const int64_t i = (int64_t)tile * 64 + lane;
+    if (i >= nnu) return;
+#pragma unroll
+    for (int q = 0; q < CS_KPAD; q++) {
+        if (k0 + q < K) {
+            const size_t o = (size_t)(k0 + q) * nnu + i;
+            const double prev = accumulate ? sigma[o] : (base + (extra ? extra[o] : 0.0));
+            sigma[o] = prev + (((acc[q] + part[0][q][lane]) + part[1][q][lane]) + part[2][q][lane]);
+        }
+    }
+}
+
 // K2a: far wings.  One wave = 64 consecutive wavenumbers x one node state; its window of lines [W0,W1) (sorted by nul)
 // is cut into wave-uniform segments so that ~90 % of the (nu, line) pairs run a 13-16 instruction branch-free body whose
 // line parameters arrive through scalar loads:
