@@ -583,7 +583,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
         const dim3 grid((unsigned)((nblk + 7) / 8 * 8), kn);   // multiple of 8: XCD-aware tile mapping (tile_block)
         // waves per tile: enough waves to fill 256 CUs x 32 wave slots about 4 times over
         const int64_t nwave = (int64_t)nt64 * kn;
-        const int split = nwave >= 32768 ? 1 : (nwave >= 16384 ? 2 : 4);
+        const int split = nwave >= 16384 ? 1 : (nwave >= 4096 ? 2 : 4);   // (re-tuned with the far wings interpolated: waves are 3x shorter)
         const int nblk_s = (nt64 * split + 3) / 4;
         const dim3 grid_s((unsigned)((nblk_s + 7) / 8 * 8), kn);
 #define CS_FAR_LAUNCH(MIX, SP) hipLaunchKernelGGL((k_voigt_far<MIX, SP>), grid_s, dim3(256), 0, s, dnu, nnu, G.L, hot, hot32, G.nu.as<double>(), \
