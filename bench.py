@@ -10,8 +10,11 @@ wavenumber ranges (strong scaling, configs[3]) and the band fluxes are combined 
 Prints ONE JSON line on rank 0.  See DESIGN.md "Measurement" for the roofline accounting.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,6 +27,17 @@ sys.path.insert(0, _ROOT)
 FLOPS_PER_PAIR = 24.0
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
+
+
+def source_stamp():
+    """sha256 (16 hex digits) of the kernel sources the loaded library was built from: PMC traffic collected offline is only
+    quoted while it belongs to these exact kernels (profiles/pmc_traffic.json carries the stamp of the build it was measured on)."""
+    h = hashlib.sha256()
+    csrc = os.path.join(_ROOT, "clearsky.jl_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -43,16 +57,26 @@ def main():
     ap.add_argument("--cpu-stride", type=int, default=0, help="cpu_baseline evaluates every n-th wavenumber (0 = size the sample for ~15 s)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, as fresh child processes, BEFORE anything
+        # in this process touches the GPU (no exec of a GPU-initialised process), and exit with the launcher's code
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if args.gpus != world:
+        print(f"error: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}", file=sys.stderr)
+        sys.exit(2)
     N = world
 
     import torch
     import clearsky_jl_amd as cs
-    from clearsky_jl_amd import workloads as W
+    import workloads as W
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the HIP path)")
@@ -76,8 +100,11 @@ def main():
     ctx = cs.Context(dev)
     ctx.set_precision(args.precision, args.far_s)
     ctx.set_interp(not args.no_interp)
+    t_setup = time.perf_counter()
     col = cs.Column(cfg["P"], cfg["g"], cfg["T"], cfg["mu"], cfg["fS"], cfg["fa"], *cfg["absorbers"], core=cfg["core"],
                     theta_s=cfg["theta_s"], want_tau=True, want_M=True, nu_range=ranges[rank], ctx=ctx)
+    col.sync()
+    setup_ms = (time.perf_counter() - t_setup) * 1e3   # one-off: closures, windows, interpolation matrices, workspaces, uploads
     # one explicit torch stream carries the kernels, the D2D copy of the band fluxes and the collective, so they are
     # ordered by the stream (torch's default stream has handle 0, which the C ABI reads as "use the context's stream")
     tstream = torch.cuda.Stream(device=dev)
@@ -137,21 +164,30 @@ def main():
     far_ms = prof["far"] / max(ngas, 1)
     alg = float(np.mean(far_bytes)) if far_bytes else 0.0
     achieved = alg / (far_ms * 1e-3) / 1e9 if far_ms > 0 else 0.0
-    traffic = None
-    try:   # PMC traffic is collected offline (rocprofv3 --pmc, separate passes) for this exact workload: profiles/
-        pm = json.load(open(os.path.join(_ROOT, "profiles", "r01_pmc_traffic.json")))
-        if args.config == "C3" and args.nnu is None and args.lines is None and N == 1 and interp_on and args.precision == "fp64":
-            kk = pm["kernels"]["k_voigt_far"]
+    # PMC traffic cannot be collected inside this process (rocprofv3 --pmc wraps the program, FETCH_SIZE and WRITE_SIZE in
+    # separate passes: tools/profile.sh writes profiles/pmc_traffic.json).  It is quoted only when that file was measured on the
+    # kernels loaded now (same source stamp) and on this exact workload; otherwise null -- never a stale number.
+    traffic, traffic_note = None, "no PMC profile of this build/workload under profiles/"
+    try:
+        pm = json.load(open(os.path.join(_ROOT, "profiles", "pmc_traffic.json")))
+        default_wl = args.nnu is None and args.lines is None and N == 1 and interp_on and args.precision == "fp64" and not args.emulate_shard
+        if pm.get("source_sha16") != source_stamp():
+            traffic_note = f"profiles/pmc_traffic.json belongs to build {pm.get('source_sha16')}, loaded kernels are {source_stamp()}"
+        elif pm.get("config") != args.config or not default_wl:
+            traffic_note = "profiles/pmc_traffic.json was measured on another workload"
+        else:
+            kk = pm["kernels"][pm["dominant"]]
             traffic = (kk["FETCH_SIZE_KB"] + kk["WRITE_SIZE_KB"]) * 1024.0
+            traffic_note = pm.get("calibration", "")
     except Exception:
-        traffic = None
+        pass
     # fp64 VALU view of the three line kernels: evaluations actually issued (per-point ones count all 64 lanes of a wave, node
     # ones 64 nodes per (interval, line)) x 24 flops, over their time.  `reference_pair_evals` is what surf! evaluates.
     evals = work["direct_evals"] + work["node_evals"]
     flops = evals * FLOPS_PER_PAIR
     line_ms = prof["nodes"] + prof["far"] + prof["near"]
     roofline = dict(bound="hbm", kernel="k_voigt_far", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=achieved / HBM_PEAK_GBS, traffic=traffic, launches_per_step=ngas, avg_launch_ms=far_ms,
+                    frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_note=traffic_note, launches_per_step=ngas, avg_launch_ms=far_ms,
                     algorithmic_bytes_per_launch=alg,
                     note="elementwise fp64 accumulate over (nu,line) pairs: VALU-bound by construction, see valu_fp64",
                     valu_fp64=dict(achieved=flops / (line_ms * 1e-3) / 1e12 if line_ms > 0 else 0.0, peak=FP64_VALU_PEAK_TFLOPS,
@@ -161,17 +197,52 @@ def main():
                                    kernels="k_cheb_nodes + k_voigt_far + k_voigt_near"),
                     interp_levels=work["levels"], kernel_ms=prof)
 
+    # the drop-in entry point (cs_fluxes_discretized: host pointers in, host arrays out, what the Julia method calls per
+    # radiate!), PCIe-inclusive -- reported beside ms_per_step, never as `value`
+    host_ptr = None
+    if rank == 0 and N == 1 and not args.emulate_shard and not col.baked and not col.U.cia:
+        from clearsky_jl_amd.core import _fluxes_discretized
+        d = cs.Column(cfg["P"], cfg["g"], cfg["T"], cfg["mu"], cfg["fS"], cfg["fa"], *cfg["absorbers"], core=cfg["core"],
+                      theta_s=cfg["theta_s"], ctx=ctx, _setup=False)
+        ctx2 = cs.Context(dev)      # a context of its own: first call = full setup, later calls re-use the resident column
+        ctx2.set_precision(args.precision, args.far_s)
+        ctx2.set_interp(not args.no_interp)
+        d.ctx = ctx2
+        d.slots = np.array([ctx2.slot_of(g_.sl) for g_ in d.gases], dtype=np.int32)
+        def timed(*bufs, reps=1):
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                Fq = _fluxes_discretized(d, *bufs)
+            return (time.perf_counter() - t1) * 1e3 / reps, Fq
+        first, _ = timed(None, None, None)
+        rep_f, Fq = timed(None, None, None, reps=5)
+        tau_h = np.zeros((d.nl, d.nnu), order="F"); Mu_h = np.zeros((d.np, d.nnu), order="F"); Md_h = np.zeros((d.np, d.nnu), order="F")
+        timed(tau_h, Mu_h, Md_h)    # (changes want_tau/want_M: one more setup)
+        rep_all, _ = timed(tau_h, Mu_h, Md_h, reps=3)
+        host_ptr = dict(first_call_ms=first, repeat_band_fluxes_ms=rep_f, repeat_with_tau_M_ms=rep_all,
+                        d2h_bytes_with_tau_M=int(tau_h.nbytes + Mu_h.nbytes + Md_h.nbytes), olr_wm2=float(Fq[0][0]))
+        del tau_h, Mu_h, Md_h
+        ctx2.close()
+
     cpu = None
     if rank == 0 and N == 1 and not args.no_cpu:
         from oracle import oracle as O
         O.use_native_build()
+        cia_data = [cs.readcia(x.x.filename) for x in col.U.cia] if col.U.cia else []
         # calibrate on a thin sample, then size the sample for roughly 15 s of CPU work
         def run_cpu(stride):
             sub = np.ascontiguousarray(nu[::stride])
             t1 = time.perf_counter()
+            extra = None
+            if cia_data:   # CIA continuum of the CPU port: numpy restatement, evaluated at the nodes like the CIA functor
+                extra = np.zeros((col.K, len(sub)))
+                for k in range(col.K):
+                    for ci, x in enumerate(col.U.cia):
+                        extra[k] += O.cia_sigma(cia_data[ci], sub, col.Tk[k], col.Pk[k], col.cia_P1[ci, k], col.cia_P2[ci, k],
+                                                extrapolate=x.x.extrapolate, singles=x.x.singles)
             ref = O.fluxes_discretized(sub, cfg["P"], cfg["g"], cfg["core"].nlobatto, col.Tn, col.mun, col.Tlev,
                                        [g.sl for g in col.gases], [g.shape for g in col.gases], [g.dnu_cut for g in col.gases],
-                                       col.conc, theta_s=cfg["theta_s"], nstream=cfg["core"].nstream)
+                                       col.conc, sigma_extra=extra, theta_s=cfg["theta_s"], nstream=cfg["core"].nstream)
             return sub, ref, time.perf_counter() - t1
         if args.cpu_stride > 0:
             stride = args.cpu_stride
@@ -193,7 +264,8 @@ def main():
                                         f"{len(nu)} wavenumbers x {nl} layers, Voigt, {cfg['lines_kind']} lines "
                                         f"({lines_total} total), Discretized(nstream=5,nlobatto=2)",
                                nnu=len(nu), layers=nl, lines=lines_total, parallelism=f"nu-shard x{N}"),
-                   olr_wm2=olr, roofline=roofline, cpu_baseline=cpu)
+                   olr_wm2=olr, setup_ms=setup_ms, host_pointer_ms=host_ptr, kernel_source_sha16=source_stamp(),
+                   roofline=roofline, cpu_baseline=cpu)
         print(json.dumps(out))
     if N > 1:
         dist.destroy_process_group()

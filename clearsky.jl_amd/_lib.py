@@ -34,6 +34,7 @@ SIGNATURES = {
     "cs_gas_clear": (C.c_int, [_vp, C.c_int]),
     "cs_set_precision": (C.c_int, [_vp, C.c_int, C.c_double]),
     "cs_set_interp": (C.c_int, [_vp, C.c_int]),
+    "cs_set_interp_plan": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int]),
     "cs_shape_batch": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_int64, _dp, C.c_int, _dp, _dp, _dp, _dp,
                                  C.c_int64]),
     "cs_bake": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int64, _dp, C.c_int, _dp, C.c_int, _dp, _dp, _dp]),
@@ -54,8 +55,8 @@ SIGNATURES = {
     "cs_column_profile": (C.c_int, [_vp, _vp, C.c_int, _dp]),
     "cs_column_flux_ptr": (C.c_int, [_vp, C.POINTER(_vp)]),
     "cs_column_flux_to": (C.c_int, [_vp, _vp, _vp]),
-    "cs_column_fetch": (C.c_int, [_vp, _dp, _dp, _dp, _dp, _dp]),
-    "cs_column_sigma_fetch": (C.c_int, [_vp, _dp]),
+    "cs_column_fetch": (C.c_int, [_vp, C.c_int64, C.c_int, _dp, _dp, _dp, _dp, _dp]),
+    "cs_column_sigma_fetch": (C.c_int, [_vp, C.c_int64, C.c_int, _dp]),
     "cs_column_counts": (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "cs_column_work": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
     "cs_interp_plan": (C.c_int, [C.c_int64, _dp, C.c_double, _ip]),

@@ -53,6 +53,7 @@ class CIATables:
     """
 
     def __init__(self, data, extrapolate: bool = False, singles: bool = False, verbose: bool = False):
+        self.filename = data if isinstance(data, str) else None
         if isinstance(data, str):
             data = readcia(data)
         ranges = sorted(set((d["numin"], d["numax"]) for d in data), key=lambda r: r[0])

@@ -242,6 +242,10 @@ class Context:
         """Far wings by Chebyshev interpolation over 256-point intervals (default on); off = every (nu, line) pair."""
         check(lib().cs_set_interp(self._h, int(bool(on))))
 
+    def set_interp_plan(self, first_level: int = -1, size_min: int = 128, size_max: int = 2048):
+        """Tuning: first interval level every gas uses (-1 = by line density) and the range of interval sizes considered."""
+        check(lib().cs_set_interp_plan(self._h, int(first_level), int(size_min), int(size_max)))
+
     def slot_of(self, sl: SpectralLines) -> int:
         """Upload `sl` (once) and return its gas slot."""
         key = id(sl)
@@ -626,13 +630,14 @@ class Column:
     """
 
     def __init__(self, P, g, T, mu, fS, fa, *absorbers, core: Optional[Discretized] = None, theta_s: float = 0.841,
-                 want_tau: bool = True, want_M: bool = True, nu_range=None, ctx: Optional[Context] = None):
+                 want_tau: bool = True, want_M: bool = True, nu_range=None, ctx: Optional[Context] = None, _setup: bool = True):
         self.ctx = ctx or default_context()
         core = core or Discretized()
         U, nu, nnu = unifyabsorbers(absorbers)
         P = as_f64(P)
         assert np.all(np.diff(P) >= 0), "pressure coordinates must be in ascending order (sorted)"
         fT, fmu = formprofile(P, T), formprofile(P, mu)
+        self._fmu = fmu            # kept: update()/run_batch() re-evaluate it at the new (T, P) nodes when no new mu is given
         self.U, self.core, self.P, self.g, self.theta_s = U, core, P, float(g), float(theta_s)
         assert 0 <= theta_s < math.pi / 2, "azimuth angle θ must be ∈ [0,π/2)"
         checkstreams(core.nstream)
@@ -679,7 +684,8 @@ class Column:
         self.want_tau, self.want_M = bool(want_tau), bool(want_M)
         self._set = False
         self._state(fT, fmu)
-        self._setup()
+        if _setup:
+            self._setup()
 
     # -- closures -> arrays ---------------------------------------------------------------------------------------
     def _state(self, fT, fmu):
@@ -748,12 +754,21 @@ class Column:
         if getattr(self.ctx, "_resident", None) is not self:
             self._setup()
 
+    def _require_resident(self, what):
+        """Results live in the context's ONE resident column: reading them after another Column has been set up on the same
+        context would return that column's data (and overrun buffers sized for this one).  Re-running setup here would discard
+        the results, so this is an error."""
+        if getattr(self.ctx, "_resident", None) is not self:
+            raise ClearSkyHIPError(-6, f"{what}: this column is no longer resident on its context (another Column was set up on "
+                                       "it); call run() again, or give each Column its own Context")
+
     def update(self, T, mu=None):
         """New temperature (and molar-mass) profile on the same grid: re-evaluates the closures and uploads the node
         states only (the RCM inner loop, radiative_convective.jl:109-113)."""
         fT = formprofile(self.P, T)
-        fmu = formprofile(self.P, mu) if mu is not None else (lambda *a: self.muk[0])
-        self._state(fT, fmu)
+        if mu is not None:
+            self._fmu = formprofile(self.P, mu)
+        self._state(fT, self._fmu)     # mu=None: the column's own mu (number, profile or mu(T,P)) at the new nodes, discretized.jl:19-27
         if self.sigma_extra is not None or getattr(self.ctx, "_resident", None) is not self:
             self._setup()
             return
@@ -778,7 +793,7 @@ class Column:
         for b in range(B):
             fT = formprofile(self.P, Ts[b])
             mu_b = mus if (mus is None or np.ndim(mus) == 0) else mus[b]
-            fmu = formprofile(self.P, mu_b) if mu_b is not None else (lambda *a: self.muk[0])
+            fmu = formprofile(self.P, mu_b) if mu_b is not None else self._fmu
             Tn, mun = lobattoevaluations(self.P, fT, fmu, nlob)
             Tk = nodevalues(Tn, nlob)
             Tn_all[b], mun_all[b] = Tn.ravel(order="F"), mun.ravel(order="F")
@@ -812,28 +827,32 @@ class Column:
         return dict(prep=ms[0], nodes=ms[1], apply=ms[2], far=ms[3], near=ms[4], rt=ms[5], reduce=ms[6])
 
     def flux_ptr(self) -> int:
+        self._require_resident("flux_ptr")
         p = C.c_void_p()
         check(lib().cs_column_flux_ptr(self.ctx.handle, C.byref(p)))
         return p.value
 
     def flux_to(self, device_ptr: int, stream: int = 0):
         """Async copy of [Fup; Fdn] (2*np doubles) into caller-owned device memory (e.g. a torch tensor's data_ptr())."""
+        self._require_resident("flux_to")
         check(lib().cs_column_flux_to(self.ctx.handle, C.c_void_p(device_ptr), C.c_void_p(stream) if stream else None))
 
     def counts(self):
+        self._require_resident("counts")
         a, b = C.c_int64(), C.c_int64()
         check(lib().cs_column_counts(self.ctx.handle, C.byref(a), C.byref(b)))
         return dict(pair_evals=a.value, lines_in_range=b.value)
 
     def work(self):
         """Evaluations the last run issued for its Voigt gases: per-point, at interpolation nodes; levels in use."""
-        self._ensure_resident()
+        self._require_resident("work")
         out = (C.c_int64 * 4)()
         check(lib().cs_column_work(self.ctx.handle, out))
         return dict(direct_evals=out[0], node_evals=out[1], levels=out[2], intervals=out[3])
 
     def fetch(self, tau=None, Mup=None, Mdn=None):
         """Copy results to host.  Returns (Fup, Fdn); fills the optional Fortran-order matrices in place."""
+        self._require_resident("fetch")
         Fup, Fdn = np.zeros(self.np), np.zeros(self.np)
         bufs = []
         ptrs = []
@@ -846,7 +865,7 @@ class Column:
             b = a if (a.flags["F_CONTIGUOUS"] and a.dtype == np.float64) else np.zeros(a.shape, order="F")
             bufs.append(b)
             ptrs.append(b.ctypes.data_as(C.POINTER(C.c_double)))
-        check(lib().cs_column_fetch(self.ctx.handle, ptrs[0], ptrs[1], ptrs[2], dptr(Fup), dptr(Fdn)))
+        check(lib().cs_column_fetch(self.ctx.handle, self.nnu, self.np, ptrs[0], ptrs[1], ptrs[2], dptr(Fup), dptr(Fdn)))
         for a, b in zip((tau, Mup, Mdn), bufs):
             if a is not None and b is not a:
                 a[...] = b
@@ -854,16 +873,56 @@ class Column:
 
     def sigma_nodes(self):
         """Total cross-section at the nodes, shape (K, nnu) (test hook)."""
+        self._require_resident("sigma_nodes")
         out = np.zeros((self.K, self.nnu))
-        check(lib().cs_column_sigma_fetch(self.ctx.handle, dptr(out)))
+        check(lib().cs_column_sigma_fetch(self.ctx.handle, self.nnu, self.K, dptr(out)))
         return out
+
+
+def _fluxes_discretized(col: "Column", tau, Mup, Mdn):
+    """One call of cs_fluxes_discretized -- the symbol the Julia method monochromaticfluxes!(…, core::HIPDiscretized, …) binds
+    (julia/ClearSkyHIP.jl) -- with the arrays laid out exactly as that ccall passes them: T/mu at the Lobatto nodes
+    [nlobatto, np-1] and conc [ngas, K] column-major, tau/M+/M- column-major [level, nu] or NULL.  `col` only carries the
+    pre-evaluated closures (Column(..., _setup=False)).  Returns (Fup, Fdn)."""
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int)) if len(a) else None
+    fp = lambda a: None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+    for a, rows in ((tau, col.nl), (Mup, col.np), (Mdn, col.np)):
+        if a is not None:
+            assert a.shape == (rows, col.nnu) and a.flags["F_CONTIGUOUS"] and a.dtype == np.float64, \
+                f"expected a Fortran-order float64 array of shape {(rows, col.nnu)}"
+    Fup, Fdn = np.zeros(col.np), np.zeros(col.np)
+    col.ctx._resident = None           # the call replaces (or re-uses) the context's resident column on the C side
+    check(lib().cs_fluxes_discretized(
+        col.ctx.handle, col.nnu, dptr(col.nu), col.np, dptr(col.P), col.g, col.core.nlobatto,
+        dptr(np.asfortranarray(col.Tn).ravel(order="F").copy()), dptr(np.asfortranarray(col.mun).ravel(order="F").copy()),
+        dptr(col.Tlev), len(col.gases), ip(col.slots), ip(col.shapes), dptr(col.cuts) if len(col.cuts) else None,
+        dptr(col.conc.ravel(order="F").copy()) if col.conc.size else None, col.sigma_gray,
+        dptr(col.sigma_extra) if col.sigma_extra is not None else None, dptr(col.S_toa), dptr(col.albedo), col.theta_s,
+        col.core.nstream, fp(tau), fp(Mup), fp(Mdn), dptr(Fup), dptr(Fdn)))
+    return Fup, Fdn
+
+
+def _b3(P, g, T, mu, fS, fa, absorbers, core, theta_s, ctx, tau, Mup, Mdn):
+    """The B3 boundary: columns of line-by-line / gray / function absorbers go through cs_fluxes_discretized (host pointers,
+    what the Julia glue calls); baked Gas objects and CIA pairs need the resident-column calls (cs_column_set_tables/_set_cia)."""
+    direct = Column(P, g, T, mu, fS, fa, *absorbers, core=core, theta_s=theta_s, want_tau=tau is not None,
+                    want_M=Mup is not None or Mdn is not None, ctx=ctx, _setup=False)
+    if not direct.baked and not direct.U.cia:
+        bufs = [None if a is None else (a if (a.flags["F_CONTIGUOUS"] and a.dtype == np.float64) else np.zeros(a.shape, order="F"))
+                for a in (tau, Mup, Mdn)]
+        F = _fluxes_discretized(direct, *bufs)
+        for a, b in zip((tau, Mup, Mdn), bufs):
+            if a is not None and b is not a:
+                a[...] = b
+        return F
+    direct._setup()
+    direct.run()
+    return direct.fetch(tau, Mup, Mdn)
 
 
 def monochromaticfluxes_(Mup, Mdn, tau, core: Discretized, P, g, T, mu, fS, fa, *absorbers, theta_s=0.841, ctx=None):
     """monochromaticfluxes!(M+, M-, tau, core::Discretized, P, g, T, mu, fS, fa, absorbers...; theta_s) fluxes.jl:238-279"""
-    col = Column(P, g, T, mu, fS, fa, *absorbers, core=core, theta_s=theta_s, want_tau=True, want_M=True, ctx=ctx)
-    col.run()
-    col.fetch(tau, Mup, Mdn)
+    _b3(P, g, T, mu, fS, fa, absorbers, core, theta_s, ctx, tau, Mup, Mdn)
     return None
 
 
@@ -880,9 +939,7 @@ def monochromaticfluxes(P, g, T, mu, fS, fa, *absorbers, core: Optional[Discreti
 
 def fluxes(P, g, T, mu, fS, fa, *absorbers, core: Optional[Discretized] = None, theta_s=0.841, ctx=None):
     """fluxes.jl:311-340 -> (F+, F-) [W/m^2] at every level; the nu-integral (intF!, shared.jl:125-137) runs on device."""
-    col = Column(P, g, T, mu, fS, fa, *absorbers, core=core, theta_s=theta_s, want_tau=False, want_M=False, ctx=ctx)
-    col.run()
-    return col.fetch()
+    return _b3(P, g, T, mu, fS, fa, absorbers, core, theta_s, ctx, None, None, None)
 
 
 def netfluxes(P, g, T, mu, fS, fa, *absorbers, **kw):
@@ -895,9 +952,7 @@ def radiate_(F: FluxPack, core: Discretized, P, g, T, mu, fS, fa, *absorbers, th
     """radiate!(F, core, P, g, T, mu, fS, fa, absorbers...) fluxes.jl:357-383"""
     U, nu, nnu = unifyabsorbers(absorbers)
     assert F.size == (len(P), nnu), "size of FluxPack does not match number of pressure or wavenumber coordinates"
-    col = Column(P, g, T, mu, fS, fa, U, core=core, theta_s=theta_s, want_tau=True, want_M=True, ctx=ctx)
-    col.run()
-    Fup, Fdn = col.fetch(F.tau, F.Mup, F.Mdn)
+    Fup, Fdn = _b3(P, g, T, mu, fS, fa, (U,), core, theta_s, ctx, F.tau, F.Mup, F.Mdn)
     F.Fup[:] = Fup
     F.Fdn[:] = Fdn
     F.Fnet[:] = Fup - Fdn

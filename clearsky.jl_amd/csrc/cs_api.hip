@@ -72,6 +72,7 @@ template <class T> int upload(DevBuf &b, const T *h, size_t n, hipStream_t s)
 
 struct GasTable {
     bool present = false;
+    uint64_t generation = 0;   // bumped by every cs_gas_upload into the slot (a resident column's windows belong to one generation)
     int64_t L = 0;
     int niso = 0;
     double mu_min = 0.0, mu_max = 0.0, ga_max = 0.0, gs_max = 0.0, na_min = 0.0, na_max = 0.0;
@@ -136,6 +137,7 @@ struct ColGas {
     DevBuf win, zones, gmax;  // [ntile64] WaveWin, [K][ntile64] Zone, [K] max Lorentz width (Voigt fast path)
     GasInterp itp;            // interpolated far wings (nlev = 0: off)
     int64_t pairs_per_state = 0, lines_in_range = 0, jlo = 0, jhi = 0;
+    uint64_t generation = 0;
 };
 
 struct Column {
@@ -143,6 +145,8 @@ struct Column {
     int64_t nnu = 0;
     int np = 0, nl = 0, nlob = 0, K = 0, nstream = 0, ngas = 0, ntile = 0, rt_bs = 256, rt_nblk = 0;
     bool want_tau = false, want_M = false, has_extra = false, has_S = false, has_alb = false;
+    bool default_wts = false;  // trapezoid weights of the column's own grid (not a shard of a larger one)
+    int interp = 0;            // the context's interpolation settings at setup time (packed)
     double g = 0, sigma_gray = 0, theta_s = 0;
     RtParams rt;
     std::vector<double> h_P, h_Pk, h_xs, h_nu;
@@ -165,7 +169,8 @@ struct cs_ctx {
     CiaDev cia[CS_MAX_CIA];
     Column col;
     int mixed = 0;
-    int interp = 1;   // far wings by Chebyshev interpolation over 256-point intervals (k_voigt_cheb)
+    int interp = 1;   // far wings by Chebyshev interpolation over 128..2048-point intervals (k_cheb_nodes / k_cheb_apply)
+    int itp_first = -1, itp_min = 128, itp_max = 2048;   // cs_set_interp_plan: first level per gas (-1 = by line density), size range
     double far_s = 1e6;
     DevBuf hot32;
     DevBuf tmpA, tmpB, tmpC;
@@ -395,14 +400,11 @@ struct Interp {
 };
 
 // interval sizes worth using on this grid: an interval of width W leaves lines over (2 cut - 2.3 W) to interpolate
-int choose_levels(const double *nu, int64_t nnu, double cut, int *itv)
+int choose_levels(const double *nu, int64_t nnu, double cut, int *itv, int szmin = 128, int szmax = 2048)
 {
     int n = 0;
     if (nnu < 128) return 0;
     const double dnu = (nu[nnu - 1] - nu[0]) / (double)(nnu - 1);
-    int szmax = 2048, szmin = 128;   // debugging knobs: restrict the interval sizes
-    if (const char *e = getenv("CLEARSKY_INTERP_MAX")) szmax = atoi(e);
-    if (const char *e = getenv("CLEARSKY_INTERP_MIN")) szmin = atoi(e);
     for (int sz = 2048; sz >= 128 && n < CS_MAX_LEVEL; sz >>= 1)
         if (sz <= szmax && sz >= szmin && 2.3 * sz * dnu <= 1.5 * cut && sz / 2 <= nnu &&
             sz * dnu > 1e-8 * std::fabs(nu[nnu - 1]))   // (nodes 1e-3 of an interval apart must stay distinct doubles)
@@ -411,9 +413,9 @@ int choose_levels(const double *nu, int64_t nnu, double cut, int *itv)
 }
 
 // the grid part: nodes [nItot][64] and interpolation matrices [nI][64][itv] per level
-int cheb_build(ChebGrid &g, const double *h_nu, const double *dnu, int64_t nnu, double cut, hipStream_t s)
+int cheb_build(const cs_ctx *ctx, ChebGrid &g, const double *h_nu, const double *dnu, int64_t nnu, double cut, hipStream_t s)
 {
-    g.nlev = choose_levels(h_nu, nnu, cut, g.itv);
+    g.nlev = choose_levels(h_nu, nnu, cut, g.itv, ctx->itp_min, ctx->itp_max);
     g.nItot = 0;
     for (int l = 0; l < g.nlev; l++) {
         g.nI[l] = (int)((nnu + g.itv[l] - 1) / g.itv[l]);
@@ -457,7 +459,7 @@ int choose_l0(const ChebGrid &g, const double *nu, int64_t nnu, double cut, doub
     return best;
 }
 
-int gas_interp_build(GasInterp &gi, ChebGrid &g, const std::vector<double> &nul, int64_t g0, int64_t g1,
+int gas_interp_build(const cs_ctx *ctx, GasInterp &gi, ChebGrid &g, const std::vector<double> &nul, int64_t g0, int64_t g1,
                      const double *nu, int64_t nnu, double cut, int K, hipStream_t s)
 {
     int rc;
@@ -469,7 +471,7 @@ int gas_interp_build(GasInterp &gi, ChebGrid &g, const std::vector<double> &nul,
         const auto b = std::lower_bound(nul.begin() + g0, nul.begin() + g1, nu[0] - cut);
         const auto e = std::upper_bound(nul.begin() + g0, nul.begin() + g1, nu[nnu - 1] + cut);
         gi.l0 = choose_l0(g, nu, nnu, cut, (double)(e - b) / span);
-        if (const char *env = getenv("CLEARSKY_INTERP_L0")) gi.l0 = std::min(std::max(atoi(env), 0), g.nlev);
+        if (ctx->itp_first >= 0) gi.l0 = std::min(ctx->itp_first, g.nlev);
         if (gi.l0 >= g.nlev) { gi.nlev = 0; gi.l0 = 0; return CS_OK; }   // too few lines: every pair directly
     }
     for (int l = 0; l < g.nlev; l++) {
@@ -668,7 +670,8 @@ int cs_gas_upload(cs_ctx *ctx, int slot, int64_t L, const double *nu, const doub
     if (L < 1 || niso < 1) return fail(CS_EINVAL, "empty line table");
     for (int64_t j = 1; j < L; j++)
         if (!(nu[j] >= nu[j - 1])) return fail(CS_EORDER, "line table must be sorted by wavenumber (par.jl:267)");
-    if (L > INT32_MAX) return fail(CS_EINVAL, "line table too long");
+    // line indices travel as int32 (windows, zones) and as 26-bit fields of the near-line queue entries (k_voigt_near)
+    if (L >= ((int64_t)1 << 26)) return fail(CS_EINVAL, "line table too long (%lld lines; the limit is 2^26 - 1 per gas)", (long long)L);
     HIPCHK(hipSetDevice(ctx->device));
     GasTable &G = ctx->gas[slot];
     hipStream_t s = ctx->stream;
@@ -695,6 +698,8 @@ int cs_gas_upload(cs_ctx *ctx, int slot, int64_t L, const double *nu, const doub
         return rc;
     HIPCHK(hipStreamSynchronize(s));
     G.present = true;
+    static uint64_t next_generation = 0;
+    G.generation = ++next_generation;
     return CS_OK;
 }
 
@@ -712,6 +717,17 @@ int cs_set_interp(cs_ctx *ctx, int on)
 {
     if (!ctx) return fail(CS_EINVAL, "ctx is NULL");
     ctx->interp = on ? 1 : 0;
+    return CS_OK;
+}
+
+int cs_set_interp_plan(cs_ctx *ctx, int first_level, int size_min, int size_max)
+{
+    if (!ctx) return fail(CS_EINVAL, "ctx is NULL");
+    if (size_min < 128 || size_max > 2048 || size_min > size_max) return fail(CS_EINVAL, "interval sizes must satisfy 128 <= size_min <= size_max <= 2048");
+    if (first_level < -1 || first_level > CS_MAX_LEVEL) return fail(CS_EINVAL, "first_level must be -1 (automatic) or 0..%d", CS_MAX_LEVEL);
+    ctx->itp_first = first_level;
+    ctx->itp_min = size_min;
+    ctx->itp_max = size_max;
     return CS_OK;
 }
 
@@ -769,8 +785,8 @@ int cs_shape_batch(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t nnu
     GasInterp ginterp;
     Interp itp;
     if (ctx->interp && shape == SH_VOIGT) {
-        if ((rc = cheb_build(cheb, nu, dnu.as<double>(), nnu, dnu_cut, s)) ||
-            (rc = gas_interp_build(ginterp, cheb, G.h_nu, g0, g1, nu, nnu, dnu_cut, kc, s)))
+        if ((rc = cheb_build(ctx, cheb, nu, dnu.as<double>(), nnu, dnu_cut, s)) ||
+            (rc = gas_interp_build(ctx, ginterp, cheb, G.h_nu, g0, g1, nu, nnu, dnu_cut, kc, s)))
             return rc;
         itp = interp_view(cheb, ginterp, kc);
     }
@@ -845,8 +861,8 @@ int cs_bake(cs_ctx *ctx, int gas_slot, int table_slot, int shape, double dnu_cut
     GasInterp ginterp;
     Interp itp;
     if (ctx->interp && shape == SH_VOIGT) {
-        if ((rc = cheb_build(cheb, nu, dnu.as<double>(), nnu, dnu_cut, s)) ||
-            (rc = gas_interp_build(ginterp, cheb, G.h_nu, g0, g1, nu, nnu, dnu_cut, kc, s)))
+        if ((rc = cheb_build(ctx, cheb, nu, dnu.as<double>(), nnu, dnu_cut, s)) ||
+            (rc = gas_interp_build(ctx, ginterp, cheb, G.h_nu, g0, g1, nu, nnu, dnu_cut, kc, s)))
             return rc;
         itp = interp_view(cheb, ginterp, kc);
     }
@@ -1140,6 +1156,8 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
     if ((rc = upload(c.nu, nu, nnu, s)) || (rc = upload(c.wts, wt.data(), nnu, s)) || (rc = upload(c.P, P, np, s)) ||
         (rc = upload(c.Pk, c.h_Pk.data(), K, s)))
         return rc;
+    c.default_wts = wts == nullptr;
+    c.interp = ctx->interp * 4096 + (ctx->itp_first + 1) * 256 + (ctx->itp_min >> 7) * 16 + (ctx->itp_max >> 7);   // every interpolation setting of the context
     c.has_extra = sigma_extra != nullptr;
     c.has_S = S_toa != nullptr;
     c.has_alb = albedo != nullptr;
@@ -1157,7 +1175,7 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
                 const double cu = dnu_cuts ? dnu_cuts[gi] : 25.0;
                 cmin = cmin > 0.0 ? std::min(cmin, cu) : cu;
             }
-        if (cmin > 0.0 && (rc = cheb_build(c.cheb, nu, c.nu.as<double>(), nnu, cmin, s))) return rc;
+        if (cmin > 0.0 && (rc = cheb_build(ctx, c.cheb, nu, c.nu.as<double>(), nnu, cmin, s))) return rc;
     }
     size_t maxL = 0;
     for (int gi = 0; gi < ngas; gi++) {
@@ -1167,6 +1185,7 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
         cg.cut = dnu_cuts ? dnu_cuts[gi] : 25.0;
         if (cg.slot < 0 || cg.slot >= CS_MAX_GAS || !ctx->gas[cg.slot].present)
             return fail(CS_EINVAL, "gas slot %d is empty", cg.slot);
+        cg.generation = ctx->gas[cg.slot].generation;
         if (cg.shape < 0 || cg.shape > 3) return fail(CS_EINVAL, "unknown shape %d", cg.shape);
         GasTable &G = ctx->gas[cg.slot];
         int64_t g0, g1;
@@ -1183,7 +1202,7 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
         HIPCHK(cg.zones.reserve((size_t)c.K * win.size() * sizeof(Zone)));
         HIPCHK(cg.gmax.reserve((size_t)c.K * sizeof(double)));
         if (c.cheb.nlev > 0 && cg.shape == SH_VOIGT &&
-            (rc = gas_interp_build(cg.itp, c.cheb, G.h_nu, g0, g1, nu, nnu, cg.cut, c.K, s)))
+            (rc = gas_interp_build(ctx, cg.itp, c.cheb, G.h_nu, g0, g1, nu, nnu, cg.cut, c.K, s)))
             return rc;
         maxL = std::max(maxL, (size_t)G.L);
     }
@@ -1486,10 +1505,13 @@ static int fetch_transposed(cs_ctx *ctx, const double *dsrc, int R, int64_t Cn, 
     return CS_OK;
 }
 
-int cs_column_fetch(cs_ctx *ctx, double *tau, double *Mup, double *Mdn, double *Fup, double *Fdn)
+int cs_column_fetch(cs_ctx *ctx, int64_t nnu, int np, double *tau, double *Mup, double *Mdn, double *Fup, double *Fdn)
 {
     if (!ctx || !ctx->col.ready) return fail(CS_ESTATE, "no resident column");
     Column &c = ctx->col;
+    if (nnu != c.nnu || np != c.np)   // the caller's buffers were sized for another column: refuse rather than overrun them
+        return fail(CS_ESTATE, "resident column is %lld wavenumbers x %d levels, caller expects %lld x %d (another column was set up on this context)",
+                    (long long)c.nnu, c.np, (long long)nnu, np);
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipDeviceSynchronize());
     int rc;
@@ -1502,10 +1524,13 @@ int cs_column_fetch(cs_ctx *ctx, double *tau, double *Mup, double *Mdn, double *
     return CS_OK;
 }
 
-int cs_column_sigma_fetch(cs_ctx *ctx, double *sigma)
+int cs_column_sigma_fetch(cs_ctx *ctx, int64_t nnu, int K, double *sigma)
 {
     if (!ctx || !ctx->col.ready || !sigma) return fail(CS_ESTATE, "no resident column");
     Column &c = ctx->col;
+    if (nnu != c.nnu || K != c.K)
+        return fail(CS_ESTATE, "resident column is %lld wavenumbers x %d node states, caller expects %lld x %d", (long long)c.nnu, c.K,
+                    (long long)nnu, K);
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(sigma, c.sigma.p, (size_t)c.K * c.nnu * sizeof(double), hipMemcpyDeviceToHost));
@@ -1530,7 +1555,7 @@ int cs_column_counts(cs_ctx *ctx, int64_t *pair_evals, int64_t *lines_in_range)
 int cs_interp_plan(int64_t nnu, const double *nu, double dnu_cut, int *interval_sizes)
 {
     if (!nu || nnu < 1 || !interval_sizes) return fail(CS_EINVAL, "bad arguments");
-    return choose_levels(nu, nnu, dnu_cut, interval_sizes);
+    return choose_levels(nu, nnu, dnu_cut, interval_sizes);   // (default size range; a context's cs_set_interp_plan may narrow it)
 }
 
 int cs_column_work(cs_ctx *ctx, int64_t *out)
@@ -1583,18 +1608,56 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
     return CS_OK;
 }
 
+// true when the resident column was set up for exactly this grid, pressure levels, rule orders and gas line-up: only the
+// thermal state and the per-call spectra differ, so a call can skip the window / interpolation-matrix / workspace setup
+static bool column_matches(cs_ctx *ctx, int64_t nnu, const double *nu, int np, const double *P, double g, int nlobatto, int ngas,
+                           const int *gas_slots, const int *shapes, const double *dnu_cuts, double sigma_gray, double theta_s,
+                           int nstream, bool want_tau, bool want_M)
+{
+    const Column &c = ctx->col;
+    if (!c.ready || !c.default_wts || c.interp != ctx->interp * 4096 + (ctx->itp_first + 1) * 256 + (ctx->itp_min >> 7) * 16 + (ctx->itp_max >> 7) || !c.tab.empty() || !c.cia.empty()) return false;
+    if (c.nnu != nnu || c.np != np || c.nlob != nlobatto || c.nstream != nstream || c.ngas != ngas) return false;
+    if (c.g != g || c.sigma_gray != sigma_gray || c.theta_s != theta_s) return false;
+    if (c.want_tau != want_tau || c.want_M != want_M) return false;
+    for (int gi = 0; gi < ngas; gi++) {
+        const ColGas &cg = c.gas[gi];
+        if (cg.slot != gas_slots[gi] || cg.shape != (shapes ? shapes[gi] : CS_SHAPE_VOIGT) || cg.cut != (dnu_cuts ? dnu_cuts[gi] : 25.0)) return false;
+        if (gas_slots[gi] < 0 || gas_slots[gi] >= CS_MAX_GAS || !ctx->gas[cg.slot].present || ctx->gas[cg.slot].generation != cg.generation) return false;
+    }
+    return memcmp(c.h_nu.data(), nu, (size_t)nnu * sizeof(double)) == 0 && memcmp(c.h_P.data(), P, (size_t)np * sizeof(double)) == 0;
+}
+
 int cs_fluxes_discretized(cs_ctx *ctx, int64_t nnu, const double *nu, int np, const double *P, double g, int nlobatto,
                           const double *T_nodes, const double *mu_nodes, const double *T_levels, int ngas,
                           const int *gas_slots, const int *shapes, const double *dnu_cuts, const double *conc,
                           double sigma_gray, const double *sigma_extra, const double *S_toa, const double *albedo,
                           double theta_s, int nstream, double *tau, double *Mup, double *Mdn, double *Fup, double *Fdn)
 {
-    int rc = cs_column_setup(ctx, nnu, nu, nullptr, np, P, g, nlobatto, T_nodes, mu_nodes, T_levels, ngas, gas_slots,
+    if (!ctx) return fail(CS_EINVAL, "ctx is NULL");
+    if (!nu || !P || nnu < 1 || np < 2) return fail(CS_EINVAL, "bad grid arguments");
+    int rc;
+    // radiate! is called once per time step / Jacobian column on an unchanged grid (radiative_convective.jl:109-171): keep the
+    // column of the previous call resident and refresh only what a call can change -- node states, fS, fa, sigma_extra
+    if (column_matches(ctx, nnu, nu, np, P, g, nlobatto, ngas, gas_slots, shapes, dnu_cuts, sigma_gray, theta_s, nstream,
+                       tau != nullptr, Mup || Mdn)) {
+        Column &c = ctx->col;
+        HIPCHK(hipSetDevice(ctx->device));
+        hipStream_t s = ctx->stream;
+        c.has_extra = sigma_extra != nullptr;
+        c.has_S = S_toa != nullptr;
+        c.has_alb = albedo != nullptr;
+        if (c.has_extra && (rc = upload(c.extra, sigma_extra, (size_t)nnu * c.K, s))) return rc;
+        if (c.has_S && (rc = upload(c.S_toa, S_toa, nnu, s))) return rc;
+        if (c.has_alb && (rc = upload(c.albedo, albedo, nnu, s))) return rc;
+        if ((rc = cs_column_update_state(ctx, T_nodes, mu_nodes, T_levels, conc, nullptr))) return rc;
+    } else {
+        rc = cs_column_setup(ctx, nnu, nu, nullptr, np, P, g, nlobatto, T_nodes, mu_nodes, T_levels, ngas, gas_slots,
                              shapes, dnu_cuts, conc, sigma_gray, sigma_extra, S_toa, albedo, theta_s, nstream,
                              tau != nullptr, (Mup || Mdn) ? 1 : 0);
-    if (rc) return rc;
+        if (rc) return rc;
+    }
     if ((rc = cs_column_run(ctx, nullptr))) return rc;
-    return cs_column_fetch(ctx, tau, Mup, Mdn, Fup, Fdn);
+    return cs_column_fetch(ctx, nnu, np, tau, Mup, Mdn, Fup, Fdn);
 }
 
 namespace {

@@ -851,7 +851,8 @@ __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu
 // (continued fraction for 100 <= s < 1e3, trapezoid + pole correction for s < 100) run with full lanes instead of
 // once per "deepest" lane -- then every lane sums its own results in ascending line order (deterministic).
 #define CS_NEAR_Q 256  // queue entries per wave; longer candidate lists go through the queue in windows
-#define CS_NEAR_R 1    // consecutive 64-point tiles per wave (2 and 4 fill the 64-wide trips better but measured slower: 0.47-0.58 vs 0.45 ms)
+#define CS_NEAR_R 1    // consecutive 64-point tiles per wave (2 and 4 fill the 64-wide trips better but measured slower: 0.47-0.58 vs 0.45 ms;
+static_assert(CS_NEAR_R == 1, "queue entries carry no sub-tile field");   //  a sub-tile field would have to come out of the 26 line-index bits)
 // candidates of lane l: for r = 0..R-1 the lines [lo[r], hi[r]) (absolute indices) against wavenumber (tile0 + r) * 64 + l
 template <int TIER>  // 0: 100 <= s < 1e3 (fad_mid), 1: s < 100 (fad_near)
 __device__ __forceinline__ void near_pass(const double *__restrict__ nu, int64_t nnu, int tile0, const int (&lo)[CS_NEAR_R],
@@ -878,7 +879,7 @@ __device__ __forceinline__ void near_pass(const double *__restrict__ nu, int64_t
         for (int r = 0; r < CS_NEAR_R; r++) {
             const int o = off + pre[r] - base;   // queue position of this sub-tile's first candidate
             const int c0 = max(-o, 0), c1 = min(CS_NEAR_Q - o, hi[r] - lo[r]);
-            for (int c = c0; c < c1; c++) qidx[o + c] = ((unsigned)lane << 26) | ((unsigned)r << 24) | (unsigned)(lo[r] + c);
+            for (int c = c0; c < c1; c++) qidx[o + c] = ((unsigned)lane << 26) | (unsigned)(lo[r] + c);   // 6 + 26 bits: cs_gas_upload rejects L >= 2^26
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -891,10 +892,10 @@ __device__ __forceinline__ void near_pass(const double *__restrict__ nu, int64_t
         double vn = 0.0;
         auto fetch = [&](int p) {
             en = qidx[p];
-            const int j = (int)(en & 0xffffffu);
+            const int j = (int)(en & 0x3ffffffu);
             hn = hk[j];
             cn = ck[j];
-            const int64_t i = (int64_t)(tile0 + (int)((en >> 24) & 3u)) * 64 + (int)(en >> 26);
+            const int64_t i = (int64_t)tile0 * 64 + (int)(en >> 26);
             vn = nu[i < nnu ? i : nnu - 1];
         };
         if (lane < nwin) fetch(lane);

@@ -8,7 +8,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import clearsky_jl_amd as cs
-from clearsky_jl_amd import workloads as W
+import workloads as W
 
 H = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "hitran")
 nu = np.linspace(1.0, 2500.0, 100_000)                       # wavenumber grid [cm^-1]

@@ -84,6 +84,11 @@ int cs_set_precision(cs_ctx *ctx, int mode, double far_s);
  * Applies to every later cs_shape_batch / cs_bake / cs_column_setup of the context.
  */
 int cs_set_interp(cs_ctx *ctx, int on);
+/* Tuning of the interpolation plan (defaults: -1, 128, 2048): `first_level` forces the first (largest) interval level every
+ * gas uses -- 0 = all levels of the grid, n = skip the n largest, >= the number of levels = none (every pair evaluated
+ * directly), -1 = chosen per gas from its line density; [size_min, size_max] restricts the interval sizes considered.
+ * Results do not depend on the plan beyond rounding (tests/test_gpu_interp.py); it only moves work between kernels. */
+int cs_set_interp_plan(cs_ctx *ctx, int first_level, int size_min, int size_max);
 
 /*
  * B1: batched in-place line shape.  For every state k:  sigma[k*ld_state + i] = shape(nu[i]; T[k], P[k], Pp[k]).
@@ -155,8 +160,10 @@ int cs_fluxes_discretized(cs_ctx *ctx, int64_t nnu, const double *nu, int np, co
  *   cs_column_run    enqueues the kernels on `stream` (a hipStream_t, NULL = the context's stream); asynchronous;
  *                    results stay in HBM;
  *   cs_column_flux_ptr  device address of [2*np] doubles (Fup then Fdn) for an in-place RCCL all-reduce;
- *   cs_column_fetch  synchronises and copies results to host (NULL = skip), layouts as in cs_fluxes_discretized;
- *   cs_column_sigma_fetch  copies the total cross-section at the nodes, [nnu, K] nu-fastest (test hook);
+ *   cs_column_fetch  synchronises and copies results to host (NULL = skip), layouts as in cs_fluxes_discretized; nnu and np
+ *                    are the sizes the caller's buffers were allocated for -- CS_ESTATE if the resident column differs
+ *                    (a context holds ONE resident column; a later cs_column_setup replaces it);
+ *   cs_column_sigma_fetch  copies the total cross-section at the nodes, [nnu, K] nu-fastest (test hook), same size check;
  *   cs_column_counts line-shape evaluations of one run (sum over nu, node, gas of lines inside the cut-off).
  */
 int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wts, int np, const double *P,
@@ -181,8 +188,8 @@ int cs_column_profile(cs_ctx *ctx, void *stream, int reps, double *ms);
 int cs_column_flux_ptr(cs_ctx *ctx, double **dF);
 /* asynchronously copy the [2*np] band fluxes (Fup then Fdn) into caller-owned DEVICE memory on `stream` */
 int cs_column_flux_to(cs_ctx *ctx, double *dst_device, void *stream);
-int cs_column_fetch(cs_ctx *ctx, double *tau, double *Mup, double *Mdn, double *Fup, double *Fdn);
-int cs_column_sigma_fetch(cs_ctx *ctx, double *sigma);
+int cs_column_fetch(cs_ctx *ctx, int64_t nnu, int np, double *tau, double *Mup, double *Mdn, double *Fup, double *Fdn);
+int cs_column_sigma_fetch(cs_ctx *ctx, int64_t nnu, int K, double *sigma);
 int cs_column_counts(cs_ctx *ctx, int64_t *pair_evals, int64_t *lines_in_range);
 /* line-shape evaluations the last cs_column_run actually issued for its Voigt gases (measurement hook): out[0] = per-point
  * evaluations of k_voigt_far/k_voigt_near (64 lanes x lines per wave), out[1] = node evaluations of k_cheb_nodes,

@@ -17,7 +17,7 @@ def _worker(rank, world, port, q):
     import torch
     import torch.distributed as dist
     import clearsky_jl_amd as cs
-    from clearsky_jl_amd import workloads as W
+    import workloads as W
     from oracle import oracle as O
     dist.init_process_group("gloo", rank=rank, world_size=world)
     cfg = W.config("C2", nnu=1200, nl=10)

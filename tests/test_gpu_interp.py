@@ -6,6 +6,8 @@ on grids chosen so that 1..5 interval levels are active, intervals are ragged, t
 Tolerance: 1e-11 vs the oracle (the repo-wide cross-section tolerance), 5e-14 on/off (interpolation error proper;
 1.3e-14 observed with five levels stacked).
 """
+import math
+
 import numpy as np
 import pytest
 
@@ -106,7 +108,11 @@ def test_column_interp_on_off(cs, lines):
     assert won["direct_evals"] + won["node_evals"] < 0.6 * woff["direct_evals"]
     assert relerr(Fon.tau, Foff.tau) < 5e-14
     sm = Foff.Mup.max()
-    assert np.max(np.abs(Fon.Mup - Foff.Mup)) < 3e-12 * sm and np.max(np.abs(Fon.Mdn - Foff.Mdn)) < 3e-12 * sm   # exp(-tau), tau ~ 1e2
+    # tau agrees to 5e-14 relative (above).  A relative change e of one layer's tau changes its transmission exp(-tau m) by
+    # e * (tau m) exp(-tau m) <= e / e_euler, and the linear-in-tau source term by as much again; an intensity crosses nl = 20
+    # layers, so |dM| <= 2 * nl / e_euler * 5e-14 * max M = 7.4e-13 * max M  (observed: 1.1e-13)
+    bound = 2 * col.nl / math.e * 5e-14 * sm
+    assert np.max(np.abs(Fon.Mup - Foff.Mup)) < bound and np.max(np.abs(Fon.Mdn - Foff.Mdn)) < bound
     assert relerr(Fon.Fup, Foff.Fup) < 1e-13
     for a, b in zip(Bon, Boff):
         assert relerr(np.asarray(a), np.asarray(b), floor=1e-9) < 1e-13
@@ -132,7 +138,7 @@ def test_more_than_65535_intervals(cs, lines, ctx_on, ctx_off):
     assert relerr(on, off, floor=1e-250) < 5e-14
 
 
-def test_first_level_choice(cs, lines, monkeypatch):
+def test_first_level_choice(cs, lines):
     """A gas may skip the largest interval sizes (choose_l0, by line density).  Forcing every possible first level -- including
     "none" -- gives the same cross-sections; the automatic choice drops levels for the sparse H2O fixture on a fine grid."""
     nu = np.linspace(1500.0, 1560.0, 30001)          # 0.002 cm^-1: five levels on the grid
@@ -141,11 +147,8 @@ def test_first_level_choice(cs, lines, monkeypatch):
     T = np.linspace(210.0, 290.0, 9)
     ref = None
     for l0 in (None, 0, 1, 3, 4, 5):
-        if l0 is None:
-            monkeypatch.delenv("CLEARSKY_INTERP_L0", raising=False)
-        else:
-            monkeypatch.setenv("CLEARSKY_INTERP_L0", str(l0))
         ctx = cs.Context(0)
+        ctx.set_interp_plan(first_level=-1 if l0 is None else l0)
         col = cs.Column(P, 9.8, T, 0.029, 0.0, 0.0, cs.DirectGas(lines("H2O"), 5e-3, nu), cs.DirectGas(lines("CH4"), 2e-6, nu),
                         core=cs.Discretized(3, 2), ctx=ctx)
         col.run()

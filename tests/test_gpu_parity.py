@@ -142,7 +142,7 @@ def test_column_co2_vs_golden(cs, golden, lines, ctx, name):
 def test_column_two_gases_vs_oracle(cs, O, lines, ctx, nlob, ns):
     """H2O + CO2 on the reference's fixtures with a function absorber, stellar beam and albedo: every output of
     monochromaticfluxes!/radiate! (tau, M+, M-, F+, F-) against the oracle."""
-    from clearsky_jl_amd import workloads as W
+    import workloads as W
     nu = np.linspace(1.0, 2500.0, 3001)
     P = cs.pressuregrid(1.0, 1e5, 13)
     T = W.earth_temperature(P)
@@ -200,7 +200,7 @@ def test_opticaldepth_and_transmittance(cs, O, lines, ctx):
 
 def test_c2_full_parity_vs_oracle(cs, O, ctx):
     """BASELINE configs[1] at full size: CO2 fixture, 1e4 wavenumbers x 40 layers -- every output against the oracle."""
-    from clearsky_jl_amd import workloads as W
+    import workloads as W
     cfg = W.config("C2")
     F = cs.radiate(cfg["P"], cfg["g"], cfg["T"], cfg["mu"], cfg["fS"], cfg["fa"], *cfg["absorbers"], core=cfg["core"], ctx=ctx)
     col = cs.Column(cfg["P"], cfg["g"], cfg["T"], cfg["mu"], cfg["fS"], cfg["fa"], *cfg["absorbers"], core=cfg["core"],
@@ -215,7 +215,7 @@ def test_c2_full_parity_vs_oracle(cs, O, ctx):
 
 @pytest.fixture(scope="module")
 def c3(cs, ctx):
-    from clearsky_jl_amd import workloads as W
+    import workloads as W
     cfg = W.config("C3")
     col = cs.Column(cfg["P"], cfg["g"], cfg["T"], cfg["mu"], cfg["fS"], cfg["fa"], *cfg["absorbers"], core=cfg["core"],
                     theta_s=cfg["theta_s"], ctx=ctx)
@@ -253,7 +253,7 @@ def test_c3_deterministic_and_shards_add_up(cs, c3, ctx):
     col.run()
     F2 = col.fetch()
     assert np.array_equal(F2[0], F.Fup) and np.array_equal(F2[1], F.Fdn)        # fixed-order reductions: bitwise repeatable
-    from clearsky_jl_amd import workloads as W
+    import workloads as W
     tot = np.zeros(2 * col.np)
     for r in W.balanced_ranges(cfg["nu"], cfg["absorbers"], 4):
         sh = cs.Column(cfg["P"], cfg["g"], cfg["T"], cfg["mu"], cfg["fS"], cfg["fa"], *cfg["absorbers"], core=cfg["core"],
@@ -282,7 +282,7 @@ def test_update_state_matches_fresh_setup(cs, lines, ctx):
 def test_c5_reduced_vs_oracle(cs, O):
     """BASELINE configs[4] physics at reduced size (4 gases incl. synthetic O3 + both CIA pairs, 100 layers, 3000 wavenumbers):
     fp64 outputs vs the oracle fed with the numpy CIA restatement."""
-    from clearsky_jl_amd import workloads as W
+    import workloads as W
     ctx = cs.Context(0)
     cfg = W.config("C5", nnu=3000)
     col = cs.Column(cfg["P"], cfg["g"], cfg["T"], cfg["mu"], 0.0, 0.0, *cfg["absorbers"], core=cfg["core"], ctx=ctx)
@@ -305,7 +305,7 @@ def test_c5_reduced_vs_oracle(cs, O):
 def test_mixed_precision_variant(cs, O, lines):
     """BASELINE configs[4]: fp32 far wings.  Cross-sections within 1e-6 of the fp64 path and of the oracle (north-star
     tolerance), OLR within 1e-5 W/m^2; widening the fp64 region (far_s) tightens the agreement; fp64 mode is untouched."""
-    from clearsky_jl_amd import workloads as W
+    import workloads as W
     ctx = cs.Context(0)
     cfg = W.config("C2", nnu=4000, nl=20)
     def run():
@@ -336,7 +336,7 @@ def test_mixed_precision_variant(cs, O, lines):
 def test_batched_columns_match_sequential(cs, lines):
     """cs_column_batch (the np+1 perturbed profiles of jacobian!, radiative_convective.jl:154-171): one device batch == the same
     profiles evaluated one after the other on the resident column (summation grouping may differ: 1e-13)."""
-    from clearsky_jl_amd import workloads as W
+    import workloads as W
     ctx = cs.Context(0)
     nu = np.linspace(400.0, 1100.0, 3000)
     P = cs.pressuregrid(5.0, 1e5, 16)

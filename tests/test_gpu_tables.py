@@ -74,7 +74,7 @@ def test_zero_row_scrub(cs, O, lines, ctx):
 @pytest.mark.parametrize("nlob", [2, 3])
 def test_column_with_baked_and_direct_gases(cs, O, lines, baked, ctx, nlob):
     """radiate! with a baked CO2 Gas + a direct H2O gas vs the oracle fed with the numpy-interpolated cross-sections."""
-    from clearsky_jl_amd import workloads as W
+    import workloads as W
     nu, Om, g, ref = baked
     h2o = cs.DirectGas(lines("H2O"), W.fC_h2o, nu)
     P = cs.pressuregrid(2.0, 1e5, 11)

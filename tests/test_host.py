@@ -157,7 +157,7 @@ def test_absorber_validation(cs, lines):
 
 
 def test_balanced_ranges(cs):
-    from clearsky_jl_amd import workloads as W
+    import workloads as W
     cfg = W.config("C2", nnu=3000)
     for n in (1, 2, 3, 8):
         r = W.balanced_ranges(cfg["nu"], cfg["absorbers"], n)

@@ -3,7 +3,7 @@ import ctypes as C, math, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import clearsky_jl_amd as cs
-from clearsky_jl_amd import workloads as W
+import workloads as W
 from clearsky_jl_amd._lib import lib, dptr, check
 
 cfg = W.config("C3")

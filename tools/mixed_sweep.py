@@ -4,7 +4,7 @@ import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import clearsky_jl_amd as cs
-from clearsky_jl_amd import workloads as W
+import workloads as W
 
 cfg = W.config(sys.argv[1] if len(sys.argv) > 1 else "C3")
 ctx = cs.Context(0)

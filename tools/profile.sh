@@ -12,9 +12,14 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $root/bench.py --steps 10 --warmup 2 --no-cpu "$@" > $out/stats.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu "$@" > $out/fetch.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu "$@" > $out/write.log 2>&1
-python3 - "$out" <<'PY'
-import csv, glob, sys, collections
-out = sys.argv[1]
+cd $root
+python3 - "$out" "$tag" "$@" <<'PY'
+import csv, glob, json, sys, collections
+sys.path.insert(0, ".")
+import bench
+out, tag, bargs = sys.argv[1], sys.argv[2], sys.argv[3:]
+traffic = dict(tag=tag, source_sha16=bench.source_stamp(), config=(bargs[bargs.index("--config") + 1] if "--config" in bargs else "C3"),
+               bench_args=bargs, units="KB per dispatch (mean over dispatches); FETCH_SIZE and WRITE_SIZE in separate passes", kernels={})
 for f in glob.glob(out + "/stats/**/*kernel_stats.csv", recursive=True):
     print(open(f).read())
 for name in ("fetch", "write"):
@@ -27,5 +32,17 @@ for name in ("fetch", "write"):
         fo.write("kernel,launches,avg_KB_per_launch\n")
         for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             fo.write(f"\"{k}\",{n},{v / n:.1f}\n")
+            if k.startswith(("void csdev::", "csdev::")):
+                kk = k.replace("void ", "").replace("csdev::", "")
+                traffic["kernels"].setdefault(kk, {})[("FETCH" if name == "fetch" else "WRITE") + "_SIZE_KB"] = round(v / n, 1)
     print(open(f"{out}/pmc_{name}_summary.csv").read())
+# dominant kernel = the one with the largest total time in the kernel trace
+best = ("", 0.0)
+for f in glob.glob(out + "/stats/**/*kernel_stats.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "csdev::" in r["Name"] and float(r["TotalDurationNs"]) > best[1]:
+            best = (r["Name"].split("(")[0].replace("void ", "").replace("csdev::", ""), float(r["TotalDurationNs"]))
+traffic["dominant"] = best[0]
+json.dump(traffic, open(out + "/pmc_traffic.json", "w"), indent=1)
+print(json.dumps(traffic)[:600])
 PY

@@ -1,14 +1,16 @@
-"""Synthetic inputs of the BASELINE.json configurations (SURVEY.md 8d "Concrete synthetic inputs")."""
+"""Synthetic inputs of the BASELINE.json configurations (SURVEY.md 8d "Concrete synthetic inputs").
+
+Bench / test support, not part of the product package: it reads the HITRAN fixture files under tests/golden/hitran and is
+imported by bench.py, tests/ and tools/ only.
+"""
 import os
 
 import numpy as np
 
-from . import constants as K
-from .cia import CIATables
-from .core import DirectGas, Discretized, GrayGas, ozonelayer, pressuregrid, psatH2O
-from .hitran import SpectralLines
+from clearsky_jl_amd import constants as K
+from clearsky_jl_amd import CIATables, DirectGas, Discretized, GrayGas, SpectralLines, ozonelayer, pressuregrid, psatH2O
 
-_HITRAN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "hitran")
+_HITRAN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "hitran")
 
 
 def fixture(name: str) -> str:
@@ -39,9 +41,11 @@ def lines(kind: str, which: str):
     return _cache[key]
 
 
-def config(name: str, nnu=None, nl=None, lines_kind=None):
+def config(name: str, nnu=None, nl=None, lines_kind=None, nu_span=(1.0, 2500.0)):
     """Returns dict(P, g, T, mu, fS, fa, absorbers, core, theta_s, nu) for
-    "C2" CO2 fixture, 1e4 nu x 40 layers;  "C3" H2O+CO2, 1e5 nu x 60 layers (synthetic ~1e5-line table by default)."""
+    "C2" CO2 fixture, 1e4 nu x 40 layers;  "C3" H2O+CO2, 1e5 nu x 60 layers (synthetic ~1e5-line table by default);
+    "C5" H2O+CO2+CH4+O3 + CIA, 5e5 nu x 100 layers.  `nu_span` cuts a window out of the 1..2500 cm^-1 grid (parity tests at
+    the full grid's spacing on a grid small enough for the CPU checker)."""
     if name == "C2":
         nnu, nl, lines_kind = nnu or 10_000, nl or 40, lines_kind or "fixture"
         gases = ["CO2"]
@@ -55,7 +59,7 @@ def config(name: str, nnu=None, nl=None, lines_kind=None):
         gases = ["H2O", "CO2", "CH4", "O3"]
     else:
         raise ValueError(name)
-    nu = np.linspace(1.0, 2500.0, nnu)
+    nu = np.linspace(float(nu_span[0]), float(nu_span[1]), nnu)
     P = pressuregrid(1.0, 1e5, nl + 1)
     T = earth_temperature(P)
     absorbers = []
