@@ -510,6 +510,7 @@ void launch_apply(hipStream_t s, const ChebApply &A, int Kpad, int64_t nnu, int 
                   int accumulate)
 {
     const int nt64 = (int)((nnu + 63) / 64);
+#ifdef CS_APPLY_VALU   // the vector-unit version (kept for A/B builds)
     const int nsg = (kn + CS_KPAD - 1) / CS_KPAD;
     if ((int64_t)nt64 * nsg <= 1200) {   // small grid: four waves per (tile, state group), 16 nodes each (0.076 -> 0.040 ms at 784; a tie at 1564, slower beyond)
         hipLaunchKernelGGL(k_cheb_apply_split, dim3((unsigned)(nt64 * nsg)), dim3(256), 0, s, A, Kpad, nnu, nt64, kn, base, extra, sigma,
@@ -518,6 +519,18 @@ void launch_apply(hipStream_t s, const ChebApply &A, int Kpad, int64_t nnu, int 
     }
     hipLaunchKernelGGL(k_cheb_apply, dim3((unsigned)(((nt64 + 3) / 4 + 7) / 8 * 8) * (unsigned)nsg), dim3(256), 0, s, A,
                        Kpad, nnu, nt64, kn, base, extra, sigma, accumulate);
+#else
+    const int kp = cheb_kpad(kn);                // sub-tiles actually in use (Kpad is the row pitch of F)
+    const int nst = kp / 16;
+    const unsigned tb8 = (unsigned)(((nt64 + 3) / 4 + 7) / 8 * 8);
+    (void)Kpad;
+    if ((int64_t)nt64 * ((nst + 3) / 4) >= 2048)   // enough (tile, 64-state chunk) waves to fill 1024 SIMDs twice
+        hipLaunchKernelGGL(k_cheb_apply_mfma<4>, dim3(tb8 * (unsigned)((nst + 3) / 4)), dim3(256), 0, s, A, Kpad, nnu, nt64, kn, base,
+                           extra, sigma, accumulate);
+    else
+        hipLaunchKernelGGL(k_cheb_apply_mfma<1>, dim3(tb8 * (unsigned)nst), dim3(256), 0, s, A, Kpad, nnu, nt64, kn, base, extra, sigma,
+                           accumulate);
+#endif
 }
 
 // K1 + K2 for one gas on `s`: parameters for `kn` states, then the line sum into sigma ([kn][nnu])

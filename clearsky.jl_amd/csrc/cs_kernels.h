@@ -683,6 +683,75 @@ __global__ __launch_bounds__(256) void k_cheb_apply_split(ChebApply A, int Kpad,
     }
 }
 
+// The same contraction on the matrix cores: v_mfma_f64_16x16x4_f64 computes D(16 states x 16 nu) += A(16 states x 4 nodes) *
+// B(4 nodes x 16 nu).  Operand layout on gfx950 (tools/ubench/mfma_f64_layout.hip): lane l holds A[l%16][l/16], B[l/16][l%16] and,
+// in register r, D[4r + l/16][l%16] -- with states as the rows of D a store of one register is four 128-byte runs of consecutive
+// wavenumbers, and both operand loads are 128-byte runs as well (F is state-fastest, C is nu-fastest).
+// One wave = one 64-point tile x NSUB*16 states: NSUB A-operands (F) and 4 B-operands (C) feed 4*NSUB matrix instructions per
+// 4-node step, so the loop is bound by the matrix pipe (~64 cycles per instruction), not by operand delivery as the vector
+// version is (64 dependent FMA steps per (level, gas), one scalar F stream per 16 states).  NSUB = 4 for full grids, 1 for small
+// ones (a nu-shard), where 4x more, 4x shorter waves fill the chip.
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+template <int NSUB>
+__global__ __launch_bounds__(256) void k_cheb_apply_mfma(ChebApply A, int Kpad, int64_t nnu, int ntile, int K, double base,
+                                                          const double *__restrict__ extra, double *__restrict__ sigma, int accumulate)
+{
+    // 1-D grid, XCD-aware as k_cheb_apply: all state chunks of a tile block go to the same XCD, back to back
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int nst = (K + 15) >> 4;                   // 16-state sub-tiles in use (Kpad, the row pitch of F, may be larger)
+    const int nsg = (nst + NSUB - 1) / NSUB;         // state chunks of NSUB sub-tiles
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int tile = ((q / nsg) * 8 + xcd) * 4 + wv;
+    if (tile >= ntile) return;
+    const int s0 = (q % nsg) * NSUB;
+    const int nsub = min(NSUB, nst - s0);            // wave-uniform
+    const int lr = lane & 15, lq = lane >> 4;
+    v4f64 acc[NSUB][4];
+#pragma unroll
+    for (int si = 0; si < NSUB; si++)
+#pragma unroll
+        for (int jt = 0; jt < 4; jt++) acc[si][jt] = v4f64{0.0, 0.0, 0.0, 0.0};
+    for (int g = 0; g < A.ngas; g++) {
+        const double *__restrict__ Fg = A.F[g];
+        for (int l = A.l0[g]; l < A.nlev; l++) {
+            const int sh = A.shift[l];
+            const int T = tile >> sh, sub = tile & ((1 << sh) - 1);
+            const size_t itv = (size_t)64 << sh;
+            const double *__restrict__ Cp = A.Cm[l] + ((size_t)T * CS_NC + lq) * itv + (size_t)sub * 64 + lr;          // node lq, point lr
+            const double *__restrict__ Fp = Fg + ((size_t)(A.ioff[l] + T) * CS_NC + lq) * Kpad + (size_t)s0 * 16 + lr;  // node lq, state lr
+#pragma unroll 2
+            for (int m = 0; m < CS_NC; m += 4) {
+                double b[4], a[NSUB];
+#pragma unroll
+                for (int jt = 0; jt < 4; jt++) b[jt] = Cp[(size_t)m * itv + jt * 16];
+#pragma unroll
+                for (int si = 0; si < NSUB; si++) a[si] = si < nsub ? Fp[(size_t)m * Kpad + si * 16] : 0.0;
+#pragma unroll
+                for (int si = 0; si < NSUB; si++)
+#pragma unroll
+                    for (int jt = 0; jt < 4; jt++) acc[si][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[si], b[jt], acc[si][jt], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int si = 0; si < NSUB; si++) {
+        if (si >= nsub) break;
+#pragma unroll
+        for (int jt = 0; jt < 4; jt++) {
+            const int64_t i = (int64_t)tile * 64 + jt * 16 + lr;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int k = (s0 + si) * 16 + 4 * r + lq;
+                if (k < K && i < nnu) {
+                    const size_t o = (size_t)k * nnu + i;
+                    const double prev = accumulate ? sigma[o] : (base + (extra ? extra[o] : 0.0));
+                    sigma[o] = prev + acc[si][jt][r];
+                }
+            }
+        }
+    }
+}
+
 // K2a: far wings.  One wave = 64 consecutive wavenumbers x one node state; its window of lines [W0,W1) (sorted by nul)
 // is cut into wave-uniform segments so that ~90 % of the (nu, line) pairs run a 13-16 instruction branch-free body whose
 // line parameters arrive through scalar loads:

@@ -102,7 +102,9 @@ def test_b3_symbol_extra_gray_and_reuse_vs_oracle(cs, O, lines, ctx):
     K = len(Pk)
     Stoa = 2e-3 * np.exp(-((nu - 800.0) / 150.0) ** 2)
     alb = np.full(len(nu), 0.3)
-    mu_prof = np.linspace(0.0285, 0.0292, len(P))                                 # a molar-mass PROFILE, not a constant
+    # a molar-mass function mu(T,P), not a constant (a mu VECTOR is unusable in the reference too: formprofile turns it into a
+    # one-argument AtmosphericProfile, fluxes.jl:13, which lobattoevaluations calls with two, discretized.jl:25)
+    mu_prof = lambda T_, P_: 0.0285 + 0.0007 * (P_ / 1e5) + 2e-6 * (T_ - 250.0)
 
     def inputs(T):
         fT, fmu = cs.formprofile(P, T), cs.formprofile(P, mu_prof)
