@@ -157,6 +157,7 @@ struct Column {
     DevBuf nu, wts, P, Pk, Tk, muk, Tlev, extra, S_toa, albedo;
     DevBuf hot, cold, sigma, tau, Mup, Mdn, partial, F, stage, ranges;
     ChebGrid cheb;             // interpolation levels of the nu grid (nlev = 0: off)
+    DevBuf chebF;              // node sums F [nItot][64][Kpad], summed over the column's gases (k_cheb_nodes accumulates)
 };
 
 }  // namespace
@@ -460,7 +461,7 @@ int choose_l0(const ChebGrid &g, const double *nu, int64_t nnu, double cut, doub
 }
 
 int gas_interp_build(const cs_ctx *ctx, GasInterp &gi, ChebGrid &g, const std::vector<double> &nul, int64_t g0, int64_t g1,
-                     const double *nu, int64_t nnu, double cut, int K, hipStream_t s)
+                     const double *nu, int64_t nnu, double cut, int K, hipStream_t s, bool own_F = true)
 {
     int rc;
     gi.nlev = g.nlev;
@@ -481,7 +482,7 @@ int gas_interp_build(const cs_ctx *ctx, GasInterp &gi, ChebGrid &g, const std::v
         HIPCHK(hipStreamSynchronize(s));   // iwin is a local
     }
     HIPCHK(gi.iz.reserve((size_t)K * g.nItot * sizeof(IZone)));
-    if (gi.F.bytes < (size_t)g.nItot * CS_NC * cheb_kpad(K) * sizeof(double)) {
+    if (own_F && gi.F.bytes < (size_t)g.nItot * CS_NC * cheb_kpad(K) * sizeof(double)) {
         HIPCHK(gi.F.reserve((size_t)g.nItot * CS_NC * cheb_kpad(K) * sizeof(double)));
         HIPCHK(hipMemsetAsync(gi.F.p, 0, gi.F.bytes, s));   // padding states stay finite
     }
@@ -524,8 +525,11 @@ void launch_apply(hipStream_t s, const ChebApply &A, int Kpad, int64_t nnu, int 
     const int nst = kp / 16;
     const unsigned tb8 = (unsigned)(((nt64 + 3) / 4 + 7) / 8 * 8);
     (void)Kpad;
-    if ((int64_t)nt64 * ((nst + 3) / 4) >= 2048)   // enough (tile, 64-state chunk) waves to fill 1024 SIMDs twice
-        hipLaunchKernelGGL(k_cheb_apply_mfma<4>, dim3(tb8 * (unsigned)((nst + 3) / 4)), dim3(256), 0, s, A, Kpad, nnu, nt64, kn, base,
+#ifndef CS_APPLY_NSUB
+#define CS_APPLY_NSUB 2
+#endif
+    if ((int64_t)nt64 * ((nst + CS_APPLY_NSUB - 1) / CS_APPLY_NSUB) >= 2048)   // enough (tile, state chunk) waves to fill 1024 SIMDs twice
+        hipLaunchKernelGGL(k_cheb_apply_mfma<CS_APPLY_NSUB>, dim3(tb8 * (unsigned)((nst + CS_APPLY_NSUB - 1) / CS_APPLY_NSUB)), dim3(256), 0, s, A, Kpad, nnu, nt64, kn, base,
                            extra, sigma, accumulate);
     else
         hipLaunchKernelGGL(k_cheb_apply_mfma<1>, dim3(tb8 * (unsigned)nst), dim3(256), 0, s, A, Kpad, nnu, nt64, kn, base, extra, sigma,
@@ -564,13 +568,15 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
         if (evg) (void)hipEventRecord(evg[0], s);
         if (itp.nlev > 0) {   // sigma = base + extra + interpolated far wings; the per-point kernels add the rest
             const int q0 = itp.ioff[itp.l0];
+            // deferred apply: the gases of a column add their node sums into ONE F (levels an earlier gas has written accumulate)
+            const int q_acc = (defer && defer->ngas > 0 && defer->l0[0] < itp.nlev) ? itp.ioff[defer->l0[0]] : itp.nItot;
             const dim3 gridn((unsigned)((kn + 3) / 4) * (unsigned)(itp.nItot - q0));
             if (hot32)
                 hipLaunchKernelGGL((k_cheb_nodes<true>), gridn, dim3(256), 0, s, itp.nodes, G.L, hot, hot32, G.nu.as<double>(), itp.iz,
-                                   itp.nItot, q0, kn, itp.Kpad, cut, itp.F);
+                                   itp.nItot, q0, q_acc, kn, itp.Kpad, cut, itp.F);
             else
                 hipLaunchKernelGGL((k_cheb_nodes<false>), gridn, dim3(256), 0, s, itp.nodes, G.L, hot, hot32, G.nu.as<double>(), itp.iz,
-                                   itp.nItot, q0, kn, itp.Kpad, cut, itp.F);
+                                   itp.nItot, q0, q_acc, kn, itp.Kpad, cut, itp.F);
             if (evg) (void)hipEventRecord(evg[1], s);
             ChebApply A0;
             ChebApply &A = defer ? *defer : A0;
@@ -582,8 +588,12 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
                 A.ioff[l] = itp.ioff[l];
                 A.Cm[l] = itp.Cm[l];
             }
-            A.l0[A.ngas] = itp.l0;
-            A.F[A.ngas++] = itp.F;
+            if (defer && A.ngas > 0) {
+                A.l0[0] = std::min(A.l0[0], itp.l0);   // same F: the sum over the gases so far
+            } else {
+                A.l0[A.ngas] = itp.l0;
+                A.F[A.ngas++] = itp.F;
+            }
             if (!defer) {   // sigma = base + extra + interpolated far wings now; the per-point kernels add the rest
                 launch_apply(s, A, itp.Kpad, nnu, kn, base, extra, sigma, accumulate);
                 accumulate = 1;
@@ -1215,9 +1225,16 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
         HIPCHK(cg.zones.reserve((size_t)c.K * win.size() * sizeof(Zone)));
         HIPCHK(cg.gmax.reserve((size_t)c.K * sizeof(double)));
         if (c.cheb.nlev > 0 && cg.shape == SH_VOIGT &&
-            (rc = gas_interp_build(ctx, cg.itp, c.cheb, G.h_nu, g0, g1, nu, nnu, cg.cut, c.K, s)))
+            (rc = gas_interp_build(ctx, cg.itp, c.cheb, G.h_nu, g0, g1, nu, nnu, cg.cut, c.K, s, false)))
             return rc;
         maxL = std::max(maxL, (size_t)G.L);
+    }
+    if (c.cheb.nlev > 0) {
+        const size_t fb = (size_t)c.cheb.nItot * CS_NC * cheb_kpad(K) * sizeof(double);
+        if (c.chebF.bytes < fb) {
+            HIPCHK(c.chebF.reserve(fb));
+            HIPCHK(hipMemsetAsync(c.chebF.p, 0, c.chebF.bytes, s));   // padding states stay finite
+        }
     }
     HIPCHK(c.hot.reserve(((size_t)K * maxL + 4) * sizeof(LineHot)));
     HIPCHK(c.cold.reserve((size_t)K * maxL * sizeof(LineCold)));
@@ -1411,7 +1428,8 @@ static int run_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev)
     for (int gi = 0; gi < c.ngas; gi++) {
         ColGas &cg = c.gas[gi];
         GasTable &G = ctx->gas[cg.slot];
-        const Interp itp = cg.itp.nlev > 0 ? interp_view(c.cheb, cg.itp, K) : Interp();
+        Interp itp = cg.itp.nlev > 0 ? interp_view(c.cheb, cg.itp, K) : Interp();
+        itp.F = c.chebF.as<double>();
         launch_gas(s, cg.shape, G, cg.jlo, cg.jhi, K, c.Tk.as<double>(), c.Pk.as<double>(), cg.Pp.as<double>(), cg.conc.as<double>(),
                    c.hot.as<LineHot>(), c.cold.as<LineCold>(), c.nu.as<double>(), c.nnu, c.ntile, cg.J0.as<int32_t>(),
                    cg.J1.as<int32_t>(), cg.win.as<WaveWin>(), cg.zones.as<Zone>(), c.ranges.as<int4>(), cg.gmax.as<double>(), cg.cut, c.sigma_gray, extra, sig, gi > 0,

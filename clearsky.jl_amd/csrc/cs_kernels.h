@@ -527,9 +527,11 @@ __global__ __launch_bounds__(256) void k_izones(IzParams P, const double *__rest
 template <bool MIXED>
 __global__ __launch_bounds__(256) void k_cheb_nodes(const double *__restrict__ nodes, int64_t L, const LineHot *__restrict__ hot,
                                                      const LineF32 *__restrict__ hot32, const double *__restrict__ gnul,
-                                                     const IZone *__restrict__ iz, int nItot, int q0, int K, int Kpad, double cut,
+                                                     const IZone *__restrict__ iz, int nItot, int q0, int q_acc, int K, int Kpad, double cut,
                                                      double *__restrict__ F)
 {
+    // q_acc: intervals >= q_acc already hold the node sums of earlier gases of the column -- add to them.  The interpolation
+    // is linear, so k_cheb_apply then carries the SUM over gases to the grid in one pass per level instead of one per (gas, level).
     // 1-D grid (an interval list can exceed the 65535 limit of gridDim.y): block = interval * nsb + state block, state fastest;
     // intervals q0 .. nItot-1 (the levels this gas uses)
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -575,7 +577,8 @@ __global__ __launch_bounds__(256) void k_cheb_nodes(const double *__restrict__ n
 #undef HI
     }
     const double acc = accL + accR;
-    F[((size_t)T * CS_NC + lane) * Kpad + k] = acc;
+    double *__restrict__ Fo = F + ((size_t)T * CS_NC + lane) * Kpad + k;
+    *Fo = T >= q_acc ? *Fo + acc : acc;
 }
 
 // sigma[k][i] (+)= sum over levels of  C_l[T_l][:, i] . F[T_l][:, k]  -- the interpolation as a small matrix product.
@@ -693,7 +696,7 @@ __global__ __launch_bounds__(256) void k_cheb_apply_split(ChebApply A, int Kpad,
 // ones (a nu-shard), where 4x more, 4x shorter waves fill the chip.
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 template <int NSUB>
-__global__ __launch_bounds__(256) void k_cheb_apply_mfma(ChebApply A, int Kpad, int64_t nnu, int ntile, int K, double base,
+__global__ __launch_bounds__(256, NSUB >= 4 ? 2 : 4) void k_cheb_apply_mfma(ChebApply A, int Kpad, int64_t nnu, int ntile, int K, double base,
                                                           const double *__restrict__ extra, double *__restrict__ sigma, int accumulate)
 {
     // 1-D grid, XCD-aware as k_cheb_apply: all state chunks of a tile block go to the same XCD, back to back
@@ -725,7 +728,7 @@ __global__ __launch_bounds__(256) void k_cheb_apply_mfma(ChebApply A, int Kpad, 
 #pragma unroll
                 for (int jt = 0; jt < 4; jt++) b[jt] = Cp[(size_t)m * itv + jt * 16];
 #pragma unroll
-                for (int si = 0; si < NSUB; si++) a[si] = si < nsub ? Fp[(size_t)m * Kpad + si * 16] : 0.0;
+                for (int si = 0; si < NSUB; si++) a[si] = Fp[(size_t)m * Kpad + min(si, nsub - 1) * 16];   // (a sub-tile past the last one re-reads it: never stored)
 #pragma unroll
                 for (int si = 0; si < NSUB; si++)
 #pragma unroll
