@@ -140,10 +140,14 @@ struct ColGas {
     uint64_t generation = 0;
 };
 
+// k_rt launch geometry (rt_geometry)
+struct RtGeom { bool ud; int tiles, nblk, threads; size_t shmem; };
+
 struct Column {
     bool ready = false;
     int64_t nnu = 0;
-    int np = 0, nl = 0, nlob = 0, K = 0, nstream = 0, ngas = 0, ntile = 0, rt_bs = 256, rt_nblk = 0;
+    int np = 0, nl = 0, nlob = 0, K = 0, nstream = 0, ngas = 0, ntile = 0;
+    RtGeom rtg = {};
     bool want_tau = false, want_M = false, has_extra = false, has_S = false, has_alb = false;
     bool default_wts = false;  // trapezoid weights of the column's own grid (not a shard of a larger one)
     int interp = 0;            // the context's interpolation settings at setup time (packed)
@@ -274,40 +278,38 @@ void launch_linesum_shape(int shape, dim3 grid, hipStream_t s, const double *nu,
     }
 }
 
+// k_rt launch geometry: up/down split (two waves per 64-point tile) while the grid has fewer than ~4 waves per SIMD,
+// tiles per block so that the grid still covers the chip
+RtGeom rt_geometry(int64_t nnu, int np, int ncol)
+{
+    RtGeom g;
+    const int64_t nwave = (nnu + 63) / 64 * ncol;
+    g.ud = nwave < 4096;
+    g.tiles = g.ud ? (nnu >= 65536 ? 2 : 1) : (nnu >= 65536 ? 4 : 1);
+    g.nblk = (int)((nnu + (int64_t)g.tiles * 64 - 1) / ((int64_t)g.tiles * 64));
+    g.threads = g.tiles * 64 * (g.ud ? 2 : 1);
+    g.shmem = ((size_t)2 * np * g.tiles + (g.ud ? (size_t)g.tiles * 64 : 0)) * sizeof(double);
+    return g;
+}
+
 template <int NS>
-void launch_rt_ns(int nblk, int bs, size_t shmem, hipStream_t s, const RtParams &p, const double *nu, const double *wts,
+void launch_rt_ns(const RtGeom &g, int B, hipStream_t s, const RtParams &p, const double *nu, const double *wts,
                   int64_t nnu, const double *sigma, const double *muk, const double *P, const double *Tlev,
                   const double *S, const double *alb, double *tau, double *Mup, double *Mdn, double *partial)
 {
-    hipLaunchKernelGGL(k_rt<NS>, dim3(nblk), dim3(bs), shmem, s, p, nu, wts, nnu, sigma, muk, P, Tlev, S, alb, tau, Mup,
-                       Mdn, partial);
+    if (g.ud)
+        hipLaunchKernelGGL((k_rt<NS, true>), dim3(g.nblk, B), dim3(g.threads), g.shmem, s, p, nu, wts, nnu, sigma, muk, P, Tlev, S, alb,
+                           tau, Mup, Mdn, partial);
+    else
+        hipLaunchKernelGGL((k_rt<NS, false>), dim3(g.nblk, B), dim3(g.threads), g.shmem, s, p, nu, wts, nnu, sigma, muk, P, Tlev, S, alb,
+                           tau, Mup, Mdn, partial);
 }
 
-template <int NS>
-void launch_rt_batch_ns(int nblk, int B, int bs, size_t shmem, hipStream_t s, const RtParams &p, const double *nu, const double *wts,
-                        int64_t nnu, const double *sigma, const double *muk, const double *P, const double *Tlev, const double *S,
-                        const double *alb, double *tau, double *Mup, double *Mdn, double *partial)
-{
-    hipLaunchKernelGGL(k_rt<NS>, dim3(nblk, B), dim3(bs), shmem, s, p, nu, wts, nnu, sigma, muk, P, Tlev, S, alb, tau, Mup, Mdn, partial);
-}
-
-void launch_rt_batch(int ns, int nblk, int B, int bs, size_t shmem, hipStream_t s, const RtParams &p, const double *nu,
-                     const double *wts, int64_t nnu, const double *sigma, const double *muk, const double *P, const double *Tlev,
-                     const double *S, const double *alb, double *tau, double *Mup, double *Mdn, double *partial)
-{
-#define CS_RT_CASE(N) case N: launch_rt_batch_ns<N>(nblk, B, bs, shmem, s, p, nu, wts, nnu, sigma, muk, P, Tlev, S, alb, tau, Mup, Mdn, partial); break;
-    switch (ns) {
-        CS_RT_CASE(1) CS_RT_CASE(2) CS_RT_CASE(3) CS_RT_CASE(4) CS_RT_CASE(5) CS_RT_CASE(6) CS_RT_CASE(7) CS_RT_CASE(8)
-        CS_RT_CASE(9) CS_RT_CASE(10) CS_RT_CASE(11) CS_RT_CASE(12) CS_RT_CASE(13) CS_RT_CASE(14) CS_RT_CASE(15) CS_RT_CASE(16)
-    }
-#undef CS_RT_CASE
-}
-
-void launch_rt(int ns, int nblk, int bs, size_t shmem, hipStream_t s, const RtParams &p, const double *nu, const double *wts,
+void launch_rt(int ns, const RtGeom &g, int B, hipStream_t s, const RtParams &p, const double *nu, const double *wts,
                int64_t nnu, const double *sigma, const double *muk, const double *P, const double *Tlev,
                const double *S, const double *alb, double *tau, double *Mup, double *Mdn, double *partial)
 {
-#define CS_RT_CASE(N) case N: launch_rt_ns<N>(nblk, bs, shmem, s, p, nu, wts, nnu, sigma, muk, P, Tlev, S, alb, tau, Mup, Mdn, partial); break;
+#define CS_RT_CASE(N) case N: launch_rt_ns<N>(g, B, s, p, nu, wts, nnu, sigma, muk, P, Tlev, S, alb, tau, Mup, Mdn, partial); break;
     switch (ns) {
         CS_RT_CASE(1) CS_RT_CASE(2) CS_RT_CASE(3) CS_RT_CASE(4) CS_RT_CASE(5) CS_RT_CASE(6) CS_RT_CASE(7) CS_RT_CASE(8)
         CS_RT_CASE(9) CS_RT_CASE(10) CS_RT_CASE(11) CS_RT_CASE(12) CS_RT_CASE(13) CS_RT_CASE(14) CS_RT_CASE(15) CS_RT_CASE(16)
@@ -1142,8 +1144,7 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
     hipStream_t s = ctx->stream;
     c.nnu = nnu; c.np = np; c.nl = np - 1; c.nlob = nlobatto; c.K = (np - 1) * (nlobatto - 1) + 1;
     c.nstream = nstream; c.ngas = ngas; c.ntile = (int)((nnu + 255) / 256);
-    c.rt_bs = nnu >= 65536 ? 256 : 64;   // small grids: one wave per block so that k_rt still covers all 256 CUs
-    c.rt_nblk = (int)((nnu + c.rt_bs - 1) / c.rt_bs);
+    c.rtg = rt_geometry(nnu, np, 1);
     c.want_tau = want_tau != 0; c.want_M = want_M != 0;
     c.g = g; c.sigma_gray = sigma_gray; c.theta_s = theta_s;
     const int K = c.K, nl = c.nl;
@@ -1182,8 +1183,10 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
     c.default_wts = wts == nullptr;
     c.interp = ctx->interp * 4096 + (ctx->itp_first + 1) * 256 + (ctx->itp_min >> 7) * 16 + (ctx->itp_max >> 7);   // every interpolation setting of the context
     c.has_extra = sigma_extra != nullptr;
-    c.has_S = S_toa != nullptr;
-    c.has_alb = albedo != nullptr;
+    // an all-zero stellar spectrum / albedo is the same as none (0*exp(..) and M*0/pi are exact zeros): skip their work, and let
+    // the upward sweep start without waiting for the downward one (k_rt<.., UD>)
+    c.has_S = S_toa != nullptr && std::any_of(S_toa, S_toa + nnu, [](double x) { return x != 0.0; });
+    c.has_alb = albedo != nullptr && std::any_of(albedo, albedo + nnu, [](double x) { return x != 0.0; });
     if (c.has_extra && (rc = upload(c.extra, sigma_extra, (size_t)nnu * K, s))) return rc;
     if (c.has_S && (rc = upload(c.S_toa, S_toa, nnu, s))) return rc;
     if (c.has_alb && (rc = upload(c.albedo, albedo, nnu, s))) return rc;
@@ -1245,7 +1248,7 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
         HIPCHK(c.Mup.reserve((size_t)np * nnu * sizeof(double)));
         HIPCHK(c.Mdn.reserve((size_t)np * nnu * sizeof(double)));
     }
-    HIPCHK(c.partial.reserve((size_t)c.rt_nblk * 2 * np * sizeof(double)));
+    HIPCHK(c.partial.reserve((size_t)c.rtg.nblk * 2 * np * sizeof(double)));
     HIPCHK(c.F.reserve((size_t)2 * np * sizeof(double)));
     HIPCHK(hipStreamSynchronize(s));
     c.ready = true;  // state upload below needs the sizes
@@ -1333,7 +1336,8 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
         return rc;
     HIPCHK(dsig.reserve((size_t)BK * c.nnu * sizeof(double)));
     HIPCHK(dtau.reserve((size_t)B * nl * c.nnu * sizeof(double)));
-    HIPCHK(dpart.reserve((size_t)B * c.rt_nblk * 2 * np * sizeof(double)));
+    const RtGeom bg = rt_geometry(c.nnu, np, B);
+    HIPCHK(dpart.reserve((size_t)B * bg.nblk * 2 * np * sizeof(double)));
     HIPCHK(dF.reserve((size_t)B * 2 * np * sizeof(double)));
     const double *extra = c.has_extra ? c.extra.as<double>() : nullptr;
     if (extra) return fail(CS_EINVAL, "host-evaluated sigma(nu,T,P) terms are not supported in batch mode");
@@ -1389,11 +1393,11 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
         }
         HIPCHK(hipStreamSynchronize(s));   // cc/pp/gb host buffers are reused by the next gas
     }
-    launch_rt_batch(c.nstream, c.rt_nblk, B, c.rt_bs, (size_t)2 * np * (c.rt_bs / 64) * sizeof(double), s, c.rt, c.nu.as<double>(),
+    launch_rt(c.nstream, bg, B, s, c.rt, c.nu.as<double>(),
                     c.wts.as<double>(), c.nnu, dsig.as<double>(), dmuk.as<double>(), c.P.as<double>(), dTlev.as<double>(),
                     c.has_S ? c.S_toa.as<double>() : nullptr, c.has_alb ? c.albedo.as<double>() : nullptr, dtau.as<double>(), nullptr,
                     nullptr, dpart.as<double>());
-    hipLaunchKernelGGL(k_freduce, dim3(2 * np, B), dim3(256), 0, s, dpart.as<double>(), c.rt_nblk, 2 * np, dF.as<double>());
+    hipLaunchKernelGGL(k_freduce, dim3(2 * np, B), dim3(256), 0, s, dpart.as<double>(), bg.nblk, 2 * np, dF.as<double>());
     HIPCHK(hipGetLastError());
     std::vector<double> F((size_t)B * 2 * np);
     HIPCHK(hipMemcpyAsync(F.data(), dF.p, F.size() * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -1452,12 +1456,12 @@ static int run_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev)
         hipLaunchKernelGGL(k_cia, dim3((unsigned)c.ntile), dim3(256), 0, s, cc.nband, cc.bands.as<CiaBand>(), cc.st.as<CiaState>(),
                            c.nu.as<double>(), c.nnu, K, cc.rho1.as<double>(), cc.rho2.as<double>(), cc.rhoa.as<double>(), sig);
     if (ev) HIPCHK(hipEventRecord(ev[e++], s));
-    launch_rt(c.nstream, c.rt_nblk, c.rt_bs, (size_t)2 * c.np * (c.rt_bs / 64) * sizeof(double), s, c.rt, c.nu.as<double>(), c.wts.as<double>(),
+    launch_rt(c.nstream, c.rtg, 1, s, c.rt, c.nu.as<double>(), c.wts.as<double>(),
               c.nnu, sig, c.muk.as<double>(), c.P.as<double>(), c.Tlev.as<double>(),
               c.has_S ? c.S_toa.as<double>() : nullptr, c.has_alb ? c.albedo.as<double>() : nullptr, c.tau.as<double>(),
               c.want_M ? c.Mup.as<double>() : nullptr, c.want_M ? c.Mdn.as<double>() : nullptr, c.partial.as<double>());
     if (ev) HIPCHK(hipEventRecord(ev[e++], s));
-    hipLaunchKernelGGL(k_freduce, dim3(2 * c.np), dim3(256), 0, s, c.partial.as<double>(), c.rt_nblk, 2 * c.np,
+    hipLaunchKernelGGL(k_freduce, dim3(2 * c.np), dim3(256), 0, s, c.partial.as<double>(), c.rtg.nblk, 2 * c.np,
                        c.F.as<double>());
     if (ev) HIPCHK(hipEventRecord(ev[e++], s));
     HIPCHK(hipGetLastError());
@@ -1675,8 +1679,8 @@ int cs_fluxes_discretized(cs_ctx *ctx, int64_t nnu, const double *nu, int np, co
         HIPCHK(hipSetDevice(ctx->device));
         hipStream_t s = ctx->stream;
         c.has_extra = sigma_extra != nullptr;
-        c.has_S = S_toa != nullptr;
-        c.has_alb = albedo != nullptr;
+        c.has_S = S_toa != nullptr && std::any_of(S_toa, S_toa + nnu, [](double x) { return x != 0.0; });
+        c.has_alb = albedo != nullptr && std::any_of(albedo, albedo + nnu, [](double x) { return x != 0.0; });
         if (c.has_extra && (rc = upload(c.extra, sigma_extra, (size_t)nnu * c.K, s))) return rc;
         if (c.has_S && (rc = upload(c.S_toa, S_toa, nnu, s))) return rc;
         if (c.has_alb && (rc = upload(c.albedo, albedo, nnu, s))) return rc;

@@ -1088,9 +1088,15 @@ __device__ __forceinline__ double wave_sum(double v)
 // (dDepth!) and the downward sweep of all NS streams at once; pass 2 walks surface -> TOA (upward sweep).
 // All NS intensities advance together, so M-[i+1] = sum_k W_k I_k + stellar beam is complete when layer i is done --
 // same summation order as the reference's stream-outer loops, no [np] scratch per lane.
-// tau is kept nu-fastest in HBM between the passes (the caller's tau output); Mup/Mdn are optional outputs.
-// red : per-block partial sums of w_j*M[i][j], layout [block][2*np] (Fup then Fdn).
-template <int NS>
+// UD = false: one wave runs both passes; tau is kept nu-fastest in HBM between them (the caller's tau output).
+// UD = true : the two passes of a 64-point tile run in TWO waves of the block side by side (waves [0,nw) go down, [nw,2nw) go
+//             up and recompute the layer optical depths they need on the way) -- each pass is a chain of ~300 dependent fp64
+//             operations per layer that no amount of lanes shortens, so with few waves per SIMD (a 1e5-point grid is 1.5, a
+//             nu-shard less) halving the chain is what halves the time.  The upward sweep starts from the surface intensity,
+//             which depends on the downward flux only through the albedo: with an albedo array the up-waves wait for it at a
+//             barrier (no overlap, same result), without one they start at once.
+// Mup/Mdn are optional outputs.  red : per-block partial sums of w_j*M[i][j], layout [block][2*np] (Fup then Fdn).
+template <int NS, bool UD>
 __global__ __launch_bounds__(256) void k_rt(RtParams p, const double *__restrict__ nu, const double *__restrict__ wts,
                                              int64_t nnu, const double *__restrict__ sigma,
                                              const double *__restrict__ muk, const double *__restrict__ P,
@@ -1099,8 +1105,9 @@ __global__ __launch_bounds__(256) void k_rt(RtParams p, const double *__restrict
                                              double *__restrict__ Mup, double *__restrict__ Mdn,
                                              double *__restrict__ partial)
 {
-    extern __shared__ double red[];  // [2*np][waves per block]
-    const int nw = blockDim.x >> 6;  // 4 waves per block for big grids, 1 for small ones (more blocks than CUs)
+    extern __shared__ double red[];  // [2*np][nw] (+ UD: [nw][64] surface downward flux)
+    const int nwv = blockDim.x >> 6;
+    const int nw = UD ? nwv >> 1 : nwv;   // 64-point tiles per block: 4 (2 with UD) for big grids, 1 for small ones (more blocks than CUs)
     {   // blockIdx.y = column of a batch (cs_column_batch): same grid, pressures and stream rule, its own node states
         const size_t b = blockIdx.y;
         sigma += b * (size_t)p.K * nnu;
@@ -1109,11 +1116,15 @@ __global__ __launch_bounds__(256) void k_rt(RtParams p, const double *__restrict
         tau += b * (size_t)(p.np - 1) * nnu;
         partial += b * (size_t)gridDim.x * 2 * p.np;
     }
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wva = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool up_role = UD && wva >= nw, down_role = !UD || wva < nw;
+    const int wv = up_role ? wva - nw : wva;
+    const int64_t j = ((int64_t)blockIdx.x * nw + wv) * 64 + lane;
     const bool live = j < nnu;
     const int64_t jj = live ? j : nnu - 1;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int np = p.np, nl = np - 1, nlob = p.nlobatto;
+    double *xch = red + (size_t)2 * np * nw;
     const double v = nu[jj];
     const double w = live ? wts[jj] : 0.0;
     const double fS = S_toa ? S_toa[jj] : 0.0;
@@ -1121,81 +1132,113 @@ __global__ __launch_bounds__(256) void k_rt(RtParams p, const double *__restrict
     const double c = p.cos_ts;
 
     double I[NS];
+    double Md = 0.0, Bprev = 0.0;
+    if (down_role) {
 #pragma unroll
-    for (int k = 0; k < NS; k++) I[k] = 0.0;
-    double b1 = p.C * (sigma[jj] / muk[0]);  // beta at node 0, discretized.jl:150
-    double Ms = c * fS;                      // M-[1] = c*fS(nu), discretized.jl:299
-    double Md = Ms;
-    double Bprev = planck(v, Tlev[0]);
-    {
-        double r = wave_sum(w * Md);
-        if (lane == 0) red[(np + 0) * nw + wv] = r;
-        if (Mdn && live) Mdn[j] = Md;
-    }
-    double sg_next = sigma[(size_t)(nlob - 1) * nnu + jj];   // end node of layer 0; later layers are fetched one layer ahead
-    for (int i = 0; i < nl; i++) {
-        const double dP = P[i + 1] - P[i];
-        double ti = (dP * p.ws[0]) * b1;
-        for (int n = 1; n < nlob - 1; n++) {
-            const int k = i * (nlob - 1) + n;
-            ti += (dP * p.ws[n]) * (p.C * (sigma[(size_t)k * nnu + jj] / muk[k]));
+        for (int k = 0; k < NS; k++) I[k] = 0.0;
+        double b1 = p.C * (sigma[jj] / muk[0]);  // beta at node 0, discretized.jl:150
+        double Ms = c * fS;                      // M-[1] = c*fS(nu), discretized.jl:299
+        Md = Ms;
+        Bprev = planck(v, Tlev[0]);
+        {
+            double r = wave_sum(w * Md);
+            if (lane == 0) red[(np + 0) * nw + wv] = r;
+            if (Mdn && live) Mdn[j] = Md;
         }
-        const int ke = (i + 1) * (nlob - 1);
-        const double sg = sg_next;
-        if (i + 1 < nl) sg_next = sigma[(size_t)(ke + nlob - 1) * nnu + jj];   // in flight during this layer's exp/divide chain
-        const double bn = p.C * (sg / muk[ke]);
-        ti += (dP * p.ws[nlob - 1]) * bn;
-        b1 = bn;
-        const double t = ti > 1e-6 ? ti : 1e-6;  // floor, discretized.jl:147,174
-        if (live) tau[(size_t)i * nnu + j] = t;
-        const double Bnext = planck(v, Tlev[i + 1]);
-        Md = 0.0;
-        const double it = 1.0 / t;
+        double sg_next = sigma[(size_t)(nlob - 1) * nnu + jj];   // end node of layer 0; later layers are fetched one layer ahead
+        for (int i = 0; i < nl; i++) {
+            const double dP = P[i + 1] - P[i];
+            double ti = (dP * p.ws[0]) * b1;
+            for (int n = 1; n < nlob - 1; n++) {
+                const int k = i * (nlob - 1) + n;
+                ti += (dP * p.ws[n]) * (p.C * (sigma[(size_t)k * nnu + jj] / muk[k]));
+            }
+            const int ke = (i + 1) * (nlob - 1);
+            const double sg = sg_next;
+            if (i + 1 < nl) sg_next = sigma[(size_t)(ke + nlob - 1) * nnu + jj];   // in flight during this layer's exp/divide chain
+            const double bn = p.C * (sg / muk[ke]);
+            ti += (dP * p.ws[nlob - 1]) * bn;
+            b1 = bn;
+            const double t = ti > 1e-6 ? ti : 1e-6;  // floor, discretized.jl:147,174
+            if (live) tau[(size_t)i * nnu + j] = t;
+            const double Bnext = planck(v, Tlev[i + 1]);
+            Md = 0.0;
+            const double it = 1.0 / t;
 #pragma unroll
-        for (int k = 0; k < NS; k++) {
-            const double tk = t * p.m[k];
-            const double tr = exp(-tk);
-            const double Be = layerplanck_inv(Bprev, Bnext, it * p.im[k], tr);
-            I[k] = I[k] * tr + Be;
-            Md += p.W[k] * I[k];
+            for (int k = 0; k < NS; k++) {
+                const double tk = t * p.m[k];
+                const double tr = exp(-tk);
+                const double Be = layerplanck_inv(Bprev, Bnext, it * p.im[k], tr);
+                I[k] = I[k] * tr + Be;
+                Md += p.W[k] * I[k];
+            }
+            if (S_toa) Ms *= exp(-t / c);   // (wave-uniform; without a stellar beam Ms stays 0)
+            Md += Ms;
+            Bprev = Bnext;
+            double r = wave_sum(w * Md);
+            if (lane == 0) red[(np + i + 1) * nw + wv] = r;
+            if (Mdn && live) Mdn[(size_t)(i + 1) * nnu + j] = Md;
         }
-        if (S_toa) Ms *= exp(-t / c);   // (wave-uniform; without a stellar beam Ms stays 0)
-        Md += Ms;
-        Bprev = Bnext;
-        double r = wave_sum(w * Md);
-        if (lane == 0) red[(np + i + 1) * nw + wv] = r;
-        if (Mdn && live) Mdn[(size_t)(i + 1) * nnu + j] = Md;
+        if (UD && albedo) xch[wv * 64 + lane] = Md;
     }
-    // surface: Lambertian reflection + Planck emission, discretized.jl:309-310
-    const double Is = Md * fa / kPi + Bprev;
-    double Mu = Is * kPi;
-    {
-        double r = wave_sum(w * Mu);
-        if (lane == 0) red[(np - 1) * nw + wv] = r;
-        if (Mup && live) Mup[(size_t)(np - 1) * nnu + j] = Mu;
-    }
-#pragma unroll
-    for (int k = 0; k < NS; k++) I[k] = Is;
-    double Bhi = Bprev;  // B at level i+1
-    double t_next = live ? tau[(size_t)(nl - 1) * nnu + j] : 1.0;
-    for (int i = nl - 1; i >= 0; i--) {
-        const double t = t_next;
-        if (i > 0) t_next = live ? tau[(size_t)(i - 1) * nnu + j] : 1.0;   // one layer ahead
-        const double Blo = planck(v, Tlev[i]);
-        Mu = 0.0;
-        const double it = 1.0 / t;
-#pragma unroll
-        for (int k = 0; k < NS; k++) {
-            const double tk = t * p.m[k];
-            const double tr = exp(-tk);
-            const double Be = layerplanck_inv(Bhi, Blo, it * p.im[k], tr);
-            I[k] = I[k] * tr + Be;
-            Mu += p.W[k] * I[k];
+    if (UD && albedo) __syncthreads();   // (block-uniform condition) the up-waves need the surface downward flux of their tile
+    if (!down_role || !UD) {
+        if (UD) {
+            Bprev = planck(v, Tlev[np - 1]);
+            Md = albedo ? xch[wv * 64 + lane] : 0.0;
         }
-        Bhi = Blo;
-        double r = wave_sum(w * Mu);
-        if (lane == 0) red[i * nw + wv] = r;
-        if (Mup && live) Mup[(size_t)i * nnu + j] = Mu;
+        // surface: Lambertian reflection + Planck emission, discretized.jl:309-310
+        const double Is = Md * fa / kPi + Bprev;
+        double Mu = Is * kPi;
+        {
+            double r = wave_sum(w * Mu);
+            if (lane == 0) red[(np - 1) * nw + wv] = r;
+            if (Mup && live) Mup[(size_t)(np - 1) * nnu + j] = Mu;
+        }
+#pragma unroll
+        for (int k = 0; k < NS; k++) I[k] = Is;
+        double Bhi = Bprev;  // B at level i+1
+        // layer optical depths on the way up: re-read from HBM (one wave ran both passes) or recomputed exactly as the
+        // downward pass forms them (UD: that pass runs beside this one and has not written them yet)
+        double t_next = 1.0, b_hi = 0.0, sg_lo = 0.0;
+        if (UD) {
+            b_hi = p.C * (sigma[(size_t)(p.K - 1) * nnu + jj] / muk[p.K - 1]);
+            sg_lo = sigma[(size_t)(nl - 1) * (nlob - 1) * nnu + jj];
+        } else {
+            t_next = live ? tau[(size_t)(nl - 1) * nnu + j] : 1.0;
+        }
+        for (int i = nl - 1; i >= 0; i--) {
+            double t;
+            if (UD) {
+                const double dP = P[i + 1] - P[i];
+                const int kl = i * (nlob - 1);
+                const double b_lo = p.C * (sg_lo / muk[kl]);
+                if (i > 0) sg_lo = sigma[(size_t)(kl - (nlob - 1)) * nnu + jj];   // one layer ahead
+                double ti = (dP * p.ws[0]) * b_lo;
+                for (int n = 1; n < nlob - 1; n++) ti += (dP * p.ws[n]) * (p.C * (sigma[(size_t)(kl + n) * nnu + jj] / muk[kl + n]));
+                ti += (dP * p.ws[nlob - 1]) * b_hi;
+                b_hi = b_lo;
+                t = ti > 1e-6 ? ti : 1e-6;
+            } else {
+                t = t_next;
+                if (i > 0) t_next = live ? tau[(size_t)(i - 1) * nnu + j] : 1.0;   // one layer ahead
+            }
+            const double Blo = planck(v, Tlev[i]);
+            Mu = 0.0;
+            const double it = 1.0 / t;
+#pragma unroll
+            for (int k = 0; k < NS; k++) {
+                const double tk = t * p.m[k];
+                const double tr = exp(-tk);
+                const double Be = layerplanck_inv(Bhi, Blo, it * p.im[k], tr);
+                I[k] = I[k] * tr + Be;
+                Mu += p.W[k] * I[k];
+            }
+            Bhi = Blo;
+            double r = wave_sum(w * Mu);
+            if (lane == 0) red[i * nw + wv] = r;
+            if (Mup && live) Mup[(size_t)i * nnu + j] = Mu;
+        }
     }
     __syncthreads();
     for (int e = threadIdx.x; e < 2 * np; e += blockDim.x) {
