@@ -549,24 +549,29 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
     // only the lines some window can reach (windows are sorted: first tile's start .. last tile's end)
     const int64_t jlo = jrange0, jhi = std::max(jrange1, jrange0);
     const int64_t tot = (int64_t)kn * (jhi - jlo);
-    if (tot > 0)
-        hipLaunchKernelGGL(k_prep, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, shape, G.dev(), jlo, jhi, kn, Tk, Pk, Ppk, scale,
-                       hot, cold, shape == SH_VOIGT ? hot32 : nullptr);
+    PrepArgs pa;
+    pa.shape = shape; pa.K = kn; pa.g = G.dev(); pa.jlo = jlo; pa.jhi = jhi;
+    pa.Tk = Tk; pa.Pk = Pk; pa.Ppk = Ppk; pa.scale = scale; pa.hot = hot; pa.cold = cold; pa.hot32 = shape == SH_VOIGT ? hot32 : nullptr;
+    const unsigned nb_prep = (unsigned)((tot + 255) / 256);
     if (shape == SH_VOIGT) {
         const int nt64 = (int)((nnu + 63) / 64);
-        hipLaunchKernelGGL(k_zones, dim3((unsigned)(((int64_t)nt64 * kn + 255) / 256)), dim3(256), 0, s, dnu, nnu, nt64, kn,
-                           G.nu.as<double>(), win, Tk, G.mu_min, G.mu_max, cut, gbound, far_s, zones);
+        ZoneArgs za;
+        za.nu = dnu; za.nul = G.nu.as<double>(); za.Tk = Tk; za.gbound = gbound; za.win = win; za.zones = zones; za.nnu = nnu;
+        za.ntile = nt64; za.K = kn; za.mu_min = G.mu_min; za.mu_max = G.mu_max; za.cut = cut; za.far_s = far_s;
+        const unsigned nb_zones = (unsigned)(((int64_t)nt64 * kn + 255) / 256);
+        IzParams P;
+        memset(&P, 0, sizeof P);
+        unsigned nb_iz = 0;
         const IZone *iz = nullptr;
         int ishift = 0;
         if (itp.nlev > 0) {
-            IzParams P;
             P.nlev = itp.nlev;
             P.nItot = itp.nItot;
             P.l0 = itp.l0;
             for (int l = 0; l < itp.nlev; l++) { P.itv[l] = itp.itv[l]; P.nI[l] = itp.nI[l]; P.ioff[l] = itp.ioff[l]; P.iwin[l] = itp.iwin[l]; }
-            hipLaunchKernelGGL(k_izones, dim3((unsigned)(((int64_t)(itp.nItot - itp.ioff[itp.l0]) * kn + 255) / 256)), dim3(256), 0, s, P, dnu, nnu, kn,
-                               G.nu.as<double>(), Tk, G.mu_min, G.mu_max, cut, gbound, far_s, itp.iz);
+            nb_iz = (unsigned)(((int64_t)(itp.nItot - itp.ioff[itp.l0]) * kn + 255) / 256);
         }
+        hipLaunchKernelGGL(k_gas_setup, dim3(nb_prep + nb_zones + nb_iz), dim3(256), 0, s, nb_prep, nb_zones, pa, za, P, itp.iz);
         if (evg) (void)hipEventRecord(evg[0], s);
         if (itp.nlev > 0) {   // sigma = base + extra + interpolated far wings; the per-point kernels add the rest
             const int q0 = itp.ioff[itp.l0];
@@ -627,6 +632,13 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
         hipLaunchKernelGGL(k_voigt_near<0>, gridq, dim3(256), 0, s, dnu, nnu, G.L, hot, cold, zones, nt64, ngrp, cut, sigma, ranges);
         hipLaunchKernelGGL(k_voigt_near<1>, gridq, dim3(256), 0, s, dnu, nnu, G.L, hot, cold, zones, nt64, ngrp, cut, sigma, ranges);
     } else {
+        if (nb_prep > 0) {
+            ZoneArgs za;
+            IzParams P;
+            memset(&za, 0, sizeof za);
+            memset(&P, 0, sizeof P);
+            hipLaunchKernelGGL(k_gas_setup, dim3(nb_prep), dim3(256), 0, s, nb_prep, 0u, pa, za, P, (IZone *)nullptr);
+        }
         if (evg) { (void)hipEventRecord(evg[0], s); (void)hipEventRecord(evg[1], s); }
         launch_linesum_shape(shape, dim3(ntile256, kn), s, dnu, nnu, G.L, hot, cold, J0, J1, cut, Tk, base, extra, sigma,
                              accumulate);

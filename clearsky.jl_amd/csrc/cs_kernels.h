@@ -69,13 +69,26 @@ __device__ __forceinline__ double cheby_qrefq(double T, int n, const double *__r
 
 // K1: one thread per (state k, line j), j in [jlo, jhi) = the lines some window of this wavenumber grid can reach (a nu-shard
 // of a multi-GPU run needs only its part of the table); j fastest so the SoA line table is read coalesced.
-__global__ __launch_bounds__(256) void k_prep(int shape, GasDev g, int64_t jlo, int64_t jhi, int K, const double *__restrict__ Tk,
-                                               const double *__restrict__ Pk, const double *__restrict__ Ppk,
-                                               const double *__restrict__ scale, LineHot *__restrict__ hot,
-                                               LineCold *__restrict__ cold, LineF32 *__restrict__ hot32)
+struct PrepArgs {
+    int shape, K;
+    GasDev g;
+    int64_t jlo, jhi;
+    const double *Tk, *Pk, *Ppk, *scale;
+    LineHot *hot;
+    LineCold *cold;
+    LineF32 *hot32;
+};
+__device__ __forceinline__ void prep_body(unsigned bid, const PrepArgs &pa)
 {
+    const int shape = pa.shape, K = pa.K;
+    const GasDev &g = pa.g;
+    const int64_t jlo = pa.jlo, jhi = pa.jhi;
+    const double *__restrict__ Tk = pa.Tk, *__restrict__ Pk = pa.Pk, *__restrict__ Ppk = pa.Ppk, *__restrict__ scale = pa.scale;
+    LineHot *__restrict__ hot = pa.hot;
+    LineCold *__restrict__ cold = pa.cold;
+    LineF32 *__restrict__ hot32 = pa.hot32;
     const int64_t nj = jhi - jlo;
-    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t idx = (int64_t)bid * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)K * nj) return;
     int k = (int)(idx / nj);
     int64_t j = jlo + (idx - (int64_t)k * nj);
@@ -202,12 +215,23 @@ struct WaveWin { int32_t W0, W1, E0, E1; };  // per 64-point tile: window, first
 struct __attribute__((aligned(16))) Zone { int32_t M0, N0, N1, M1, Q0, Q1, pad1, pad2; };
 
 // node-state dependent zone bounds, one thread per (state, tile)
-__global__ __launch_bounds__(256) void k_zones(const double *__restrict__ nu, int64_t nnu, int ntile, int K,
-                                                const double *__restrict__ nul, const WaveWin *__restrict__ win,
-                                                const double *__restrict__ Tk, double mu_min, double mu_max, double cut,
-                                                const double *__restrict__ gbound, double far_s, Zone *__restrict__ zones)
+struct ZoneArgs {
+    const double *nu, *nul, *Tk, *gbound;
+    const WaveWin *win;
+    Zone *zones;
+    int64_t nnu;
+    int ntile, K;
+    double mu_min, mu_max, cut, far_s;
+};
+__device__ __forceinline__ void zones_body(unsigned bid, const ZoneArgs &a)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const double *__restrict__ nu = a.nu, *__restrict__ nul = a.nul, *__restrict__ Tk = a.Tk, *__restrict__ gbound = a.gbound;
+    const WaveWin *__restrict__ win = a.win;
+    Zone *__restrict__ zones = a.zones;
+    const int64_t nnu = a.nnu;
+    const int ntile = a.ntile, K = a.K;
+    const double mu_min = a.mu_min, mu_max = a.mu_max, cut = a.cut, far_s = a.far_s;
+    const int idx = bid * blockDim.x + threadIdx.x;
     if (idx >= ntile * K) return;
     const int k = idx / ntile, t = idx - k * ntile;
     const int64_t i0 = (int64_t)t * 64, i1 = (i0 + 63 < nnu ? i0 + 63 : nnu - 1);
@@ -462,13 +486,14 @@ __device__ __forceinline__ bool izone_outer(const IzParams &P, int l, int T, con
     Z1 = upper(vhi + dZ, Z0, w.E1);
     return true;
 }
-__global__ __launch_bounds__(256) void k_izones(IzParams P, const double *__restrict__ nu, int64_t nnu, int K,
-                                                 const double *__restrict__ nul, const double *__restrict__ Tk, double mu_min,
-                                                 double mu_max, double cut, const double *__restrict__ gbound, double far_s,
-                                                 IZone *__restrict__ iz)
+__device__ __forceinline__ void izones_body(unsigned bid, const IzParams &P, const ZoneArgs &a, IZone *__restrict__ iz)
 {
+    const double *__restrict__ nu = a.nu, *__restrict__ nul = a.nul, *__restrict__ Tk = a.Tk, *__restrict__ gbound = a.gbound;
+    const int64_t nnu = a.nnu;
+    const int K = a.K;
+    const double mu_min = a.mu_min, mu_max = a.mu_max, cut = a.cut, far_s = a.far_s;
     // zones of all levels live in one array [K][nItot]; level l starts at ioff[l]
-    const int idx0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const int idx0 = bid * blockDim.x + threadIdx.x;
     const int q0 = P.ioff[P.l0], nq = P.nItot - q0;
     if (idx0 >= nq * K) return;
     const int k = idx0 / nq, q = q0 + (idx0 - k * nq);
@@ -519,6 +544,16 @@ __global__ __launch_bounds__(256) void k_izones(IzParams P, const double *__rest
         }
     }
     iz[idx] = z;
+}
+
+// K1 and the zone bounds of one gas in ONE launch: the three jobs are independent of each other (blocks [0,nb_prep) prepare the
+// line records, the next nb_zones blocks the per-tile zones, the rest the interval zones), so fusing them only removes two
+// dependent kernel boundaries per gas -- which is what a nu-shard of a multi-GPU run, a few hundred tiles, spends its time on.
+__global__ __launch_bounds__(256) void k_gas_setup(unsigned nb_prep, unsigned nb_zones, PrepArgs pa, ZoneArgs za, IzParams ip, IZone *__restrict__ iz)
+{
+    if (blockIdx.x < nb_prep) prep_body(blockIdx.x, pa);
+    else if (blockIdx.x < nb_prep + nb_zones) zones_body(blockIdx.x - nb_prep, za);
+    else izones_body(blockIdx.x - nb_prep - nb_zones, ip, za, iz);
 }
 
 // one wave = the 64 Chebyshev nodes of one interval x one node state: far-wing sums at the nodes -> F[interval][node][state].
