@@ -16,6 +16,7 @@ HEADER = os.path.join(os.path.dirname(_HERE), "include", "clearsky_hip.h")
 CS_MAX_GAS = 16
 CS_MAX_TABLE = 16
 CS_MAX_CIA = 8
+CS_MAX_ACCEL = 4
 CHEB_LD = 16
 SHAPES = {"voigt": 0, "lorentz": 1, "doppler": 2, "PHCO2": 3, "phco2": 3}
 
@@ -60,7 +61,13 @@ SIGNATURES = {
     "cs_column_counts": (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "cs_column_work": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
     "cs_interp_plan": (C.c_int, [C.c_int64, _dp, C.c_double, _ip]),
-    "cs_column_batch": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp]),
+    "cs_column_batch": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
+    "cs_shape_points": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_int64, _dp, C.c_int, _dp, _dp, _dp, _dp, C.c_int64]),
+    "cs_column_sigma_run": (C.c_int, [_vp, _vp]),
+    "cs_accel_store": (C.c_int, [_vp, C.c_int]),
+    "cs_accel_clear": (C.c_int, [_vp, C.c_int]),
+    "cs_accel_eval": (C.c_int, [_vp, C.c_int, C.c_double, C.c_int64, C.c_int64, _dp]),
+    "cs_column_set_accel": (C.c_int, [_vp, C.c_int]),
     "cs_column_update_state": (C.c_int, [_vp, _dp, _dp, _dp, _dp, _dp]),
     "cs_par_count": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64)]),
     "cs_par_parse": (C.c_int, [C.c_char_p, C.c_int64, C.POINTER(C.c_int16), C.c_char_p, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),

@@ -15,7 +15,7 @@ from typing import Callable, Optional, Sequence
 import numpy as np
 
 from . import constants as K
-from ._lib import (CHEB_LD, CS_MAX_CIA, CS_MAX_GAS, CS_MAX_TABLE, SHAPES, ClearSkyHIPError, as_f64, check, dptr, lib)
+from ._lib import (CHEB_LD, CS_MAX_ACCEL, CS_MAX_CIA, CS_MAX_GAS, CS_MAX_TABLE, SHAPES, ClearSkyHIPError, as_f64, check, dptr, lib)
 from .hitran import TMAX, TMIN, SpectralLines
 from .cia import CIATables, cia, readcia
 
@@ -335,6 +335,19 @@ def shape_batch(sl: SpectralLines, shape, nu, T, P, Pp, dnu_cut=25.0, ctx: Optio
     return out
 
 
+def shape_points(sl: SpectralLines, shape, nu, T, P, Pp, dnu_cut=25.0, ctx: Optional[Context] = None):
+    """The scalar-wavenumber methods shape(nu, sl, T, P, Pp, dnu_cut) (line_shapes.jl:399-405 etc.) mapped over `nu` and over
+    the states: every line with |nu - nul| <= dnu_cut counts (includedlines(::Real), :12-16).  Returns (K, nnu)."""
+    ctx = ctx or default_context()
+    nu = as_f64(np.atleast_1d(nu))
+    T, P, Pp = (as_f64(np.atleast_1d(a)) for a in (T, P, Pp))
+    out = np.zeros((len(T), len(nu)))
+    sh = SHAPES[shape] if isinstance(shape, str) else int(shape)
+    check(lib().cs_shape_points(ctx.handle, ctx.slot_of(sl), sh, float(dnu_cut), len(nu), dptr(nu), len(T), dptr(T), dptr(P), dptr(Pp),
+                                dptr(out), len(nu)))
+    return out
+
+
 def _shape_inplace(name, default_cut):
     def f_(sigma, nu, sl, T, P, Pp, dnu_cut=default_cut, ctx=None):
         r = shape_batch(sl, name, nu, [T], [P], [Pp], dnu_cut, ctx)
@@ -342,8 +355,8 @@ def _shape_inplace(name, default_cut):
         return None
 
     def f(nu, sl, T, P, Pp, dnu_cut=default_cut, ctx=None):
-        if np.ndim(nu) == 0:
-            return float(shape_batch(sl, name, [float(nu)], [T], [P], [Pp], dnu_cut, ctx)[0, 0])
+        if np.ndim(nu) == 0:   # the scalar-nu method: inclusive cut-off, no end-point pre-filter (line_shapes.jl:12-16)
+            return float(shape_points(sl, name, [float(nu)], [T], [P], [Pp], dnu_cut, ctx)[0, 0])
         return shape_batch(sl, name, nu, [T], [P], [Pp], dnu_cut, ctx)[0]
 
     f_.__doc__ = f"{name}!(sigma, nu, sl, T, P, Pp, dnu_cut={default_cut}) -- absorption/line_shapes.jl; fills sigma in place"
@@ -403,6 +416,17 @@ class DirectGas(AbstractGas):
 
     def concentration(self, T, P):
         return self.fC(T, P)
+
+    def __call__(self, *a, ctx: Optional["Context"] = None):
+        """g(i, T, P) or g(T, P): the function absorber C*shape(nu, sl, T, P, C*P) at wavenumber index i (0-based) or at every
+        wavenumber (the scalar access sigma-chain uses, absorbers.jl:84-92)"""
+        if len(a) == 3:
+            i, T, P = a
+            Cv = self.fC(T, P)
+            return Cv * float(shape_points(self.sl, self.shape, [self.nu[int(i)]], [T], [P], [Cv * P], self.dnu_cut, ctx)[0, 0])
+        T, P = a
+        Cv = self.fC(T, P)
+        return Cv * shape_points(self.sl, self.shape, self.nu, [T], [P], [Cv * P], self.dnu_cut, ctx)[0]
 
 
 class GrayGas(AbstractGas):
@@ -532,7 +556,7 @@ class UnifiedAbsorber:
         assert len(absorbers) > 0, "no absorbers... nothing to group"
         assert len(absorbers) == len(set(map(id, absorbers))), "duplicate absorbers"
         for a in absorbers:
-            if not (isinstance(a, (AbstractGas, CIATables)) or callable(a)):
+            if isinstance(a, (UnifiedAbsorber, AcceleratedAbsorber)) or not (isinstance(a, (AbstractGas, CIATables)) or callable(a)):
                 raise TypeError("absorbers must only be gases (<: Gas), CIA objects, or functions in the form σ(ν, T, P)")
         self.gas = tuple(a for a in absorbers if isinstance(a, AbstractGas))
         if not self.gas:
@@ -545,6 +569,152 @@ class UnifiedAbsorber:
             "gases must have identical wavenumber vectors"
         self.nu = nu0
         self.nnu = len(nu0)
+
+    def __call__(self, *a):
+        """U(i, T, P) = Sigma(U, i, T, P) (absorbers.jl:95,97) or U(T, P) (all wavenumbers, :99): the sigma-chain over gases, CIA
+        objects and functions (absorbers.jl:84-92).  i is 0-based."""
+        if len(a) == 3:
+            i, T, P = a
+            v = self.nu[int(i)]
+            return (sum(g_(int(i), T, P) for g_ in self.gas) + sum(x(v, T, P) for x in self.cia) + sum(f(v, T, P) for f in self.fun))
+        T, P = a
+        out = np.zeros(self.nnu)
+        for g_ in self.gas:
+            out = out + np.asarray(g_(T, P), float)
+        for x in self.cia:
+            out = out + np.array([x(v, T, P) for v in self.nu])
+        for f in self.fun:
+            try:
+                out = out + np.asarray(f(self.nu, T, P), float)
+            except Exception:
+                out = out + np.array([f(v, T, P) for v in self.nu], float)
+        return out
+
+    def update_(self, T):
+        """blank, for similarity with AcceleratedAbsorber (absorbers.jl:80)"""
+        return None
+
+
+def pressurelimits(gases):
+    """absorbers.jl:248-256: (largest Pmin, smallest Pmax) over the baked Gas members; (0, inf) without any"""
+    g = [g_ for g_ in gases if isinstance(g_, Gas)]
+    if not g:
+        return 0.0, float("inf")
+    return max(g_.Omega.Pmin for g_ in g), min(g_.Omega.Pmax for g_ in g)
+
+
+def temperaturelimits(x):
+    """absorbers.jl:258-270: accepts a tuple of gases, a UnifiedAbsorber or an AcceleratedAbsorber"""
+    gases = x.U.gas if isinstance(x, AcceleratedAbsorber) else (x.gas if isinstance(x, UnifiedAbsorber) else x)
+    g = [g_ for g_ in gases if isinstance(g_, Gas)]
+    if not g:
+        return 0.0, float("inf")
+    return max(g_.Omega.Tmin for g_ in g), min(g_.Omega.Tmax for g_ in g)
+
+
+def checkpressures(x, Ps, Pt):
+    """absorbers.jl:101,209,237-246"""
+    gases = x.U.gas if isinstance(x, AcceleratedAbsorber) else (x.gas if isinstance(x, UnifiedAbsorber) else x)
+    assert Ps > Pt, "Pₛ must be greater than Pₜ"
+    Pmin, Pmax = pressurelimits(gases)
+    for P in (Ps, Pt):
+        assert P >= Pmin, f"Pressure {P} Pa too low, domain minimum is {Pmin}"
+        assert P <= Pmax, f"Pressure {P} Pa too low, domain minimum is {Pmax}"
+
+
+def Sigma(A, i: int, T, P):
+    """Σ(𝒜, i, T, P) (absorbers.jl:95,203): total cross-section at wavenumber index i (0-based); an AcceleratedAbsorber ignores T"""
+    if isinstance(A, AcceleratedAbsorber):
+        return A(i, P)
+    return A(i, T, P)
+
+
+class AcceleratedAbsorber:
+    """AcceleratedAbsorber(T, P, absorbers...) (absorbers.jl:114-166): per-wavenumber ln Sigma on the pressure knots P, interpolated
+    linearly in ln P.  The knots' cross-sections Sigma(U, i, T_k, P_k) are evaluated by the line kernels for every wavenumber and
+    knot at once and stay in HBM (cs_accel_store); `update_(A, T)` = update!(A, T) (:173-200) re-evaluates them."""
+
+    def __init__(self, T, P, *absorbers, ctx: Optional[Context] = None):
+        if len(absorbers) == 1 and isinstance(absorbers[0], AcceleratedAbsorber):   # absorbers.jl:161-164
+            A = absorbers[0]
+            assert np.all(np.asarray(P, float)[np.argsort(P)] == A.P), \
+                "cannot change AcceleratedAbsorber's pressure coordinates after construction"
+            self.__dict__ = A.__dict__
+            return
+        self.ctx = ctx or default_context()
+        U = absorbers[0] if (len(absorbers) == 1 and isinstance(absorbers[0], UnifiedAbsorber)) else UnifiedAbsorber(*absorbers)
+        P = np.asarray(P, float)
+        T = np.asarray(T, float)
+        assert len(P) == len(T)
+        idx = np.argsort(P, kind="stable")       # absorbers.jl:140-142
+        self.P, self.T = P[idx].copy(), T[idx].copy()
+        self.U, self.nu, self.nnu = U, U.nu, U.nnu
+        used = getattr(self.ctx, "_accel_used", set())
+        free = [s_ for s_ in range(CS_MAX_ACCEL) if s_ not in used]
+        if not free:
+            raise ClearSkyHIPError(-1, "no free accelerated-absorber slot (CS_MAX_ACCEL per context)")
+        self.slot = free[0]
+        used.add(self.slot)
+        self.ctx._accel_used = used
+        self._knots = None
+        self.update_(self.T)
+
+    def __del__(self):
+        try:
+            if getattr(self.ctx, "_h", None) and self.ctx._h.value and hasattr(self, "slot"):
+                lib().cs_accel_clear(self.ctx._h, self.slot)
+                self.ctx._accel_used.discard(self.slot)
+        except Exception:
+            pass
+
+    def update_(self, T, idx=None):
+        """update!(A, T) / update!(A, T, idx) (absorbers.jl:173-200).  idx is 0-based; a single-knot update re-evaluates the
+        whole set of knots (one pass of the kernels either way)."""
+        if idx is not None:
+            Tn = self.T.copy()
+            Tn[int(idx)] = float(T)
+            T = Tn
+        T = np.asarray(T, float)
+        assert len(T) == len(self.P)
+        Pk, Tk = self.P, T
+        lnP = np.log(Pk)
+        fT = lambda p: float(Tk[int(np.argmin(np.abs(lnP - math.log(p))))])     # the knot's own temperature at the knot
+        if self._knots is None:
+            # a column whose node k is knot k: nlobatto = 2, levels = knots (g, mu, fS, fa play no role in the cross-sections)
+            self._knots = Column(Pk, 1.0, fT, 1.0, None, None, self.U, core=Discretized(1, 2), want_tau=False, want_M=False,
+                                 ctx=self.ctx, _warn=False)
+        else:
+            self._knots.update(fT)
+        self._knots._ensure_resident()
+        check(lib().cs_accel_store(self.ctx.handle, self.slot))
+        self.T = T.copy()
+        return None
+
+    def __call__(self, *a):
+        """A(i, P) = exp(phi_i(ln P)) and A(P) for all wavenumbers (absorbers.jl:203-207).  i is 0-based."""
+        if len(a) == 2:
+            i, P = a
+            out = np.zeros(1)
+            check(lib().cs_accel_eval(self.ctx.handle, self.slot, float(P), int(i), 1, dptr(out)))
+            return float(out[0])
+        out = np.zeros(self.nnu)
+        check(lib().cs_accel_eval(self.ctx.handle, self.slot, float(a[0]), 0, self.nnu, dptr(out)))
+        return out
+
+    def __repr__(self):
+        return f"AcceleratedAbsorber ({len(self.P)} pressure samples)"
+
+
+def update_(A, T, idx=None):
+    """update!(A, T[, idx]) for either absorber type (absorbers.jl:80,173)"""
+    return A.update_(T) if idx is None or isinstance(A, UnifiedAbsorber) else A.update_(T, idx)
+
+
+class _NoAbsorbers:
+    """the (empty) member lists of a column whose cross-sections come from an AcceleratedAbsorber"""
+
+    def __init__(self, nu):
+        self.gas, self.cia, self.fun, self.nu, self.nnu = (), (), (), nu, len(nu)
 
 
 class CIA:
@@ -571,7 +741,7 @@ def unifyabsorbers(absorbers):
     """absorbers.jl:214-223"""
     if len(absorbers) == 0:
         raise ValueError("no absorbers")
-    if len(absorbers) == 1 and isinstance(absorbers[0], UnifiedAbsorber):
+    if len(absorbers) == 1 and isinstance(absorbers[0], (UnifiedAbsorber, AcceleratedAbsorber)):
         U = absorbers[0]
     else:
         U = UnifiedAbsorber(*absorbers)
@@ -630,17 +800,24 @@ class Column:
     """
 
     def __init__(self, P, g, T, mu, fS, fa, *absorbers, core: Optional[Discretized] = None, theta_s: float = 0.841,
-                 want_tau: bool = True, want_M: bool = True, nu_range=None, ctx: Optional[Context] = None, _setup: bool = True):
-        self.ctx = ctx or default_context()
+                 want_tau: bool = True, want_M: bool = True, nu_range=None, ctx: Optional[Context] = None, _setup: bool = True,
+                 _warn: bool = True):
         core = core or Discretized()
         U, nu, nnu = unifyabsorbers(absorbers)
+        self.accel = U if isinstance(U, AcceleratedAbsorber) else None
+        if self.accel is not None:
+            assert ctx is None or ctx is self.accel.ctx, "an AcceleratedAbsorber lives on the context it was built on"
+            ctx = self.accel.ctx
+            U = _NoAbsorbers(self.accel.nu)      # the slot stands for all absorbers (absorbers.jl:216)
+        self.ctx = ctx or default_context()
         P = as_f64(P)
         assert np.all(np.diff(P) >= 0), "pressure coordinates must be in ascending order (sorted)"
         fT, fmu = formprofile(P, T), formprofile(P, mu)
         self._fmu = fmu            # kept: update()/run_batch() re-evaluate it at the new (T, P) nodes when no new mu is given
         self.U, self.core, self.P, self.g, self.theta_s = U, core, P, float(g), float(theta_s)
         assert 0 <= theta_s < math.pi / 2, "azimuth angle θ must be ∈ [0,π/2)"
-        checkstreams(core.nstream)
+        if _warn:
+            checkstreams(core.nstream)
         self.np, self.nl = len(P), len(P) - 1
         nlob = core.nlobatto
         self.K = self.nl * (nlob - 1) + 1
@@ -738,6 +915,8 @@ class Column:
             check(lib().cs_column_set_tables(self.ctx.handle, len(slots), slots.ctypes.data_as(C.POINTER(C.c_int)),
                                              dptr(self.conc_tab.ravel(order="F").copy())))
         self._set_cia()
+        if self.accel is not None:
+            check(lib().cs_column_set_accel(self.ctx.handle, self.accel.slot))
         self._set = True
         self.ctx._resident = self      # a context holds ONE resident column
 
@@ -782,14 +961,18 @@ class Column:
         """Band fluxes of B temperature profiles on this column's grid in one device batch (the np+1 perturbed profiles of
         jacobian!, or the profiles of an RCM loop: radiative_convective.jl:109-171).  Ts: [B, np] level temperatures (or a
         list of callables fT(P)); mus: None (keep the molar mass), a number, or per-profile profiles.  Returns (Fup, Fdn) of
-        shape [B, np].  Only line-by-line gases (and the gray term) may be members."""
+        shape [B, np].  Members: line-by-line gases, baked Gas objects, CIA pairs, the gray term, or an AcceleratedAbsorber
+        (whose cross-sections are shared by all B states, as in jacobian!); function absorbers cannot be batched."""
         self._ensure_resident()
         B = len(Ts)
         nlob = self.core.nlobatto
         nn = nlob * self.nl
+        ng, nt, nc = len(self.gases), len(self.baked), len(self.U.cia)
         Tn_all, mun_all = np.zeros((B, nn)), np.zeros((B, nn))
         Tlev_all = np.zeros((B, self.np))
-        conc_all = np.zeros((B, max(len(self.gases), 1) * self.K))
+        conc_all = np.zeros((B, max(ng, 1) * self.K))
+        ctab_all = np.zeros((B, max(nt, 1) * self.K))
+        P1_all, P2_all = np.zeros((B, max(nc, 1) * self.K)), np.zeros((B, max(nc, 1) * self.K))
         for b in range(B):
             fT = formprofile(self.P, Ts[b])
             mu_b = mus if (mus is None or np.ndim(mus) == 0) else mus[b]
@@ -798,15 +981,24 @@ class Column:
             Tk = nodevalues(Tn, nlob)
             Tn_all[b], mun_all[b] = Tn.ravel(order="F"), mun.ravel(order="F")
             Tlev_all[b] = [fT(p) for p in self.P]
-            cc = np.zeros((len(self.gases), self.K), order="F")
-            for gi, g_ in enumerate(self.gases):
-                for k in range(self.K):
-                    cc[gi, k] = g_.fC(Tk[k], self.Pk[k])
-            if len(self.gases):
-                conc_all[b] = cc.ravel(order="F")
+            for arr, members, n in ((conc_all, self.gases, ng), (ctab_all, self.baked, nt)):
+                if n:
+                    cc = np.zeros((n, self.K), order="F")
+                    for gi, g_ in enumerate(members):
+                        for k in range(self.K):
+                            cc[gi, k] = g_.fC(Tk[k], self.Pk[k])
+                    arr[b] = cc.ravel(order="F")
+            if nc:
+                p1, p2 = np.zeros((nc, self.K), order="F"), np.zeros((nc, self.K), order="F")
+                for ci, x in enumerate(self.U.cia):
+                    for k in range(self.K):
+                        p1[ci, k] = self.Pk[k] * x.g1.concentration(Tk[k], self.Pk[k])      # cia…jl:378-382
+                        p2[ci, k] = self.Pk[k] * x.g2.concentration(Tk[k], self.Pk[k])
+                P1_all[b], P2_all[b] = p1.ravel(order="F"), p2.ravel(order="F")
         Fup, Fdn = np.zeros((B, self.np)), np.zeros((B, self.np))
-        check(lib().cs_column_batch(self.ctx.handle, B, dptr(Tn_all), dptr(mun_all), dptr(Tlev_all), dptr(conc_all), dptr(Fup),
-                                    dptr(Fdn)))
+        check(lib().cs_column_batch(self.ctx.handle, B, dptr(Tn_all), dptr(mun_all), dptr(Tlev_all), dptr(conc_all),
+                                    dptr(ctab_all) if nt else None, dptr(P1_all) if nc else None, dptr(P2_all) if nc else None,
+                                    dptr(Fup), dptr(Fdn)))
         return Fup, Fdn
 
     # -- execution -------------------------------------------------------------------------------------------------
@@ -814,6 +1006,11 @@ class Column:
         """Enqueue one evaluation (asynchronous).  `stream` is a raw hipStream_t (e.g. torch's cuda_stream) or 0."""
         self._ensure_resident()
         check(lib().cs_column_run(self.ctx.handle, C.c_void_p(stream) if stream else None))
+
+    def sigma_run(self, stream: int = 0):
+        """Only the cross-section stage: Sigma(absorbers, i, T_k, P_k) for every wavenumber and node (asynchronous)."""
+        self._ensure_resident()
+        check(lib().cs_column_sigma_run(self.ctx.handle, C.c_void_p(stream) if stream else None))
 
     def sync(self):
         check(lib().cs_column_sync(self.ctx.handle))
@@ -904,10 +1101,11 @@ def _fluxes_discretized(col: "Column", tau, Mup, Mdn):
 
 def _b3(P, g, T, mu, fS, fa, absorbers, core, theta_s, ctx, tau, Mup, Mdn):
     """The B3 boundary: columns of line-by-line / gray / function absorbers go through cs_fluxes_discretized (host pointers,
-    what the Julia glue calls); baked Gas objects and CIA pairs need the resident-column calls (cs_column_set_tables/_set_cia)."""
+    what the Julia glue calls); baked Gas objects, CIA pairs and an AcceleratedAbsorber need the resident-column calls
+    (cs_column_set_tables / _set_cia / _set_accel)."""
     direct = Column(P, g, T, mu, fS, fa, *absorbers, core=core, theta_s=theta_s, want_tau=tau is not None,
                     want_M=Mup is not None or Mdn is not None, ctx=ctx, _setup=False)
-    if not direct.baked and not direct.U.cia:
+    if not direct.baked and not direct.U.cia and direct.accel is None:
         bufs = [None if a is None else (a if (a.flags["F_CONTIGUOUS"] and a.dtype == np.float64) else np.zeros(a.shape, order="F"))
                 for a in (tau, Mup, Mdn)]
         F = _fluxes_discretized(direct, *bufs)
@@ -974,7 +1172,7 @@ def opticaldepth(P, g, T, mu, theta, *absorbers, nlobatto: int = 4, ctx=None):
     assert 0 <= theta < math.pi / 2, "azimuth angle θ must be ∈ [0,π/2)"
     P = np.sort(as_f64(P))
     col = Column(P, g, T, mu, None, None, *absorbers, core=Discretized(5, nlobatto), want_tau=False, want_M=False, ctx=ctx)
-    col.run()
+    col.sigma_run()
     sig = col.sigma_nodes()
     Cc = 1e-4 * K.Na / g
     _, ws = lobattonodes(nlobatto)

@@ -105,6 +105,19 @@ struct ColTab {
     DevBuf W, conc;  // [M][K], [K]
 };
 
+// AcceleratedAbsorber (absorbers.jl:114-203): ln sigma on pressure knots, per wavenumber
+struct AccelDev {
+    bool present = false;
+    int64_t nnu = 0;
+    int nk = 0;
+    std::vector<double> lnP, nu;   // knots (ascending), wavenumbers
+    DevBuf L;                      // [nk][nnu]
+};
+struct ColAccel {
+    int slot = -1;                 // -1: none
+    DevBuf cell, x, xa, xb;        // per node: knot interval and the three abscissae of the LinearInterpolator formula
+};
+
 struct CiaBandHost {
     std::vector<double> nu, T;
     DevBuf dnu, dlnk;
@@ -157,6 +170,7 @@ struct Column {
     std::vector<ColGas> gas;
     std::vector<ColTab> tab;
     std::vector<ColCia> cia;
+    ColAccel accel;
     std::vector<double> h_Tk;
     DevBuf nu, wts, P, Pk, Tk, muk, Tlev, extra, S_toa, albedo;
     DevBuf hot, cold, sigma, tau, Mup, Mdn, partial, F, stage, ranges;
@@ -172,6 +186,7 @@ struct cs_ctx {
     GasTable gas[CS_MAX_GAS];
     TableDev tab[CS_MAX_TABLE];
     CiaDev cia[CS_MAX_CIA];
+    AccelDev accel[CS_MAX_ACCEL];
     Column col;
     int mixed = 0;
     int interp = 1;   // far wings by Chebyshev interpolation over 128..2048-point intervals (k_cheb_nodes / k_cheb_apply)
@@ -295,21 +310,21 @@ RtGeom rt_geometry(int64_t nnu, int np, int ncol)
 template <int NS>
 void launch_rt_ns(const RtGeom &g, int B, hipStream_t s, const RtParams &p, const double *nu, const double *wts,
                   int64_t nnu, const double *sigma, const double *muk, const double *P, const double *Tlev,
-                  const double *S, const double *alb, double *tau, double *Mup, double *Mdn, double *partial)
+                  const double *S, const double *alb, double *tau, double *Mup, double *Mdn, double *partial, size_t sig_bstride)
 {
     if (g.ud)
         hipLaunchKernelGGL((k_rt<NS, true>), dim3(g.nblk, B), dim3(g.threads), g.shmem, s, p, nu, wts, nnu, sigma, muk, P, Tlev, S, alb,
-                           tau, Mup, Mdn, partial);
+                           tau, Mup, Mdn, partial, sig_bstride);
     else
         hipLaunchKernelGGL((k_rt<NS, false>), dim3(g.nblk, B), dim3(g.threads), g.shmem, s, p, nu, wts, nnu, sigma, muk, P, Tlev, S, alb,
-                           tau, Mup, Mdn, partial);
+                           tau, Mup, Mdn, partial, sig_bstride);
 }
 
 void launch_rt(int ns, const RtGeom &g, int B, hipStream_t s, const RtParams &p, const double *nu, const double *wts,
                int64_t nnu, const double *sigma, const double *muk, const double *P, const double *Tlev,
-               const double *S, const double *alb, double *tau, double *Mup, double *Mdn, double *partial)
+               const double *S, const double *alb, double *tau, double *Mup, double *Mdn, double *partial, size_t sig_bstride = 0)
 {
-#define CS_RT_CASE(N) case N: launch_rt_ns<N>(g, B, s, p, nu, wts, nnu, sigma, muk, P, Tlev, S, alb, tau, Mup, Mdn, partial); break;
+#define CS_RT_CASE(N) case N: launch_rt_ns<N>(g, B, s, p, nu, wts, nnu, sigma, muk, P, Tlev, S, alb, tau, Mup, Mdn, partial, sig_bstride); break;
     switch (ns) {
         CS_RT_CASE(1) CS_RT_CASE(2) CS_RT_CASE(3) CS_RT_CASE(4) CS_RT_CASE(5) CS_RT_CASE(6) CS_RT_CASE(7) CS_RT_CASE(8)
         CS_RT_CASE(9) CS_RT_CASE(10) CS_RT_CASE(11) CS_RT_CASE(12) CS_RT_CASE(13) CS_RT_CASE(14) CS_RT_CASE(15) CS_RT_CASE(16)
@@ -775,8 +790,23 @@ int cs_gas_clear(cs_ctx *ctx, int slot)
     return CS_OK;
 }
 
+static int shape_impl(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t nnu, const double *nu, int K,
+                      const double *T, const double *P, const double *Pp, double *sigma, int64_t ld_state, bool strict);
+
 int cs_shape_batch(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t nnu, const double *nu, int K,
                    const double *T, const double *P, const double *Pp, double *sigma, int64_t ld_state)
+{
+    return shape_impl(ctx, slot, shape, dnu_cut, nnu, nu, K, T, P, Pp, sigma, ld_state, true);
+}
+
+int cs_shape_points(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t nnu, const double *nu, int K,
+                    const double *T, const double *P, const double *Pp, double *sigma, int64_t ld_state)
+{
+    return shape_impl(ctx, slot, shape, dnu_cut, nnu, nu, K, T, P, Pp, sigma, ld_state, false);
+}
+
+static int shape_impl(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t nnu, const double *nu, int K,
+                      const double *T, const double *P, const double *Pp, double *sigma, int64_t ld_state, bool strict)
 {
     if (!ctx) return fail(CS_EINVAL, "ctx is NULL");
     if (slot < 0 || slot >= CS_MAX_GAS || !ctx->gas[slot].present) return fail(CS_EINVAL, "gas slot %d is empty", slot);
@@ -789,7 +819,7 @@ int cs_shape_batch(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t nnu
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     int64_t g0, g1, pairs, inr;
-    included_range(G.h_nu, nu[0], nu[nnu - 1], dnu_cut, true, g0, g1);
+    included_range(G.h_nu, nu[0], nu[nnu - 1], dnu_cut, strict, g0, g1);
     std::vector<int32_t> J0, J1;
     tile_windows(G.h_nu, g0, g1, nu, nnu, dnu_cut, J0, J1, pairs, inr);
     const int ntile = (int)J0.size();
@@ -1054,13 +1084,15 @@ int cs_cia_clear(cs_ctx *ctx, int cia_slot)
     return CS_OK;
 }
 
-// per-node inputs of a CIA pair: temperature cells of every band + number densities (cia(k,T,Pa,P1,P2), :295-303)
-static int upload_cia_state(cs_ctx *ctx, ColCia &cc, const double *P1, const double *P2, int stride, int idx)
+// per-state inputs of a CIA pair: temperature cells of every band + number densities (cia(k,T,Pa,P1,P2), :295-303).
+// Kn states with temperatures T, air pressures Pa and partial pressures P1/P2 (element k at P[idx + stride*k]); results go to the
+// given device buffers (a column's own, or a batch's)
+static int upload_cia_states(cs_ctx *ctx, int slot, int flags, int Kn, const double *T, const double *Pa, const double *P1,
+                             const double *P2, int stride, int idx, DevBuf &dst, DevBuf &d1, DevBuf &d2, DevBuf &da)
 {
-    Column &c = ctx->col;
-    CiaDev &cd = ctx->cia[cc.slot];
-    const int K = c.K, nband = (int)cd.bands.size();
-    const bool extrap = cc.flags & 1, singles = cc.flags & 2;
+    CiaDev &cd = ctx->cia[slot];
+    const int K = Kn, nband = (int)cd.bands.size();
+    const bool extrap = flags & 1, singles = flags & 2;
     std::vector<CiaState> st((size_t)nband * K);
     for (int b = 0; b < nband; b++) {
         const std::vector<double> &Tg = cd.bands[b].T;
@@ -1068,13 +1100,13 @@ static int upload_cia_state(cs_ctx *ctx, ColCia &cc, const double *P1, const dou
         for (int k = 0; k < K; k++) {
             CiaState s;
             s.use = 0; s.jT = 0; s.fT = 0.0;
-            const double T = c.h_Tk[k];
+            const double Tk = T[k];
             if (nt == 1) {
                 s.use = singles ? 1 : 0;
             } else {
-                double Te = T;
-                if (T >= Tg.front() && T <= Tg.back()) s.use = 1;                       // :258
-                else if (extrap) { s.use = 1; Te = T > Tg.back() ? Tg.back() : Tg.front(); }  // :261-263
+                double Te = Tk;
+                if (Tk >= Tg.front() && Tk <= Tg.back()) s.use = 1;                       // :258
+                else if (extrap) { s.use = 1; Te = Tk > Tg.back() ? Tg.back() : Tg.front(); }  // :261-263
                 if (s.use) {
                     int j = (int)(std::upper_bound(Tg.begin(), Tg.end(), Te) - Tg.begin()) - 1;
                     j = std::min(std::max(j, 0), nt - 2);
@@ -1087,17 +1119,22 @@ static int upload_cia_state(cs_ctx *ctx, ColCia &cc, const double *P1, const dou
     }
     std::vector<double> r1(K), r2(K), ra(K);
     for (int k = 0; k < K; k++) {
-        const double T = c.h_Tk[k], Pa = c.h_Pk[k];
-        r1[k] = (P1[idx + (size_t)stride * k] / kAtm) * (273.15 / T);   // amagat, :297-298 (T0 = 273.15, constants.jl:23)
-        r2[k] = (P2[idx + (size_t)stride * k] / kAtm) * (273.15 / T);
-        ra[k] = 1e-6 * Pa / (kKb * T);                                  // molecules/cm^3, :300
+        r1[k] = (P1[idx + (size_t)stride * k] / kAtm) * (273.15 / T[k]);   // amagat, :297-298 (T0 = 273.15, constants.jl:23)
+        r2[k] = (P2[idx + (size_t)stride * k] / kAtm) * (273.15 / T[k]);
+        ra[k] = 1e-6 * Pa[k] / (kKb * T[k]);                               // molecules/cm^3, :300
     }
     hipStream_t s = ctx->stream;
     int rc;
-    if ((rc = upload(cc.st, st.data(), st.size(), s)) || (rc = upload(cc.rho1, r1.data(), K, s)) ||
-        (rc = upload(cc.rho2, r2.data(), K, s)) || (rc = upload(cc.rhoa, ra.data(), K, s)))
+    if ((rc = upload(dst, st.data(), st.size(), s)) || (rc = upload(d1, r1.data(), K, s)) ||
+        (rc = upload(d2, r2.data(), K, s)) || (rc = upload(da, ra.data(), K, s)))
         return rc;
+    HIPCHK(hipStreamSynchronize(s));   // the host vectors are locals
     return CS_OK;
+}
+static int upload_cia_state(cs_ctx *ctx, ColCia &cc, const double *P1, const double *P2, int stride, int idx)
+{
+    Column &c = ctx->col;
+    return upload_cia_states(ctx, cc.slot, cc.flags, c.K, c.h_Tk.data(), c.h_Pk.data(), P1, P2, stride, idx, cc.st, cc.rho1, cc.rho2, cc.rhoa);
 }
 
 int cs_column_set_cia(cs_ctx *ctx, int ncia, const int *cia_slots, const int *flags, const double *P1, const double *P2)
@@ -1129,6 +1166,109 @@ int cs_column_set_cia(cs_ctx *ctx, int ncia, const int *cia_slots, const int *fl
         }
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    return CS_OK;
+}
+
+static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e);
+
+// ---- AcceleratedAbsorber (absorbers.jl:114-203) -------------------------------------------------------------------------
+int cs_accel_store(cs_ctx *ctx, int accel_slot)
+{
+    if (!ctx || !ctx->col.ready) return fail(CS_ESTATE, "cs_column_setup has not been called");
+    if (accel_slot < 0 || accel_slot >= CS_MAX_ACCEL) return fail(CS_EINVAL, "accelerated-absorber slot %d out of range", accel_slot);
+    Column &c = ctx->col;
+    if (c.accel.slot >= 0) return fail(CS_ESTATE, "the resident column is itself an accelerated absorber");
+    if (c.K < 2) return fail(CS_EINVAL, "need at least two pressure knots");
+    for (int k = 1; k < c.K; k++)
+        if (!(c.h_Pk[k] > c.h_Pk[k - 1])) return fail(CS_EORDER, "knot pressures must be strictly ascending");
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    int e = 0, rc;
+    if ((rc = sigma_impl(ctx, s, nullptr, e))) return rc;   // Sigma(U, i, T_k, P_k) for every i and knot k (update!, absorbers.jl:173-200)
+    AccelDev &ad = ctx->accel[accel_slot];
+    const int64_t n = (int64_t)c.K * c.nnu;
+    HIPCHK(ad.L.reserve((size_t)n * sizeof(double)));
+    hipLaunchKernelGGL(k_accel_store, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, c.sigma.as<double>(), ad.L.as<double>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));
+    ad.nnu = c.nnu;
+    ad.nk = c.K;
+    ad.nu = c.h_nu;
+    ad.lnP.resize(c.K);
+    for (int k = 0; k < c.K; k++) ad.lnP[k] = std::log(c.h_Pk[k]);
+    ad.present = true;
+    return CS_OK;
+}
+
+int cs_accel_clear(cs_ctx *ctx, int accel_slot)
+{
+    if (!ctx || accel_slot < 0 || accel_slot >= CS_MAX_ACCEL) return fail(CS_EINVAL, "bad accelerated-absorber slot");
+    if (ctx->col.accel.slot == accel_slot) { ctx->col.accel.slot = -1; ctx->col.ready = false; }
+    ctx->accel[accel_slot] = AccelDev();
+    return CS_OK;
+}
+
+// knot interval and abscissae of LinearInterpolator(lnP, y, NoBoundaries())(x): the cell of x clamped to the end cells (extrapolation)
+static void accel_cells(const AccelDev &ad, int K, const double *P, std::vector<int32_t> &cell, std::vector<double> &x,
+                        std::vector<double> &xa, std::vector<double> &xb)
+{
+    cell.resize(K); x.resize(K); xa.resize(K); xb.resize(K);
+    for (int k = 0; k < K; k++) {
+        x[k] = std::log(P[k]);
+        int i = (int)(std::upper_bound(ad.lnP.begin(), ad.lnP.end(), x[k]) - ad.lnP.begin()) - 1;
+        i = std::min(std::max(i, 0), ad.nk - 2);
+        cell[k] = i;
+        xa[k] = ad.lnP[i];
+        xb[k] = ad.lnP[i + 1];
+    }
+}
+
+int cs_accel_eval(cs_ctx *ctx, int accel_slot, double P, int64_t i0, int64_t n, double *sigma_out)
+{
+    if (!ctx || accel_slot < 0 || accel_slot >= CS_MAX_ACCEL || !ctx->accel[accel_slot].present) return fail(CS_EINVAL, "accelerated-absorber slot is empty");
+    AccelDev &ad = ctx->accel[accel_slot];
+    if (i0 < 0 || n < 1 || i0 + n > ad.nnu || !sigma_out) return fail(CS_EINVAL, "wavenumber range out of bounds");
+    if (!(P > 0)) return fail(CS_EINVAL, "pressure must be positive");
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    std::vector<int32_t> cell;
+    std::vector<double> x, xa, xb;
+    accel_cells(ad, 1, &P, cell, x, xa, xb);
+    DevBuf dc, dx, da, db;
+    int rc;
+    if ((rc = upload(dc, cell.data(), 1, s)) || (rc = upload(dx, x.data(), 1, s)) || (rc = upload(da, xa.data(), 1, s)) ||
+        (rc = upload(db, xb.data(), 1, s)))
+        return rc;
+    HIPCHK(ctx->tmpC.reserve((size_t)ad.nnu * sizeof(double)));
+    hipLaunchKernelGGL(k_accel_eval, dim3((unsigned)((ad.nnu + 255) / 256), 1), dim3(256), 0, s, ad.L.as<double>(), ad.nnu, 1, dc.as<int32_t>(),
+                       dx.as<double>(), da.as<double>(), db.as<double>(), 0.0, (const double *)nullptr, ctx->tmpC.as<double>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(sigma_out, ctx->tmpC.as<double>() + i0, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return CS_OK;
+}
+
+int cs_column_set_accel(cs_ctx *ctx, int accel_slot)
+{
+    if (!ctx || !ctx->col.ready) return fail(CS_ESTATE, "cs_column_setup has not been called");
+    Column &c = ctx->col;
+    if (accel_slot < 0) { c.accel.slot = -1; return CS_OK; }
+    if (accel_slot >= CS_MAX_ACCEL || !ctx->accel[accel_slot].present) return fail(CS_EINVAL, "accelerated-absorber slot %d is empty", accel_slot);
+    // an AcceleratedAbsorber stands for ALL absorbers of a column (unifyabsorbers(::Tuple{AcceleratedAbsorber}), absorbers.jl:216)
+    if (c.ngas > 0 || !c.tab.empty() || !c.cia.empty()) return fail(CS_EINVAL, "a column over an accelerated absorber has no other absorbers");
+    AccelDev &ad = ctx->accel[accel_slot];
+    if (ad.nnu != c.nnu || !std::equal(ad.nu.begin(), ad.nu.end(), c.h_nu.begin())) return fail(CS_EINVAL, "wavenumber grids differ");
+    HIPCHK(hipSetDevice(ctx->device));
+    std::vector<int32_t> cell;
+    std::vector<double> x, xa, xb;
+    accel_cells(ad, c.K, c.h_Pk.data(), cell, x, xa, xb);
+    int rc;
+    hipStream_t s = ctx->stream;
+    if ((rc = upload(c.accel.cell, cell.data(), c.K, s)) || (rc = upload(c.accel.x, x.data(), c.K, s)) ||
+        (rc = upload(c.accel.xa, xa.data(), c.K, s)) || (rc = upload(c.accel.xb, xb.data(), c.K, s)))
+        return rc;
+    HIPCHK(hipStreamSynchronize(s));
+    c.accel.slot = accel_slot;
     return CS_OK;
 }
 
@@ -1266,6 +1406,7 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
     c.ready = true;  // state upload below needs the sizes
     c.tab.clear();
     c.cia.clear();
+    c.accel.slot = -1;
     if ((rc = cs_column_update_state(ctx, T_nodes, mu_nodes, T_levels, conc, nullptr))) { c.ready = false; return rc; }
     return CS_OK;
 }
@@ -1315,12 +1456,13 @@ int cs_column_update_state(cs_ctx *ctx, const double *T_nodes, const double *mu_
 }
 
 int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_nodes, const double *T_levels,
-                    const double *conc, double *Fup, double *Fdn)
+                    const double *conc, const double *conc_tab, const double *cia_P1, const double *cia_P2, double *Fup, double *Fdn)
 {
     if (!ctx || !ctx->col.ready) return fail(CS_ESTATE, "cs_column_setup has not been called");
     Column &c = ctx->col;
     if (B < 1 || B > 65535) return fail(CS_EINVAL, "batch size must be in [1, 65535]");
-    if (!c.tab.empty() || !c.cia.empty()) return fail(CS_EINVAL, "opacity tables and CIA pairs are not supported in batch mode");
+    if (!c.tab.empty() && !conc_tab) return fail(CS_EINVAL, "the resident column has opacity tables: conc_tab is required");
+    if (!c.cia.empty() && (!cia_P1 || !cia_P2)) return fail(CS_EINVAL, "the resident column has CIA pairs: cia_P1 and cia_P2 are required");
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const int K = c.K, nl = c.nl, nlob = c.nlob, np = c.np;
@@ -1342,21 +1484,25 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
     int rc;
     for (int gi = 0; gi < c.ngas; gi++)
         if ((rc = check_gas_states(ctx->gas[c.gas[gi].slot], (int)BK, Tk.data()))) return rc;
+    const double *extra = c.has_extra ? c.extra.as<double>() : nullptr;
+    if (extra) return fail(CS_EINVAL, "host-evaluated sigma(nu,T,P) terms are not supported in batch mode");
+    const bool shared_sigma = c.accel.slot >= 0;   // AcceleratedAbsorber: cross-sections do not depend on the thermal state (absorbers.jl:203)
     DevBuf dTk, dPk, dmuk, dTlev, dsig, dtau, dpart, dF, dranges, dconc, dPp, dgb, dzones, dizones, dF2, hot, cold;
     if ((rc = upload(dTk, Tk.data(), BK, s)) || (rc = upload(dPk, Pk.data(), BK, s)) || (rc = upload(dmuk, muk.data(), BK, s)) ||
         (rc = upload(dTlev, T_levels, (size_t)B * np, s)))
         return rc;
-    HIPCHK(dsig.reserve((size_t)BK * c.nnu * sizeof(double)));
-    HIPCHK(dtau.reserve((size_t)B * nl * c.nnu * sizeof(double)));
     const RtGeom bg = rt_geometry(c.nnu, np, B);
+    if (!shared_sigma) HIPCHK(dsig.reserve((size_t)BK * c.nnu * sizeof(double)));
+    HIPCHK(dtau.reserve((size_t)B * nl * c.nnu * sizeof(double)));
     HIPCHK(dpart.reserve((size_t)B * bg.nblk * 2 * np * sizeof(double)));
     HIPCHK(dF.reserve((size_t)B * 2 * np * sizeof(double)));
-    const double *extra = c.has_extra ? c.extra.as<double>() : nullptr;
-    if (extra) return fail(CS_EINVAL, "host-evaluated sigma(nu,T,P) terms are not supported in batch mode");
-    if (c.ngas == 0) {
+    double *sig = shared_sigma ? c.sigma.as<double>() : dsig.as<double>();
+    if (shared_sigma) {
+        int e = 0;
+        if ((rc = sigma_impl(ctx, s, nullptr, e))) return rc;
+    } else if (c.ngas == 0) {
         const int64_t tot = BK * c.nnu;
-        hipLaunchKernelGGL(k_fill, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, tot, c.sigma_gray, (const double *)nullptr,
-                           dsig.as<double>());
+        hipLaunchKernelGGL(k_fill, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, tot, c.sigma_gray, (const double *)nullptr, sig);
     }
     size_t maxL = 0;
     for (auto &g : c.gas) maxL = std::max(maxL, (size_t)ctx->gas[g.slot].L);
@@ -1399,16 +1545,61 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
             launch_gas(s, cg.shape, G, cg.jlo, cg.jhi, kn, dTk.as<double>() + k0, dPk.as<double>() + k0, dPp.as<double>() + k0,
                        dconc.as<double>() + k0, hot.as<LineHot>(), cold.as<LineCold>(), c.nu.as<double>(), c.nnu, c.ntile,
                        cg.J0.as<int32_t>(), cg.J1.as<int32_t>(), cg.win.as<WaveWin>(), dzones.as<Zone>(), dranges.as<int4>(),
-                       dgb.as<double>() + k0, cg.cut, c.sigma_gray, nullptr, dsig.as<double>() + (size_t)k0 * c.nnu, gi > 0, nullptr,
+                       dgb.as<double>() + k0, cg.cut, c.sigma_gray, nullptr, sig + (size_t)k0 * c.nnu, gi > 0, nullptr,
                        (ctx->mixed && cg.shape == SH_VOIGT) ? ctx->hot32.as<LineF32>() : nullptr, ctx->far_s, itp);
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipStreamSynchronize(s));   // cc/pp/gb host buffers are reused by the next gas
     }
+    // baked gases of the column at all B*K states: the Gas functor fC(T,P)*exp(Phi(T, ln P)) (gases.jl:85,278) -- what RCM holds
+    // inside its AcceleratedAbsorber (radiative_convective.jl:6-103)
+    if (!shared_sigma && !c.tab.empty()) {
+        const int nt = (int)c.tab.size();
+        std::vector<double> W, ct(BK);
+        DevBuf dW, dct;
+        for (int t = 0; t < nt; t++) {
+            TableDev &tb = ctx->tab[c.tab[t].slot];
+            if ((rc = table_weights(tb, (int)BK, Tk.data(), Pk.data(), W))) return rc;
+            for (int b = 0; b < B; b++)
+                for (int k = 0; k < K; k++) {
+                    const double v = conc_tab[(size_t)b * nt * K + t + (size_t)nt * k];
+                    if (!(v >= 0 && v <= 1)) return fail(CS_EINVAL, "gas molar concentrations must be in [0,1], not %g", v);
+                    ct[(size_t)b * K + k] = v;
+                }
+            if ((rc = upload(dW, W.data(), W.size(), s)) || (rc = upload(dct, ct.data(), BK, s))) return rc;
+            const int M = tb.nT * tb.nP;
+            if ((size_t)M * CS_TAB_KC * sizeof(double) > 65536)
+                HIPCHK(hipFuncSetAttribute((const void *)k_table_eval, hipFuncAttributeMaxDynamicSharedMemorySize, M * CS_TAB_KC * (int)sizeof(double)));
+            if (BK > (int64_t)65535 * CS_TAB_KC) return fail(CS_EINVAL, "too many batch states for the opacity-table kernel (%lld)", (long long)BK);
+            hipLaunchKernelGGL(k_table_eval, dim3((unsigned)c.ntile, (unsigned)((BK + CS_TAB_KC - 1) / CS_TAB_KC)), dim3(256),
+                               (size_t)M * CS_TAB_KC * sizeof(double), s, tb.Z.as<double>(), M, c.nnu, dW.as<double>(), (int)BK,
+                               dct.as<double>(), sig);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(s));   // W/ct host and device buffers are reused by the next table
+        }
+    }
+    if (!shared_sigma && !c.cia.empty()) {
+        const int nc = (int)c.cia.size();
+        DevBuf dst, d1, d2, da;
+        std::vector<double> p1(BK), p2(BK);
+        for (int t = 0; t < nc; t++) {
+            ColCia &ci = c.cia[t];
+            for (int b = 0; b < B; b++)
+                for (int k = 0; k < K; k++) {
+                    p1[(size_t)b * K + k] = cia_P1[(size_t)b * nc * K + t + (size_t)nc * k];
+                    p2[(size_t)b * K + k] = cia_P2[(size_t)b * nc * K + t + (size_t)nc * k];
+                }
+            if ((rc = upload_cia_states(ctx, ci.slot, ci.flags, (int)BK, Tk.data(), Pk.data(), p1.data(), p2.data(), 1, 0, dst, d1, d2, da))) return rc;
+            hipLaunchKernelGGL(k_cia, dim3((unsigned)c.ntile), dim3(256), 0, s, ci.nband, ci.bands.as<CiaBand>(), dst.as<CiaState>(),
+                               c.nu.as<double>(), c.nnu, (int)BK, d1.as<double>(), d2.as<double>(), da.as<double>(), sig);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(s));
+        }
+    }
     launch_rt(c.nstream, bg, B, s, c.rt, c.nu.as<double>(),
-                    c.wts.as<double>(), c.nnu, dsig.as<double>(), dmuk.as<double>(), c.P.as<double>(), dTlev.as<double>(),
+                    c.wts.as<double>(), c.nnu, sig, dmuk.as<double>(), c.P.as<double>(), dTlev.as<double>(),
                     c.has_S ? c.S_toa.as<double>() : nullptr, c.has_alb ? c.albedo.as<double>() : nullptr, dtau.as<double>(), nullptr,
-                    nullptr, dpart.as<double>());
+                    nullptr, dpart.as<double>(), shared_sigma ? 0 : (size_t)K * c.nnu);
     hipLaunchKernelGGL(k_freduce, dim3(2 * np, B), dim3(256), 0, s, dpart.as<double>(), bg.nblk, 2 * np, dF.as<double>());
     HIPCHK(hipGetLastError());
     std::vector<double> F((size_t)B * 2 * np);
@@ -1421,16 +1612,19 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
     return CS_OK;
 }
 
-// enqueue one evaluation; when ev != NULL an event is recorded between the kernel classes (ev must hold 4*ngas+4)
-static int run_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev)
+// the cross-section stage of one evaluation: sigma[K][nnu] of all absorbers of the resident column at its node states
+// (Sigma(A, i, T, P) of absorbers.jl:95 for every i and node).  ev: see run_impl; e counts the events recorded.
+static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e)
 {
     Column &c = ctx->col;
     const int K = c.K;
     double *sig = c.sigma.as<double>();
     const double *extra = c.has_extra ? c.extra.as<double>() : nullptr;
-    int e = 0;
-    if (ev) HIPCHK(hipEventRecord(ev[e++], s));
-    if (c.ngas == 0) {
+    if (c.accel.slot >= 0) {   // AcceleratedAbsorber: exp of the ln P-interpolated ln sigma (absorbers.jl:203)
+        AccelDev &ad = ctx->accel[c.accel.slot];
+        hipLaunchKernelGGL(k_accel_eval, dim3((unsigned)c.ntile, K), dim3(256), 0, s, ad.L.as<double>(), c.nnu, K, c.accel.cell.as<int32_t>(),
+                           c.accel.x.as<double>(), c.accel.xa.as<double>(), c.accel.xb.as<double>(), c.sigma_gray, extra, sig);
+    } else if (c.ngas == 0) {
         const int64_t tot = (int64_t)K * c.nnu;
         hipLaunchKernelGGL(k_fill, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, tot, c.sigma_gray, extra, sig);
     }
@@ -1453,7 +1647,7 @@ static int run_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev)
                    (ctx->mixed && cg.shape == SH_VOIGT) ? ctx->hot32.as<LineF32>() : nullptr, ctx->far_s, itp, &apply);
         if (ev) { e += 3; HIPCHK(hipEventRecord(ev[e++], s)); }
     }
-    // interpolated far wings of all gases: sigma += sum_gas sum_level C F  (one pass over C and sigma)
+    // interpolated far wings of all gases: sigma += sum_level C (sum_gas F)  (one pass over C and sigma)
     if (apply.ngas > 0) launch_apply(s, apply, cheb_kpad(K), c.nnu, K, 0.0, nullptr, sig, 1);
     for (auto &t : c.tab) {  // baked gases: sigma += fC * exp(Phi(T, ln P))
         TableDev &tb = ctx->tab[t.slot];
@@ -1467,6 +1661,18 @@ static int run_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev)
     for (auto &cc : c.cia)  // CIA pairs
         hipLaunchKernelGGL(k_cia, dim3((unsigned)c.ntile), dim3(256), 0, s, cc.nband, cc.bands.as<CiaBand>(), cc.st.as<CiaState>(),
                            c.nu.as<double>(), c.nnu, K, cc.rho1.as<double>(), cc.rho2.as<double>(), cc.rhoa.as<double>(), sig);
+    HIPCHK(hipGetLastError());
+    return CS_OK;
+}
+
+// enqueue one evaluation; when ev != NULL an event is recorded between the kernel classes (ev must hold 4*ngas+4)
+static int run_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev)
+{
+    Column &c = ctx->col;
+    double *sig = c.sigma.as<double>();
+    int e = 0, rc;
+    if (ev) HIPCHK(hipEventRecord(ev[e++], s));
+    if ((rc = sigma_impl(ctx, s, ev, e))) return rc;
     if (ev) HIPCHK(hipEventRecord(ev[e++], s));
     launch_rt(c.nstream, c.rtg, 1, s, c.rt, c.nu.as<double>(), c.wts.as<double>(),
               c.nnu, sig, c.muk.as<double>(), c.P.as<double>(), c.Tlev.as<double>(),
@@ -1478,6 +1684,13 @@ static int run_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev)
     if (ev) HIPCHK(hipEventRecord(ev[e++], s));
     HIPCHK(hipGetLastError());
     return CS_OK;
+}
+
+int cs_column_sigma_run(cs_ctx *ctx, void *stream)
+{
+    if (!ctx || !ctx->col.ready) return fail(CS_ESTATE, "cs_column_setup has not been called");
+    int e = 0;
+    return sigma_impl(ctx, stream ? (hipStream_t)stream : ctx->stream, nullptr, e);
 }
 
 int cs_column_run(cs_ctx *ctx, void *stream)
@@ -1662,7 +1875,7 @@ static bool column_matches(cs_ctx *ctx, int64_t nnu, const double *nu, int np, c
                            int nstream, bool want_tau, bool want_M)
 {
     const Column &c = ctx->col;
-    if (!c.ready || !c.default_wts || c.interp != ctx->interp * 4096 + (ctx->itp_first + 1) * 256 + (ctx->itp_min >> 7) * 16 + (ctx->itp_max >> 7) || !c.tab.empty() || !c.cia.empty()) return false;
+    if (!c.ready || c.accel.slot >= 0 || !c.default_wts || c.interp != ctx->interp * 4096 + (ctx->itp_first + 1) * 256 + (ctx->itp_min >> 7) * 16 + (ctx->itp_max >> 7) || !c.tab.empty() || !c.cia.empty()) return false;
     if (c.nnu != nnu || c.np != np || c.nlob != nlobatto || c.nstream != nstream || c.ngas != ngas) return false;
     if (c.g != g || c.sigma_gray != sigma_gray || c.theta_s != theta_s) return false;
     if (c.want_tau != want_tau || c.want_M != want_M) return false;

@@ -1138,14 +1138,14 @@ __global__ __launch_bounds__(256) void k_rt(RtParams p, const double *__restrict
                                              const double *__restrict__ Tlev, const double *__restrict__ S_toa,
                                              const double *__restrict__ albedo, double *__restrict__ tau,
                                              double *__restrict__ Mup, double *__restrict__ Mdn,
-                                             double *__restrict__ partial)
+                                             double *__restrict__ partial, size_t sig_bstride)
 {
     extern __shared__ double red[];  // [2*np][nw] (+ UD: [nw][64] surface downward flux)
     const int nwv = blockDim.x >> 6;
     const int nw = UD ? nwv >> 1 : nwv;   // 64-point tiles per block: 4 (2 with UD) for big grids, 1 for small ones (more blocks than CUs)
     {   // blockIdx.y = column of a batch (cs_column_batch): same grid, pressures and stream rule, its own node states
         const size_t b = blockIdx.y;
-        sigma += b * (size_t)p.K * nnu;
+        sigma += b * sig_bstride;     // K*nnu, or 0 when the columns of a batch share their cross-sections (AcceleratedAbsorber)
         muk += b * p.K;
         Tlev += b * p.np;
         tau += b * (size_t)(p.np - 1) * nnu;
@@ -1436,6 +1436,32 @@ __global__ __launch_bounds__(256) void k_cia(int nband, const CiaBand *__restric
         }
         if (ktot != 0.0) sigma[(size_t)k * nnu + i] += (ktot * Lo2) * rho1[k] * rho2[k] / rhoa[k];
     }
+}
+
+// ---- AcceleratedAbsorber (absorbers.jl:114-203): per-wavenumber ln sigma on pressure knots, linear in ln P -----------------
+// update!: L[i][nu] = max(ln sigma[i][nu], ln floatmin)  (absorbers.jl:185-196)
+__global__ __launch_bounds__(256) void k_accel_store(int64_t n, const double *__restrict__ sigma, double *__restrict__ L)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double lt = log(2.2250738585072014e-308);
+    const double l = log(sigma[i]);
+    L[i] = (l < lt) ? lt : l;     // (ln 0 = -inf and NaN-free inputs: the comparison is the reference's)
+}
+// Sigma(A, i, T, P) = exp(phi_i(ln P)) at every node state k (absorbers.jl:203): LinearInterpolator without boundaries,
+// cell[k] = knot interval, x[k] = ln P_k, xa/xb = its ends -- (x - xa)*(yb - ya)/(xb - xa) + ya.   sigma[k][nu] = base + extra + that
+__global__ __launch_bounds__(256) void k_accel_eval(const double *__restrict__ L, int64_t nnu, int K, const int32_t *__restrict__ cell,
+                                                     const double *__restrict__ x, const double *__restrict__ xa,
+                                                     const double *__restrict__ xb, double base, const double *__restrict__ extra,
+                                                     double *__restrict__ sigma)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int k = blockIdx.y;
+    if (i >= nnu) return;
+    const int c = cell[k];
+    const double ya = L[(size_t)c * nnu + i], yb = L[(size_t)(c + 1) * nnu + i];
+    const size_t o = (size_t)k * nnu + i;
+    sigma[o] = (base + (extra ? extra[o] : 0.0)) + exp((x[k] - xa[k]) * (yb - ya) / (xb[k] - xa[k]) + ya);
 }
 
 __global__ void k_faddeeva(int64_t n, const double *__restrict__ x, const double *__restrict__ y, double *__restrict__ out)

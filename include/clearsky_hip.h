@@ -42,6 +42,7 @@ enum { CS_SHAPE_VOIGT = 0, CS_SHAPE_LORENTZ = 1, CS_SHAPE_DOPPLER = 2, CS_SHAPE_
 #define CS_MAX_GAS 16
 #define CS_MAX_TABLE 16
 #define CS_MAX_CIA 8
+#define CS_MAX_ACCEL 4
 #define CS_CHEB_LD 16 /* leading dimension of the Chebyshev coefficient table */
 #define CS_MAX_STREAM 16
 #define CS_MAX_LOBATTO 16
@@ -111,6 +112,13 @@ int cs_shape_batch(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t nnu
  * The table stays in HBM as slot `table_slot` and is evaluated by cs_column_set_tables / cs_column_run through the
  * 2-D Chebyshev interpolant (BichebyshevInterpolator, gases.jl:80,85) in barycentric form.
  */
+/* The same kernels with the semantics of the scalar-wavenumber methods  voigt(nu, sl, T, P, Pp, dnu_cut)  etc. (line_shapes.jl:
+ * 399-405, 290-296, 177-183, 514-520) mapped over the n wavenumbers: every line with |nu - nul| <= dnu_cut counts
+ * (includedlines(::Real), line_shapes.jl:12-16; no strict end-point pre-filter).  This is what a function absorber
+ * (nu,T,P) -> C*voigt(nu, sl, T, P, C*P) and the scalar Sigma(U, i, T, P) (absorbers.jl:84-95) evaluate.  nu ascending. */
+int cs_shape_points(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t nnu, const double *nu, int K,
+                    const double *T, const double *P, const double *Pp, double *sigma, int64_t ld_state);
+
 int cs_bake(cs_ctx *ctx, int gas_slot, int table_slot, int shape, double dnu_cut, int64_t nnu, const double *nu, int nT,
             const double *T, int nP, const double *P, const double *conc, double *lnsigma_out);
 int cs_table_clear(cs_ctx *ctx, int table_slot);
@@ -180,6 +188,9 @@ int cs_column_set_tables(cs_ctx *ctx, int ntab, const int *table_slots, const do
  * (= P*concentration(g, T, P), :378-382); flags[c] bit 0 = extrapolate, bit 1 = singles (:163). */
 int cs_column_set_cia(cs_ctx *ctx, int ncia, const int *cia_slots, const int *flags, const double *P1, const double *P2);
 int cs_column_run(cs_ctx *ctx, void *stream);
+/* only the cross-section stage of cs_column_run: sigma[K][nnu] = Sigma(absorbers, i, T_k, P_k) for every wavenumber and node
+ * (absorbers.jl:95), left in HBM for cs_column_sigma_fetch / cs_accel_store.  Asynchronous. */
+int cs_column_sigma_run(cs_ctx *ctx, void *stream);
 int cs_column_sync(cs_ctx *ctx);
 /* run `reps` evaluations with HIP events between the kernel classes on `stream`; ms[7] = average milliseconds per
  * evaluation spent in {k_prep+k_zones+k_izones, k_cheb_nodes, k_cheb_apply (+ k_table_eval, k_cia), k_voigt_far (or
@@ -217,13 +228,33 @@ int cs_par_parse(const char *filename, int64_t n, int16_t *M, char *I, double *n
 /*
  * B thermal states of the resident column in one go: the np+1 perturbed profiles of jacobian! or the successive profiles of
  * an RCM step loop (radiative_convective.jl:109-171).  Line sums for all B*K node states go through K1/K2 as one batch
- * (chunked to bound the workspace), then one k_rt launch solves the B columns side by side.  Gas members must be
- * line-by-line gases (plus the gray / host-evaluated terms of the setup); tables and CIA pairs are not batched.
+ * (chunked to bound the workspace), baked tables and CIA pairs of the column are evaluated at all B*K states, then one k_rt
+ * launch solves the B columns side by side.  (Host-evaluated sigma_extra terms cannot be batched: CS_EINVAL.)
  *   T_nodes, mu_nodes : [B][nlobatto*(np-1)]   T_levels : [B][np]   conc : [B][ngas*K]  (each column laid out as in
- *   cs_column_update_state);  outputs Fup, Fdn : [B][np] on the host.  The resident column's own state is left untouched.
+ *   cs_column_update_state);  conc_tab : [B][ntab*K] (as cs_column_set_tables; NULL without tables);  cia_P1, cia_P2 :
+ *   [B][ncia*K] (as cs_column_set_cia; NULL without CIA pairs);  outputs Fup, Fdn : [B][np] on the host.
+ * The resident column's own state is left untouched.
  */
 int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_nodes, const double *T_levels,
-                    const double *conc, double *Fup, double *Fdn);
+                    const double *conc, const double *conc_tab, const double *cia_P1, const double *cia_P2, double *Fup, double *Fdn);
+
+/*
+ * AcceleratedAbsorber (absorbers.jl:114-203): per wavenumber, ln Sigma on a set of pressure knots, interpolated linearly in
+ * ln P (LinearInterpolator, NoBoundaries) -- what RCM holds and hands to radiate! on every step (radiative_convective.jl:95,113).
+ *   cs_accel_store   : AcceleratedAbsorber(T, P, U) and update!(A, T) (:134-200).  The knots are the node states of the RESIDENT
+ *                      column (set it up over U's members with nlobatto = 2, so that node k = knot k = (T_k, P_k)); evaluates
+ *                      Sigma(U, i, T_k, P_k) for every wavenumber and knot in one pass of the line kernels and keeps
+ *                      max(ln Sigma, ln floatmin) in HBM as slot `accel_slot`.  Call again after cs_column_update_state = update!.
+ *   cs_accel_eval    : Sigma(A, i, T, P) = exp(phi_i(ln P)) for wavenumbers [i0, i0+n)  (:203; A(i, P), A(P) :205-207)
+ *   cs_column_set_accel : the resident column (set up with ngas = 0) takes its cross-sections from the slot -- a column over an
+ *                      AcceleratedAbsorber (unifyabsorbers(::Tuple{AcceleratedAbsorber}) :216).  In cs_column_batch such a column's
+ *                      cross-sections are evaluated once and shared by the B thermal states, as in jacobian! (the reference never
+ *                      calls update! between the perturbed radiate! calls, radiative_convective.jl:154-171).
+ */
+int cs_accel_store(cs_ctx *ctx, int accel_slot);
+int cs_accel_clear(cs_ctx *ctx, int accel_slot);
+int cs_accel_eval(cs_ctx *ctx, int accel_slot, double P, int64_t i0, int64_t n, double *sigma_out);
+int cs_column_set_accel(cs_ctx *ctx, int accel_slot);
 
 /* Scalar helpers exported for tests of the host logic (same formulas the kernels use). */
 int cs_streamnodes(int n, double *m, double *W);    /* core/shared.jl:4-21 */
