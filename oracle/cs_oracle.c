@@ -130,9 +130,73 @@ static double fad_near(double x, double y)
     return res;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Second back-end: ACM TOMS Algorithm 985 (M. R. Zaghloul, "Simple, efficient, and relatively accurate approximation for the
+ * evaluation of the Faddeyeva function", ACM Trans. Math. Softw. 44(2), 2017) -- the algorithm the reference's dependency
+ * Faddeyeva985.jl (version unpinned, source NOT under /root/reference; call site line_shapes.jl:375) implements.
+ * RESTATED FROM THE PUBLISHED ALGORITHM AS RECALLED, UNVERIFIABLE HERE: region boundaries in |z|^2 (3.8e4, 256, 62, 30) with
+ * 1..4 convergents of the Laplace continued fraction, Hui et al.'s (1978) p = 6 rational approximation for y^2 >= 0.072 and
+ * Humlicek's (1982) w4 region-IV form below.  Checked here only for self-consistency: maximum relative error of Re w against
+ * scipy's wofz over 8e5 random points = 4.9e-5 (the paper states < 4e-5), per region 3.9e-5 / 3.9e-5 / 2.5e-5 / 4.0e-5 / 4.9e-5
+ * / 2.1e-5 (tools/alg985_gap.py).  Its only purpose is to put a NUMBER on how far cross-sections and fluxes computed with the
+ * exact function (this oracle, the kernels) can sit from what the Julia reference prints: DESIGN.md section 4.
+ * ------------------------------------------------------------------------------------------ */
+static int fad_backend = 0;   /* 0: exact (default), 1: Algorithm 985 as restated above */
+void cso_set_faddeeva_backend(int b) { fad_backend = b; }
+int cso_get_faddeeva_backend(void) { return fad_backend; }
+
+typedef struct { double re, im; } cplx;
+static cplx c_mul(cplx a, cplx b) { cplx r = {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; return r; }
+static cplx c_div(cplx a, cplx b) { double d = b.re * b.re + b.im * b.im; cplx r = {(a.re * b.re + a.im * b.im) / d, (a.im * b.re - a.re * b.im) / d}; return r; }
+static cplx c_add(cplx a, double c) { cplx r = {a.re + c, a.im}; return r; }
+static cplx c_scale(cplx a, double c) { cplx r = {a.re * c, a.im * c}; return r; }
+
+static double fad_985(double x, double y)
+{
+    const double isqpi = 0.56418958354775628695;
+    const cplx z = {x, y}, iz = {-y, x};                       /* i z */
+    const double s = x * x + y * y;
+    cplx zz = c_mul(z, z), w;
+    if (s >= 3.8e4) {                                          /* w = (i/sqrt(pi)) / z */
+        cplx i1 = {0.0, isqpi};
+        w = c_div(i1, z);
+    } else if (s >= 256.0) {                                   /* i z/sqrt(pi) / (z^2 - 1/2) */
+        w = c_div(c_scale(iz, isqpi), c_add(zz, -0.5));
+    } else if (s >= 62.0) {                                    /* (i/sqrt(pi)) (z^2 - 1) / (z (z^2 - 3/2)) */
+        cplx i1 = {0.0, isqpi};
+        w = c_div(c_mul(i1, c_add(zz, -1.0)), c_mul(z, c_add(zz, -1.5)));
+    } else if (s >= 30.0 && y * y >= 1e-13) {                  /* (i z/sqrt(pi)) (z^2 - 5/2) / (z^2 (z^2 - 3) + 3/4) */
+        w = c_div(c_mul(c_scale(iz, isqpi), c_add(zz, -2.5)), c_add(c_mul(zz, c_add(zz, -3.0)), 0.75));
+    } else {
+        const cplx t = {y, -x};                                /* t = y - i x */
+        if (y * y >= 0.072) {                                  /* Hui, Armstrong & Wray (1978), p = 6 */
+            static const double a[7] = {122.6079, 214.3824, 181.9285, 93.15558, 30.18014, 5.912626, 0.5641896};
+            static const double b[7] = {122.6079, 352.7306, 457.3345, 348.7039, 170.3540, 53.99291, 10.47986};
+            cplx num = {a[6], 0.0}, den = {1.0, 0.0};
+            for (int k = 5; k >= 0; k--) num = c_add(c_mul(num, t), a[k]);
+            for (int k = 6; k >= 0; k--) den = c_add(c_mul(den, t), b[k]);
+            w = c_div(num, den);
+        } else {                                               /* Humlicek (1982) w4, region IV */
+            const cplx u = c_mul(t, t);
+            const double e = exp(u.re);
+            cplx ex = {e * cos(u.im), e * sin(u.im)};
+            static const double p[7] = {36183.31, 3321.9905, 1540.787, 219.0313, 35.76683, 1.320522, 0.56419};
+            static const double q[7] = {32066.6, 24322.84, 9022.228, 2186.181, 364.2191, 61.57037, 1.841439};
+            cplx num = {p[6], 0.0}, den = {q[6] - u.re, -u.im};          /* p6 ; (q6 - u) */
+            for (int k = 5; k >= 0; k--) { cplx m = c_mul(u, num); num.re = p[k] - m.re; num.im = -m.im; }
+            for (int k = 5; k >= 0; k--) { cplx m = c_mul(u, den); den.re = q[k] - m.re; den.im = -m.im; }
+            cplx r = c_div(c_mul(t, num), den);
+            w.re = ex.re - r.re;
+            w.im = ex.im - r.im;
+        }
+    }
+    return w.re;
+}
+
 double cso_faddeeva_re(double x, double y)
 {
     fad_init();
+    if (fad_backend == 1) return fad_985(fabs(x), y);
     x = fabs(x);
     double s = x * x + y * y;
     if (s >= 1.0e4) return fad_far(x, y, s);

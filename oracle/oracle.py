@@ -72,6 +72,8 @@ def lib():
                                              C.POINTER(C.POINTER(_Lines)), C.POINTER(C.c_int), _dp, _dp, C.c_double, _dp,
                                              _dp, _dp, C.c_double, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp]
         L.cso_num_threads.restype = C.c_int
+        L.cso_set_faddeeva_backend.argtypes = [C.c_int]
+        L.cso_get_faddeeva_backend.restype = C.c_int
         _lib = L
     return _lib
 
@@ -95,6 +97,22 @@ class Lines:
         assert self.cheb.shape == (len(self.ncheb), CHEB_LD)
         self.c = _Lines(len(self.a[0]), *[_p(x) for x in self.a], self.iso.ctypes.data_as(C.POINTER(C.c_int16)),
                         len(self.ncheb), self.ncheb.ctypes.data_as(C.POINTER(C.c_int32)), _p(self.cheb))
+
+
+class faddeeva_backend:
+    """with faddeeva_backend("alg985"): ...  -- evaluate the oracle with its restatement of ACM TOMS Algorithm 985 (what the
+    reference's Faddeyeva985 dependency implements; unverifiable here) instead of the exact function.  Only for quantifying the
+    expected disagreement with the Julia reference; every parity test uses the exact back-end."""
+
+    def __init__(self, name):
+        self.b = {"exact": 0, "alg985": 1}[name]
+
+    def __enter__(self):
+        self.old = lib().cso_get_faddeeva_backend()
+        lib().cso_set_faddeeva_backend(self.b)
+
+    def __exit__(self, *a):
+        lib().cso_set_faddeeva_backend(self.old)
 
 
 def faddeeva(x, y):
