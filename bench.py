@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--config", default="C3")
     ap.add_argument("--lines", default=None, help="synthetic | fixture")
     ap.add_argument("--nnu", type=int, default=None)
+    ap.add_argument("--shape", default="voigt", help="line shape of every gas: voigt (headline) | lorentz | doppler | PHCO2")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--precision", default="fp64", help="fp64 (headline) | mixed (fp32 far wings, BASELINE configs[4])")
     ap.add_argument("--no-interp", action="store_true", help="evaluate every (nu, line) pair (no far-wing interpolation)")
@@ -92,7 +93,7 @@ def main():
         else:
             dist.init_process_group(args.dist_backend)
 
-    cfg = W.config(args.config, nnu=args.nnu, lines_kind=args.lines)
+    cfg = W.config(args.config, nnu=args.nnu, lines_kind=args.lines, shape=args.shape)
     nu, nl = cfg["nu"], cfg["nl"]
     ranges = W.balanced_ranges(nu, cfg["absorbers"], N)
     if args.emulate_shard:
@@ -172,7 +173,7 @@ def main():
     traffic, traffic_note = None, "no PMC profile of this build/workload under profiles/"
     try:
         pm = json.load(open(os.path.join(_ROOT, "profiles", "pmc_traffic.json")))
-        default_wl = args.nnu is None and args.lines is None and N == 1 and interp_on and args.precision == "fp64" and not args.emulate_shard
+        default_wl = args.nnu is None and args.lines is None and args.shape == "voigt" and N == 1 and interp_on and args.precision == "fp64" and not args.emulate_shard
         if pm.get("source_sha16") != source_stamp():
             traffic_note = f"profiles/pmc_traffic.json belongs to build {pm.get('source_sha16')}, loaded kernels are {source_stamp()}"
         elif pm.get("config") != args.config or not default_wl:
@@ -263,7 +264,7 @@ def main():
                    higher_is_better=True, scaling="strong", vs_baseline=None,
                    dtype="f64" if args.precision == "fp64" else f"f64 with f32 far wings (x^2 >= {args.far_s:g})", data="synthetic",
                    config=dict(workload=f"{cfg['name']}: {'+'.join(g.formula for g in col.gases)}{' + CIA' if col.U.cia else ''} column, "
-                                        f"{len(nu)} wavenumbers x {nl} layers, Voigt, {cfg['lines_kind']} lines "
+                                        f"{len(nu)} wavenumbers x {nl} layers, {args.shape}, {cfg['lines_kind']} lines "
                                         f"({lines_total} total), Discretized(nstream=5,nlobatto=2)",
                                nnu=len(nu), layers=nl, lines=lines_total, parallelism=f"nu-shard x{N}"),
                    olr_wm2=olr, setup_ms=setup_ms, host_pointer_ms=host_ptr, kernel_source_sha16=source_stamp(),

@@ -365,6 +365,16 @@ void tile_windows(const std::vector<double> &nul, int64_t g0, int64_t g1, const 
     inrange = (std::upper_bound(b, e, nu[nnu - 1] + cut) - std::lower_bound(b, e, nu[0] - cut));
 }
 
+// Doppler profile exp(-(dnu/alpha)^2) (line_shapes.jl:160): beyond sqrt(750) widths it is an exact zero in fp64 (exp(-745.2) is
+// the smallest denormal), so the windows of the Doppler line sum only need the lines within that reach of a tile -- a bound for
+// every state: the widest line is the one at the upper end of the grid, at TMAX, of the lightest isotopologue (line_shapes.jl:144)
+double window_reach(int shape, const GasTable &G, double numax, double cut)
+{
+    if (shape != SH_DOPPLER) return cut;
+    const double amax = ((numax + cut) / kC) * std::sqrt(2.0 * kRgas * kTmax / G.mu_min);
+    return std::min(cut, std::sqrt(750.0) * amax * (1.0 + 1e-6));
+}
+
 int64_t count_pairs(const std::vector<double> &nul, const double *nu, int64_t nnu, double cut)
 {
     int64_t pairs = 0;
@@ -568,10 +578,13 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
     pa.shape = shape; pa.K = kn; pa.g = G.dev(); pa.jlo = jlo; pa.jhi = jhi;
     pa.Tk = Tk; pa.Pk = Pk; pa.Ppk = Ppk; pa.scale = scale; pa.hot = hot; pa.cold = cold; pa.hot32 = shape == SH_VOIGT ? hot32 : nullptr;
     const unsigned nb_prep = (unsigned)((tot + 255) / 256);
-    if (shape == SH_VOIGT) {
+    const bool lor = shape == SH_LORENTZ;   // lorentz! runs on the same far-wing machinery with its own (exact) body
+    if (shape == SH_VOIGT || lor) {
+        if (lor) hot32 = nullptr;           // (no fp32 variant of the Lorentz body)
         const int nt64 = (int)((nnu + 63) / 64);
         ZoneArgs za;
         za.nu = dnu; za.nul = G.nu.as<double>(); za.Tk = Tk; za.gbound = gbound; za.win = win; za.zones = zones; za.nnu = nnu;
+        za.lorentz = lor ? 1 : 0;
         za.ntile = nt64; za.K = kn; za.mu_min = G.mu_min; za.mu_max = G.mu_max; za.cut = cut; za.far_s = far_s;
         const unsigned nb_zones = (unsigned)(((int64_t)nt64 * kn + 255) / 256);
         IzParams P;
@@ -593,11 +606,14 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
             // deferred apply: the gases of a column add their node sums into ONE F (levels an earlier gas has written accumulate)
             const int q_acc = (defer && defer->ngas > 0 && defer->l0[0] < itp.nlev) ? itp.ioff[defer->l0[0]] : itp.nItot;
             const dim3 gridn((unsigned)((kn + 3) / 4) * (unsigned)(itp.nItot - q0));
-            if (hot32)
-                hipLaunchKernelGGL((k_cheb_nodes<true>), gridn, dim3(256), 0, s, itp.nodes, G.L, hot, hot32, G.nu.as<double>(), itp.iz,
+            if (lor)
+                hipLaunchKernelGGL((k_cheb_nodes<false, true>), gridn, dim3(256), 0, s, itp.nodes, G.L, hot, hot32, G.nu.as<double>(), itp.iz,
+                                   itp.nItot, q0, q_acc, kn, itp.Kpad, cut, itp.F);
+            else if (hot32)
+                hipLaunchKernelGGL((k_cheb_nodes<true, false>), gridn, dim3(256), 0, s, itp.nodes, G.L, hot, hot32, G.nu.as<double>(), itp.iz,
                                    itp.nItot, q0, q_acc, kn, itp.Kpad, cut, itp.F);
             else
-                hipLaunchKernelGGL((k_cheb_nodes<false>), gridn, dim3(256), 0, s, itp.nodes, G.L, hot, hot32, G.nu.as<double>(), itp.iz,
+                hipLaunchKernelGGL((k_cheb_nodes<false, false>), gridn, dim3(256), 0, s, itp.nodes, G.L, hot, hot32, G.nu.as<double>(), itp.iz,
                                    itp.nItot, q0, q_acc, kn, itp.Kpad, cut, itp.F);
             if (evg) (void)hipEventRecord(evg[1], s);
             ChebApply A0;
@@ -633,19 +649,26 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
         const int split = nwave >= 16384 ? 1 : (nwave >= 4096 ? 2 : 4);   // (re-tuned with the far wings interpolated: waves are 3x shorter)
         const int nblk_s = (nt64 * split + 3) / 4;
         const dim3 grid_s((unsigned)((nblk_s + 7) / 8 * 8), kn);
-#define CS_FAR_LAUNCH(MIX, SP) hipLaunchKernelGGL((k_voigt_far<MIX, SP>), grid_s, dim3(256), 0, s, dnu, nnu, G.L, hot, hot32, G.nu.as<double>(), \
+#define CS_FAR_LAUNCH(MIX, SP) hipLaunchKernelGGL((k_voigt_far<MIX, SP, false>), grid_s, dim3(256), 0, s, dnu, nnu, G.L, hot, hot32, G.nu.as<double>(), \
                                                   win, zones, nt64, nblk_s, cut, base, extra, sigma, accumulate, ranges, iz, itp.nItot, ishift)
-        if (hot32) {
+#define CS_LOR_LAUNCH(SP) hipLaunchKernelGGL((k_voigt_far<false, SP, true>), grid_s, dim3(256), 0, s, dnu, nnu, G.L, hot, hot32, G.nu.as<double>(), \
+                                                  win, zones, nt64, nblk_s, cut, base, extra, sigma, accumulate, ranges, iz, itp.nItot, ishift)
+        if (lor) {
+            if (split == 1) CS_LOR_LAUNCH(1); else if (split == 2) CS_LOR_LAUNCH(2); else CS_LOR_LAUNCH(4);
+        } else if (hot32) {
             if (split == 1) CS_FAR_LAUNCH(true, 1); else if (split == 2) CS_FAR_LAUNCH(true, 2); else CS_FAR_LAUNCH(true, 4);
         } else {
             if (split == 1) CS_FAR_LAUNCH(false, 1); else if (split == 2) CS_FAR_LAUNCH(false, 2); else CS_FAR_LAUNCH(false, 4);
         }
 #undef CS_FAR_LAUNCH
+#undef CS_LOR_LAUNCH
         if (evg) (void)hipEventRecord(evg[2], s);
-        const int ngrp = (nt64 + CS_NEAR_R - 1) / CS_NEAR_R;   // near kernels: one wave = CS_NEAR_R consecutive tiles
-        const dim3 gridq((unsigned)((ngrp + 3) / 4), kn);
-        hipLaunchKernelGGL(k_voigt_near<0>, gridq, dim3(256), 0, s, dnu, nnu, G.L, hot, cold, zones, nt64, ngrp, cut, sigma, ranges);
-        hipLaunchKernelGGL(k_voigt_near<1>, gridq, dim3(256), 0, s, dnu, nnu, G.L, hot, cold, zones, nt64, ngrp, cut, sigma, ranges);
+        if (!lor) {
+            const int ngrp = (nt64 + CS_NEAR_R - 1) / CS_NEAR_R;   // near kernels: one wave = CS_NEAR_R consecutive tiles
+            const dim3 gridq((unsigned)((ngrp + 3) / 4), kn);
+            hipLaunchKernelGGL(k_voigt_near<0>, gridq, dim3(256), 0, s, dnu, nnu, G.L, hot, cold, zones, nt64, ngrp, cut, sigma, ranges);
+            hipLaunchKernelGGL(k_voigt_near<1>, gridq, dim3(256), 0, s, dnu, nnu, G.L, hot, cold, zones, nt64, ngrp, cut, sigma, ranges);
+        }
     } else {
         if (nb_prep > 0) {
             ZoneArgs za;
@@ -821,7 +844,7 @@ static int shape_impl(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t 
     int64_t g0, g1, pairs, inr;
     included_range(G.h_nu, nu[0], nu[nnu - 1], dnu_cut, strict, g0, g1);
     std::vector<int32_t> J0, J1;
-    tile_windows(G.h_nu, g0, g1, nu, nnu, dnu_cut, J0, J1, pairs, inr);
+    tile_windows(G.h_nu, g0, g1, nu, nnu, window_reach(shape, G, nu[nnu - 1], dnu_cut), J0, J1, pairs, inr);
     const int ntile = (int)J0.size();
     DevBuf dnu, dT, dP, dPp, dJ0, dJ1, hot, cold, dsig, dwin, dzones, dgmax, dranges;
     std::vector<WaveWin> win;
@@ -851,7 +874,7 @@ static int shape_impl(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t 
     ChebGrid cheb;
     GasInterp ginterp;
     Interp itp;
-    if (ctx->interp && shape == SH_VOIGT) {
+    if (ctx->interp && (shape == SH_VOIGT || shape == SH_LORENTZ)) {
         if ((rc = cheb_build(ctx, cheb, nu, dnu.as<double>(), nnu, dnu_cut, s)) ||
             (rc = gas_interp_build(ctx, ginterp, cheb, G.h_nu, g0, g1, nu, nnu, dnu_cut, kc, s)))
             return rc;
@@ -902,7 +925,7 @@ int cs_bake(cs_ctx *ctx, int gas_slot, int table_slot, int shape, double dnu_cut
     int64_t g0, g1, pairs, inr;
     included_range(G.h_nu, nu[0], nu[nnu - 1], dnu_cut, true, g0, g1);
     std::vector<int32_t> J0, J1;
-    tile_windows(G.h_nu, g0, g1, nu, nnu, dnu_cut, J0, J1, pairs, inr);
+    tile_windows(G.h_nu, g0, g1, nu, nnu, window_reach(shape, G, nu[nnu - 1], dnu_cut), J0, J1, pairs, inr);
     std::vector<WaveWin> win;
     wave_windows(G.h_nu, g0, g1, nu, nnu, dnu_cut, win);
     const int ntile = (int)J0.size();
@@ -927,7 +950,7 @@ int cs_bake(cs_ctx *ctx, int gas_slot, int table_slot, int shape, double dnu_cut
     ChebGrid cheb;
     GasInterp ginterp;
     Interp itp;
-    if (ctx->interp && shape == SH_VOIGT) {
+    if (ctx->interp && (shape == SH_VOIGT || shape == SH_LORENTZ)) {
         if ((rc = cheb_build(ctx, cheb, nu, dnu.as<double>(), nnu, dnu_cut, s)) ||
             (rc = gas_interp_build(ctx, ginterp, cheb, G.h_nu, g0, g1, nu, nnu, dnu_cut, kc, s)))
             return rc;
@@ -1349,7 +1372,7 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
     if (ctx->interp) {   // interval sizes from the narrowest Voigt cut-off of the column
         double cmin = 0.0;
         for (int gi = 0; gi < ngas; gi++)
-            if ((shapes ? shapes[gi] : CS_SHAPE_VOIGT) == SH_VOIGT) {
+            if ((shapes ? shapes[gi] : CS_SHAPE_VOIGT) == SH_VOIGT || (shapes ? shapes[gi] : CS_SHAPE_VOIGT) == SH_LORENTZ) {
                 const double cu = dnu_cuts ? dnu_cuts[gi] : 25.0;
                 cmin = cmin > 0.0 ? std::min(cmin, cu) : cu;
             }
@@ -1369,7 +1392,9 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
         int64_t g0, g1;
         included_range(G.h_nu, nu[0], nu[nnu - 1], cg.cut, false, g0, g1);
         std::vector<int32_t> J0, J1;
-        tile_windows(G.h_nu, g0, g1, nu, nnu, cg.cut, J0, J1, cg.pairs_per_state, cg.lines_in_range);
+        tile_windows(G.h_nu, g0, g1, nu, nnu, window_reach(cg.shape, G, nu[nnu - 1], cg.cut), J0, J1, cg.pairs_per_state, cg.lines_in_range);
+        cg.lines_in_range = std::upper_bound(G.h_nu.begin() + g0, G.h_nu.begin() + g1, nu[nnu - 1] + cg.cut) -
+                            std::lower_bound(G.h_nu.begin() + g0, G.h_nu.begin() + g1, nu[0] - cg.cut);   // (the reference's count: inside the cut-off)
         cg.jlo = J0.front();
         cg.jhi = J1.back();
         std::vector<WaveWin> win;
@@ -1379,7 +1404,7 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
             return rc;
         HIPCHK(cg.zones.reserve((size_t)c.K * win.size() * sizeof(Zone)));
         HIPCHK(cg.gmax.reserve((size_t)c.K * sizeof(double)));
-        if (c.cheb.nlev > 0 && cg.shape == SH_VOIGT &&
+        if (c.cheb.nlev > 0 && (cg.shape == SH_VOIGT || cg.shape == SH_LORENTZ) &&
             (rc = gas_interp_build(ctx, cg.itp, c.cheb, G.h_nu, g0, g1, nu, nnu, cg.cut, c.K, s, false)))
             return rc;
         maxL = std::max(maxL, (size_t)G.L);
@@ -1828,7 +1853,7 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
     const int nt64 = (int)((c.nnu + 63) / 64);
     int64_t direct = 0, nodes = 0;
     for (auto &g : c.gas) {
-        if (g.shape != SH_VOIGT) continue;
+        if (g.shape != SH_VOIGT && g.shape != SH_LORENTZ) continue;
         std::vector<WaveWin> win(nt64);
         std::vector<Zone> zn((size_t)K * nt64);
         HIPCHK(hipMemcpy(win.data(), g.win.p, win.size() * sizeof(WaveWin), hipMemcpyDeviceToHost));

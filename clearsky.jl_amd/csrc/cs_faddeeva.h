@@ -28,6 +28,14 @@ __device__ __forceinline__ double rcp_nr(double s)
     return r;
 }
 
+// 1/s to ~2e-15 over the whole fp64 range: v_rcp_f64 seed (4.5e-8) + one Newton step
+__device__ __forceinline__ double rcp_nr1(double s)
+{
+    double r = __builtin_amdgcn_rcp(s);
+    double e = __builtin_fma(-s, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+
 // 1/s to ~3e-15 for the far-wing series (s >= 1e4): single-precision reciprocal seed (v_cvt_f32_f64, v_rcp_f32,
 // v_cvt_f64_f32 = 1.7 FMA-equivalents, against 3.2 for v_rcp_f64 and 12 for an IEEE division; tools/ubench) + one Newton
 // step.  s beyond the f32 range gives a zero seed and a zero term (the true term is < 1e-38 of the line strength).

@@ -172,7 +172,8 @@ __global__ __launch_bounds__(256) void k_linesum(const double *__restrict__ nu, 
             if (SHAPE == SH_LORENTZ) {
                 acc += h.p2 / __builtin_fma(dv, dv, h.p1);
             } else if (SHAPE == SH_DOPPLER) {
-                acc += h.p2 * exp(-(dv * dv) * h.p1);
+                const double a2 = (dv * dv) * h.p1;
+                if (a2 < 750.0) acc += h.p2 * exp(-a2);   // (beyond: an exact zero in fp64, as the reference's exp gives)
             } else if (SHAPE == SH_VOIGT) {
                 const double x = dv * h.p1;
                 const double s = __builtin_fma(x, x, h.p2);
@@ -220,7 +221,7 @@ struct ZoneArgs {
     const WaveWin *win;
     Zone *zones;
     int64_t nnu;
-    int ntile, K;
+    int ntile, K, lorentz;   // lorentz: pure Lorentz profile -- one body everywhere, no Doppler core, no near zone
     double mu_min, mu_max, cut, far_s;
 };
 __device__ __forceinline__ void zones_body(unsigned bid, const ZoneArgs &a)
@@ -237,6 +238,21 @@ __device__ __forceinline__ void zones_body(unsigned bid, const ZoneArgs &a)
     const int64_t i0 = (int64_t)t * 64, i1 = (i0 + 63 < nnu ? i0 + 63 : nnu - 1);
     const double vlo = nu[i0], vhi = nu[i1];
     const WaveWin w = win[t];
+    if (a.lorentz) {
+        // every line takes the (exact) Lorentz body, so the zones only say where the cut-off predicate is needed: the window is
+        // split at the first line at or above the tile (an empty "near zone" there keeps the interpolated sets, which are clamped
+        // against it, on their own sides); [Q0, split) and [split, Q1) run with the predicate, [E0, Q0) and [Q1, E1) -- lines
+        // inside the cut-off of every lane -- without
+        int lo = w.W0, hi = w.W1;
+        while (lo < hi) { const int m = (lo + hi) >> 1; if (nul[m] < vlo) lo = m + 1; else hi = m; }
+        Zone z;
+        z.N0 = z.N1 = lo;
+        z.M0 = z.Q0 = min(lo, w.E1);
+        z.M1 = z.Q1 = max(lo, w.E0);
+        z.pad1 = z.pad2 = 0;
+        zones[idx] = z;
+        return;
+    }
     // largest Doppler width any line of the window can have at this temperature (alphadoppler, line_shapes.jl:144)
     const double vth = sqrt(2.0 * kRgas * Tk[k]);
     const double amax = ((vhi + cut) / kC) * vth / sqrt(mu_min);
@@ -290,10 +306,17 @@ __device__ __forceinline__ FarK load_fark()
 //   0  s >= 1e6 and y^2 <= 60 : 1 + u (1.5 + u (3.75 - 2 y^2))                          13 VALU instructions
 //   1  s >= 1e6               : 1 + u (1.5 + u (3.75 - 2 y^2 + t (12 t - 15)))           16
 //   2  s >= 1e4               : all four terms                                           20
-template <bool PRED, int MODE>
+//   LOR: the Lorentz profile itself, (C S gamma/pi) / (dnu^2 + gamma^2) with hot = {nul, gamma^2, C S gamma/pi} -- exact at any
+//        distance, 8 VALU instructions (lorentz!, line_shapes.jl:273,313-324)
+template <bool PRED, int MODE, bool LOR = false>
 __device__ __forceinline__ double far_term(const LineHot &h, double v, double cut, const FarK &c)
 {
     const double dv = v - h.nul;
+    if (LOR) {
+        double r = h.p2 * rcp_nr1(__builtin_fma(dv, dv, h.p1));
+        if (PRED) r = (fabs(dv) > cut) ? 0.0 : r;
+        return r;
+    }
     const double x = dv * h.p1;
     const double s = __builtin_fma(x, x, h.p2);
     const double u = rcp_fast(s);
@@ -317,21 +340,21 @@ __device__ __forceinline__ double far_term(const LineHot &h, double v, double cu
     return r;
 }
 
-template <bool PRED, int MODE>
+template <bool PRED, int MODE, bool LOR = false>
 __device__ __forceinline__ double far_segment(double acc, double v, const LineHot *__restrict__ hk, int j0, int j1, double cut,
                                               const FarK &c)
 {
 #pragma unroll 4
-    for (int j = j0; j < j1; j++) acc += far_term<PRED, MODE>(hk[j], v, cut, c);
+    for (int j = j0; j < j1; j++) acc += far_term<PRED, MODE, LOR>(hk[j], v, cut, c);
     return acc;
 }
 // the same lines from j1-1 down to j0 (lines right of nu: farthest = smallest terms first)
-template <bool PRED, int MODE>
+template <bool PRED, int MODE, bool LOR = false>
 __device__ __forceinline__ double far_segment_rev(double acc, double v, const LineHot *__restrict__ hk, int j0, int j1, double cut,
                                                   const FarK &c)
 {
 #pragma unroll 4
-    for (int j = j1 - 1; j >= j0; j--) acc += far_term<PRED, MODE>(hk[j], v, cut, c);
+    for (int j = j1 - 1; j >= j0; j--) acc += far_term<PRED, MODE, LOR>(hk[j], v, cut, c);
     return acc;
 }
 
@@ -467,7 +490,7 @@ struct IzParams {
 // E0, Z0, Z1, E1 of (level l, interval T, state with thermal speed vth); false if the set is empty
 __device__ __forceinline__ bool izone_outer(const IzParams &P, int l, int T, const double *__restrict__ nu, int64_t nnu,
                                             const double *__restrict__ nul, double vth, double mu_min, double cut, double &vlo,
-                                            double &vhi, double &dA, int &E0, int &Z0, int &Z1, int &E1)
+                                            double &vhi, double &dA, int &E0, int &Z0, int &Z1, int &E1, bool lorentz = false)
 {
     const int itv = P.itv[l];
     const int64_t i0 = (int64_t)T * itv, i1 = (i0 + itv - 1 < nnu ? i0 + itv - 1 : nnu - 1);
@@ -478,7 +501,7 @@ __device__ __forceinline__ bool izone_outer(const IzParams &P, int l, int T, con
     if (w.E1 <= w.E0) { E0 = Z0 = Z1 = E1 = w.E0; return false; }   // (then the parent has nothing either: the sets are nested)
     const double h = 0.5 * (vhi - vlo);
     const double amax = ((vhi + cut) / kC) * vth / sqrt(mu_min);
-    dA = 100.0 * amax / kSqLn2 * (1.0 + 1e-6);
+    dA = lorentz ? 0.0 : 100.0 * amax / kSqLn2 * (1.0 + 1e-6);   // (a Lorentz profile has no Doppler core to stay clear of)
     const double dZ = fmax(dA, kChebMargin * h);
     auto lower = [&](double val, int a, int b) { while (a < b) { int m = (a + b) >> 1; if (nul[m] < val) a = m + 1; else b = m; } return a; };
     auto upper = [&](double val, int a, int b) { while (a < b) { int m = (a + b) >> 1; if (nul[m] <= val) a = m + 1; else b = m; } return a; };
@@ -504,7 +527,7 @@ __device__ __forceinline__ void izones_body(unsigned bid, const IzParams &P, con
     const double vth = sqrt(2.0 * kRgas * Tk[k]);
     double vlo, vhi, dA;
     IZone z;
-    if (!izone_outer(P, l, T, nu, nnu, nul, vth, mu_min, cut, vlo, vhi, dA, z.E0, z.Z0, z.Z1, z.E1)) {
+    if (!izone_outer(P, l, T, nu, nnu, nul, vth, mu_min, cut, vlo, vhi, dA, z.E0, z.Z0, z.Z1, z.E1, a.lorentz)) {
         z.Q0 = z.M0 = z.M1 = z.Q1 = z.P0 = z.P1 = z.P2 = z.P3 = z.E0;
         iz[idx] = z;
         return;
@@ -530,6 +553,7 @@ __device__ __forceinline__ void izones_body(unsigned bid, const IzParams &P, con
     } else {
         z.Q0 = z.E0; z.Q1 = z.E1;
     }
+    if (a.lorentz) { z.Q0 = z.M0 = z.Z0; z.Q1 = z.M1 = z.Z1; }   // one body: the whole set runs as "mode 0"
     // the parent's own set is nested in this one ([E0,E1) grows and [Z0,Z1) shrinks with the interval); clamp it anyway
     z.P0 = z.P1 = z.E0;
     z.P2 = z.P3 = z.E1;
@@ -538,7 +562,7 @@ __device__ __forceinline__ void izones_body(unsigned bid, const IzParams &P, con
         for (int r = P.itv[l - 1] / P.itv[l]; r > 1; r >>= 1) pshift++;
         double pvlo, pvhi, pdA;
         int qE0, qZ0, qZ1, qE1;
-        if (izone_outer(P, l - 1, T >> pshift, nu, nnu, nul, vth, mu_min, cut, pvlo, pvhi, pdA, qE0, qZ0, qZ1, qE1)) {
+        if (izone_outer(P, l - 1, T >> pshift, nu, nnu, nul, vth, mu_min, cut, pvlo, pvhi, pdA, qE0, qZ0, qZ1, qE1, a.lorentz)) {
             if (qZ0 > qE0) { z.P0 = min(max(qE0, z.E0), z.Z0); z.P1 = min(max(qZ0, z.P0), z.Z0); }
             if (qE1 > qZ1) { z.P2 = min(max(qZ1, z.Z1), z.E1); z.P3 = min(max(qE1, z.P2), z.E1); }
         }
@@ -559,7 +583,7 @@ __global__ __launch_bounds__(256) void k_gas_setup(unsigned nb_prep, unsigned nb
 // one wave = the 64 Chebyshev nodes of one interval x one node state: far-wing sums at the nodes -> F[interval][node][state].
 // All levels run in one launch over the concatenated interval list (largest intervals, i.e. longest waves, first).
 #define CS_KPAD 16   // F rows are padded to a multiple of 16 states (k_cheb_apply reads 16 at a time with scalar loads)
-template <bool MIXED>
+template <bool MIXED, bool LOR>
 __global__ __launch_bounds__(256) void k_cheb_nodes(const double *__restrict__ nodes, int64_t L, const LineHot *__restrict__ hot,
                                                      const LineF32 *__restrict__ hot32, const double *__restrict__ gnul,
                                                      const IZone *__restrict__ iz, int nItot, int q0, int q_acc, int K, int Kpad, double cut,
@@ -592,10 +616,10 @@ __global__ __launch_bounds__(256) void k_cheb_nodes(const double *__restrict__ n
             accL = far_segment32<false, 0>(accL, v, gnul, hf, LO(z.E0), HI(z.Q0), cut);
             accL = far_segment32<false, 1>(accL, v, gnul, hf, LO(z.Q0), HI(z.M0), cut);
         } else {
-            accL = far_segment<false, 0>(accL, v, hk, LO(z.E0), HI(z.Q0), cut, c);
-            accL = far_segment<false, 1>(accL, v, hk, LO(z.Q0), HI(z.M0), cut, c);
+            accL = far_segment<false, 0, LOR>(accL, v, hk, LO(z.E0), HI(z.Q0), cut, c);
+            accL = far_segment<false, 1, LOR>(accL, v, hk, LO(z.Q0), HI(z.M0), cut, c);
         }
-        accL = far_segment<false, 2>(accL, v, hk, LO(z.M0), HI(z.Z0), cut, c);
+        accL = far_segment<false, 2, LOR>(accL, v, hk, LO(z.M0), HI(z.Z0), cut, c);
     }
     for (int cw = 0; cw < 2; cw++) {
         const int p0 = cw == 0 ? z.P3 : z.Z1, p1 = cw == 0 ? z.E1 : z.P2;
@@ -604,10 +628,10 @@ __global__ __launch_bounds__(256) void k_cheb_nodes(const double *__restrict__ n
             accR = far_segment32_rev<false, 0>(accR, v, gnul, hf, LO(z.Q1), HI(z.E1), cut);
             accR = far_segment32_rev<false, 1>(accR, v, gnul, hf, LO(z.M1), HI(z.Q1), cut);
         } else {
-            accR = far_segment_rev<false, 0>(accR, v, hk, LO(z.Q1), HI(z.E1), cut, c);
-            accR = far_segment_rev<false, 1>(accR, v, hk, LO(z.M1), HI(z.Q1), cut, c);
+            accR = far_segment_rev<false, 0, LOR>(accR, v, hk, LO(z.Q1), HI(z.E1), cut, c);
+            accR = far_segment_rev<false, 1, LOR>(accR, v, hk, LO(z.M1), HI(z.Q1), cut, c);
         }
-        accR = far_segment_rev<false, 2>(accR, v, hk, LO(z.Z1), HI(z.M1), cut, c);
+        accR = far_segment_rev<false, 2, LOR>(accR, v, hk, LO(z.Z1), HI(z.M1), cut, c);
 #undef LO
 #undef HI
     }
@@ -795,7 +819,7 @@ __global__ __launch_bounds__(256, NSUB >= 4 ? 2 : 4) void k_cheb_apply_mfma(Cheb
 // line parameters arrive through scalar loads:
 //   [W0,a) left edge (cut-off predicate) | [a,M0) far | [M0,N0) mid-far | [N0,N1) near zone | [N1,M1) | [M1,b) | [b,W1)
 // In the near zone only the pairs with s >= 1e4 are summed here; the others belong to k_voigt_near.
-template <bool MIXED, int S>
+template <bool MIXED, int S, bool LOR>
 __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu, int64_t nnu, int64_t L,
                                                     const LineHot *__restrict__ hot, const LineF32 *__restrict__ hot32,
                                                     const double *__restrict__ gnul, const WaveWin *__restrict__ win,
@@ -872,13 +896,13 @@ __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu
                 acc = far_segment32<true, 1>(acc, v, gnul, hf, LO(z.Q0), HI(a1), cut);
                 acc = far_segment32<false, 1>(acc, v, gnul, hf, LO(a1), HI(z.M0), cut);
             } else {
-                acc = far_segment<true, 0>(acc, v, hk, LO(w.W0), HI(a), cut, c);
-                acc = far_segment<false, 0>(acc, v, hk, LO(a), HI(z.Q0), cut, c);
-                acc = far_segment<true, 1>(acc, v, hk, LO(z.Q0), HI(a1), cut, c);
-                acc = far_segment<false, 1>(acc, v, hk, LO(a1), HI(z.M0), cut, c);
+                acc = far_segment<true, 0, LOR>(acc, v, hk, LO(w.W0), HI(a), cut, c);
+                acc = far_segment<false, 0, LOR>(acc, v, hk, LO(a), HI(z.Q0), cut, c);
+                acc = far_segment<true, 1, LOR>(acc, v, hk, LO(z.Q0), HI(a1), cut, c);
+                acc = far_segment<false, 1, LOR>(acc, v, hk, LO(a1), HI(z.M0), cut, c);
             }
         }
-        acc = far_segment<true, 2>(acc, v, hk, LO(z.M0), HI(z.N0), cut, c);
+        acc = far_segment<true, 2, LOR>(acc, v, hk, LO(z.M0), HI(z.N0), cut, c);
         // near zone: six-term series where s >= 1e3; the index ranges of this lane's s < 1e3 and s < 100 lines go to
         // k_voigt_near through `ranges` (relative to N0; empty = {0,0})
         if (HI(z.N1) > LO(z.N0)) {
@@ -909,7 +933,7 @@ __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu
                 if (in && s < kMidS) { cl = min(cl, j); ch = j; }
             }
         }
-        acc = far_segment<true, 2>(acc, v, hk, LO(z.N1), HI(z.M1), cut, c);
+        acc = far_segment<true, 2, LOR>(acc, v, hk, LO(z.N1), HI(z.M1), cut, c);
         {   // right of the wave: [M1,b1) | [b1,Q1) 3-term | [Q1,b) | [b,W1) 2-term, beyond E1 with the cut-off predicate
             const int b1 = max(min(w.E1, z.Q1), z.M1), bq = max(min(w.E1, w.W1), z.Q1);
             if (MIXED) {
@@ -918,10 +942,10 @@ __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu
                 acc = far_segment32<false, 0>(acc, v, gnul, hf, LO(z.Q1), HI(bq), cut);
                 acc = far_segment32<true, 0>(acc, v, gnul, hf, LO(bq), HI(w.W1), cut);
             } else {
-                acc = far_segment<false, 1>(acc, v, hk, LO(z.M1), HI(b1), cut, c);
-                acc = far_segment<true, 1>(acc, v, hk, LO(b1), HI(z.Q1), cut, c);
-                acc = far_segment<false, 0>(acc, v, hk, LO(z.Q1), HI(bq), cut, c);
-                acc = far_segment<true, 0>(acc, v, hk, LO(bq), HI(w.W1), cut, c);
+                acc = far_segment<false, 1, LOR>(acc, v, hk, LO(z.M1), HI(b1), cut, c);
+                acc = far_segment<true, 1, LOR>(acc, v, hk, LO(b1), HI(z.Q1), cut, c);
+                acc = far_segment<false, 0, LOR>(acc, v, hk, LO(z.Q1), HI(bq), cut, c);
+                acc = far_segment<true, 0, LOR>(acc, v, hk, LO(bq), HI(w.W1), cut, c);
             }
         }
 #undef LO
@@ -944,9 +968,11 @@ __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu
         int2 r0, r1;   // two planes of int2 inside the int4 workspace (k_voigt_near<0>, <1>)
         r0.x = bh >= bl ? bl - z.N0 : 0; r0.y = bh >= bl ? bh + 1 - z.N0 : 0;
         r1.x = ch >= cl ? cl - z.N0 : 0; r1.y = ch >= cl ? ch + 1 - z.N0 : 0;
-        int2 *__restrict__ rp = reinterpret_cast<int2 *>(ranges);
-        rp[(size_t)k * nnu + i] = r0;
-        rp[((size_t)gridDim.y + k) * nnu + i] = r1;
+        if (!LOR) {   // (a Lorentz profile has no near-line kernels to hand anything to)
+            int2 *__restrict__ rp = reinterpret_cast<int2 *>(ranges);
+            rp[(size_t)k * nnu + i] = r0;
+            rp[((size_t)gridDim.y + k) * nnu + i] = r1;
+        }
         const size_t o = (size_t)k * nnu + i;
         const double prev = accumulate ? sigma[o] : (base + (extra ? extra[o] : 0.0));
         sigma[o] = prev + acc;

@@ -165,3 +165,48 @@ def test_first_level_choice(cs, lines):
         else:
             assert relerr(sig, ref, floor=1e-250) < 5e-14, l0
     assert auto > full > 0          # the sparse tables skip the largest intervals: more node evaluations, fewer matrix passes
+
+
+@pytest.mark.parametrize("gas", ["CO2", "H2O"])
+def test_lorentz_fast_path(cs, O, lines, ctx_on, ctx_off, gas):
+    """lorentz! (line_shapes.jl:273,313-324) on the far-wing machinery with its own exact body: interpolated far wings (fine grid,
+    several interval levels) vs the oracle, which evaluates every pair, and vs the device with interpolation off."""
+    sl = lines(gas)
+    nu = np.linspace(640.0, 700.0, 24001) if gas == "CO2" else np.linspace(1500.0, 1560.0, 24001)
+    assert len(cs.interp_plan(nu, 25.0)) >= 4
+    T, P, Pp = map(list, zip(*STATES))
+    on = cs.shape_batch(sl, "lorentz", nu, T, P, Pp, 25.0, ctx_on)
+    off = cs.shape_batch(sl, "lorentz", nu, T, P, Pp, 25.0, ctx_off)
+    assert relerr(on, off, floor=1e-250) < 5e-14
+    for k in range(len(T)):
+        so = O.shape_bang("lorentz", nu, sl, T[k], P[k], Pp[k], 25.0)
+        assert np.array_equal(on[k] == 0, so == 0)
+        assert relerr(on[k], so, floor=1e-250) < 5e-12
+    # a narrow and a wide cut-off, ragged tail
+    for cut, n in ((3.0, 7777), (120.0, 9001)):
+        nu2 = np.linspace(2300.0, 2330.0, n)
+        a = cs.shape_batch(lines("CO2"), "lorentz", nu2, T[:2], P[:2], Pp[:2], cut, ctx_on)
+        for k in range(2):
+            assert relerr(a[k], O.shape_bang("lorentz", nu2, lines("CO2"), T[k], P[k], Pp[k], cut), floor=1e-250) < 5e-12
+
+
+def test_lorentz_and_doppler_columns_vs_oracle(cs, O, lines):
+    """Whole columns with the other shapes on a fine grid (the Doppler sum only walks the lines within the profile's non-zero
+    reach, sqrt(750) Doppler widths: beyond, exp(-x^2) is an exact zero in fp64)."""
+    ctx = cs.Context(0)
+    nu = np.linspace(660.0, 680.0, 8001)
+    P = cs.pressuregrid(1.0, 1e5, 13)
+    T = np.linspace(205.0, 290.0, 13)
+    for shape, tol in (("lorentz", 1e-11), ("doppler", 1e-9)):
+        g1 = cs.DirectGas(lines("CO2"), 400e-6, nu, shape=shape)
+        g2 = cs.DirectGas(lines("H2O"), 3e-3, nu, shape=shape)
+        col = cs.Column(P, 9.8, T, 0.029, 0.0, 0.0, g1, g2, core=cs.Discretized(5, 2), ctx=ctx)
+        col.run()
+        tau = np.zeros((col.nl, col.nnu), order="F")
+        F = col.fetch(tau)
+        r = O.fluxes_discretized(nu, P, 9.8, 2, col.Tn, col.mun, col.Tlev, [g1.sl, g2.sl], [shape] * 2, [25.0] * 2, col.conc, want_sigma=True)
+        s = col.sigma_nodes()
+        assert np.array_equal(s == 0, r["sigma"] == 0)
+        assert relerr(s, r["sigma"], floor=1e-300) < tol
+        assert relerr(tau, r["tau"]) < tol and abs(F[0][0] - r["Fup"][0]) < 1e-10 * r["Fup"][0]
+    ctx.close()

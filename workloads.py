@@ -41,7 +41,7 @@ def lines(kind: str, which: str):
     return _cache[key]
 
 
-def config(name: str, nnu=None, nl=None, lines_kind=None, nu_span=(1.0, 2500.0)):
+def config(name: str, nnu=None, nl=None, lines_kind=None, nu_span=(1.0, 2500.0), shape="voigt"):
     """Returns dict(P, g, T, mu, fS, fa, absorbers, core, theta_s, nu) for
     "C2" CO2 fixture, 1e4 nu x 40 layers;  "C3" H2O+CO2, 1e5 nu x 60 layers (synthetic ~1e5-line table by default);
     "C5" H2O+CO2+CH4+O3 + CIA, 5e5 nu x 100 layers.  `nu_span` cuts a window out of the 1..2500 cm^-1 grid (parity tests at
@@ -66,7 +66,7 @@ def config(name: str, nnu=None, nl=None, lines_kind=None, nu_span=(1.0, 2500.0))
     for gname in gases:
         fC = {"H2O": fC_h2o, "CO2": 400e-6, "CH4": 1.8e-6, "O3": lambda T, P_: ozonelayer(P_)}[gname]
         kind = "synthetic" if gname == "O3" else lines_kind
-        absorbers.append(DirectGas(lines(kind, gname), fC, nu))
+        absorbers.append(DirectGas(lines(kind, gname), fC, nu, shape=shape))   # (PHCO2: its default 500 cm^-1 cut-off)
     if name == "C5":
         absorbers.append(CIATables(fixture("CO2-CO2_2018.cia")))
         absorbers.append(CIATables(fixture("CO2-CH4_2018.cia")))
