@@ -365,6 +365,32 @@ void tile_windows(const std::vector<double> &nul, int64_t g0, int64_t g1, const 
     inrange = (std::upper_bound(b, e, nu[nnu - 1] + cut) - std::lower_bound(b, e, nu[0] - cut));
 }
 
+// The far kernel hands k_voigt_near the near-line ranges of every (nu, node) as 20-bit offsets into the tile's near zone and
+// 12-bit counts.  Bound both for any state (widest Doppler width: upper end of the grid, TMAX, lightest isotopologue) and
+// refuse tables too dense for the fields -- 4096 lines within a few Doppler widths is ~1e5 lines per cm^-1, far beyond HITEMP.
+int check_near_density(const GasTable &G, const double *nu, int64_t nnu, double cut)
+{
+    const double amax = ((nu[nnu - 1] + cut) / kC) * std::sqrt(2.0 * kRgas * kTmax / G.mu_min);
+    const double dA = 100.0 * amax / kSqLn2 * (1.0 + 1e-6), r0 = std::sqrt(kSerS) * amax / kSqLn2 * 1.01;
+    double span = 0.0;
+    for (int64_t i0 = 0; i0 < nnu; i0 += 64) span = std::max(span, nu[std::min<int64_t>(i0 + 63, nnu - 1)] - nu[i0]);
+    const std::vector<double> &v = G.h_nu;
+    auto max_in = [&](double width) {
+        int64_t best = 0;
+        size_t a = 0;
+        for (size_t b = 0; b < v.size(); b++) {
+            while (v[b] - v[a] > width) a++;
+            best = std::max<int64_t>(best, (int64_t)(b - a + 1));
+        }
+        return best;
+    };
+    const int64_t nzone = max_in(span + 2.0 * dA), npt = max_in(2.0 * r0);
+    if (nzone >= (1 << 20) || npt >= (1 << 12))
+        return fail(CS_EINVAL, "line table too dense for the near-line hand-off: %lld lines within %.3g cm^-1, %lld within %.3g cm^-1",
+                    (long long)nzone, span + 2.0 * dA, (long long)npt, 2.0 * r0);
+    return CS_OK;
+}
+
 // Doppler profile exp(-(dnu/alpha)^2) (line_shapes.jl:160): beyond sqrt(750) widths it is an exact zero in fp64 (exp(-745.2) is
 // the smallest denormal), so the windows of the Doppler line sum only need the lines within that reach of a tile -- a bound for
 // every state: the widest line is the one at the upper end of the grid, at TMAX, of the lightest isotopologue (line_shapes.jl:144)
@@ -567,7 +593,7 @@ void launch_apply(hipStream_t s, const ChebApply &A, int Kpad, int64_t nnu, int 
 // K1 + K2 for one gas on `s`: parameters for `kn` states, then the line sum into sigma ([kn][nnu])
 void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, int64_t jrange1, int kn, const double *Tk, const double *Pk, const double *Ppk,
                 const double *scale, LineHot *hot, LineCold *cold, const double *dnu, int64_t nnu, int ntile256,
-                const int32_t *J0, const int32_t *J1, const WaveWin *win, Zone *zones, int4 *ranges, const double *gbound, double cut, double base,
+                const int32_t *J0, const int32_t *J1, const WaveWin *win, Zone *zones, int2 *ranges, const double *gbound, double cut, double base,
                 const double *extra, double *sigma, int accumulate, hipEvent_t *evg,   // NULL or 3 events: after K1, nodes, far
                 LineF32 *hot32 = nullptr, double far_s = 1e6, Interp itp = Interp(), ChebApply *defer = nullptr)
 {
@@ -643,12 +669,12 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
             (void)hipEventRecord(evg[1], s);
         }
         const int nblk = (nt64 + 3) / 4;
-        const dim3 grid((unsigned)((nblk + 7) / 8 * 8), kn);   // multiple of 8: XCD-aware tile mapping (tile_block)
+
         // waves per tile: enough waves to fill 256 CUs x 32 wave slots about 4 times over
         const int64_t nwave = (int64_t)nt64 * kn;
         const int split = nwave >= 16384 ? 1 : (nwave >= 4096 ? 2 : 4);   // (re-tuned with the far wings interpolated: waves are 3x shorter)
         const int nblk_s = (nt64 * split + 3) / 4;
-        const dim3 grid_s((unsigned)((nblk_s + 7) / 8 * 8), kn);
+        const dim3 grid_s((unsigned)((nblk_s + 7) / 8 * 8), kn);   // multiple of 8: XCD-aware tile mapping (tile_block)
 #define CS_FAR_LAUNCH(MIX, SP) hipLaunchKernelGGL((k_voigt_far<MIX, SP, false>), grid_s, dim3(256), 0, s, dnu, nnu, G.L, hot, hot32, G.nu.as<double>(), \
                                                   win, zones, nt64, nblk_s, cut, base, extra, sigma, accumulate, ranges, iz, itp.nItot, ishift)
 #define CS_LOR_LAUNCH(SP) hipLaunchKernelGGL((k_voigt_far<false, SP, true>), grid_s, dim3(256), 0, s, dnu, nnu, G.L, hot, hot32, G.nu.as<double>(), \
@@ -839,6 +865,7 @@ static int shape_impl(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t 
     if ((rc = check_ascending(nu, nnu))) return rc;
     GasTable &G = ctx->gas[slot];
     if ((rc = check_gas_states(G, K, T))) return rc;
+    if (shape == SH_VOIGT && (rc = check_near_density(G, nu, nnu, dnu_cut))) return rc;
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     int64_t g0, g1, pairs, inr;
@@ -854,7 +881,7 @@ static int shape_impl(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t 
         (rc = upload(dwin, win.data(), win.size(), s)))
         return rc;
     // bound the workspace: process the states in chunks
-    const size_t per_state = (size_t)G.L * (sizeof(LineHot) + sizeof(LineCold)) + (size_t)nnu * (sizeof(double) + sizeof(int4));
+    const size_t per_state = (size_t)G.L * (sizeof(LineHot) + sizeof(LineCold)) + (size_t)nnu * (sizeof(double) + sizeof(int2));
     int kc = (int)std::max<size_t>(1, std::min<size_t>({(size_t)K, ((size_t)4 << 30) / per_state, (size_t)65535}));   // gridDim.y limit
     HIPCHK(hot.reserve(((size_t)kc * G.L + 4) * sizeof(LineHot)));
     HIPCHK(cold.reserve((size_t)kc * G.L * sizeof(LineCold)));
@@ -866,7 +893,7 @@ static int shape_impl(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t 
         HIPCHK(ctx->hot32.reserve(((size_t)kc * G.L + 4) * sizeof(LineF32)));
         mix32 = ctx->hot32.as<LineF32>();
     }
-    HIPCHK(dranges.reserve((size_t)kc * nnu * sizeof(int4)));
+    HIPCHK(dranges.reserve((size_t)kc * nnu * sizeof(int2)));
     {
         std::vector<double> gb = gamma_bound(G, K, T, P, Pp);
         if ((rc = upload(dgmax, gb.data(), K, s))) return rc;
@@ -884,7 +911,7 @@ static int shape_impl(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t 
         const int kn = std::min(kc, K - k0);
         launch_gas(s, shape, G, J0.front(), J1.back(), kn, dT.as<double>() + k0, dP.as<double>() + k0, dPp.as<double>() + k0, nullptr,
                    hot.as<LineHot>(), cold.as<LineCold>(), dnu.as<double>(), nnu, ntile, dJ0.as<int32_t>(), dJ1.as<int32_t>(),
-                   dwin.as<WaveWin>(), dzones.as<Zone>(), dranges.as<int4>(), dgmax.as<double>() + k0, dnu_cut, 0.0, nullptr, dsig.as<double>(), 0, nullptr,
+                   dwin.as<WaveWin>(), dzones.as<Zone>(), dranges.as<int2>(), dgmax.as<double>() + k0, dnu_cut, 0.0, nullptr, dsig.as<double>(), 0, nullptr,
                    mix32, ctx->far_s, itp);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpy2DAsync(sigma + (size_t)k0 * ld_state, ld_state * sizeof(double), dsig.p, nnu * sizeof(double),
@@ -918,6 +945,7 @@ int cs_bake(cs_ctx *ctx, int gas_slot, int table_slot, int shape, double dnu_cut
         }
     GasTable &G = ctx->gas[gas_slot];
     if ((rc = check_gas_states(G, M, Ts.data()))) return rc;
+    if (shape == SH_VOIGT && (rc = check_near_density(G, nu, nnu, dnu_cut))) return rc;
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     TableDev &tb = ctx->tab[table_slot];
@@ -936,12 +964,12 @@ int cs_bake(cs_ctx *ctx, int gas_slot, int table_slot, int shape, double dnu_cut
         (rc = upload(dwin, win.data(), win.size(), s)) || (rc = upload(dgb, gb.data(), M, s)))
         return rc;
     HIPCHK(tb.Z.reserve((size_t)M * nnu * sizeof(double)));
-    const size_t per_state = (size_t)G.L * (sizeof(LineHot) + sizeof(LineCold)) + (size_t)nnu * sizeof(int4);
+    const size_t per_state = (size_t)G.L * (sizeof(LineHot) + sizeof(LineCold)) + (size_t)nnu * sizeof(int2);
     const int kc = (int)std::max<size_t>(1, std::min<size_t>({(size_t)M, ((size_t)4 << 30) / per_state, (size_t)65535}));
     HIPCHK(hot.reserve(((size_t)kc * G.L + 4) * sizeof(LineHot)));
     HIPCHK(cold.reserve((size_t)kc * G.L * sizeof(LineCold)));
     HIPCHK(dzones.reserve((size_t)kc * win.size() * sizeof(Zone)));
-    HIPCHK(dranges.reserve((size_t)kc * nnu * sizeof(int4)));
+    HIPCHK(dranges.reserve((size_t)kc * nnu * sizeof(int2)));
     LineF32 *mix32 = nullptr;
     if (ctx->mixed && shape == SH_VOIGT) {
         HIPCHK(ctx->hot32.reserve(((size_t)kc * G.L + 4) * sizeof(LineF32)));
@@ -960,7 +988,7 @@ int cs_bake(cs_ctx *ctx, int gas_slot, int table_slot, int shape, double dnu_cut
         const int kn = std::min(kc, M - k0);
         launch_gas(s, shape, G, J0.front(), J1.back(), kn, dT.as<double>() + k0, dP.as<double>() + k0, dPp.as<double>() + k0, nullptr, hot.as<LineHot>(),
                    cold.as<LineCold>(), dnu.as<double>(), nnu, ntile, dJ0.as<int32_t>(), dJ1.as<int32_t>(), dwin.as<WaveWin>(),
-                   dzones.as<Zone>(), dranges.as<int4>(), dgb.as<double>() + k0, dnu_cut, 0.0, nullptr, tb.Z.as<double>() + (size_t)k0 * nnu, 0, nullptr,
+                   dzones.as<Zone>(), dranges.as<int2>(), dgb.as<double>() + k0, dnu_cut, 0.0, nullptr, tb.Z.as<double>() + (size_t)k0 * nnu, 0, nullptr,
                    mix32, ctx->far_s, itp);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(s));
@@ -1389,6 +1417,7 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
         cg.generation = ctx->gas[cg.slot].generation;
         if (cg.shape < 0 || cg.shape > 3) return fail(CS_EINVAL, "unknown shape %d", cg.shape);
         GasTable &G = ctx->gas[cg.slot];
+        if (cg.shape == SH_VOIGT && (rc = check_near_density(G, nu, nnu, cg.cut))) return rc;
         int64_t g0, g1;
         included_range(G.h_nu, nu[0], nu[nnu - 1], cg.cut, false, g0, g1);
         std::vector<int32_t> J0, J1;
@@ -1419,7 +1448,7 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
     HIPCHK(c.hot.reserve(((size_t)K * maxL + 4) * sizeof(LineHot)));
     HIPCHK(c.cold.reserve((size_t)K * maxL * sizeof(LineCold)));
     HIPCHK(c.sigma.reserve((size_t)K * nnu * sizeof(double)));
-    if (ngas > 0) HIPCHK(c.ranges.reserve((size_t)K * nnu * sizeof(int4)));
+    if (ngas > 0) HIPCHK(c.ranges.reserve((size_t)K * nnu * sizeof(int2)));
     HIPCHK(c.tau.reserve((size_t)nl * nnu * sizeof(double)));
     if (c.want_M) {
         HIPCHK(c.Mup.reserve((size_t)np * nnu * sizeof(double)));
@@ -1531,12 +1560,12 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
     }
     size_t maxL = 0;
     for (auto &g : c.gas) maxL = std::max(maxL, (size_t)ctx->gas[g.slot].L);
-    const size_t per_state = maxL * (sizeof(LineHot) + sizeof(LineCold) + (ctx->mixed ? sizeof(LineF32) : 0)) + (size_t)c.nnu * sizeof(int4);
+    const size_t per_state = maxL * (sizeof(LineHot) + sizeof(LineCold) + (ctx->mixed ? sizeof(LineF32) : 0)) + (size_t)c.nnu * sizeof(int2);
     const int kc = (int)std::max<size_t>(1, std::min<size_t>({(size_t)BK, ((size_t)8 << 30) / std::max<size_t>(per_state, 1), (size_t)65535}));
     if (c.ngas > 0) {
         HIPCHK(hot.reserve(((size_t)kc * maxL + 4) * sizeof(LineHot)));
         HIPCHK(cold.reserve((size_t)kc * maxL * sizeof(LineCold)));
-        HIPCHK(dranges.reserve((size_t)kc * c.nnu * sizeof(int4)));
+        HIPCHK(dranges.reserve((size_t)kc * c.nnu * sizeof(int2)));
         if (ctx->mixed) HIPCHK(ctx->hot32.reserve(((size_t)kc * maxL + 4) * sizeof(LineF32)));
     }
     std::vector<double> cc(BK), pp(BK);
@@ -1569,7 +1598,7 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
             const int kn = (int)std::min<int64_t>(kc, BK - k0);
             launch_gas(s, cg.shape, G, cg.jlo, cg.jhi, kn, dTk.as<double>() + k0, dPk.as<double>() + k0, dPp.as<double>() + k0,
                        dconc.as<double>() + k0, hot.as<LineHot>(), cold.as<LineCold>(), c.nu.as<double>(), c.nnu, c.ntile,
-                       cg.J0.as<int32_t>(), cg.J1.as<int32_t>(), cg.win.as<WaveWin>(), dzones.as<Zone>(), dranges.as<int4>(),
+                       cg.J0.as<int32_t>(), cg.J1.as<int32_t>(), cg.win.as<WaveWin>(), dzones.as<Zone>(), dranges.as<int2>(),
                        dgb.as<double>() + k0, cg.cut, c.sigma_gray, nullptr, sig + (size_t)k0 * c.nnu, gi > 0, nullptr,
                        (ctx->mixed && cg.shape == SH_VOIGT) ? ctx->hot32.as<LineF32>() : nullptr, ctx->far_s, itp);
             HIPCHK(hipGetLastError());
@@ -1667,7 +1696,7 @@ static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e)
         itp.F = c.chebF.as<double>();
         launch_gas(s, cg.shape, G, cg.jlo, cg.jhi, K, c.Tk.as<double>(), c.Pk.as<double>(), cg.Pp.as<double>(), cg.conc.as<double>(),
                    c.hot.as<LineHot>(), c.cold.as<LineCold>(), c.nu.as<double>(), c.nnu, c.ntile, cg.J0.as<int32_t>(),
-                   cg.J1.as<int32_t>(), cg.win.as<WaveWin>(), cg.zones.as<Zone>(), c.ranges.as<int4>(), cg.gmax.as<double>(), cg.cut, c.sigma_gray, extra, sig, gi > 0,
+                   cg.J1.as<int32_t>(), cg.win.as<WaveWin>(), cg.zones.as<Zone>(), c.ranges.as<int2>(), cg.gmax.as<double>(), cg.cut, c.sigma_gray, extra, sig, gi > 0,
                    ev ? ev + e : nullptr,
                    (ctx->mixed && cg.shape == SH_VOIGT) ? ctx->hot32.as<LineF32>() : nullptr, ctx->far_s, itp, &apply);
         if (ev) { e += 3; HIPCHK(hipEventRecord(ev[e++], s)); }

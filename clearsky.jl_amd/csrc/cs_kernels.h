@@ -412,9 +412,12 @@ __device__ __forceinline__ double far_segment32_rev(double acc, double v, const 
     return __builtin_fma((double)part, kMixUnscale, acc);
 }
 
-// blockIdx.x -> block of 4 wave tiles.  Workgroups are dealt round-robin over the 8 XCDs, so block b and b+8 share an
-// L2: give each XCD one contiguous eighth of the spectrum, whose overlapping line windows then stay in that L2.
-// gridDim.x is a multiple of 8 (speed only: any placement is correct).
+// blockIdx.x -> block of 4 wave tiles.  Workgroups are dealt round-robin over the 8 XCDs (private L2 each), so block b and b+8
+// share an L2: give each XCD one contiguous eighth of the spectrum, whose overlapping line windows then stay in that L2 and
+// leave it once.  Measured at C3 (profiles/r02_notes.md): plain block order fetches every record ~2.4x (FETCH 237 MiB per launch,
+// by whichever XCDs a tile's neighbours land on), this order 123 MiB = the algorithmic bytes, for 3 % more kernel time (the
+// kernel is VALU-bound either way; a cost-balanced two-stretch variant was slower still).  gridDim.x is a multiple of 8;
+// speed/traffic only -- any placement is correct.
 __device__ __forceinline__ int tile_block(int nblk)
 {
     const int chunk = (nblk + 7) >> 3;
@@ -825,7 +828,7 @@ __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu
                                                     const double *__restrict__ gnul, const WaveWin *__restrict__ win,
                                                     const Zone *__restrict__ zones, int ntile, int nblk, double cut,
                                                     double base, const double *__restrict__ extra,
-                                                    double *__restrict__ sigma, int accumulate, int4 *__restrict__ ranges,
+                                                    double *__restrict__ sigma, int accumulate, int2 *__restrict__ ranges,
                                                     const IZone *__restrict__ iz, int nI, int ishift)
 {
     // iz != NULL: the lines [E0,Z0) U [Z1,E1) of the tile's parent interval (tile >> ishift, smallest interval size) were
@@ -835,9 +838,7 @@ __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu
     // chip otherwise (a nu-shard of a multi-GPU run, bake on a short grid).
     __shared__ double acc_sh[S > 1 ? 256 : 1];
     __shared__ int4 rng_sh[S > 1 ? 256 : 1];
-    // XCD-aware order only without interpolation: then a tile's window spans +-25 cm^-1 of lines and neighbours share them in L2;
-    // with the far wings interpolated the window is a few cm^-1 and the plain order is 3 % faster
-    const int tb = iz ? (int)blockIdx.x : tile_block(nblk);
+    const int tb = tile_block(nblk);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave-uniform by construction:
     const int tile = tb * (4 / S) + wv / S;                                                      // tell the compiler, so that the
     const int part = wv % S;                                                                     // line records stay scalar loads
@@ -965,11 +966,12 @@ __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu
         }
     }
     if (i < nnu) {
-        int2 r0, r1;   // two planes of int2 inside the int4 workspace (k_voigt_near<0>, <1>)
-        r0.x = bh >= bl ? bl - z.N0 : 0; r0.y = bh >= bl ? bh + 1 - z.N0 : 0;
-        r1.x = ch >= cl ? cl - z.N0 : 0; r1.y = ch >= cl ? ch + 1 - z.N0 : 0;
+        // hand-off to k_voigt_near<0>, <1>: per (nu, node) and tier one word, (first line - N0) << 12 | count -- 8 bytes per
+        // spectral point and node in all (cs_api.hip refuses tables dense enough to overflow 20 + 12 bits: check_near_density)
         if (!LOR) {   // (a Lorentz profile has no near-line kernels to hand anything to)
-            int2 *__restrict__ rp = reinterpret_cast<int2 *>(ranges);
+            const unsigned r0 = bh >= bl ? ((unsigned)(bl - z.N0) << 12) | (unsigned)(bh + 1 - bl) : 0u;
+            const unsigned r1 = ch >= cl ? ((unsigned)(cl - z.N0) << 12) | (unsigned)(ch + 1 - cl) : 0u;
+            unsigned *__restrict__ rp = reinterpret_cast<unsigned *>(ranges);
             rp[(size_t)k * nnu + i] = r0;
             rp[((size_t)gridDim.y + k) * nnu + i] = r1;
         }
@@ -1068,7 +1070,7 @@ template <int TIER>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_voigt_near(const double *__restrict__ nu, int64_t nnu, int64_t L,
                                                      const LineHot *__restrict__ hot, const LineCold *__restrict__ cold,
                                                      const Zone *__restrict__ zones, int ntile, int ngrp, double cut,
-                                                     double *__restrict__ sigma, const int4 *__restrict__ ranges)
+                                                     double *__restrict__ sigma, const int2 *__restrict__ ranges)
 {
     __shared__ unsigned qidx_s[4][CS_NEAR_Q];
     __shared__ double qres_s[4][CS_NEAR_Q];
@@ -1079,8 +1081,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     const int k = blockIdx.y;
     const LineHot *__restrict__ hk = hot + (size_t)k * L;
     const LineCold *__restrict__ ck = cold + (size_t)k * L;
-    // two planes of int2 inside the int4 workspace: tier 0 ranges, then tier 1 ranges, [gridDim.y][nnu] each
-    const int2 *__restrict__ rp = reinterpret_cast<const int2 *>(ranges) + (size_t)TIER * gridDim.y * nnu + (size_t)k * nnu;
+    // two planes of packed words: tier 0 ranges, then tier 1 ranges, [gridDim.y][nnu] each
+    const unsigned *__restrict__ rp = reinterpret_cast<const unsigned *>(ranges) + (size_t)TIER * gridDim.y * nnu + (size_t)k * nnu;
     int lo[CS_NEAR_R], hi[CS_NEAR_R];
     double acc[CS_NEAR_R];
 #pragma unroll
@@ -1090,10 +1092,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
         lo[r] = hi[r] = 0;
         acc[r] = 0.0;
         if (tile < ntile && i < nnu) {
-            const int2 q = rp[i];
+            const unsigned q = rp[i];
             const int N0 = zones[(size_t)k * ntile + tile].N0;
-            lo[r] = N0 + q.x;
-            hi[r] = N0 + q.y;
+            lo[r] = N0 + (int)(q >> 12);
+            hi[r] = lo[r] + (int)(q & 0xfffu);
         }
     }
     near_pass<TIER>(nu, nnu, tile0, lo, hi, acc, hk, ck, cut, qidx_s[wv], qres_s[wv]);
