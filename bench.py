@@ -25,6 +25,11 @@ sys.path.insert(0, _ROOT)
 
 # flops of one far-wing Voigt term in k_voigt_far: 14 fp64 VALU instructions (ISA count, mode 0/1 mix), FMAs = 2 flops
 FLOPS_PER_PAIR = 24.0
+# VALU instructions per (lane, line) of each loop body, counted in the gfx950 ISA of k_voigt_far / k_cheb_nodes (hipcc -S, loops
+# unrolled by 4: 52/68/64/80/96/148 per four lines; profiles/r02_notes.md).  The 2-/3-/4-term far-wing bodies are the same
+# instructions in both kernels; "_cut" adds the cut-off compare + select (and |dnu|).
+VALU_PER_LINE = dict(t2=13, t2_cut=17, t3=16, t3_cut=20, t4=20, t4_cut=24, near_zone=37)
+VALU_ISSUE_PEAK = 256 * 4 * 16 * 2.4e9     # fp64-rate lane-instructions per second: 256 CU x 4 SIMD x 16 lanes x 2.4 GHz
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 
@@ -189,6 +194,17 @@ def main():
     evals = work["direct_evals"] + work["node_evals"]
     flops = evals * FLOPS_PER_PAIR
     line_ms = prof["nodes"] + prof["far"] + prof["near"]
+    # measured instruction mix: lane-instructions each far-wing kernel issues = sum over its loop bodies of (lines x 64 lanes) x VALU
+    # instructions per line (ISA), over its HIP-event time, against the fp64-rate issue peak (all 64 lanes of a wave count, also
+    # those the cut-off predicate masks)
+    db, nb = work.get("direct_by_body", {}), work.get("node_by_body", {})
+    far_instr = sum(db.get(b, 0) * VALU_PER_LINE[b] for b in db)
+    node_instr = sum(nb.get(b, 0) * VALU_PER_LINE[b] for b in nb)
+    valu_issue = dict(unit="fraction of the fp64-rate VALU issue peak (256 CU x 4 SIMD x 16 lanes x 2.4 GHz)", valu_per_line=VALU_PER_LINE,
+                      k_voigt_far=dict(lane_instr=far_instr, ms=prof["far"], frac=(far_instr / (prof["far"] * 1e-3) / VALU_ISSUE_PEAK) if prof["far"] > 0 else None,
+                                       lines_x_lanes_by_body=db),
+                      k_cheb_nodes=dict(lane_instr=node_instr, ms=prof["nodes"], frac=(node_instr / (prof["nodes"] * 1e-3) / VALU_ISSUE_PEAK) if prof["nodes"] > 0 else None,
+                                        lines_x_nodes_by_body=nb))
     roofline = dict(bound="hbm", kernel="k_voigt_far", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_note=traffic_note, launches_per_step=ngas, avg_launch_ms=far_ms,
                     algorithmic_bytes_per_launch=alg,
@@ -198,6 +214,7 @@ def main():
                                    evals_issued=evals, direct_evals=work["direct_evals"], node_evals=work["node_evals"],
                                    reference_pair_evals=cnt["pair_evals"], flops_per_eval=FLOPS_PER_PAIR,
                                    kernels="k_cheb_nodes + k_voigt_far + k_voigt_near"),
+                    valu_issue=valu_issue,
                     interp_levels=work["levels"], kernel_ms=prof)
 
     # the drop-in entry point (cs_fluxes_discretized: host pointers in, host arrays out, what the Julia method calls per

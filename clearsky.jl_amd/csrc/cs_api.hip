@@ -1449,7 +1449,7 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
     HIPCHK(c.cold.reserve((size_t)K * maxL * sizeof(LineCold)));
     HIPCHK(c.sigma.reserve((size_t)K * nnu * sizeof(double)));
     if (ngas > 0) HIPCHK(c.ranges.reserve((size_t)K * nnu * sizeof(int2)));
-    HIPCHK(c.tau.reserve((size_t)nl * nnu * sizeof(double)));
+    if (c.want_tau) HIPCHK(c.tau.reserve((size_t)nl * nnu * sizeof(double)));   // (band fluxes only: no optical depth is stored)
     if (c.want_M) {
         HIPCHK(c.Mup.reserve((size_t)np * nnu * sizeof(double)));
         HIPCHK(c.Mdn.reserve((size_t)np * nnu * sizeof(double)));
@@ -1547,7 +1547,6 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
         return rc;
     const RtGeom bg = rt_geometry(c.nnu, np, B);
     if (!shared_sigma) HIPCHK(dsig.reserve((size_t)BK * c.nnu * sizeof(double)));
-    HIPCHK(dtau.reserve((size_t)B * nl * c.nnu * sizeof(double)));
     HIPCHK(dpart.reserve((size_t)B * bg.nblk * 2 * np * sizeof(double)));
     HIPCHK(dF.reserve((size_t)B * 2 * np * sizeof(double)));
     double *sig = shared_sigma ? c.sigma.as<double>() : dsig.as<double>();
@@ -1652,8 +1651,8 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
     }
     launch_rt(c.nstream, bg, B, s, c.rt, c.nu.as<double>(),
                     c.wts.as<double>(), c.nnu, sig, dmuk.as<double>(), c.P.as<double>(), dTlev.as<double>(),
-                    c.has_S ? c.S_toa.as<double>() : nullptr, c.has_alb ? c.albedo.as<double>() : nullptr, dtau.as<double>(), nullptr,
-                    nullptr, dpart.as<double>(), shared_sigma ? 0 : (size_t)K * c.nnu);
+                    c.has_S ? c.S_toa.as<double>() : nullptr, c.has_alb ? c.albedo.as<double>() : nullptr, (double *)nullptr, nullptr,
+                    nullptr, dpart.as<double>(), shared_sigma ? 0 : (size_t)K * c.nnu);   // batches return band fluxes only: no tau stored
     hipLaunchKernelGGL(k_freduce, dim3(2 * np, B), dim3(256), 0, s, dpart.as<double>(), bg.nblk, 2 * np, dF.as<double>());
     HIPCHK(hipGetLastError());
     std::vector<double> F((size_t)B * 2 * np);
@@ -1730,7 +1729,7 @@ static int run_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev)
     if (ev) HIPCHK(hipEventRecord(ev[e++], s));
     launch_rt(c.nstream, c.rtg, 1, s, c.rt, c.nu.as<double>(), c.wts.as<double>(),
               c.nnu, sig, c.muk.as<double>(), c.P.as<double>(), c.Tlev.as<double>(),
-              c.has_S ? c.S_toa.as<double>() : nullptr, c.has_alb ? c.albedo.as<double>() : nullptr, c.tau.as<double>(),
+              c.has_S ? c.S_toa.as<double>() : nullptr, c.has_alb ? c.albedo.as<double>() : nullptr, c.want_tau ? c.tau.as<double>() : nullptr,
               c.want_M ? c.Mup.as<double>() : nullptr, c.want_M ? c.Mdn.as<double>() : nullptr, c.partial.as<double>());
     if (ev) HIPCHK(hipEventRecord(ev[e++], s));
     hipLaunchKernelGGL(k_freduce, dim3(2 * c.np), dim3(256), 0, s, c.partial.as<double>(), c.rtg.nblk, 2 * c.np,
@@ -1829,6 +1828,7 @@ int cs_column_fetch(cs_ctx *ctx, int64_t nnu, int np, double *tau, double *Mup, 
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipDeviceSynchronize());
     int rc;
+    if (tau && !c.want_tau) return fail(CS_ESTATE, "column was set up without want_tau");
     if (tau && (rc = fetch_transposed(ctx, c.tau.as<double>(), c.nl, c.nnu, tau))) return rc;
     if ((Mup || Mdn) && !c.want_M) return fail(CS_ESTATE, "column was set up without want_M");
     if (Mup && (rc = fetch_transposed(ctx, c.Mup.as<double>(), c.np, c.nnu, Mup))) return rc;
@@ -1881,6 +1881,9 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
     const int K = c.K;
     const int nt64 = (int)((c.nnu + 63) / 64);
     int64_t direct = 0, nodes = 0;
+    int64_t body[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // per-point lines by body: 2-term, 2-term+cut-off, 3-term, 3-term+cut-off, 4-term+cut-off,
+                                                     // near-zone pass; node lines: 2-, 3-, 4-term
+    auto seg = [](int lo, int hi, int p0, int p1) { return (int64_t)std::max(0, std::min(hi, p1) - std::max(lo, p0)); };
     for (auto &g : c.gas) {
         if (g.shape != SH_VOIGT && g.shape != SH_LORENTZ) continue;
         std::vector<WaveWin> win(nt64);
@@ -1897,6 +1900,16 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
                 for (int q = q0; q < nItot; q++) {
                     const IZone &z = iz[(size_t)k * nItot + q];
                     nodes += (int64_t)CS_NC * ((z.P0 - z.E0) + (z.Z0 - z.P1) + (z.P2 - z.Z1) + (z.E1 - z.P3));
+                    // the same segments k_cheb_nodes runs: [E0,P0) U [P1,Z0) left, [Z1,P2) U [P3,E1) right, cut at Q and M
+                    const int lo4[4] = {z.E0, z.P1, z.P3, z.Z1}, hi4[4] = {z.P0, z.Z0, z.E1, z.P2};
+                    for (int w4 = 0; w4 < 4; w4++) {
+                        const int p0 = lo4[w4], p1 = hi4[w4];
+                        if (w4 < 2) {
+                            body[6] += seg(z.E0, z.Q0, p0, p1); body[7] += seg(z.Q0, z.M0, p0, p1); body[8] += seg(z.M0, z.Z0, p0, p1);
+                        } else {
+                            body[6] += seg(z.Q1, z.E1, p0, p1); body[7] += seg(z.M1, z.Q1, p0, p1); body[8] += seg(z.Z1, z.M1, p0, p1);
+                        }
+                    }
                 }
         }
         int ishift = 0;
@@ -1906,19 +1919,36 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
                 const WaveWin &w = win[t];
                 const Zone &z = zn[(size_t)k * nt64 + t];
                 int64_t n = w.W1 - w.W0;
+                int sa0 = z.M0, sa1 = z.M0, sb0 = z.M1, sb1 = z.M1;
                 if (nlev > 0) {   // same clamps as k_voigt_far
                     const IZone &zi = iz[(size_t)k * nItot + c.cheb.ioff[nlev - 1] + (t >> ishift)];
-                    const int sa0 = std::min(std::max(zi.E0, w.W0), z.N0), sa1 = std::min(std::max(zi.Z0, sa0), z.N0);
-                    const int sb0 = std::max(std::min(zi.Z1, w.W1), z.N1), sb1 = std::max(std::min(zi.E1, w.W1), sb0);
+                    sa0 = std::min(std::max(zi.E0, w.W0), z.N0); sa1 = std::min(std::max(zi.Z0, sa0), z.N0);
+                    sb0 = std::max(std::min(zi.Z1, w.W1), z.N1); sb1 = std::max(std::min(zi.E1, w.W1), sb0);
                     n -= (sa1 - sa0) + (sb1 - sb0);
                 }
                 direct += 64 * n;
+                // the same segments k_voigt_far runs inside its three clip windows
+                const int a = std::min(std::max(w.E0, w.W0), z.Q0), a1 = std::min(std::max(w.E0, z.Q0), z.M0);
+                const int b1 = std::max(std::min(w.E1, z.Q1), z.M1), bq = std::max(std::min(w.E1, w.W1), z.Q1);
+                const int cl[3] = {w.W0, sa1, sb1}, ch[3] = {sa0, sb0, w.W1};
+                for (int cw = 0; cw < 3; cw++) {
+                    const int p0 = cl[cw], p1 = ch[cw];
+                    if (p0 >= p1) continue;
+                    body[1] += seg(w.W0, a, p0, p1) + seg(bq, w.W1, p0, p1);
+                    body[0] += seg(a, z.Q0, p0, p1) + seg(z.Q1, bq, p0, p1);
+                    body[3] += seg(z.Q0, a1, p0, p1) + seg(b1, z.Q1, p0, p1);
+                    body[2] += seg(a1, z.M0, p0, p1) + seg(z.M1, b1, p0, p1);
+                    body[4] += seg(z.M0, z.N0, p0, p1) + seg(z.N1, z.M1, p0, p1);
+                    body[5] += seg(z.N0, z.N1, p0, p1);
+                }
             }
     }
     out[0] = direct;
     out[1] = nodes;
     out[2] = c.cheb.nlev;
     out[3] = c.cheb.nItot;
+    for (int q = 0; q < 6; q++) out[4 + q] = 64 * body[q];
+    for (int q = 6; q < 9; q++) out[4 + q] = (int64_t)CS_NC * body[q];
     return CS_OK;
 }
 

@@ -1151,7 +1151,8 @@ __device__ __forceinline__ double wave_sum(double v)
 // (dDepth!) and the downward sweep of all NS streams at once; pass 2 walks surface -> TOA (upward sweep).
 // All NS intensities advance together, so M-[i+1] = sum_k W_k I_k + stellar beam is complete when layer i is done --
 // same summation order as the reference's stream-outer loops, no [np] scratch per lane.
-// UD = false: one wave runs both passes; tau is kept nu-fastest in HBM between them (the caller's tau output).
+// UD = false: one wave runs both passes; tau is kept nu-fastest in HBM between them when the caller wants it (tau != NULL),
+//             otherwise the upward pass recomputes it from the cross-sections and no optical depth is ever stored.
 // UD = true : the two passes of a 64-point tile run in TWO waves of the block side by side (waves [0,nw) go down, [nw,2nw) go
 //             up and recompute the layer optical depths they need on the way) -- each pass is a chain of ~300 dependent fp64
 //             operations per layer that no amount of lanes shortens, so with few waves per SIMD (a 1e5-point grid is 1.5, a
@@ -1176,7 +1177,7 @@ __global__ __launch_bounds__(256) void k_rt(RtParams p, const double *__restrict
         sigma += b * sig_bstride;     // K*nnu, or 0 when the columns of a batch share their cross-sections (AcceleratedAbsorber)
         muk += b * p.K;
         Tlev += b * p.np;
-        tau += b * (size_t)(p.np - 1) * nnu;
+        if (tau) tau += b * (size_t)(p.np - 1) * nnu;
         partial += b * (size_t)gridDim.x * 2 * p.np;
     }
     const int lane = threadIdx.x & 63;
@@ -1223,7 +1224,7 @@ __global__ __launch_bounds__(256) void k_rt(RtParams p, const double *__restrict
             ti += (dP * p.ws[nlob - 1]) * bn;
             b1 = bn;
             const double t = ti > 1e-6 ? ti : 1e-6;  // floor, discretized.jl:147,174
-            if (live) tau[(size_t)i * nnu + j] = t;
+            if (tau && live) tau[(size_t)i * nnu + j] = t;
             const double Bnext = planck(v, Tlev[i + 1]);
             Md = 0.0;
             const double it = 1.0 / t;
@@ -1263,8 +1264,9 @@ __global__ __launch_bounds__(256) void k_rt(RtParams p, const double *__restrict
         double Bhi = Bprev;  // B at level i+1
         // layer optical depths on the way up: re-read from HBM (one wave ran both passes) or recomputed exactly as the
         // downward pass forms them (UD: that pass runs beside this one and has not written them yet)
+        const bool recompute = UD || !tau;   // no tau output requested ("OLR-only"): optical depths never touch HBM
         double t_next = 1.0, b_hi = 0.0, sg_lo = 0.0;
-        if (UD) {
+        if (recompute) {
             b_hi = p.C * (sigma[(size_t)(p.K - 1) * nnu + jj] / muk[p.K - 1]);
             sg_lo = sigma[(size_t)(nl - 1) * (nlob - 1) * nnu + jj];
         } else {
@@ -1272,7 +1274,7 @@ __global__ __launch_bounds__(256) void k_rt(RtParams p, const double *__restrict
         }
         for (int i = nl - 1; i >= 0; i--) {
             double t;
-            if (UD) {
+            if (recompute) {
                 const double dP = P[i + 1] - P[i];
                 const int kl = i * (nlob - 1);
                 const double b_lo = p.C * (sg_lo / muk[kl]);

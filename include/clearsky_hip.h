@@ -204,7 +204,10 @@ int cs_column_sigma_fetch(cs_ctx *ctx, int64_t nnu, int K, double *sigma);
 int cs_column_counts(cs_ctx *ctx, int64_t *pair_evals, int64_t *lines_in_range);
 /* line-shape evaluations the last cs_column_run actually issued for its Voigt gases (measurement hook): out[0] = per-point
  * evaluations of k_voigt_far/k_voigt_near (64 lanes x lines per wave), out[1] = node evaluations of k_cheb_nodes,
- * out[2] = interpolation levels in use, out[3] = intervals over all levels.  cs_column_counts is the reference's count. */
+ * out[2] = interpolation levels in use, out[3] = intervals over all levels; out[4..9] = the per-point evaluations by loop body
+ * (2-term, 2-term + cut-off predicate, 3-term, 3-term + predicate, 4-term + predicate, near-zone pass), out[10..12] = the node
+ * evaluations by body (2-, 3-, 4-term) -- what bench.py weights with the VALU instruction count of each body.  `out` holds 13
+ * values.  cs_column_counts is the reference's count. */
 int cs_column_work(cs_ctx *ctx, int64_t *out);
 /* interval sizes (descending, <= 5, each 128..2048 points) cs_set_interp(on) would use for this grid and cut-off; returns
  * their number (0: the grid is too coarse for the cut-off -- every pair is evaluated directly) */

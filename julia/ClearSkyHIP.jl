@@ -205,6 +205,17 @@ end # module
 #       cs_column_set_cia(ctx, ncia, slots, flags, P1[ncia,K], P2[ncia,K]) ; cs_column_run ; cs_column_fetch(τ, M⁺, M⁻, F⁺, F⁻)
 #   with conc_tab[t,k] = fC_t(T_k,P_k) and P1/P2 = P_k*concentration(g₁/g₂, T_k, P_k) (cia…jl:378-382), all evaluated on
 #   the Julia side at the node states (T_k, P_k) built in the method above.
+#   AcceleratedAbsorber / update! / Σ(A, i, T, P) (absorbers.jl:114-207), what RCM holds (radiative_convective.jl:95):
+#       knots = a resident column over U's members with nlobatto = 2 on the knot pressures (node k = knot k = (T_k, P_k));
+#       cs_accel_store(ctx, slot) evaluates ln Σ(U, i, T_k, P_k) for every ν and knot and keeps it in HBM; call it again after
+#       cs_column_update_state(new T) = update!(A, T);  cs_accel_eval(ctx, slot, P, i-1, 1, out) = Σ(A, i, ·, P);
+#       a column over A: cs_column_setup(ngas = 0, …) ; cs_column_set_accel(ctx, slot) ; cs_column_run ; cs_column_fetch.
+#       jacobian! (radiative_convective.jl:154-171): cs_column_batch(ctx, np+1, T_nodes, μ_nodes, T_levels, conc, conc_tab,
+#       cia_P1, cia_P2, F⁺[np, B], F⁻[np, B]) evaluates all perturbed profiles side by side.
+#   Scalar Σ(U, i, T, P) (absorbers.jl:95): cs_shape_points = the scalar-ν line-shape methods (inclusive cut-off) for DirectGas
+#       members, cs_table_eval for baked ones; CIA and function members stay Julia calls.
+#   This file has never been executed (no Julia toolchain on either box): tests/test_gpu_boundary.py drives the same symbol
+#   with the same memory layout through ctypes.
 #   cs_set_precision(ctx, 1, 1e6) selects the fp32 far-wing variant (BASELINE configs[4]).
 #   cs_set_interp(ctx, 0) switches the far-wing interpolation off (every (nu, line) pair evaluated, as surf! does); it is on
 #   by default and exact to rounding (DESIGN.md section 3, K2c).
