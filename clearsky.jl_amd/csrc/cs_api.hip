@@ -180,7 +180,11 @@ struct Column {
 
 }  // namespace
 
+// workspace of the PHCO2 fast path (k_phco2): per-(state, line) chi factors and per-tile region windows
+struct PhScratch { DevBuf fac, win; double nu_lo = 0.0, nu_hi = 0.0, nu_c = 0.0; };   // nu_lo/nu_hi: ends of the grid, set by the caller
+
 struct cs_ctx {
+    PhScratch ph;
     int device = 0;
     hipStream_t stream = nullptr;
     GasTable gas[CS_MAX_GAS];
@@ -590,12 +594,27 @@ void launch_apply(hipStream_t s, const ChebApply &A, int Kpad, int64_t nnu, int 
 #endif
 }
 
+// PHCO2 fast path preconditions + workspace.  Returns false -> generic kernel.
+bool phco2_fast_ok(const GasTable &G, int64_t nnu, double cut, int kn, PhScratch *ph)
+{
+    if (cut < 130.0 || nnu < 2 || !(ph->nu_hi > ph->nu_lo)) return false;
+    // widest near zone of any state must stay inside the chi = 1 core (|dnu| < 3 cm^-1) of its tile
+    const double amax = ((ph->nu_hi + cut) / kC) * std::sqrt(2.0 * kRgas * kTmax / G.mu_min);
+    if (100.0 * amax / kSqLn2 * (1.0 + 1e-6) > 2.9) return false;
+    const int nt64 = (int)((nnu + 63) / 64);
+    if ((ph->nu_hi - ph->nu_lo) / (double)(nnu - 1) * 64.0 > 5.0) return false;   // (mean tile span; wider tiles are handled, just not faster)
+    if (ph->fac.reserve((size_t)6 * kn * G.L * sizeof(double)) != hipSuccess) return false;
+    if (ph->win.reserve((size_t)nt64 * sizeof(PhWin)) != hipSuccess) return false;
+    ph->nu_c = 0.5 * (ph->nu_lo + ph->nu_hi);
+    return true;
+}
+
 // K1 + K2 for one gas on `s`: parameters for `kn` states, then the line sum into sigma ([kn][nnu])
 void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, int64_t jrange1, int kn, const double *Tk, const double *Pk, const double *Ppk,
                 const double *scale, LineHot *hot, LineCold *cold, const double *dnu, int64_t nnu, int ntile256,
                 const int32_t *J0, const int32_t *J1, const WaveWin *win, Zone *zones, int2 *ranges, const double *gbound, double cut, double base,
                 const double *extra, double *sigma, int accumulate, hipEvent_t *evg,   // NULL or 3 events: after K1, nodes, far
-                LineF32 *hot32 = nullptr, double far_s = 1e6, Interp itp = Interp(), ChebApply *defer = nullptr)
+                LineF32 *hot32 = nullptr, double far_s = 1e6, Interp itp = Interp(), ChebApply *defer = nullptr, PhScratch *ph = nullptr)
 {
     // only the lines some window can reach (windows are sorted: first tile's start .. last tile's end)
     const int64_t jlo = jrange0, jhi = std::max(jrange1, jrange0);
@@ -603,6 +622,8 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
     PrepArgs pa;
     pa.shape = shape; pa.K = kn; pa.g = G.dev(); pa.jlo = jlo; pa.jhi = jhi;
     pa.Tk = Tk; pa.Pk = Pk; pa.Ppk = Ppk; pa.scale = scale; pa.hot = hot; pa.cold = cold; pa.hot32 = shape == SH_VOIGT ? hot32 : nullptr;
+    pa.phfac = nullptr;
+    pa.nu_c = 0.0;
     const unsigned nb_prep = (unsigned)((tot + 255) / 256);
     const bool lor = shape == SH_LORENTZ;   // lorentz! runs on the same far-wing machinery with its own (exact) body
     if (shape == SH_VOIGT || lor) {
@@ -695,6 +716,28 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
             hipLaunchKernelGGL(k_voigt_near<0>, gridq, dim3(256), 0, s, dnu, nnu, G.L, hot, cold, zones, nt64, ngrp, cut, sigma, ranges);
             hipLaunchKernelGGL(k_voigt_near<1>, gridq, dim3(256), 0, s, dnu, nnu, G.L, hot, cold, zones, nt64, ngrp, cut, sigma, ranges);
         }
+    } else if (shape == SH_PHCO2 && ph && phco2_fast_ok(G, nnu, cut, kn, ph)) {
+        // PHCO2 fast path (k_phco2): region-uniform far lines with factorised chi; needs the cut-off edges inside region 3 and the
+        // near zone inside the chi = 1 core (phco2_fast_ok), else the generic kernel below
+        const int nt64 = (int)((nnu + 63) / 64);
+        pa.phfac = ph->fac.as<double>();
+        pa.nu_c = ph->nu_c;
+        ZoneArgs za;
+        za.nu = dnu; za.nul = G.nu.as<double>(); za.Tk = Tk; za.gbound = gbound; za.win = win; za.zones = zones; za.nnu = nnu;
+        za.lorentz = 0;
+        za.ntile = nt64; za.K = kn; za.mu_min = G.mu_min; za.mu_max = G.mu_max; za.cut = cut; za.far_s = far_s;
+        const unsigned nb_zones = (unsigned)(((int64_t)nt64 * kn + 255) / 256);
+        IzParams P;
+        memset(&P, 0, sizeof P);
+        hipLaunchKernelGGL(k_gas_setup, dim3(nb_prep + nb_zones), dim3(256), 0, s, nb_prep, nb_zones, pa, za, P, (IZone *)nullptr);
+        PhArgs pw;
+        pw.nu = dnu; pw.nul = G.nu.as<double>(); pw.nnu = nnu; pw.ntile = nt64; pw.J0 = (int32_t)jlo; pw.J1 = (int32_t)jhi; pw.cut = cut;
+        pw.out = ph->win.as<PhWin>();
+        hipLaunchKernelGGL(k_phwin, dim3((unsigned)((nt64 + 255) / 256)), dim3(256), 0, s, pw);
+        if (evg) { (void)hipEventRecord(evg[0], s); (void)hipEventRecord(evg[1], s); }
+        hipLaunchKernelGGL(k_phco2, dim3((unsigned)((nt64 + 3) / 4), kn), dim3(256), 0, s, dnu, nnu, G.L, hot, cold, ph->fac.as<double>(), ph->nu_c,
+                           ph->win.as<PhWin>(), zones, nt64, cut, Tk, kn, base, extra, sigma, accumulate);
+        if (evg) (void)hipEventRecord(evg[2], s);
     } else {
         if (nb_prep > 0) {
             ZoneArgs za;
@@ -866,6 +909,7 @@ static int shape_impl(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t 
     GasTable &G = ctx->gas[slot];
     if ((rc = check_gas_states(G, K, T))) return rc;
     if (shape == SH_VOIGT && (rc = check_near_density(G, nu, nnu, dnu_cut))) return rc;
+    ctx->ph.nu_lo = nu[0]; ctx->ph.nu_hi = nu[nnu - 1];
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     int64_t g0, g1, pairs, inr;
@@ -912,7 +956,7 @@ static int shape_impl(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t 
         launch_gas(s, shape, G, J0.front(), J1.back(), kn, dT.as<double>() + k0, dP.as<double>() + k0, dPp.as<double>() + k0, nullptr,
                    hot.as<LineHot>(), cold.as<LineCold>(), dnu.as<double>(), nnu, ntile, dJ0.as<int32_t>(), dJ1.as<int32_t>(),
                    dwin.as<WaveWin>(), dzones.as<Zone>(), dranges.as<int2>(), dgmax.as<double>() + k0, dnu_cut, 0.0, nullptr, dsig.as<double>(), 0, nullptr,
-                   mix32, ctx->far_s, itp);
+                   mix32, ctx->far_s, itp, nullptr, &ctx->ph);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpy2DAsync(sigma + (size_t)k0 * ld_state, ld_state * sizeof(double), dsig.p, nnu * sizeof(double),
                                 nnu * sizeof(double), kn, hipMemcpyDeviceToHost, s));
@@ -946,6 +990,7 @@ int cs_bake(cs_ctx *ctx, int gas_slot, int table_slot, int shape, double dnu_cut
     GasTable &G = ctx->gas[gas_slot];
     if ((rc = check_gas_states(G, M, Ts.data()))) return rc;
     if (shape == SH_VOIGT && (rc = check_near_density(G, nu, nnu, dnu_cut))) return rc;
+    ctx->ph.nu_lo = nu[0]; ctx->ph.nu_hi = nu[nnu - 1];
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     TableDev &tb = ctx->tab[table_slot];
@@ -989,7 +1034,7 @@ int cs_bake(cs_ctx *ctx, int gas_slot, int table_slot, int shape, double dnu_cut
         launch_gas(s, shape, G, J0.front(), J1.back(), kn, dT.as<double>() + k0, dP.as<double>() + k0, dPp.as<double>() + k0, nullptr, hot.as<LineHot>(),
                    cold.as<LineCold>(), dnu.as<double>(), nnu, ntile, dJ0.as<int32_t>(), dJ1.as<int32_t>(), dwin.as<WaveWin>(),
                    dzones.as<Zone>(), dranges.as<int2>(), dgb.as<double>() + k0, dnu_cut, 0.0, nullptr, tb.Z.as<double>() + (size_t)k0 * nnu, 0, nullptr,
-                   mix32, ctx->far_s, itp);
+                   mix32, ctx->far_s, itp, nullptr, &ctx->ph);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(s));
     }
@@ -1568,6 +1613,7 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
         if (ctx->mixed) HIPCHK(ctx->hot32.reserve(((size_t)kc * maxL + 4) * sizeof(LineF32)));
     }
     std::vector<double> cc(BK), pp(BK);
+    ctx->ph.nu_lo = c.h_nu.front(); ctx->ph.nu_hi = c.h_nu.back();
     for (int gi = 0; gi < c.ngas; gi++) {
         ColGas &cg = c.gas[gi];
         GasTable &G = ctx->gas[cg.slot];
@@ -1599,7 +1645,7 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
                        dconc.as<double>() + k0, hot.as<LineHot>(), cold.as<LineCold>(), c.nu.as<double>(), c.nnu, c.ntile,
                        cg.J0.as<int32_t>(), cg.J1.as<int32_t>(), cg.win.as<WaveWin>(), dzones.as<Zone>(), dranges.as<int2>(),
                        dgb.as<double>() + k0, cg.cut, c.sigma_gray, nullptr, sig + (size_t)k0 * c.nnu, gi > 0, nullptr,
-                       (ctx->mixed && cg.shape == SH_VOIGT) ? ctx->hot32.as<LineF32>() : nullptr, ctx->far_s, itp);
+                       (ctx->mixed && cg.shape == SH_VOIGT) ? ctx->hot32.as<LineF32>() : nullptr, ctx->far_s, itp, nullptr, &ctx->ph);
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipStreamSynchronize(s));   // cc/pp/gb host buffers are reused by the next gas
@@ -1688,6 +1734,7 @@ static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e)
     }
     ChebApply apply;
     apply.ngas = 0;
+    ctx->ph.nu_lo = c.h_nu.front(); ctx->ph.nu_hi = c.h_nu.back();
     for (int gi = 0; gi < c.ngas; gi++) {
         ColGas &cg = c.gas[gi];
         GasTable &G = ctx->gas[cg.slot];
@@ -1697,7 +1744,7 @@ static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e)
                    c.hot.as<LineHot>(), c.cold.as<LineCold>(), c.nu.as<double>(), c.nnu, c.ntile, cg.J0.as<int32_t>(),
                    cg.J1.as<int32_t>(), cg.win.as<WaveWin>(), cg.zones.as<Zone>(), c.ranges.as<int2>(), cg.gmax.as<double>(), cg.cut, c.sigma_gray, extra, sig, gi > 0,
                    ev ? ev + e : nullptr,
-                   (ctx->mixed && cg.shape == SH_VOIGT) ? ctx->hot32.as<LineF32>() : nullptr, ctx->far_s, itp, &apply);
+                   (ctx->mixed && cg.shape == SH_VOIGT) ? ctx->hot32.as<LineF32>() : nullptr, ctx->far_s, itp, &apply, &ctx->ph);
         if (ev) { e += 3; HIPCHK(hipEventRecord(ev[e++], s)); }
     }
     // interpolated far wings of all gases: sigma += sum_level C (sum_gas F)  (one pass over C and sigma)

@@ -77,6 +77,8 @@ struct PrepArgs {
     LineHot *hot;
     LineCold *cold;
     LineF32 *hot32;
+    double *phfac;    // PHCO2 fast path: [6][K][L] line factors exp(+-b_r(T) (nul - nu_c)), r = 1..3 (NULL: not needed)
+    double nu_c;      // reference wavenumber of those factors (centre of the grid)
 };
 __device__ __forceinline__ void prep_body(unsigned bid, const PrepArgs &pa)
 {
@@ -125,6 +127,14 @@ __device__ __forceinline__ void prep_body(unsigned bid, const PrepArgs &pa)
     }
     hot[idx] = h;
     cold[idx] = c;
+    if (pa.phfac) {   // chi(dnu) = exp(a_r - b_r |nu - nul|) in region r (line_shapes.jl:467-481) factorises into a per-lane and a per-line part
+        const double B1 = 0.0888 - 0.16 * exp(-0.0041 * T), B2 = 0.0526 * exp(-0.00152 * T);
+        const double dl = nul - pa.nu_c;
+        const size_t KL = (size_t)K * g.L;
+        pa.phfac[0 * KL + idx] = exp(B1 * dl);      pa.phfac[3 * KL + idx] = exp(-B1 * dl);
+        pa.phfac[1 * KL + idx] = exp(B2 * dl);      pa.phfac[4 * KL + idx] = exp(-B2 * dl);
+        pa.phfac[2 * KL + idx] = exp(0.0232 * dl);  pa.phfac[5 * KL + idx] = exp(-0.0232 * dl);
+    }
     if (hot32) {
         LineF32 f;
         f.d = (float)h.p1; f.y2 = (float)h.p2; f.ay = (float)(h.p3 * kMixScale); f.c2 = (float)(3.75 - 2.0 * h.p2);
@@ -975,6 +985,182 @@ __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu
             rp[(size_t)k * nnu + i] = r0;
             rp[((size_t)gridDim.y + k) * nnu + i] = r1;
         }
+        const size_t o = (size_t)k * nnu + i;
+        const double prev = accumulate ? sigma[o] : (base + (extra ? extra[o] : 0.0));
+        sigma[o] = prev + acc;
+    }
+}
+
+// ---- PHCO2 (Perrin & Hartmann sub-Lorentzian CO2 wings, line_shapes.jl:467-540) ------------------------------------------------
+// PHCO2 = voigt with the Lorentz width scaled by chi(|dnu|): 1 below 3 cm^-1, then exp(a_r - b_r |dnu|) on [3,30), [30,120),
+// [120, cut] with temperature-dependent a_r, b_r.  The default cut-off is 500 cm^-1, i.e. ~2e4 lines per point at 20 lines per
+// cm^-1 -- all but a few hundred of them far enough from the whole 64-point tile to (i) sit in ONE region r and on one side for
+// every lane and (ii) take the asymptotic far-wing body.  For those, chi = [exp(a_r -+ b_r (nu - nu_c))] x [exp(+- b_r (nul - nu_c))]:
+// a per-lane factor formed once per wave and a per-(state, line) factor k_prep tabulates, so a pair costs the far body + 4
+// multiplies, with wave-uniform scalar loads -- no exponential per pair.  What is left (lines within 3 cm^-1 of the tile, and those
+// whose region boundary or cut-off edge... falls inside the tile) goes through the generic per-lane body.
+// Per 64-point tile (state-independent): line indices of the region boundaries, computed in k_gas_setup.
+struct PhWin {
+    int32_t W0, L3, L2a, L2, L1a, L1, C0, C1, R1, R1b, R2, R2b, R3, W1;
+    // uniform sets: [W0,L3) r=3 left | [L2a,L2) r=2 left | [L1a,L1) r=1 left | [R1,R1b) r=1 right | [R2,R2b) r=2 right | [R3,W1) r=3 right
+    // generic sets: [L3,L2a), [L2,L1a), [L1,R1) (contains the chi = 1 core [C0,C1)), [R1b,R2), [R2b,R3)
+    int32_t E0, E1;   // lines inside the cut-off of every lane (as WaveWin)
+};
+struct PhArgs { const double *nu, *nul; int64_t nnu; int ntile; int32_t J0, J1; double cut; PhWin *out; };
+__device__ __forceinline__ void phwin_body(unsigned bid, const PhArgs &a)
+{
+    const int t = bid * blockDim.x + threadIdx.x;
+    if (t >= a.ntile) return;
+    const int64_t i0 = (int64_t)t * 64, i1 = (i0 + 63 < a.nnu ? i0 + 63 : a.nnu - 1);
+    const double vlo = a.nu[i0], vhi = a.nu[i1];
+    const double *__restrict__ nul = a.nul;
+    const double tol = 1e-9 * (fabs(vhi) + a.cut + 1.0);   // boundary lines go to the generic sets (chi is continuous across them)
+    auto lower = [&](double val) { int lo = a.J0, hi = a.J1; while (lo < hi) { const int m = (lo + hi) >> 1; if (nul[m] < val) lo = m + 1; else hi = m; } return lo; };
+    PhWin w;
+    w.W0 = lower(vlo - a.cut - tol);
+    w.W1 = lower(vhi + a.cut + tol);
+    w.L3 = lower(vlo - 120.0 - tol);     // left of it: dnu >= 120 for every lane
+    w.L2a = lower(vhi - 120.0 + tol);    // from here: dnu < 120 for every lane
+    w.L2 = lower(vlo - 30.0 - tol);
+    w.L1a = lower(vhi - 30.0 + tol);
+    w.L1 = lower(vlo - 3.0 - tol);
+    w.C0 = lower(vhi - 3.0 + tol);
+    w.C1 = lower(vlo + 3.0 - tol);
+    w.R1 = lower(vhi + 3.0 + tol);       // from here (right side): dnu >= 3 for every lane
+    w.R1b = lower(vlo + 30.0 - tol);
+    w.R2 = lower(vhi + 30.0 + tol);
+    w.R2b = lower(vlo + 120.0 - tol);
+    w.R3 = lower(vhi + 120.0 + tol);
+    // a tile wider than a region: empty uniform sets (everything generic)
+    w.L3 = max(w.L3, w.W0); w.L2a = max(w.L2a, w.L3); w.L2 = max(w.L2, w.L2a); w.L1a = max(w.L1a, w.L2); w.L1 = max(w.L1, w.L1a);
+    w.R1 = max(w.R1, w.L1); w.R1b = max(w.R1b, w.R1); w.R2 = max(w.R2, w.R1b); w.R2b = max(w.R2b, w.R2); w.R3 = max(w.R3, w.R2b);
+    w.W1 = max(w.W1, w.R3);
+    w.C0 = min(max(w.C0, w.L1), w.R1); w.C1 = min(max(w.C1, w.C0), w.R1);
+    w.E0 = min(max(lower(vhi - a.cut + tol), w.W0), w.W1);
+    w.E1 = min(max(lower(vlo + a.cut - tol), w.E0), w.W1);
+    a.out[t] = w;
+}
+
+__global__ __launch_bounds__(256) void k_phwin(PhArgs a) { phwin_body(blockIdx.x, a); }
+
+// far-wing term with a per-lane Lorentz-width factor chi: y -> chi y.  FOUR: 4-term series (s >= 1e4), else 2-term + y-dependent u^2
+// terms (exact wherever k_zones' Q bounds put a line, which it derived for the unscaled, i.e. larger, y)
+template <bool PRED, bool FOUR>
+__device__ __forceinline__ double ph_term(const LineHot &h, double chi, double v, double cut, const FarK &c)
+{
+    const double dv = v - h.nul;
+    const double x = dv * h.p1;
+    const double y2 = (h.p2 * chi) * chi;
+    const double s = __builtin_fma(x, x, y2);
+    const double u = rcp_fast(s);
+    double P;
+    if (FOUR) {
+        const double t = y2 * u;
+        const double p3 = __builtin_fma(__builtin_fma(__builtin_fma(c.km120, t, c.k210), t, c.km105), t, c.k13p125);
+        const double p2 = __builtin_fma(__builtin_fma(c.k12, t, c.km15), t, c.k3p75);
+        const double p1 = __builtin_fma(-2.0, t, c.k1p5);
+        P = __builtin_fma(u, __builtin_fma(u, __builtin_fma(u, p3, p2), p1), 1.0);
+    } else {
+        const double t = y2 * u;
+        const double q = __builtin_fma(t, __builtin_fma(c.k12, t, c.km15), __builtin_fma(y2, -2.0, c.k3p75));
+        P = __builtin_fma(__builtin_fma(q, u, c.k1p5), u, 1.0);
+    }
+    double r = ((h.p3 * chi) * u) * P;
+    if (PRED) r = (fabs(dv) > cut) ? 0.0 : r;
+    return r;
+}
+template <bool PRED, bool FOUR>
+__device__ __forceinline__ double ph_segment(double acc, double v, double glane, const LineHot *__restrict__ hk, const double *__restrict__ fk,
+                                             int j0, int j1, double cut, const FarK &c)
+{
+#pragma unroll 4
+    for (int j = j0; j < j1; j++) acc += ph_term<PRED, FOUR>(hk[j], glane * fk[j], v, cut, c);
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void k_phco2(const double *__restrict__ nu, int64_t nnu, int64_t L, const LineHot *__restrict__ hot,
+                                               const LineCold *__restrict__ cold, const double *__restrict__ phfac, double nu_c,
+                                               const PhWin *__restrict__ pw, const Zone *__restrict__ zones, int ntile, double cut,
+                                               const double *__restrict__ Tk, int K, double base, const double *__restrict__ extra,
+                                               double *__restrict__ sigma, int accumulate)
+{
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int tile = (int)blockIdx.x * 4 + wv;
+    if (tile >= ntile) return;
+    const int k = blockIdx.y;
+    const int64_t i = (int64_t)tile * 64 + lane;
+    const double v = nu[i < nnu ? i : nnu - 1];
+    const LineHot *__restrict__ hk = hot + (size_t)k * L;
+    const LineCold *__restrict__ ck = cold + (size_t)k * L;
+    const size_t KL = (size_t)K * L;
+    const PhWin w = pw[tile];
+    const Zone z = zones[(size_t)k * ntile + tile];
+    const FarK c = load_fark();
+    const double T = Tk[k];
+    const double B1 = 0.0888 - 0.16 * exp(-0.0041 * T), B2 = 0.0526 * exp(-0.00152 * T), B3 = 0.0232;
+    // chi in region r: exp(a_r - b_r dnu) with a_1 = 3 B1, a_2 = -27 B1 + 30 B2, a_3 = -27 B1 - 90 B2 + 120 B3 (line_shapes.jl:467-481)
+    const double a1 = 3.0 * B1, a2 = -27.0 * B1 + 30.0 * B2, a3 = -27.0 * B1 - 90.0 * B2 + 120.0 * B3;
+    const double dc = v - nu_c;
+    double acc = 0.0;
+    // uniform sets: region r, side; inside [Q0,Q1) (k_zones) the 4-term series, outside the 2-/3-term body; cut-off edges with the
+    // predicate (they sit in region 3: the launcher only takes this kernel for cut-offs beyond 130 cm^-1)
+    {
+        const double *f = phfac + 2 * KL + (size_t)k * L;   // exp(+B3 (nul - nu_c)), left side
+        const double g = exp(a3 - B3 * dc);
+        const int e = min(max(w.E0, w.W0), w.L3), q = min(max(z.Q0, e), w.L3);
+        acc = ph_segment<true, false>(acc, v, g, hk, f, w.W0, e, cut, c);
+        acc = ph_segment<false, false>(acc, v, g, hk, f, e, q, cut, c);
+        acc = ph_segment<false, true>(acc, v, g, hk, f, q, w.L3, cut, c);
+    }
+    {
+        const double *f = phfac + 1 * KL + (size_t)k * L;
+        const double g = exp(a2 - B2 * dc);
+        const int q = min(max(z.Q0, w.L2a), w.L2);
+        acc = ph_segment<false, false>(acc, v, g, hk, f, w.L2a, q, cut, c);
+        acc = ph_segment<false, true>(acc, v, g, hk, f, q, w.L2, cut, c);
+    }
+    {
+        const double *f = phfac + 0 * KL + (size_t)k * L;
+        const double g = exp(a1 - B1 * dc);
+        const int q = min(max(z.Q0, w.L1a), w.L1);
+        acc = ph_segment<false, false>(acc, v, g, hk, f, w.L1a, q, cut, c);
+        acc = ph_segment<false, true>(acc, v, g, hk, f, q, w.L1, cut, c);
+    }
+    {
+        const double *f = phfac + 3 * KL + (size_t)k * L;   // exp(-B1 (nul - nu_c)), right side
+        const double g = exp(a1 + B1 * dc);
+        const int q = min(max(z.Q1, w.R1), w.R1b);
+        acc = ph_segment<false, true>(acc, v, g, hk, f, w.R1, q, cut, c);
+        acc = ph_segment<false, false>(acc, v, g, hk, f, q, w.R1b, cut, c);
+    }
+    {
+        const double *f = phfac + 4 * KL + (size_t)k * L;
+        const double g = exp(a2 + B2 * dc);
+        const int q = min(max(z.Q1, w.R2), w.R2b);
+        acc = ph_segment<false, true>(acc, v, g, hk, f, w.R2, q, cut, c);
+        acc = ph_segment<false, false>(acc, v, g, hk, f, q, w.R2b, cut, c);
+    }
+    {
+        const double *f = phfac + 5 * KL + (size_t)k * L;
+        const double g = exp(a3 + B3 * dc);
+        const int e = max(min(w.E1, w.W1), w.R3), q = min(max(z.Q1, w.R3), e);
+        acc = ph_segment<false, true>(acc, v, g, hk, f, w.R3, q, cut, c);
+        acc = ph_segment<false, false>(acc, v, g, hk, f, q, e, cut, c);
+        acc = ph_segment<true, false>(acc, v, g, hk, f, e, w.W1, cut, c);
+    }
+    // generic sets: per-lane chi and the full Faddeeva (line_shapes.jl:496-499)
+    const int gl[5] = {w.L3, w.L2, w.L1, w.R1b, w.R2b}, gh[5] = {w.L2a, w.L1a, w.R1, w.R2, w.R3};
+    for (int r = 0; r < 5; r++)
+        for (int j = gl[r]; j < gh[r]; j++) {
+            const LineHot h = hk[j];
+            const double dv = v - h.nul;
+            if (!(fabs(dv) > cut)) {
+                const LineCold cc = ck[j];
+                const double chi = chi_phco2(fabs(dv), B1, B2);
+                acc = __builtin_fma(cc.A, fad_re(dv * h.p1, chi * cc.y), acc);
+            }
+        }
+    if (i < nnu) {
         const size_t o = (size_t)k * nnu + i;
         const double prev = accumulate ? sigma[o] : (base + (extra ? extra[o] : 0.0));
         sigma[o] = prev + acc;

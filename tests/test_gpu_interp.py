@@ -210,3 +210,34 @@ def test_lorentz_and_doppler_columns_vs_oracle(cs, O, lines):
         assert relerr(s, r["sigma"], floor=1e-300) < tol
         assert relerr(tau, r["tau"]) < tol and abs(F[0][0] - r["Fup"][0]) < 1e-10 * r["Fup"][0]
     ctx.close()
+
+
+def test_phco2_fast_path(cs, O, lines, ctx_on):
+    """PHCO2! (line_shapes.jl:467-540) at its default 500 cm^-1 cut-off on fine grids: far lines run region by region with the
+    factorised chi (k_phco2), the rest through the generic per-lane body -- against the oracle, which evaluates chi and the full
+    profile for every pair.  Grids cross every region boundary (3, 30, 120 cm^-1 from line clusters) and the cut-off edge."""
+    sl = lines("CO2")
+    T, P, Pp = map(list, zip(*STATES))
+    for lo, hi, n in ((600.0, 760.0, 6401), (2200.0, 2420.0, 7001), (30.0, 95.0, 3003)):
+        nu = np.linspace(lo, hi, n)
+        a = cs.shape_batch(sl, "PHCO2", nu, T, P, Pp, 500.0, ctx_on)
+        for k in range(len(T)):
+            so = O.shape_bang("PHCO2", nu, sl, T[k], P[k], Pp[k], 500.0)
+            assert np.array_equal(a[k] == 0, so == 0)
+            assert relerr(a[k], so, floor=1e-250) < 2e-11
+    # narrower cut-offs: 200 cm^-1 still takes the fast path, 100 cm^-1 falls back to the generic kernel; same answers
+    nu = np.linspace(640.0, 700.0, 4001)
+    for cut in (200.0, 100.0):
+        a = cs.shape_batch(sl, "PHCO2", nu, T[:2], P[:2], Pp[:2], cut, ctx_on)
+        for k in range(2):
+            assert relerr(a[k], O.shape_bang("PHCO2", nu, sl, T[k], P[k], Pp[k], cut), floor=1e-250) < 2e-11
+    # a whole column (scalar-nu semantics, accumulation onto a second gas)
+    Pl = cs.pressuregrid(10.0, 1e5, 9)
+    Tl = np.linspace(210.0, 290.0, 9)
+    g1 = cs.DirectGas(sl, 0.5, nu, shape="PHCO2")
+    g2 = cs.DirectGas(lines("H2O"), 1e-3, nu)
+    col = cs.Column(Pl, 9.8, Tl, 0.04, 0.0, 0.0, g2, g1, core=cs.Discretized(5, 2), ctx=ctx_on)
+    col.run()
+    r = O.fluxes_discretized(nu, Pl, 9.8, 2, col.Tn, col.mun, col.Tlev, [g2.sl, g1.sl], ["voigt", "PHCO2"], [25.0, 500.0], col.conc,
+                             want_sigma=True)
+    assert relerr(col.sigma_nodes(), r["sigma"], floor=1e-300) < 2e-11
