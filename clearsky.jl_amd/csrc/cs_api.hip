@@ -150,6 +150,7 @@ struct ColGas {
     DevBuf win, zones, gmax;  // [ntile64] WaveWin, [K][ntile64] Zone, [K] max Lorentz width (Voigt fast path)
     GasInterp itp;            // interpolated far wings (nlev = 0: off)
     int64_t pairs_per_state = 0, lines_in_range = 0, jlo = 0, jhi = 0;
+    int xtiles = 0;           // longest XCD stretch of the far kernel's tile order, in tiles (wave_windows)
     uint64_t generation = 0;
 };
 
@@ -414,8 +415,12 @@ int64_t count_pairs(const std::vector<double> &nul, const double *nu, int64_t nn
 }
 
 // per-64-point windows of the Voigt fast path: [W0,W1) superset window, [E0,E1) lines inside every lane's cut-off
-void wave_windows(const std::vector<double> &nul, int64_t g0, int64_t g1, const double *nu, int64_t nnu, double cut,
-                  std::vector<WaveWin> &win, int span = 64)
+// For span == 64 (the tiles of k_voigt_far) three more entries follow the nt windows: the block order of that kernel (tile_block).
+// xc[0..8] = tile indices (multiples of 4) of eight contiguous stretches of the spectrum, one per XCD, when the line table is
+// dense enough for its records to matter in that kernel's HBM traffic (32 B x lines against 16 B x wavenumbers per state:
+// contiguous from L >= nnu / 8); xc[0] = -1 = plain block order otherwise.  Returns the number of tiles per XCD (grid size).
+int wave_windows(const std::vector<double> &nul, int64_t g0, int64_t g1, const double *nu, int64_t nnu, double cut,
+                 std::vector<WaveWin> &win, int span = 64)
 {
     const int nt = (int)((nnu + span - 1) / span);
     win.resize(nt);
@@ -433,6 +438,16 @@ void wave_windows(const std::vector<double> &nul, int64_t g0, int64_t g1, const 
         w.E1 = std::min(std::max(w.E1, w.E0), w.W1);
         win[t] = w;
     }
+    if (span != 64) return 0;
+    int32_t xc[12] = {0};
+    const int nt4 = (nt + 3) / 4 * 4;
+    const int per = ((nt4 / 4 + 7) / 8) * 4;      // tiles per XCD, a multiple of 4
+    const int64_t inrange = (std::upper_bound(b, e, nu[nnu - 1] + cut) - std::lower_bound(b, e, nu[0] - cut));
+    for (int x = 0; x <= 8; x++) xc[x] = std::min(x * per, nt4);
+    if (inrange * 8 < nnu) xc[0] = -1;
+    win.resize(nt + 3);
+    memcpy(&win[nt], xc, sizeof xc);
+    return per;
 }
 
 // upper bound of gammalorentz (line_shapes.jl:255-257) over a gas's lines at every state
@@ -612,7 +627,7 @@ bool phco2_fast_ok(const GasTable &G, int64_t nnu, double cut, int kn, PhScratch
 // K1 + K2 for one gas on `s`: parameters for `kn` states, then the line sum into sigma ([kn][nnu])
 void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, int64_t jrange1, int kn, const double *Tk, const double *Pk, const double *Ppk,
                 const double *scale, LineHot *hot, LineCold *cold, const double *dnu, int64_t nnu, int ntile256,
-                const int32_t *J0, const int32_t *J1, const WaveWin *win, Zone *zones, int2 *ranges, const double *gbound, double cut, double base,
+                const int32_t *J0, const int32_t *J1, const WaveWin *win, int xtiles, Zone *zones, int2 *ranges, const double *gbound, double cut, double base,
                 const double *extra, double *sigma, int accumulate, hipEvent_t *evg,   // NULL or 3 events: after K1, nodes, far
                 LineF32 *hot32 = nullptr, double far_s = 1e6, Interp itp = Interp(), ChebApply *defer = nullptr, PhScratch *ph = nullptr)
 {
@@ -695,7 +710,8 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
         const int64_t nwave = (int64_t)nt64 * kn;
         const int split = nwave >= 16384 ? 1 : (nwave >= 4096 ? 2 : 4);   // (re-tuned with the far wings interpolated: waves are 3x shorter)
         const int nblk_s = (nt64 * split + 3) / 4;
-        const dim3 grid_s((unsigned)((nblk_s + 7) / 8 * 8), kn);   // multiple of 8: XCD-aware tile mapping (tile_block)
+        // 8 x (blocks of the longest XCD stretch): XCD-aware tile mapping (tile_block); xtiles is a multiple of 4 tiles
+        const dim3 grid_s((unsigned)(8 * (xtiles * split / 4)), kn);
 #define CS_FAR_LAUNCH(MIX, SP) hipLaunchKernelGGL((k_voigt_far<MIX, SP, false>), grid_s, dim3(256), 0, s, dnu, nnu, G.L, hot, hot32, G.nu.as<double>(), \
                                                   win, zones, nt64, nblk_s, cut, base, extra, sigma, accumulate, ranges, iz, itp.nItot, ishift)
 #define CS_LOR_LAUNCH(SP) hipLaunchKernelGGL((k_voigt_far<false, SP, true>), grid_s, dim3(256), 0, s, dnu, nnu, G.L, hot, hot32, G.nu.as<double>(), \
@@ -919,7 +935,7 @@ static int shape_impl(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t 
     const int ntile = (int)J0.size();
     DevBuf dnu, dT, dP, dPp, dJ0, dJ1, hot, cold, dsig, dwin, dzones, dgmax, dranges;
     std::vector<WaveWin> win;
-    wave_windows(G.h_nu, g0, g1, nu, nnu, dnu_cut, win);
+    const int xtiles = wave_windows(G.h_nu, g0, g1, nu, nnu, dnu_cut, win);
     if ((rc = upload(dnu, nu, nnu, s)) || (rc = upload(dT, T, K, s)) || (rc = upload(dP, P, K, s)) ||
         (rc = upload(dPp, Pp, K, s)) || (rc = upload(dJ0, J0.data(), ntile, s)) || (rc = upload(dJ1, J1.data(), ntile, s)) ||
         (rc = upload(dwin, win.data(), win.size(), s)))
@@ -955,7 +971,7 @@ static int shape_impl(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t 
         const int kn = std::min(kc, K - k0);
         launch_gas(s, shape, G, J0.front(), J1.back(), kn, dT.as<double>() + k0, dP.as<double>() + k0, dPp.as<double>() + k0, nullptr,
                    hot.as<LineHot>(), cold.as<LineCold>(), dnu.as<double>(), nnu, ntile, dJ0.as<int32_t>(), dJ1.as<int32_t>(),
-                   dwin.as<WaveWin>(), dzones.as<Zone>(), dranges.as<int2>(), dgmax.as<double>() + k0, dnu_cut, 0.0, nullptr, dsig.as<double>(), 0, nullptr,
+                   dwin.as<WaveWin>(), xtiles, dzones.as<Zone>(), dranges.as<int2>(), dgmax.as<double>() + k0, dnu_cut, 0.0, nullptr, dsig.as<double>(), 0, nullptr,
                    mix32, ctx->far_s, itp, nullptr, &ctx->ph);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpy2DAsync(sigma + (size_t)k0 * ld_state, ld_state * sizeof(double), dsig.p, nnu * sizeof(double),
@@ -1000,7 +1016,7 @@ int cs_bake(cs_ctx *ctx, int gas_slot, int table_slot, int shape, double dnu_cut
     std::vector<int32_t> J0, J1;
     tile_windows(G.h_nu, g0, g1, nu, nnu, window_reach(shape, G, nu[nnu - 1], dnu_cut), J0, J1, pairs, inr);
     std::vector<WaveWin> win;
-    wave_windows(G.h_nu, g0, g1, nu, nnu, dnu_cut, win);
+    const int xtiles = wave_windows(G.h_nu, g0, g1, nu, nnu, dnu_cut, win);
     const int ntile = (int)J0.size();
     DevBuf dnu, dT, dP, dPp, dJ0, dJ1, hot, cold, dwin, dzones, dgb, dranges;
     std::vector<double> gb = gamma_bound(G, M, Ts.data(), Ps.data(), Pp.data());
@@ -1032,7 +1048,7 @@ int cs_bake(cs_ctx *ctx, int gas_slot, int table_slot, int shape, double dnu_cut
     for (int k0 = 0; k0 < M; k0 += kc) {
         const int kn = std::min(kc, M - k0);
         launch_gas(s, shape, G, J0.front(), J1.back(), kn, dT.as<double>() + k0, dP.as<double>() + k0, dPp.as<double>() + k0, nullptr, hot.as<LineHot>(),
-                   cold.as<LineCold>(), dnu.as<double>(), nnu, ntile, dJ0.as<int32_t>(), dJ1.as<int32_t>(), dwin.as<WaveWin>(),
+                   cold.as<LineCold>(), dnu.as<double>(), nnu, ntile, dJ0.as<int32_t>(), dJ1.as<int32_t>(), dwin.as<WaveWin>(), xtiles,
                    dzones.as<Zone>(), dranges.as<int2>(), dgb.as<double>() + k0, dnu_cut, 0.0, nullptr, tb.Z.as<double>() + (size_t)k0 * nnu, 0, nullptr,
                    mix32, ctx->far_s, itp, nullptr, &ctx->ph);
         HIPCHK(hipGetLastError());
@@ -1472,7 +1488,7 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
         cg.jlo = J0.front();
         cg.jhi = J1.back();
         std::vector<WaveWin> win;
-        wave_windows(G.h_nu, g0, g1, nu, nnu, cg.cut, win);
+        cg.xtiles = wave_windows(G.h_nu, g0, g1, nu, nnu, cg.cut, win);
         if ((rc = upload(cg.J0, J0.data(), J0.size(), s)) || (rc = upload(cg.J1, J1.data(), J1.size(), s)) ||
             (rc = upload(cg.win, win.data(), win.size(), s)))
             return rc;
@@ -1643,7 +1659,7 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
             const int kn = (int)std::min<int64_t>(kc, BK - k0);
             launch_gas(s, cg.shape, G, cg.jlo, cg.jhi, kn, dTk.as<double>() + k0, dPk.as<double>() + k0, dPp.as<double>() + k0,
                        dconc.as<double>() + k0, hot.as<LineHot>(), cold.as<LineCold>(), c.nu.as<double>(), c.nnu, c.ntile,
-                       cg.J0.as<int32_t>(), cg.J1.as<int32_t>(), cg.win.as<WaveWin>(), dzones.as<Zone>(), dranges.as<int2>(),
+                       cg.J0.as<int32_t>(), cg.J1.as<int32_t>(), cg.win.as<WaveWin>(), cg.xtiles, dzones.as<Zone>(), dranges.as<int2>(),
                        dgb.as<double>() + k0, cg.cut, c.sigma_gray, nullptr, sig + (size_t)k0 * c.nnu, gi > 0, nullptr,
                        (ctx->mixed && cg.shape == SH_VOIGT) ? ctx->hot32.as<LineF32>() : nullptr, ctx->far_s, itp, nullptr, &ctx->ph);
             HIPCHK(hipGetLastError());
@@ -1742,7 +1758,7 @@ static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e)
         itp.F = c.chebF.as<double>();
         launch_gas(s, cg.shape, G, cg.jlo, cg.jhi, K, c.Tk.as<double>(), c.Pk.as<double>(), cg.Pp.as<double>(), cg.conc.as<double>(),
                    c.hot.as<LineHot>(), c.cold.as<LineCold>(), c.nu.as<double>(), c.nnu, c.ntile, cg.J0.as<int32_t>(),
-                   cg.J1.as<int32_t>(), cg.win.as<WaveWin>(), cg.zones.as<Zone>(), c.ranges.as<int2>(), cg.gmax.as<double>(), cg.cut, c.sigma_gray, extra, sig, gi > 0,
+                   cg.J1.as<int32_t>(), cg.win.as<WaveWin>(), cg.xtiles, cg.zones.as<Zone>(), c.ranges.as<int2>(), cg.gmax.as<double>(), cg.cut, c.sigma_gray, extra, sig, gi > 0,
                    ev ? ev + e : nullptr,
                    (ctx->mixed && cg.shape == SH_VOIGT) ? ctx->hot32.as<LineF32>() : nullptr, ctx->far_s, itp, &apply, &ctx->ph);
         if (ev) { e += 3; HIPCHK(hipEventRecord(ev[e++], s)); }

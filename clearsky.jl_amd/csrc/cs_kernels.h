@@ -422,16 +422,21 @@ __device__ __forceinline__ double far_segment32_rev(double acc, double v, const 
     return __builtin_fma((double)part, kMixUnscale, acc);
 }
 
-// blockIdx.x -> block of 4 wave tiles.  Workgroups are dealt round-robin over the 8 XCDs (private L2 each), so block b and b+8
-// share an L2: give each XCD one contiguous eighth of the spectrum, whose overlapping line windows then stay in that L2 and
-// leave it once.  Measured at C3 (profiles/r02_notes.md): plain block order fetches every record ~2.4x (FETCH 237 MiB per launch,
-// by whichever XCDs a tile's neighbours land on), this order 123 MiB = the algorithmic bytes, for 3 % more kernel time (the
-// kernel is VALU-bound either way; a cost-balanced two-stretch variant was slower still).  gridDim.x is a multiple of 8;
-// speed/traffic only -- any placement is correct.
-__device__ __forceinline__ int tile_block(int nblk)
+// blockIdx.x -> block of 4/S wave tiles.  Workgroups are dealt round-robin over the 8 XCDs (private L2 each), so blocks b and
+// b+8 share an L2.  With a dense line table the records are a third of this kernel's bytes and plain block order makes every XCD
+// fetch most of them (C3: FETCH 237 MiB per launch): give each XCD one contiguous eighth of the spectrum, whose overlapping line
+// windows then stay in that L2 and leave HBM once (123 MiB = the algorithmic bytes).  That order costs time -- +3 % at C3, +14 %
+// on the sparse tables of C5, and neither equal-cost stretches nor finer interleaving (2-8 blocks per XCD at a time) removed it
+// (profiles/r02_notes.md) -- so the host chooses it only where the records matter (wave_windows: xc[0] >= 0).
+// Speed/traffic only: any placement is correct.
+__device__ __forceinline__ int tile_block(const int32_t *__restrict__ xc, int tiles_per_block, bool &valid)
 {
-    const int chunk = (nblk + 7) >> 3;
-    return (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    valid = true;
+    if (xc[0] < 0) return blockIdx.x;   // plain order
+    const int x = blockIdx.x & 7, r = blockIdx.x >> 3;
+    const int b0 = xc[x] / tiles_per_block, b1 = xc[x + 1] / tiles_per_block;
+    valid = b0 + r < b1;
+    return b0 + r;
 }
 
 // ---- K2c: far wings by spectral interpolation ---------------------------------------------------------------------------
@@ -848,11 +853,12 @@ __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu
     // chip otherwise (a nu-shard of a multi-GPU run, bake on a short grid).
     __shared__ double acc_sh[S > 1 ? 256 : 1];
     __shared__ int4 rng_sh[S > 1 ? 256 : 1];
-    const int tb = tile_block(nblk);
+    bool in_stretch;
+    const int tb = tile_block(reinterpret_cast<const int32_t *>(win + ntile), 4 / S, in_stretch);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave-uniform by construction:
     const int tile = tb * (4 / S) + wv / S;                                                      // tell the compiler, so that the
     const int part = wv % S;                                                                     // line records stay scalar loads
-    const bool work = tb < nblk && tile < ntile;
+    const bool work = in_stretch && tb < nblk && tile < ntile;
     if (S == 1 && !work) return;
     const int k = blockIdx.y;
     const int64_t i = (int64_t)tile * 64 + lane;
