@@ -953,7 +953,7 @@ static int shape_impl(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t 
         HIPCHK(ctx->hot32.reserve(((size_t)kc * G.L + 4) * sizeof(LineF32)));
         mix32 = ctx->hot32.as<LineF32>();
     }
-    HIPCHK(dranges.reserve((size_t)kc * nnu * sizeof(int2)));
+    HIPCHK(dranges.reserve((size_t)kc * nnu * sizeof(int2) + (size_t)2 * kc * ((nnu + 63) / 64) * sizeof(int)));   // + per-(tile, state) flags
     {
         std::vector<double> gb = gamma_bound(G, K, T, P, Pp);
         if ((rc = upload(dgmax, gb.data(), K, s))) return rc;
@@ -1030,7 +1030,7 @@ int cs_bake(cs_ctx *ctx, int gas_slot, int table_slot, int shape, double dnu_cut
     HIPCHK(hot.reserve(((size_t)kc * G.L + 4) * sizeof(LineHot)));
     HIPCHK(cold.reserve((size_t)kc * G.L * sizeof(LineCold)));
     HIPCHK(dzones.reserve((size_t)kc * win.size() * sizeof(Zone)));
-    HIPCHK(dranges.reserve((size_t)kc * nnu * sizeof(int2)));
+    HIPCHK(dranges.reserve((size_t)kc * nnu * sizeof(int2) + (size_t)2 * kc * ((nnu + 63) / 64) * sizeof(int)));   // + per-(tile, state) flags
     LineF32 *mix32 = nullptr;
     if (ctx->mixed && shape == SH_VOIGT) {
         HIPCHK(ctx->hot32.reserve(((size_t)kc * G.L + 4) * sizeof(LineF32)));
@@ -1509,7 +1509,7 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
     HIPCHK(c.hot.reserve(((size_t)K * maxL + 4) * sizeof(LineHot)));
     HIPCHK(c.cold.reserve((size_t)K * maxL * sizeof(LineCold)));
     HIPCHK(c.sigma.reserve((size_t)K * nnu * sizeof(double)));
-    if (ngas > 0) HIPCHK(c.ranges.reserve((size_t)K * nnu * sizeof(int2)));
+    if (ngas > 0) HIPCHK(c.ranges.reserve((size_t)K * nnu * sizeof(int2) + (size_t)2 * K * ((nnu + 63) / 64) * sizeof(int)));   // + per-(tile, state) flags
     if (c.want_tau) HIPCHK(c.tau.reserve((size_t)nl * nnu * sizeof(double)));   // (band fluxes only: no optical depth is stored)
     if (c.want_M) {
         HIPCHK(c.Mup.reserve((size_t)np * nnu * sizeof(double)));
@@ -1625,7 +1625,7 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
     if (c.ngas > 0) {
         HIPCHK(hot.reserve(((size_t)kc * maxL + 4) * sizeof(LineHot)));
         HIPCHK(cold.reserve((size_t)kc * maxL * sizeof(LineCold)));
-        HIPCHK(dranges.reserve((size_t)kc * c.nnu * sizeof(int2)));
+        HIPCHK(dranges.reserve((size_t)kc * c.nnu * sizeof(int2) + (size_t)2 * kc * ((c.nnu + 63) / 64) * sizeof(int)));
         if (ctx->mixed) HIPCHK(ctx->hot32.reserve(((size_t)kc * maxL + 4) * sizeof(LineF32)));
     }
     std::vector<double> cc(BK), pp(BK);

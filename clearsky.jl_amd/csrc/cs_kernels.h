@@ -981,19 +981,29 @@ __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu
             bl = min(bl, r.x); bh = max(bh, r.y); cl = min(cl, r.z); ch = max(ch, r.w);
         }
     }
-    if (i < nnu) {
-        // hand-off to k_voigt_near<0>, <1>: per (nu, node) and tier one word, (first line - N0) << 12 | count -- 8 bytes per
-        // spectral point and node in all (cs_api.hip refuses tables dense enough to overflow 20 + 12 bits: check_near_density)
-        if (!LOR) {   // (a Lorentz profile has no near-line kernels to hand anything to)
-            const unsigned r0 = bh >= bl ? ((unsigned)(bl - z.N0) << 12) | (unsigned)(bh + 1 - bl) : 0u;
-            const unsigned r1 = ch >= cl ? ((unsigned)(cl - z.N0) << 12) | (unsigned)(ch + 1 - cl) : 0u;
-            unsigned *__restrict__ rp = reinterpret_cast<unsigned *>(ranges);
-            rp[(size_t)k * nnu + i] = r0;
-            rp[((size_t)gridDim.y + k) * nnu + i] = r1;
-        }
+    const bool live = i < nnu;
+    if (live) {
         const size_t o = (size_t)k * nnu + i;
         const double prev = accumulate ? sigma[o] : (base + (extra ? extra[o] : 0.0));
         sigma[o] = prev + acc;
+    }
+    // hand-off to k_voigt_near<0>, <1>: per (nu, node) and tier one word, (first line - N0) << 12 | count -- 8 bytes per
+    // spectral point and node in all (cs_api.hip refuses tables dense enough to overflow 20 + 12 bits: check_near_density) --
+    // and per (tile, node) and tier a flag "some lane has candidates": tiles without any (most tiles of a sparse table, every
+    // tile of a high-pressure state, where y^2 alone exceeds 1e3) skip the store here and the whole wave there
+    if (!LOR) {   // (a Lorentz profile has no near-line kernels to hand anything to)
+        const unsigned r0 = (live && bh >= bl) ? ((unsigned)(bl - z.N0) << 12) | (unsigned)(bh + 1 - bl) : 0u;
+        const unsigned r1 = (live && ch >= cl) ? ((unsigned)(cl - z.N0) << 12) | (unsigned)(ch + 1 - cl) : 0u;
+        const bool any0 = __any(r0 != 0u), any1 = __any(r1 != 0u);
+        unsigned *__restrict__ rp = reinterpret_cast<unsigned *>(ranges);
+        const size_t plane = (size_t)gridDim.y * nnu;
+        if (any0 && live) rp[(size_t)k * nnu + i] = r0;
+        if (any1 && live) rp[plane + (size_t)k * nnu + i] = r1;
+        if (lane == 0) {
+            unsigned *__restrict__ fl = rp + 2 * plane;
+            fl[(size_t)k * ntile + tile] = any0 ? 1u : 0u;
+            fl[((size_t)gridDim.y + k) * ntile + tile] = any1 ? 1u : 0u;
+        }
     }
 }
 
@@ -1273,7 +1283,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     const int k = blockIdx.y;
     const LineHot *__restrict__ hk = hot + (size_t)k * L;
     const LineCold *__restrict__ ck = cold + (size_t)k * L;
-    // two planes of packed words: tier 0 ranges, then tier 1 ranges, [gridDim.y][nnu] each
+    // two planes of packed words: tier 0 ranges, then tier 1 ranges, [gridDim.y][nnu] each; behind them the per-(tile, node) flags
+    {
+        const unsigned *__restrict__ fl = reinterpret_cast<const unsigned *>(ranges) + 2 * (size_t)gridDim.y * nnu;
+        if (fl[((size_t)TIER * gridDim.y + k) * ntile + grp] == 0u) return;   // (wave-uniform: CS_NEAR_R = 1, group = tile)
+    }
     const unsigned *__restrict__ rp = reinterpret_cast<const unsigned *>(ranges) + (size_t)TIER * gridDim.y * nnu + (size_t)k * nnu;
     int lo[CS_NEAR_R], hi[CS_NEAR_R];
     double acc[CS_NEAR_R];
