@@ -34,6 +34,37 @@ def test_no_oracle_in_product():
                 assert "oracle" not in txt.lower().replace("# oracle", ""), f"{f} mentions the oracle"
 
 
+def test_product_imports_and_links_without_the_oracle():
+    """Stronger than the text check: (i) the package imports, loads the HIP library and resolves every ABI symbol in a fresh
+    interpreter in which `oracle` cannot be imported at all; (ii) the shared library's dynamic dependencies name no oracle object;
+    (iii) with the HIP library absent the product raises instead of falling back to anything."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, types\n"
+        "class _Block:\n"
+        "    def find_spec(self, name, path=None, target=None):\n"
+        "        if name == 'oracle' or name.startswith('oracle.'):\n"
+        "            raise ImportError('oracle is test infrastructure: blocked')\n"
+        "sys.meta_path.insert(0, _Block())\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import clearsky_jl_amd as cs\n"
+        "L = cs.lib()\n"
+        "assert all(hasattr(L, n) for n in cs.SIGNATURES)\n"
+        "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules)\n"
+        "print('ok', len(cs.SIGNATURES))\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith("ok"), out.stderr[-1500:]
+    import clearsky_jl_amd as cs
+    dyn = subprocess.run(["readelf", "-d", cs.LIB_PATH], capture_output=True, text=True).stdout
+    assert "NEEDED" in dyn and "oracle" not in dyn.lower()
+    code2 = (f"import sys, os\nsys.path.insert(0, {ROOT!r})\nos.environ['CLEARSKY_HIP_LIB'] = '/nonexistent/libclearsky_hip.so'\n"
+             "import clearsky_jl_amd as cs\n"
+             "try:\n    cs.lib()\nexcept cs.ClearSkyHIPError as e:\n    print('raised', e.code)\n")
+    out2 = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=300)
+    assert out2.stdout.startswith("raised -100"), out2.stdout + out2.stderr[-800:]
+
+
 def test_molparam_structure(cs):
     """Mirror of the reference's only active test, test/test_molparam.jl:1-18."""
     for M, mp in cs.MOLPARAM.items():
