@@ -1074,6 +1074,28 @@ int cs_table_clear(cs_ctx *ctx, int table_slot)
     return CS_OK;
 }
 
+// sigma[k][nu] += conc[k] * exp(sum_m Z[m][nu] W[m][k]) for K states (the Gas functor, gases.jl:85,278)
+#ifndef CS_TABLE_NSUB
+#define CS_TABLE_NSUB 2
+#endif
+static int launch_table_eval(hipStream_t s, const double *Z, int M, int64_t nnu, const double *W, int K, const double *conc, double *sigma)
+{
+#ifdef CS_TABLE_VALU   // the vector-unit version (kept for A/B builds)
+    const int ntile = (int)((nnu + 255) / 256);
+    if ((size_t)M * CS_TAB_KC * sizeof(double) > 65536)
+        HIPCHK(hipFuncSetAttribute((const void *)k_table_eval, hipFuncAttributeMaxDynamicSharedMemorySize, M * CS_TAB_KC * (int)sizeof(double)));
+    hipLaunchKernelGGL(k_table_eval, dim3((unsigned)ntile, (unsigned)((K + CS_TAB_KC - 1) / CS_TAB_KC)), dim3(256),
+                       (size_t)M * CS_TAB_KC * sizeof(double), s, Z, M, nnu, W, K, conc, sigma);
+#else
+    const int nt64 = (int)((nnu + 63) / 64);
+    const int nst = (K + 15) / 16, nsg = (nst + CS_TABLE_NSUB - 1) / CS_TABLE_NSUB;
+    const int64_t nblk = (int64_t)((nt64 + 3) / 4) * nsg;
+    if (nblk > 0x7fffffffLL) return fail(CS_EINVAL, "too many (tile, state) blocks for the opacity-table kernel");
+    hipLaunchKernelGGL(k_table_eval_mfma<CS_TABLE_NSUB>, dim3((unsigned)nblk), dim3(256), 0, s, Z, M, nnu, nt64, W, K, conc, sigma);
+#endif
+    return CS_OK;
+}
+
 // W[m][k] = a_i(T_k) b_j(ln P_k), m = i + nT*j
 static int table_weights(const TableDev &tb, int K, const double *Tk, const double *Pk, std::vector<double> &W)
 {
@@ -1109,8 +1131,7 @@ int cs_table_eval(cs_ctx *ctx, int table_slot, double T, double P, int64_t i0, i
     if ((rc = upload(ctx->tmpA, W.data(), M, s)) || (rc = upload(ctx->tmpB, &one, 1, s))) return rc;
     HIPCHK(ctx->tmpC.reserve((size_t)tb.nnu * sizeof(double)));
     HIPCHK(hipMemsetAsync(ctx->tmpC.p, 0, (size_t)tb.nnu * sizeof(double), s));
-    hipLaunchKernelGGL(k_table_eval, dim3((unsigned)((tb.nnu + 255) / 256), 1), dim3(256), (size_t)M * CS_TAB_KC * sizeof(double), s,
-                       tb.Z.as<double>(), M, tb.nnu, ctx->tmpA.as<double>(), 1, ctx->tmpB.as<double>(), ctx->tmpC.as<double>());
+    if ((rc = launch_table_eval(s, tb.Z.as<double>(), M, tb.nnu, ctx->tmpA.as<double>(), 1, ctx->tmpB.as<double>(), ctx->tmpC.as<double>()))) return rc;
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(sigma_out, ctx->tmpC.as<double>() + i0, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -1683,12 +1704,7 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
                 }
             if ((rc = upload(dW, W.data(), W.size(), s)) || (rc = upload(dct, ct.data(), BK, s))) return rc;
             const int M = tb.nT * tb.nP;
-            if ((size_t)M * CS_TAB_KC * sizeof(double) > 65536)
-                HIPCHK(hipFuncSetAttribute((const void *)k_table_eval, hipFuncAttributeMaxDynamicSharedMemorySize, M * CS_TAB_KC * (int)sizeof(double)));
-            if (BK > (int64_t)65535 * CS_TAB_KC) return fail(CS_EINVAL, "too many batch states for the opacity-table kernel (%lld)", (long long)BK);
-            hipLaunchKernelGGL(k_table_eval, dim3((unsigned)c.ntile, (unsigned)((BK + CS_TAB_KC - 1) / CS_TAB_KC)), dim3(256),
-                               (size_t)M * CS_TAB_KC * sizeof(double), s, tb.Z.as<double>(), M, c.nnu, dW.as<double>(), (int)BK,
-                               dct.as<double>(), sig);
+            if ((rc = launch_table_eval(s, tb.Z.as<double>(), M, c.nnu, dW.as<double>(), (int)BK, dct.as<double>(), sig))) return rc;
             HIPCHK(hipGetLastError());
             HIPCHK(hipStreamSynchronize(s));   // W/ct host and device buffers are reused by the next table
         }
@@ -1767,12 +1783,8 @@ static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e)
     if (apply.ngas > 0) launch_apply(s, apply, cheb_kpad(K), c.nnu, K, 0.0, nullptr, sig, 1);
     for (auto &t : c.tab) {  // baked gases: sigma += fC * exp(Phi(T, ln P))
         TableDev &tb = ctx->tab[t.slot];
-        const int M = tb.nT * tb.nP;
-        if ((size_t)M * CS_TAB_KC * sizeof(double) > 65536)
-            HIPCHK(hipFuncSetAttribute((const void *)k_table_eval, hipFuncAttributeMaxDynamicSharedMemorySize, M * CS_TAB_KC * (int)sizeof(double)));
-        hipLaunchKernelGGL(k_table_eval, dim3((unsigned)c.ntile, (unsigned)((K + CS_TAB_KC - 1) / CS_TAB_KC)), dim3(256),
-                           (size_t)M * CS_TAB_KC * sizeof(double), s, tb.Z.as<double>(), M, c.nnu, t.W.as<double>(), K,
-                           t.conc.as<double>(), sig);
+        int rc2;
+        if ((rc2 = launch_table_eval(s, tb.Z.as<double>(), tb.nT * tb.nP, c.nnu, t.W.as<double>(), K, t.conc.as<double>(), sig))) return rc2;
     }
     for (auto &cc : c.cia)  // CIA pairs
         hipLaunchKernelGGL(k_cia, dim3((unsigned)c.ntile), dim3(256), 0, s, cc.nband, cc.bands.as<CiaBand>(), cc.st.as<CiaState>(),

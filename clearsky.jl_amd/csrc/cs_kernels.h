@@ -1613,6 +1613,62 @@ __global__ __launch_bounds__(256) void k_table_eval(const double *__restrict__ Z
     }
 }
 
+// The same on the matrix cores (the contraction over the nT*nP table nodes is the dense part of Mode T): D(16 states x 16 nu) +=
+// A(16 states x 4 table nodes) * B(4 table nodes x 16 nu) with v_mfma_f64_16x16x4, operands as in k_cheb_apply_mfma.  One wave =
+// one 64-point tile x NSUB*16 states, so the ln sigma table is read from HBM once per NSUB*16 states instead of once per 16
+// (k_table_eval: 4 passes over 230 MB per gas at K = 61 -- HBM-bound at 0.42 ms per gas; this: profiles/r02_notes.md).
+template <int NSUB>
+__global__ __launch_bounds__(256, NSUB >= 4 ? 2 : 4) void k_table_eval_mfma(const double *__restrict__ Z, int M, int64_t nnu, int ntile,
+                                                                            const double *__restrict__ W, int K, const double *__restrict__ conc,
+                                                                            double *__restrict__ sigma)
+{
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int nst = (K + 15) >> 4, nsg = (nst + NSUB - 1) / NSUB;
+    const int tile = (int)(blockIdx.x / nsg) * 4 + wv;
+    if (tile >= ntile) return;
+    const int s0 = (int)(blockIdx.x % nsg) * NSUB;
+    const int lr = lane & 15, lq = lane >> 4;
+    v4f64 acc[NSUB][4];
+#pragma unroll
+    for (int si = 0; si < NSUB; si++)
+#pragma unroll
+        for (int jt = 0; jt < 4; jt++) acc[si][jt] = v4f64{0.0, 0.0, 0.0, 0.0};
+    // B: Z[m0 + lq][nu]; the last tile may run past nnu: clamp the column (never stored)
+    int64_t col[4];
+#pragma unroll
+    for (int jt = 0; jt < 4; jt++) { const int64_t i = (int64_t)tile * 64 + jt * 16 + lr; col[jt] = i < nnu ? i : nnu - 1; }
+    int kcol[NSUB];
+#pragma unroll
+    for (int si = 0; si < NSUB; si++) { const int k = (s0 + si) * 16 + lr; kcol[si] = k < K ? k : -1; }
+#pragma unroll 2
+    for (int m = 0; m < M; m += 4) {
+        const int mm = m + lq;
+        const bool ok = mm < M;
+        const double *__restrict__ zr = Z + (size_t)(ok ? mm : 0) * nnu;
+        const double *__restrict__ wr = W + (size_t)(ok ? mm : 0) * K;
+        double b[4], a[NSUB];
+#pragma unroll
+        for (int jt = 0; jt < 4; jt++) b[jt] = ok ? zr[col[jt]] : 0.0;
+#pragma unroll
+        for (int si = 0; si < NSUB; si++) a[si] = (ok && kcol[si] >= 0) ? wr[kcol[si]] : 0.0;
+#pragma unroll
+        for (int si = 0; si < NSUB; si++)
+#pragma unroll
+            for (int jt = 0; jt < 4; jt++) acc[si][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[si], b[jt], acc[si][jt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int si = 0; si < NSUB; si++)
+#pragma unroll
+        for (int jt = 0; jt < 4; jt++) {
+            const int64_t i = (int64_t)tile * 64 + jt * 16 + lr;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int k = (s0 + si) * 16 + 4 * r + lq;
+                if (k < K && i < nnu) sigma[(size_t)k * nnu + i] += conc[k] * exp(acc[si][jt][r]);
+            }
+        }
+}
+
 // ---- collision-induced absorption (collision_induced_absorption.jl:145-303) ----------------------------------------------
 // One CIA object = a few bands; a band is ln k on a (nu, T) grid evaluated bilinearly (BilinearInterpolator of ln k with
 // NoBoundaries, :207) or a single-temperature range evaluated linearly in nu (:188).  Per node state the host prepares the
