@@ -246,6 +246,11 @@ class Context:
         """Tuning: first interval level every gas uses (-1 = by line density) and the range of interval sizes considered."""
         check(lib().cs_set_interp_plan(self._h, int(first_level), int(size_min), int(size_max)))
 
+    def set_matrix_cores(self, on=True):
+        """Separable far-wing node sums on the matrix cores: True/1 (default) where the grid is long enough to pay, 2 always,
+        False/0 every node sum on the vector unit."""
+        check(lib().cs_set_matrix_cores(self._h, int(on)))
+
     def slot_of(self, sl: SpectralLines) -> int:
         """Upload `sl` (once) and return its gas slot."""
         key = id(sl)
@@ -1043,11 +1048,11 @@ class Column:
     def work(self):
         """Evaluations the last run issued for its Voigt gases: per-point, at interpolation nodes; levels in use."""
         self._require_resident("work")
-        out = (C.c_int64 * 13)()
+        out = (C.c_int64 * 14)()
         check(lib().cs_column_work(self.ctx.handle, out))
         return dict(direct_evals=out[0], node_evals=out[1], levels=out[2], intervals=out[3],
                     direct_by_body=dict(zip(("t2", "t2_cut", "t3", "t3_cut", "t4_cut", "near_zone"), [out[4 + q] for q in range(6)])),
-                    node_by_body=dict(zip(("t2", "t3", "t4"), [out[10 + q] for q in range(3)])))
+                    node_by_body=dict(zip(("t2", "t3", "t4"), [out[10 + q] for q in range(3)])), node_evals_matrix=out[13])
 
     def fetch(self, tau=None, Mup=None, Mdn=None):
         """Copy results to host.  Returns (Fup, Fdn); fills the optional Fortran-order matrices in place."""

@@ -141,7 +141,7 @@ struct ChebGrid {
     DevBuf Cm[CS_MAX_LEVEL];    // [nI][64][itv]
 };
 // per gas on that grid: windows per level, zones [K][nItot], node sums F [nItot][64][Kpad]
-struct GasInterp { int nlev = 0, l0 = 0; DevBuf iwin[CS_MAX_LEVEL], iz, F; };   // levels l0 .. nlev-1 of the grid are in use
+struct GasInterp { int nlev = 0, l0 = 0; DevBuf iwin[CS_MAX_LEVEL], iz, F, sep; };   // sep: SepZone [K/16][nItot] (matrix-core node sums)   // levels l0 .. nlev-1 of the grid are in use
 
 struct ColGas {
     int slot = 0, shape = 0;
@@ -196,6 +196,7 @@ struct cs_ctx {
     int mixed = 0;
     int interp = 1;   // far wings by Chebyshev interpolation over 128..2048-point intervals (k_cheb_nodes / k_cheb_apply)
     int itp_first = -1, itp_min = 128, itp_max = 2048;   // cs_set_interp_plan: first level per gas (-1 = by line density), size range
+    int matrix_nodes = 1;   // cs_set_matrix_cores: separable far-wing node sums on v_mfma_f64 (k_cheb_nodes_mx)
     double far_s = 1e6;
     DevBuf hot32;
     DevBuf tmpA, tmpB, tmpC;
@@ -470,6 +471,8 @@ struct Interp {
     const WaveWin *iwin[CS_MAX_LEVEL];
     IZone *iz = nullptr;
     double *F = nullptr;
+    SepZone *sep = nullptr;   // NULL: every node sum on the vector unit
+    bool sep_always = false;  // cs_set_matrix_cores(ctx, 2): also on grids too short to fill the chip with (interval, state group) blocks
 };
 
 // interval sizes worth using on this grid: an interval of width W leaves lines over (2 cut - 2.3 W) to interpolate
@@ -554,6 +557,7 @@ int gas_interp_build(const cs_ctx *ctx, GasInterp &gi, ChebGrid &g, const std::v
         HIPCHK(hipStreamSynchronize(s));   // iwin is a local
     }
     HIPCHK(gi.iz.reserve((size_t)K * g.nItot * sizeof(IZone)));
+    HIPCHK(gi.sep.reserve((size_t)((K + 15) / 16) * g.nItot * sizeof(SepZone)));
     if (own_F && gi.F.bytes < (size_t)g.nItot * CS_NC * cheb_kpad(K) * sizeof(double)) {
         HIPCHK(gi.F.reserve((size_t)g.nItot * CS_NC * cheb_kpad(K) * sizeof(double)));
         HIPCHK(hipMemsetAsync(gi.F.p, 0, gi.F.bytes, s));   // padding states stay finite
@@ -571,6 +575,7 @@ Interp interp_view(const ChebGrid &g, const GasInterp &gi, int K, IZone *iz_over
     v.nodes = g.nodes.as<double>();
     v.iz = iz_override ? iz_override : gi.iz.as<IZone>();
     v.F = gi.F.as<double>();
+    v.sep = gi.sep.as<SepZone>();
     for (int l = 0; l < gi.nlev; l++) {
         v.itv[l] = g.itv[l]; v.nI[l] = g.nI[l]; v.ioff[l] = g.ioff[l];
         v.Cm[l] = g.Cm[l].as<double>();
@@ -624,6 +629,14 @@ bool phco2_fast_ok(const GasTable &G, int64_t nnu, double cut, int kn, PhScratch
     return true;
 }
 
+// matrix-core node sums (k_cheb_nodes_mx): fp64 Voigt only, and by default only where there are enough (interval, state group)
+// blocks to fill the chip -- on a short grid (a nu-shard) the one-state-per-wave vector kernel has the shorter critical path
+// (1/8 of C3: 0.17 vs 0.25 ms)
+static bool sep_in_use(bool have_sep, bool always, int nblocks_intervals, int kn, bool lor, bool mixed)
+{
+    return have_sep && !lor && !mixed && (always || (int64_t)nblocks_intervals * ((kn + 15) / 16) >= 2048);
+}
+
 // K1 + K2 for one gas on `s`: parameters for `kn` states, then the line sum into sigma ([kn][nnu])
 void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, int64_t jrange1, int kn, const double *Tk, const double *Pk, const double *Ppk,
                 const double *scale, LineHot *hot, LineCold *cold, const double *dnu, int64_t nnu, int ntile256,
@@ -668,15 +681,27 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
             // deferred apply: the gases of a column add their node sums into ONE F (levels an earlier gas has written accumulate)
             const int q_acc = (defer && defer->ngas > 0 && defer->l0[0] < itp.nlev) ? itp.ioff[defer->l0[0]] : itp.nItot;
             const dim3 gridn((unsigned)((kn + 3) / 4) * (unsigned)(itp.nItot - q0));
+            const int ngrp = (kn + 15) / 16;
+            const bool use_sep = sep_in_use(itp.sep != nullptr, itp.sep_always, itp.nItot - q0, kn, lor, hot32 != nullptr);
+            if (use_sep) {   // pieces of the interpolated sets the matrix cores take (needs the interval zones of k_gas_setup)
+                SepArgs sa;
+                sa.nodes = itp.nodes; sa.nul = G.nu.as<double>(); sa.gbound = gbound; sa.Tk = Tk; sa.iz = itp.iz; sa.out = itp.sep;
+                sa.nItot = itp.nItot; sa.q0 = q0; sa.K = kn; sa.ngrp = ngrp; sa.mu_min = G.mu_min; sa.cut = cut;
+                hipLaunchKernelGGL(k_sepzones, dim3((unsigned)(((int64_t)(itp.nItot - q0) * ngrp + 255) / 256)), dim3(256), 0, s, sa);
+            }
+            const SepZone *sepz = use_sep ? itp.sep : nullptr;
             if (lor)
                 hipLaunchKernelGGL((k_cheb_nodes<false, true>), gridn, dim3(256), 0, s, itp.nodes, G.L, hot, hot32, G.nu.as<double>(), itp.iz,
-                                   itp.nItot, q0, q_acc, kn, itp.Kpad, cut, itp.F);
+                                   itp.nItot, q0, q_acc, kn, itp.Kpad, cut, itp.F, sepz);
             else if (hot32)
                 hipLaunchKernelGGL((k_cheb_nodes<true, false>), gridn, dim3(256), 0, s, itp.nodes, G.L, hot, hot32, G.nu.as<double>(), itp.iz,
-                                   itp.nItot, q0, q_acc, kn, itp.Kpad, cut, itp.F);
+                                   itp.nItot, q0, q_acc, kn, itp.Kpad, cut, itp.F, sepz);
             else
                 hipLaunchKernelGGL((k_cheb_nodes<false, false>), gridn, dim3(256), 0, s, itp.nodes, G.L, hot, hot32, G.nu.as<double>(), itp.iz,
-                                   itp.nItot, q0, q_acc, kn, itp.Kpad, cut, itp.F);
+                                   itp.nItot, q0, q_acc, kn, itp.Kpad, cut, itp.F, sepz);
+            if (use_sep)
+                hipLaunchKernelGGL(k_cheb_nodes_mx, dim3((unsigned)(itp.nItot - q0) * (unsigned)ngrp), dim3(256), 0, s, itp.nodes, G.L, hot, itp.sep,
+                                   itp.nItot, q0, kn, itp.Kpad, ngrp, itp.F);
             if (evg) (void)hipEventRecord(evg[1], s);
             ChebApply A0;
             ChebApply &A = defer ? *defer : A0;
@@ -891,6 +916,13 @@ int cs_set_interp_plan(cs_ctx *ctx, int first_level, int size_min, int size_max)
     return CS_OK;
 }
 
+int cs_set_matrix_cores(cs_ctx *ctx, int on)
+{
+    if (!ctx) return fail(CS_EINVAL, "ctx is NULL");
+    ctx->matrix_nodes = on < 0 ? 0 : (on > 2 ? 2 : on);
+    return CS_OK;
+}
+
 int cs_gas_clear(cs_ctx *ctx, int slot)
 {
     if (!ctx || slot < 0 || slot >= CS_MAX_GAS) return fail(CS_EINVAL, "bad slot");
@@ -966,6 +998,8 @@ static int shape_impl(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t 
             (rc = gas_interp_build(ctx, ginterp, cheb, G.h_nu, g0, g1, nu, nnu, dnu_cut, kc, s)))
             return rc;
         itp = interp_view(cheb, ginterp, kc);
+        if (!ctx->matrix_nodes) itp.sep = nullptr;
+        itp.sep_always = ctx->matrix_nodes == 2;
     }
     for (int k0 = 0; k0 < K; k0 += kc) {
         const int kn = std::min(kc, K - k0);
@@ -1044,6 +1078,8 @@ int cs_bake(cs_ctx *ctx, int gas_slot, int table_slot, int shape, double dnu_cut
             (rc = gas_interp_build(ctx, ginterp, cheb, G.h_nu, g0, g1, nu, nnu, dnu_cut, kc, s)))
             return rc;
         itp = interp_view(cheb, ginterp, kc);
+        if (!ctx->matrix_nodes) itp.sep = nullptr;
+        itp.sep_always = ctx->matrix_nodes == 2;
     }
     for (int k0 = 0; k0 < M; k0 += kc) {
         const int kn = std::min(kc, M - k0);
@@ -1623,7 +1659,7 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
     const double *extra = c.has_extra ? c.extra.as<double>() : nullptr;
     if (extra) return fail(CS_EINVAL, "host-evaluated sigma(nu,T,P) terms are not supported in batch mode");
     const bool shared_sigma = c.accel.slot >= 0;   // AcceleratedAbsorber: cross-sections do not depend on the thermal state (absorbers.jl:203)
-    DevBuf dTk, dPk, dmuk, dTlev, dsig, dtau, dpart, dF, dranges, dconc, dPp, dgb, dzones, dizones, dF2, hot, cold;
+    DevBuf dTk, dPk, dmuk, dTlev, dsig, dtau, dpart, dF, dranges, dconc, dPp, dgb, dzones, dizones, dF2, dsep, hot, cold;
     if ((rc = upload(dTk, Tk.data(), BK, s)) || (rc = upload(dPk, Pk.data(), BK, s)) || (rc = upload(dmuk, muk.data(), BK, s)) ||
         (rc = upload(dTlev, T_levels, (size_t)B * np, s)))
         return rc;
@@ -1675,6 +1711,9 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
             }
             itp = interp_view(c.cheb, cg.itp, kc, dizones.as<IZone>());
             itp.F = dF2.as<double>();
+            HIPCHK(dsep.reserve((size_t)((kc + 15) / 16) * c.cheb.nItot * sizeof(SepZone)));   // (the column's own buffer is sized for K states)
+            itp.sep = ctx->matrix_nodes ? dsep.as<SepZone>() : nullptr;
+            itp.sep_always = ctx->matrix_nodes == 2;
         }
         for (int64_t k0 = 0; k0 < BK; k0 += kc) {
             const int kn = (int)std::min<int64_t>(kc, BK - k0);
@@ -1772,6 +1811,8 @@ static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e)
         GasTable &G = ctx->gas[cg.slot];
         Interp itp = cg.itp.nlev > 0 ? interp_view(c.cheb, cg.itp, K) : Interp();
         itp.F = c.chebF.as<double>();
+        if (!ctx->matrix_nodes) itp.sep = nullptr;
+        itp.sep_always = ctx->matrix_nodes == 2;
         launch_gas(s, cg.shape, G, cg.jlo, cg.jhi, K, c.Tk.as<double>(), c.Pk.as<double>(), cg.Pp.as<double>(), cg.conc.as<double>(),
                    c.hot.as<LineHot>(), c.cold.as<LineCold>(), c.nu.as<double>(), c.nnu, c.ntile, cg.J0.as<int32_t>(),
                    cg.J1.as<int32_t>(), cg.win.as<WaveWin>(), cg.xtiles, cg.zones.as<Zone>(), c.ranges.as<int2>(), cg.gmax.as<double>(), cg.cut, c.sigma_gray, extra, sig, gi > 0,
@@ -1955,7 +1996,7 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
     HIPCHK(hipDeviceSynchronize());
     const int K = c.K;
     const int nt64 = (int)((c.nnu + 63) / 64);
-    int64_t direct = 0, nodes = 0;
+    int64_t direct = 0, nodes = 0, sepn = 0;   // sepn: (node, line, state) triples summed on the matrix cores
     int64_t body[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // per-point lines by body: 2-term, 2-term+cut-off, 3-term, 3-term+cut-off, 4-term+cut-off,
                                                      // near-zone pass; node lines: 2-, 3-, 4-term
     auto seg = [](int lo, int hi, int p0, int p1) { return (int64_t)std::max(0, std::min(hi, p1) - std::max(lo, p0)); };
@@ -1971,15 +2012,28 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
             iz.resize((size_t)K * nItot);
             HIPCHK(hipMemcpy(iz.data(), g.itp.iz.p, iz.size() * sizeof(IZone), hipMemcpyDeviceToHost));
             const int q0 = c.cheb.ioff[g.itp.l0];
+            const bool use_sep = sep_in_use(ctx->matrix_nodes != 0, ctx->matrix_nodes == 2, nItot - q0, K, g.shape != SH_VOIGT, ctx->mixed != 0);
+            std::vector<SepZone> sz;
+            if (use_sep) {
+                sz.resize((size_t)((K + 15) / 16) * nItot);
+                HIPCHK(hipMemcpy(sz.data(), g.itp.sep.p, sz.size() * sizeof(SepZone), hipMemcpyDeviceToHost));
+            }
             for (int k = 0; k < K; k++)
                 for (int q = q0; q < nItot; q++) {
                     const IZone &z = iz[(size_t)k * nItot + q];
                     nodes += (int64_t)CS_NC * ((z.P0 - z.E0) + (z.Z0 - z.P1) + (z.P2 - z.Z1) + (z.E1 - z.P3));
-                    // the same segments k_cheb_nodes runs: [E0,P0) U [P1,Z0) left, [Z1,P2) U [P3,E1) right, cut at Q and M
-                    const int lo4[4] = {z.E0, z.P1, z.P3, z.Z1}, hi4[4] = {z.P0, z.Z0, z.E1, z.P2};
-                    for (int w4 = 0; w4 < 4; w4++) {
-                        const int p0 = lo4[w4], p1 = hi4[w4];
-                        if (w4 < 2) {
+                    // the same segments k_cheb_nodes runs: [E0,P0) U [P1,Z0) left, [Z1,P2) U [P3,E1) right, each minus the piece
+                    // the matrix-core kernel takes, cut at Q and M
+                    int sa[4] = {z.P0, z.Z0, z.Z1, z.P3}, sb[4] = {z.P0, z.Z0, z.Z1, z.P3};
+                    if (use_sep) {
+                        const SepZone &s4 = sz[(size_t)(k >> 4) * nItot + q];
+                        for (int p = 0; p < 4; p++)
+                            if (s4.b[p] > s4.a[p]) { sa[p] = s4.a[p]; sb[p] = s4.b[p]; sepn += (int64_t)CS_NC * (s4.b[p] - s4.a[p]); }
+                    }
+                    const int lo8[8] = {z.E0, sb[0], z.P1, sb[1], sb[3], z.P3, sb[2], z.Z1}, hi8[8] = {sa[0], z.P0, sa[1], z.Z0, z.E1, sa[3], z.P2, sa[2]};
+                    for (int w8 = 0; w8 < 8; w8++) {
+                        const int p0 = lo8[w8], p1 = hi8[w8];
+                        if (w8 < 4) {
                             body[6] += seg(z.E0, z.Q0, p0, p1); body[7] += seg(z.Q0, z.M0, p0, p1); body[8] += seg(z.M0, z.Z0, p0, p1);
                         } else {
                             body[6] += seg(z.Q1, z.E1, p0, p1); body[7] += seg(z.M1, z.Q1, p0, p1); body[8] += seg(z.Z1, z.M1, p0, p1);
@@ -2024,6 +2078,7 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
     out[3] = c.cheb.nItot;
     for (int q = 0; q < 6; q++) out[4 + q] = 64 * body[q];
     for (int q = 6; q < 9; q++) out[4 + q] = (int64_t)CS_NC * body[q];
+    out[13] = sepn;
     return CS_OK;
 }
 

@@ -299,16 +299,24 @@ __device__ __forceinline__ void zones_body(unsigned bid, const ZoneArgs &a)
 }
 
 // constants of the series kept in VGPRs for the whole kernel (gfx950 VALU instructions take one constant-bus operand:
-// the line parameter; a second literal would cost a v_mov per use).  Loaded from memory so they are not rematerialised.
+// the line parameter; a second literal would cost a v_mov per use).
 struct FarK { double k1p5, k3p75, k12, km15, km105, k13p125, k210, km120; };
 __device__ const double kFarTable[19] = {1.5, 3.75, 12.0, -15.0, -105.0, 13.125, 210.0, -120.0,
                                          59.0625, -787.5, 2835.0, -3780.0, 1680.0,                           // a4*U8 in t
                                          324.84375, -6496.875, 36382.5, -83160.0, 83160.0, -30240.0};       // a5*U10 in t
+// an opaque constant in a VGPR pair: the empty asm hides the value from the optimiser, which would otherwise rematerialise it as
+// a literal (a v_mov per use) -- and costs no memory access (the first version loaded the table with eight volatile loads, i.e.
+// eight serialised round trips at the start of every wave: most of a short wave's life on a sparse line table)
+__device__ __forceinline__ double vgpr_const(double x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
 __device__ __forceinline__ FarK load_fark()
 {
-    const volatile double *t = kFarTable;
     FarK c;
-    c.k1p5 = t[0]; c.k3p75 = t[1]; c.k12 = t[2]; c.km15 = t[3]; c.km105 = t[4]; c.k13p125 = t[5]; c.k210 = t[6]; c.km120 = t[7];
+    c.k1p5 = vgpr_const(1.5); c.k3p75 = vgpr_const(3.75); c.k12 = vgpr_const(12.0); c.km15 = vgpr_const(-15.0);
+    c.km105 = vgpr_const(-105.0); c.k13p125 = vgpr_const(13.125); c.k210 = vgpr_const(210.0); c.km120 = vgpr_const(-120.0);
     return c;
 }
 
@@ -601,11 +609,63 @@ __global__ __launch_bounds__(256) void k_gas_setup(unsigned nb_prep, unsigned nb
 // one wave = the 64 Chebyshev nodes of one interval x one node state: far-wing sums at the nodes -> F[interval][node][state].
 // All levels run in one launch over the concatenated interval list (largest intervals, i.e. longest waves, first).
 #define CS_KPAD 16   // F rows are padded to a multiple of 16 states (k_cheb_apply reads 16 at a time with scalar loads)
+// Far lines whose 4-term series in 1/dnu^2 is exact for all 16 states of a state group (k_cheb_nodes_mx below) are summed
+// on the matrix cores; per (state group, interval) their four pieces -- sub-ranges of [E0,P0), [P1,Z0), [Z1,P2), [P3,E1) common to
+// the group's states -- are what this kernel then skips.
+struct __attribute__((aligned(16))) SepZone { int32_t a[4], b[4]; };   // piece p = [a[p], b[p]); empty: a = b
+
+// vector-unit node sum of one (interval, state) at the lane's node v: own set minus the parent's -- [E0,P0) U [P1,Z0) left of the
+// interval, [Z1,P2) U [P3,E1) right of it -- each minus the piece [sa[p], sb[p]) the matrix cores take.  Both sides are summed from
+// the far end towards the interval (increasing terms): the rounding error of a node sum then stays a few ulp of the sum itself,
+// which the interpolation amplifies by up to (2.3/0.3)^2.
+template <bool MIXED, bool LOR>
+__device__ __forceinline__ double node_sum_valu(double v, const LineHot *__restrict__ hk, const LineF32 *__restrict__ hf,
+                                                const double *__restrict__ gnul, const IZone &z, const int (&sa)[4], const int (&sb)[4],
+                                                double cut, const FarK &c)
+{
+    double accL = 0.0, accR = 0.0;
+    {
+        const int wl[4] = {z.E0, sb[0], z.P1, sb[1]}, wh[4] = {sa[0], z.P0, sa[1], z.Z0};
+        for (int cw = 0; cw < 4; cw++) {
+            const int p0 = wl[cw], p1 = wh[cw];
+            if (p0 >= p1) continue;
+#define LO(x) max((x), p0)
+#define HI(x) min((x), p1)
+            if (MIXED) {
+                accL = far_segment32<false, 0>(accL, v, gnul, hf, LO(z.E0), HI(z.Q0), cut);
+                accL = far_segment32<false, 1>(accL, v, gnul, hf, LO(z.Q0), HI(z.M0), cut);
+            } else {
+                accL = far_segment<false, 0, LOR>(accL, v, hk, LO(z.E0), HI(z.Q0), cut, c);
+                accL = far_segment<false, 1, LOR>(accL, v, hk, LO(z.Q0), HI(z.M0), cut, c);
+            }
+            accL = far_segment<false, 2, LOR>(accL, v, hk, LO(z.M0), HI(z.Z0), cut, c);
+        }
+    }
+    {
+        const int wl[4] = {sb[3], z.P3, sb[2], z.Z1}, wh[4] = {z.E1, sa[3], z.P2, sa[2]};   // far end first
+        for (int cw = 0; cw < 4; cw++) {
+            const int p0 = wl[cw], p1 = wh[cw];
+            if (p0 >= p1) continue;
+            if (MIXED) {
+                accR = far_segment32_rev<false, 0>(accR, v, gnul, hf, LO(z.Q1), HI(z.E1), cut);
+                accR = far_segment32_rev<false, 1>(accR, v, gnul, hf, LO(z.M1), HI(z.Q1), cut);
+            } else {
+                accR = far_segment_rev<false, 0, LOR>(accR, v, hk, LO(z.Q1), HI(z.E1), cut, c);
+                accR = far_segment_rev<false, 1, LOR>(accR, v, hk, LO(z.M1), HI(z.Q1), cut, c);
+            }
+            accR = far_segment_rev<false, 2, LOR>(accR, v, hk, LO(z.Z1), HI(z.M1), cut, c);
+#undef LO
+#undef HI
+        }
+    }
+    return accL + accR;
+}
+
 template <bool MIXED, bool LOR>
 __global__ __launch_bounds__(256) void k_cheb_nodes(const double *__restrict__ nodes, int64_t L, const LineHot *__restrict__ hot,
                                                      const LineF32 *__restrict__ hot32, const double *__restrict__ gnul,
                                                      const IZone *__restrict__ iz, int nItot, int q0, int q_acc, int K, int Kpad, double cut,
-                                                     double *__restrict__ F)
+                                                     double *__restrict__ F, const SepZone *__restrict__ sep)
 {
     // q_acc: intervals >= q_acc already hold the node sums of earlier gases of the column -- add to them.  The interpolation
     // is linear, so k_cheb_apply then carries the SUM over gases to the grid in one pass per level instead of one per (gas, level).
@@ -614,48 +674,171 @@ __global__ __launch_bounds__(256) void k_cheb_nodes(const double *__restrict__ n
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int nsb = (K + 3) >> 2;
     const int T = q0 + (int)(blockIdx.x / nsb);
-    const int k = (int)(blockIdx.x % nsb) * 4 + wv;
+    // state block rotated by the interval: workgroups go round-robin to the 8 XCDs, and with the matrix cores taking most far lines
+    // of the low-pressure states the work left here sits in the last state blocks -- unrotated, on half of the XCDs
+    const int k = (int)((blockIdx.x % nsb + (sep ? T : 0)) % nsb) * 4 + wv;   // (unrotated, a state block stays on one XCD: its records stay in that L2)
     if (k >= K) return;
     const LineHot *__restrict__ hk = hot + (size_t)k * L;
     const LineF32 *__restrict__ hf = MIXED ? hot32 + (size_t)k * L : nullptr;
     const double v = nodes[(size_t)T * CS_NC + lane];
     const IZone z = iz[(size_t)k * nItot + T];
     const FarK c = load_fark();
-    // own set minus the parent's: [E0,P0) U [P1,Z0) left of the interval, [Z1,P2) U [P3,E1) right of it.  Both sides are summed
-    // from the far end towards the interval (increasing terms): the rounding error of a node sum then stays a few ulp of the
-    // sum itself, which the interpolation amplifies by up to (2.3/0.3)^2 at the far end of the interval.
-    double accL = 0.0, accR = 0.0;
-    for (int cw = 0; cw < 2; cw++) {
-        const int p0 = cw == 0 ? z.E0 : z.P1, p1 = cw == 0 ? z.P0 : z.Z0;
-        if (p0 >= p1) continue;
-#define LO(x) max((x), p0)
-#define HI(x) min((x), p1)
-        if (MIXED) {
-            accL = far_segment32<false, 0>(accL, v, gnul, hf, LO(z.E0), HI(z.Q0), cut);
-            accL = far_segment32<false, 1>(accL, v, gnul, hf, LO(z.Q0), HI(z.M0), cut);
-        } else {
-            accL = far_segment<false, 0, LOR>(accL, v, hk, LO(z.E0), HI(z.Q0), cut, c);
-            accL = far_segment<false, 1, LOR>(accL, v, hk, LO(z.Q0), HI(z.M0), cut, c);
-        }
-        accL = far_segment<false, 2, LOR>(accL, v, hk, LO(z.M0), HI(z.Z0), cut, c);
+    int sa[4] = {z.P0, z.Z0, z.Z1, z.P3}, sb[4] = {z.P0, z.Z0, z.Z1, z.P3};   // (no matrix-core pieces: empty ones at the window ends)
+    if (!MIXED && !LOR && sep) {
+        const SepZone sz = sep[(size_t)(k >> 4) * nItot + T];
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+            if (sz.b[p] > sz.a[p]) { sa[p] = sz.a[p]; sb[p] = sz.b[p]; }
     }
-    for (int cw = 0; cw < 2; cw++) {
-        const int p0 = cw == 0 ? z.P3 : z.Z1, p1 = cw == 0 ? z.E1 : z.P2;
-        if (p0 >= p1) continue;
-        if (MIXED) {
-            accR = far_segment32_rev<false, 0>(accR, v, gnul, hf, LO(z.Q1), HI(z.E1), cut);
-            accR = far_segment32_rev<false, 1>(accR, v, gnul, hf, LO(z.M1), HI(z.Q1), cut);
-        } else {
-            accR = far_segment_rev<false, 0, LOR>(accR, v, hk, LO(z.Q1), HI(z.E1), cut, c);
-            accR = far_segment_rev<false, 1, LOR>(accR, v, hk, LO(z.M1), HI(z.Q1), cut, c);
-        }
-        accR = far_segment_rev<false, 2, LOR>(accR, v, hk, LO(z.Z1), HI(z.M1), cut, c);
-#undef LO
-#undef HI
-    }
-    const double acc = accL + accR;
+    const double acc = node_sum_valu<MIXED, LOR>(v, hk, hf, gnul, z, sa, sb, cut, c);
     double *__restrict__ Fo = F + ((size_t)T * CS_NC + lane) * Kpad + k;
     *Fo = T >= q_acc ? *Fo + acc : acc;
+}
+
+// ---- K2d: state-separable far wings on the matrix cores ------------------------------------------------------------------------
+// Far from the line the Voigt term is a power series in w = 1/dnu^2 whose coefficients carry ALL the state dependence
+// (tools/voigt_series.py):  A K(x,y) = sum_{n=1..4} C_n w^n,  C_n = (A y/sqrt(pi)) c_n(y^2) / d^(2n),  c_1 = 1, c_2 = 3/2 - y^2,
+// c_3 = 15/4 - 5 y^2 + y^4, c_4 = 105/8 - 105/4 y^2 + 21/2 y^4 - y^6; truncation below 1e-17 where
+// |dnu| >= 133.6 sqrt(gamma^2 + 4.33 alpha^2).  The node sums of 16 states are then a matrix product
+//     F[state][node] += sum_line sum_n C_n[state][line] * w[line][node]^n
+// which v_mfma_f64_16x16x4 does with K = four LINES per instruction and one instruction per term: every lane owns one
+// (node, line) pair of a 16-node sub-tile, forms w .. w^4 (10 VALU instructions) and, as (state, line), the four coefficients
+// of its own record; 16 matrix instructions per 4 lines x 64 nodes x 16 states.  The loop runs at the matrix pipe's rate (0.92
+// of it in tools/ubench/sep_nodes.hip: 2.5x the scalar-load VALU loop for the same triples) and leaves the vector unit to the
+// kernels beside it.  One wave = one interval x one group of 16 states; pieces from k_sepzones.
+struct SepArgs {
+    const double *nodes, *nul, *gbound, *Tk;
+    const IZone *iz;
+    SepZone *out;
+    int nItot, q0, K, ngrp;
+    double mu_min, cut;
+};
+// per (state group, interval): the four pieces common to the group's states, clipped to the distance at which the 4-term series
+// holds for the widest line of the group (gbound: Lorentz width bound per state; Doppler width at the upper end of the window)
+__global__ __launch_bounds__(256) void k_sepzones(SepArgs a)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nq = a.nItot - a.q0;
+    if (idx >= nq * a.ngrp) return;
+    const int g = idx / nq, T = a.q0 + (idx - g * nq);
+    const double vhi = a.nodes[(size_t)T * CS_NC], vlo = a.nodes[(size_t)T * CS_NC + CS_NC - 1];   // nodes run from the upper end down
+    int lo[4] = {0, 0, 0, 0}, hi[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+    double R = 0.0;
+    int E0 = 0, E1 = 0;
+    for (int k = g * 16; k < min(g * 16 + 16, a.K); k++) {
+        const IZone z = a.iz[(size_t)k * a.nItot + T];
+        lo[0] = max(lo[0], z.E0); hi[0] = min(hi[0], z.P0);
+        lo[1] = max(lo[1], z.P1); hi[1] = min(hi[1], z.Z0);
+        lo[2] = max(lo[2], z.Z1); hi[2] = min(hi[2], z.P2);
+        lo[3] = max(lo[3], z.P3); hi[3] = min(hi[3], z.E1);
+        E0 = z.E0; E1 = z.E1;
+        const double amax = ((vhi + a.cut) / kC) * sqrt(2.0 * kRgas * a.Tk[k]) / sqrt(a.mu_min);
+        const double gb = a.gbound[k];
+        R = fmax(R, 133.6 * sqrt(gb * gb + 4.33 * amax * amax) * (1.0 + 1e-6));
+    }
+    const double *__restrict__ nul = a.nul;
+    auto lower = [&](double val, int p, int q) { while (p < q) { const int m = (p + q) >> 1; if (nul[m] < val) p = m + 1; else q = m; } return p; };
+    auto upper = [&](double val, int p, int q) { while (p < q) { const int m = (p + q) >> 1; if (nul[m] <= val) p = m + 1; else q = m; } return p; };
+    const int S0 = lower(vlo - R, E0, E1), S1 = upper(vhi + R, S0, E1);
+    SepZone z;
+    for (int p = 0; p < 4; p++) {
+        int pa = lo[p], pb = hi[p];
+        if (p < 2) pb = min(pb, S0); else pa = max(pa, S1);
+        if (pb - pa < 8) { pa = 0; pb = 0; }   // (too short to be worth a wave's trip)
+        z.a[p] = pa; z.b[p] = pb;
+    }
+    a.out[(size_t)g * a.nItot + T] = z;
+}
+
+typedef double v4f64_sep __attribute__((ext_vector_type(4)));
+#define CS_MX_PITCH 66   // LDS row pitch (doubles) of the partial sums: rows of the four lane groups land on different banks
+// One block = one interval x one group of 16 states: every piece is cut into four runs of lines (multiples of 4), wave w takes
+// run w -- far end first on both sides -- with the next record in flight while the 16 matrix instructions of a step issue; the
+// four partial sums meet in LDS, are added in wave order and added to F (k_cheb_nodes, which runs first, has written the rest).
+// (Tried: the vector part of the same (interval, group) in the same block, four states per wave, so that both pipes work side by
+// side -- the matrix and vector phases do overlap, but the vector loop lives on eight waves per SIMD hiding its scalar loads, and
+// this kernel's registers and LDS allow four: 0.94 ms for a quarter of the vector work, profiles/r02_notes.md.)
+__global__ __launch_bounds__(256) void k_cheb_nodes_mx(const double *__restrict__ nodes, int64_t L, const LineHot *__restrict__ hot,
+                                                       const SepZone *__restrict__ sep, int nItot, int q0, int K, int Kpad, int ngrp,
+                                                       double *__restrict__ F)
+{
+    __shared__ double part[4][16][CS_MX_PITCH];
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int T = q0 + (int)(blockIdx.x / ngrp);
+    const int g = (int)((blockIdx.x % ngrp + T) % ngrp);   // (rotated: the groups differ in work and would alias with the XCD round-robin)
+    const SepZone z = sep[(size_t)g * nItot + T];
+    if (!(z.b[0] > z.a[0] || z.b[1] > z.a[1] || z.b[2] > z.a[2] || z.b[3] > z.a[3])) return;   // (block-uniform)
+    {
+        const int lr = lane & 15, lq = lane >> 4;
+        const int kk = min(g * 16 + lr, K - 1);                       // (a group's tail states re-read the last one: never stored)
+        const LineHot *__restrict__ hk = hot + (size_t)kk * L;
+        double vn[4];
+#pragma unroll
+        for (int st = 0; st < 4; st++) vn[st] = nodes[(size_t)T * CS_NC + st * 16 + lr];
+        v4f64_sep acc[4];
+#pragma unroll
+        for (int st = 0; st < 4; st++) acc[st] = v4f64_sep{0.0, 0.0, 0.0, 0.0};
+        // the lane's record as (state lr, line lq) gives the four coefficients (A operand) and, as (node lr, line lq), the line position
+        auto step = [&](const LineHot &h, bool valid) {
+            const double id2 = rcp_nr1(h.p1 * h.p1);
+            const double y2 = h.p2;
+            const double c2 = 1.5 - y2;
+            const double c3 = __builtin_fma(y2, y2 - 5.0, 3.75);
+            const double c4 = __builtin_fma(y2, __builtin_fma(y2, 10.5 - y2, -26.25), 13.125);
+            const double C1 = valid ? h.p3 * id2 : 0.0;
+            const double C2 = C1 * id2;
+            const double C3 = C2 * id2;
+            const double C4 = C3 * id2;
+            const double a1 = C1, a2 = C2 * c2, a3 = C3 * c3, a4 = C4 * c4;
+#pragma unroll
+            for (int st = 0; st < 4; st++) {
+                const double dv = vn[st] - h.nul;
+                const double s2 = dv * dv;
+                double w = rcp_fast(s2);
+                w = __builtin_fma(w, __builtin_fma(-s2, w, 1.0), w);   // second Newton step: the matrix pipe sets the pace, the VALU has slack
+                const double w2 = w * w, w3 = w2 * w, w4 = w2 * w2;
+                acc[st] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, w, acc[st], 0, 0, 0);
+                acc[st] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, w2, acc[st], 0, 0, 0);
+                acc[st] = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, w3, acc[st], 0, 0, 0);
+                acc[st] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4, w4, acc[st], 0, 0, 0);
+            }
+        };
+        // left pieces ascending, right pieces descending: wave 0 owns the far end of every piece.  The load of step t + 1 is issued
+        // before the matrix instructions of step t and waited for after them.
+        for (int pp = 0; pp < 4; pp++) {
+            const int p = pp < 2 ? pp : 5 - pp;          // 0, 1, 3, 2
+            const bool asc = pp < 2;
+            const int n = z.b[p] - z.a[p];
+            if (n <= 0) continue;
+            const int run = ((n + 15) >> 4) << 2;
+            const int ja = asc ? z.a[p] + wv * run : max(z.b[p] - (wv + 1) * run, z.a[p]);
+            const int jb = asc ? min(ja + run, z.b[p]) : z.b[p] - wv * run;
+            if (ja >= jb) continue;
+            const int nst = (jb - ja + 3) >> 2;
+            const int b0 = asc ? ja + lq : jb - 4 + lq, db = asc ? 4 : -4;   // line of this lane group at step t: b0 + t db
+            auto rec = [&](int t) { return hk[min(max(b0 + t * db, ja), jb - 1)]; };
+            auto ok = [&](int t) { const int j = b0 + t * db; return j >= ja && j < jb; };
+            LineHot cur = rec(0);
+            for (int t = 0; t < nst; t++) {
+                const LineHot nxt = rec(t + 1);      // (past the end: a harmless re-read of an end record, never used)
+                __builtin_amdgcn_sched_barrier(0);   // keep the load here: the scheduler would sink it behind the matrix instructions
+                step(cur, ok(t));
+                __builtin_amdgcn_sched_barrier(0);   // ... and the wait for it there
+                cur = nxt;
+            }
+        }
+#pragma unroll
+        for (int st = 0; st < 4; st++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) part[wv][4 * r + lq][st * 16 + lr] = acc[st][r];   // D[state 4r + lq][node 16 st + lr]
+    }
+    __syncthreads();
+    for (int s4 = 0; s4 < 4; s4++) {
+        const int ks = 4 * wv + s4, k = g * 16 + ks;
+        if (k >= K) break;
+        double *__restrict__ Fo = F + ((size_t)T * CS_NC + lane) * Kpad + k;
+        *Fo += ((part[0][ks][lane] + part[1][ks][lane]) + part[2][ks][lane]) + part[3][ks][lane];
+    }
 }
 
 // sigma[k][i] (+)= sum over levels of  C_l[T_l][:, i] . F[T_l][:, k]  -- the interpolation as a small matrix product.
@@ -923,8 +1106,8 @@ __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu
         // near zone: six-term series where s >= 1e3; the index ranges of this lane's s < 1e3 and s < 100 lines go to
         // k_voigt_near through `ranges` (relative to N0; empty = {0,0})
         if (HI(z.N1) > LO(z.N0)) {
-            const volatile double *tb2 = kFarTable;
-            const double q40 = tb2[8], q41 = tb2[9], q42 = tb2[10], q43 = tb2[11], q44 = tb2[12];
+            const volatile double *tb2 = kFarTable;   // (loaded here, by the waves that have a near zone: as opaque register constants
+            const double q40 = tb2[8], q41 = tb2[9], q42 = tb2[10], q43 = tb2[11], q44 = tb2[12];   // they cost the kernel 22 VGPRs)
             const double q50 = tb2[13], q51 = tb2[14], q52 = tb2[15], q53 = tb2[16], q54 = tb2[17], q55 = tb2[18];
 #pragma unroll 4
             for (int j = LO(z.N0); j < HI(z.N1); j++) {

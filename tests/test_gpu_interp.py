@@ -241,3 +241,38 @@ def test_phco2_fast_path(cs, O, lines, ctx_on):
     r = O.fluxes_discretized(nu, Pl, 9.8, 2, col.Tn, col.mun, col.Tlev, [g2.sl, g1.sl], ["voigt", "PHCO2"], [25.0, 500.0], col.conc,
                              want_sigma=True)
     assert relerr(col.sigma_nodes(), r["sigma"], floor=1e-300) < 2e-11
+
+
+def test_matrix_core_node_sums_on_off(cs, O, lines):
+    """K2d: far lines inside the validity range of the 4-term series in 1/dnu^2 are summed at the nodes as a matrix product on
+    v_mfma_f64_16x16x4 (k_cheb_nodes_mx); the rest stays on the vector unit.  Same cross-sections as with every node sum on the
+    vector unit (5e-14) and as the oracle (1e-11), for state groups that mix low and high pressures, a ragged last group (K = 41),
+    a dense synthetic table and the sparse fixtures, the column, shape-batch and batch paths."""
+    nu = np.linspace(580.0, 780.0, 20000)
+    P = cs.pressuregrid(1.0, 1e5, 21)
+    T = cs.AtmosphericProfile(P, np.linspace(200.0, 295.0, 21))
+    dense = cs.SpectralLines.synthetic(2, 20000, 77, numin=500.0, numax=860.0)
+    res = {}
+    for on in (True, False):
+        c = cs.Context(0)
+        c.set_matrix_cores(2 if on else 0)   # (2: also on this grid, too short for the default to choose the matrix path)
+        gases = [cs.DirectGas(dense, 400e-6, nu), cs.DirectGas(lines("H2O"), 5e-3, nu)]
+        col = cs.Column(P, 9.8, T, 0.029, 0.0, 0.0, *gases, core=cs.Discretized(4, 3), want_tau=True, want_M=False, ctx=c)
+        assert col.K == 41
+        col.run()
+        tau = np.zeros((col.nl, col.nnu), order="F")
+        F = col.fetch(tau)
+        B = col.run_batch([T, cs.AtmosphericProfile(P, np.linspace(205.0, 288.0, 21))])
+        sb = cs.shape_batch(dense, "voigt", nu, [220.0, 296.0, 250.0], [50.0, 101325.0, 3e3], [0.02, 40.53, 1.2], 25.0, c)
+        res[on] = (col.sigma_nodes(), tau, F, B, sb, col)
+        if on:
+            r = O.fluxes_discretized(nu, P, 9.8, 3, col.Tn, col.mun, col.Tlev, [dense, lines("H2O")], ["voigt"] * 2, [25.0] * 2, col.conc,
+                                     nstream=4, want_sigma=True)
+            assert relerr(res[on][0], r["sigma"], floor=1e-300) < 1e-11 and relerr(tau, r["tau"]) < 1e-11
+        c.close()
+    a, b = res[True], res[False]
+    assert relerr(a[0], b[0], floor=1e-300) < 5e-14 and relerr(a[1], b[1]) < 5e-14
+    assert relerr(a[2][0], b[2][0]) < 1e-13
+    assert relerr(np.asarray(a[3][0]), np.asarray(b[3][0])) < 1e-13
+    assert relerr(a[4], b[4], floor=1e-250) < 5e-14
+    assert not np.array_equal(a[0], b[0])            # (the two paths really differ in rounding: the matrix-core one ran)
