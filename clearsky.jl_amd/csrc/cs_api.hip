@@ -141,7 +141,8 @@ struct ChebGrid {
     DevBuf Cm[CS_MAX_LEVEL];    // [nI][64][itv]
 };
 // per gas on that grid: windows per level, zones [K][nItot], node sums F [nItot][64][Kpad]
-struct GasInterp { int nlev = 0, l0 = 0; DevBuf iwin[CS_MAX_LEVEL], iz, F, sep; };   // sep: SepZone [K/16][nItot] (matrix-core node sums)   // levels l0 .. nlev-1 of the grid are in use
+struct GasInterp { int nlev = 0, l0 = 0; DevBuf iwin[CS_MAX_LEVEL], iz, F, sep, edge; };   // levels l0 .. nlev-1 of the grid are in use; sep: SepZone [K/16][nItot]
+                                                                                          // (matrix-core node sums), edge: int2 [K/16][tiles] (matrix-core window ends)
 
 struct ColGas {
     int slot = 0, shape = 0;
@@ -472,6 +473,7 @@ struct Interp {
     IZone *iz = nullptr;
     double *F = nullptr;
     SepZone *sep = nullptr;   // NULL: every node sum on the vector unit
+    int2 *edge = nullptr;     // NULL: the window ends of the per-point sum on the vector unit
     bool sep_always = false;  // cs_set_matrix_cores(ctx, 2): also on grids too short to fill the chip with (interval, state group) blocks
 };
 
@@ -558,6 +560,7 @@ int gas_interp_build(const cs_ctx *ctx, GasInterp &gi, ChebGrid &g, const std::v
     }
     HIPCHK(gi.iz.reserve((size_t)K * g.nItot * sizeof(IZone)));
     HIPCHK(gi.sep.reserve((size_t)((K + 15) / 16) * g.nItot * sizeof(SepZone)));
+    HIPCHK(gi.edge.reserve((size_t)((K + 15) / 16) * (size_t)((nnu + 63) / 64) * sizeof(int2)));
     if (own_F && gi.F.bytes < (size_t)g.nItot * CS_NC * cheb_kpad(K) * sizeof(double)) {
         HIPCHK(gi.F.reserve((size_t)g.nItot * CS_NC * cheb_kpad(K) * sizeof(double)));
         HIPCHK(hipMemsetAsync(gi.F.p, 0, gi.F.bytes, s));   // padding states stay finite
@@ -576,6 +579,7 @@ Interp interp_view(const ChebGrid &g, const GasInterp &gi, int K, IZone *iz_over
     v.iz = iz_override ? iz_override : gi.iz.as<IZone>();
     v.F = gi.F.as<double>();
     v.sep = gi.sep.as<SepZone>();
+    v.edge = gi.edge.as<int2>();
     for (int l = 0; l < gi.nlev; l++) {
         v.itv[l] = g.itv[l]; v.nI[l] = g.nI[l]; v.ioff[l] = g.ioff[l];
         v.Cm[l] = g.Cm[l].as<double>();
@@ -667,6 +671,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
         unsigned nb_iz = 0;
         const IZone *iz = nullptr;
         int ishift = 0;
+        bool use_edge = false;   // window ends of the per-point sum on the matrix cores (k_voigt_edge_mx; with the far wings interpolated only)
         if (itp.nlev > 0) {
             P.nlev = itp.nlev;
             P.nItot = itp.nItot;
@@ -683,11 +688,20 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
             const dim3 gridn((unsigned)((kn + 3) / 4) * (unsigned)(itp.nItot - q0));
             const int ngrp = (kn + 15) / 16;
             const bool use_sep = sep_in_use(itp.sep != nullptr, itp.sep_always, itp.nItot - q0, kn, lor, hot32 != nullptr);
-            if (use_sep) {   // pieces of the interpolated sets the matrix cores take (needs the interval zones of k_gas_setup)
+            use_edge = sep_in_use(itp.edge != nullptr, itp.sep_always, nt64, kn, lor, hot32 != nullptr);
+            if (use_sep || use_edge) {   // what the matrix cores take of the interpolated sets and of the window ends (needs the zones of k_gas_setup)
                 SepArgs sa;
                 sa.nodes = itp.nodes; sa.nul = G.nu.as<double>(); sa.gbound = gbound; sa.Tk = Tk; sa.iz = itp.iz; sa.out = itp.sep;
                 sa.nItot = itp.nItot; sa.q0 = q0; sa.K = kn; sa.ngrp = ngrp; sa.mu_min = G.mu_min; sa.cut = cut;
-                hipLaunchKernelGGL(k_sepzones, dim3((unsigned)(((int64_t)(itp.nItot - q0) * ngrp + 255) / 256)), dim3(256), 0, s, sa);
+                EdgeArgs ea;
+                ea.nu = dnu; ea.nul = G.nu.as<double>(); ea.gbound = gbound; ea.Tk = Tk; ea.win = win; ea.zones = zones;
+                ea.iz = itp.iz + itp.ioff[itp.nlev - 1]; ea.out = itp.edge; ea.nnu = nnu; ea.ntile = nt64; ea.K = kn; ea.ngrp = ngrp;
+                ea.nI = itp.nItot; ea.ishift = 0;
+                for (int r = itp.itv[itp.nlev - 1] / 64; r > 1; r >>= 1) ea.ishift++;
+                ea.mu_min = G.mu_min; ea.cut = cut;
+                const unsigned nb_sep = use_sep ? (unsigned)(((int64_t)(itp.nItot - q0) * ngrp + 255) / 256) : 0u;
+                const unsigned nb_edge = use_edge ? (unsigned)(((int64_t)nt64 * ngrp + 255) / 256) : 0u;
+                hipLaunchKernelGGL(k_mxzones, dim3(nb_sep + nb_edge), dim3(256), 0, s, nb_sep, sa, ea);
             }
             const SepZone *sepz = use_sep ? itp.sep : nullptr;
             if (lor)
@@ -738,9 +752,10 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
         // 8 x (blocks of the longest XCD stretch): XCD-aware tile mapping (tile_block); xtiles is a multiple of 4 tiles
         const dim3 grid_s((unsigned)(8 * (xtiles * split / 4)), kn);
 #define CS_FAR_LAUNCH(MIX, SP) hipLaunchKernelGGL((k_voigt_far<MIX, SP, false>), grid_s, dim3(256), 0, s, dnu, nnu, G.L, hot, hot32, G.nu.as<double>(), \
-                                                  win, zones, nt64, nblk_s, cut, base, extra, sigma, accumulate, ranges, iz, itp.nItot, ishift)
+                                                  win, zones, nt64, nblk_s, cut, base, extra, sigma, accumulate, ranges, iz, itp.nItot, ishift, edgez)
 #define CS_LOR_LAUNCH(SP) hipLaunchKernelGGL((k_voigt_far<false, SP, true>), grid_s, dim3(256), 0, s, dnu, nnu, G.L, hot, hot32, G.nu.as<double>(), \
-                                                  win, zones, nt64, nblk_s, cut, base, extra, sigma, accumulate, ranges, iz, itp.nItot, ishift)
+                                                  win, zones, nt64, nblk_s, cut, base, extra, sigma, accumulate, ranges, iz, itp.nItot, ishift, edgez)
+        const int2 *edgez = use_edge ? itp.edge : nullptr;
         if (lor) {
             if (split == 1) CS_LOR_LAUNCH(1); else if (split == 2) CS_LOR_LAUNCH(2); else CS_LOR_LAUNCH(4);
         } else if (hot32) {
@@ -750,6 +765,9 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
         }
 #undef CS_FAR_LAUNCH
 #undef CS_LOR_LAUNCH
+        if (use_edge)
+            hipLaunchKernelGGL(k_voigt_edge_mx, dim3((unsigned)((nt64 + 3) / 4), (unsigned)((kn + 15) / 16)), dim3(256), 0, s, dnu, nnu, G.L, hot, win,
+                               itp.edge, nt64, kn, cut, sigma);
         if (evg) (void)hipEventRecord(evg[2], s);
         if (!lor) {
             const int ngrp = (nt64 + CS_NEAR_R - 1) / CS_NEAR_R;   // near kernels: one wave = CS_NEAR_R consecutive tiles
@@ -998,7 +1016,7 @@ static int shape_impl(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t 
             (rc = gas_interp_build(ctx, ginterp, cheb, G.h_nu, g0, g1, nu, nnu, dnu_cut, kc, s)))
             return rc;
         itp = interp_view(cheb, ginterp, kc);
-        if (!ctx->matrix_nodes) itp.sep = nullptr;
+        if (!ctx->matrix_nodes) itp.sep = nullptr, itp.edge = nullptr;
         itp.sep_always = ctx->matrix_nodes == 2;
     }
     for (int k0 = 0; k0 < K; k0 += kc) {
@@ -1078,7 +1096,7 @@ int cs_bake(cs_ctx *ctx, int gas_slot, int table_slot, int shape, double dnu_cut
             (rc = gas_interp_build(ctx, ginterp, cheb, G.h_nu, g0, g1, nu, nnu, dnu_cut, kc, s)))
             return rc;
         itp = interp_view(cheb, ginterp, kc);
-        if (!ctx->matrix_nodes) itp.sep = nullptr;
+        if (!ctx->matrix_nodes) itp.sep = nullptr, itp.edge = nullptr;
         itp.sep_always = ctx->matrix_nodes == 2;
     }
     for (int k0 = 0; k0 < M; k0 += kc) {
@@ -1659,7 +1677,7 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
     const double *extra = c.has_extra ? c.extra.as<double>() : nullptr;
     if (extra) return fail(CS_EINVAL, "host-evaluated sigma(nu,T,P) terms are not supported in batch mode");
     const bool shared_sigma = c.accel.slot >= 0;   // AcceleratedAbsorber: cross-sections do not depend on the thermal state (absorbers.jl:203)
-    DevBuf dTk, dPk, dmuk, dTlev, dsig, dtau, dpart, dF, dranges, dconc, dPp, dgb, dzones, dizones, dF2, dsep, hot, cold;
+    DevBuf dTk, dPk, dmuk, dTlev, dsig, dtau, dpart, dF, dranges, dconc, dPp, dgb, dzones, dizones, dF2, dsep, dedge, hot, cold;
     if ((rc = upload(dTk, Tk.data(), BK, s)) || (rc = upload(dPk, Pk.data(), BK, s)) || (rc = upload(dmuk, muk.data(), BK, s)) ||
         (rc = upload(dTlev, T_levels, (size_t)B * np, s)))
         return rc;
@@ -1712,7 +1730,9 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
             itp = interp_view(c.cheb, cg.itp, kc, dizones.as<IZone>());
             itp.F = dF2.as<double>();
             HIPCHK(dsep.reserve((size_t)((kc + 15) / 16) * c.cheb.nItot * sizeof(SepZone)));   // (the column's own buffer is sized for K states)
+            HIPCHK(dedge.reserve((size_t)((kc + 15) / 16) * nt64 * sizeof(int2)));
             itp.sep = ctx->matrix_nodes ? dsep.as<SepZone>() : nullptr;
+            itp.edge = ctx->matrix_nodes ? dedge.as<int2>() : nullptr;
             itp.sep_always = ctx->matrix_nodes == 2;
         }
         for (int64_t k0 = 0; k0 < BK; k0 += kc) {
@@ -1811,7 +1831,7 @@ static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e)
         GasTable &G = ctx->gas[cg.slot];
         Interp itp = cg.itp.nlev > 0 ? interp_view(c.cheb, cg.itp, K) : Interp();
         itp.F = c.chebF.as<double>();
-        if (!ctx->matrix_nodes) itp.sep = nullptr;
+        if (!ctx->matrix_nodes) itp.sep = nullptr, itp.edge = nullptr;
         itp.sep_always = ctx->matrix_nodes == 2;
         launch_gas(s, cg.shape, G, cg.jlo, cg.jhi, K, c.Tk.as<double>(), c.Pk.as<double>(), cg.Pp.as<double>(), cg.conc.as<double>(),
                    c.hot.as<LineHot>(), c.cold.as<LineCold>(), c.nu.as<double>(), c.nnu, c.ntile, cg.J0.as<int32_t>(),
@@ -1996,7 +2016,7 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
     HIPCHK(hipDeviceSynchronize());
     const int K = c.K;
     const int nt64 = (int)((c.nnu + 63) / 64);
-    int64_t direct = 0, nodes = 0, sepn = 0;   // sepn: (node, line, state) triples summed on the matrix cores
+    int64_t direct = 0, nodes = 0, sepn = 0, edgen = 0;   // sepn, edgen: (node | point, line, state) triples summed on the matrix cores
     int64_t body[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // per-point lines by body: 2-term, 2-term+cut-off, 3-term, 3-term+cut-off, 4-term+cut-off,
                                                      // near-zone pass; node lines: 2-, 3-, 4-term
     auto seg = [](int lo, int hi, int p0, int p1) { return (int64_t)std::max(0, std::min(hi, p1) - std::max(lo, p0)); };
@@ -2043,27 +2063,39 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
         }
         int ishift = 0;
         if (nlev > 0) for (int r = c.cheb.itv[nlev - 1] / 64; r > 1; r >>= 1) ishift++;
+        const bool use_edge = nlev > 0 && sep_in_use(ctx->matrix_nodes != 0, ctx->matrix_nodes == 2, nt64, K, g.shape != SH_VOIGT, ctx->mixed != 0);
+        std::vector<int2> ez;
+        if (use_edge) {
+            ez.resize((size_t)((K + 15) / 16) * nt64);
+            HIPCHK(hipMemcpy(ez.data(), g.itp.edge.p, ez.size() * sizeof(int2), hipMemcpyDeviceToHost));
+        }
         for (int k = 0; k < K; k++)
             for (int t = 0; t < nt64; t++) {
-                const WaveWin &w = win[t];
+                WaveWin w = win[t];
                 const Zone &z = zn[(size_t)k * nt64 + t];
+                const int W0 = w.W0, W1 = w.W1;
+                if (use_edge) {   // the window ends k_voigt_edge_mx takes
+                    const int2 e = ez[(size_t)(k >> 4) * nt64 + t];
+                    edgen += 64 * (int64_t)((e.x - W0) + (W1 - e.y));
+                    w.W0 = e.x; w.W1 = e.y;
+                }
                 int64_t n = w.W1 - w.W0;
                 int sa0 = z.M0, sa1 = z.M0, sb0 = z.M1, sb1 = z.M1;
                 if (nlev > 0) {   // same clamps as k_voigt_far
                     const IZone &zi = iz[(size_t)k * nItot + c.cheb.ioff[nlev - 1] + (t >> ishift)];
-                    sa0 = std::min(std::max(zi.E0, w.W0), z.N0); sa1 = std::min(std::max(zi.Z0, sa0), z.N0);
-                    sb0 = std::max(std::min(zi.Z1, w.W1), z.N1); sb1 = std::max(std::min(zi.E1, w.W1), sb0);
+                    sa0 = std::min(std::max(zi.E0, W0), z.N0); sa1 = std::min(std::max(zi.Z0, sa0), z.N0);
+                    sb0 = std::max(std::min(zi.Z1, W1), z.N1); sb1 = std::max(std::min(zi.E1, W1), sb0);
                     n -= (sa1 - sa0) + (sb1 - sb0);
                 }
                 direct += 64 * n;
                 // the same segments k_voigt_far runs inside its three clip windows
-                const int a = std::min(std::max(w.E0, w.W0), z.Q0), a1 = std::min(std::max(w.E0, z.Q0), z.M0);
-                const int b1 = std::max(std::min(w.E1, z.Q1), z.M1), bq = std::max(std::min(w.E1, w.W1), z.Q1);
+                const int a = std::min(std::max(w.E0, W0), z.Q0), a1 = std::min(std::max(w.E0, z.Q0), z.M0);
+                const int b1 = std::max(std::min(w.E1, z.Q1), z.M1), bq = std::max(std::min(w.E1, W1), z.Q1);
                 const int cl[3] = {w.W0, sa1, sb1}, ch[3] = {sa0, sb0, w.W1};
                 for (int cw = 0; cw < 3; cw++) {
                     const int p0 = cl[cw], p1 = ch[cw];
                     if (p0 >= p1) continue;
-                    body[1] += seg(w.W0, a, p0, p1) + seg(bq, w.W1, p0, p1);
+                    body[1] += seg(W0, a, p0, p1) + seg(bq, W1, p0, p1);
                     body[0] += seg(a, z.Q0, p0, p1) + seg(z.Q1, bq, p0, p1);
                     body[3] += seg(z.Q0, a1, p0, p1) + seg(b1, z.Q1, p0, p1);
                     body[2] += seg(a1, z.M0, p0, p1) + seg(z.M1, b1, p0, p1);
@@ -2079,6 +2111,7 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
     for (int q = 0; q < 6; q++) out[4 + q] = 64 * body[q];
     for (int q = 6; q < 9; q++) out[4 + q] = (int64_t)CS_NC * body[q];
     out[13] = sepn;
+    out[14] = edgen;
     return CS_OK;
 }
 

@@ -705,7 +705,7 @@ __global__ __launch_bounds__(256) void k_cheb_nodes(const double *__restrict__ n
 // (node, line) pair of a 16-node sub-tile, forms w .. w^4 (10 VALU instructions) and, as (state, line), the four coefficients
 // of its own record; 16 matrix instructions per 4 lines x 64 nodes x 16 states.  The loop runs at the matrix pipe's rate (0.92
 // of it in tools/ubench/sep_nodes.hip: 2.5x the scalar-load VALU loop for the same triples) and leaves the vector unit to the
-// kernels beside it.  One wave = one interval x one group of 16 states; pieces from k_sepzones.
+// kernels beside it.  Pieces from sepzones_body (k_mxzones).
 struct SepArgs {
     const double *nodes, *nul, *gbound, *Tk;
     const IZone *iz;
@@ -715,9 +715,9 @@ struct SepArgs {
 };
 // per (state group, interval): the four pieces common to the group's states, clipped to the distance at which the 4-term series
 // holds for the widest line of the group (gbound: Lorentz width bound per state; Doppler width at the upper end of the window)
-__global__ __launch_bounds__(256) void k_sepzones(SepArgs a)
+__device__ __forceinline__ void sepzones_body(unsigned bid, const SepArgs &a)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int idx = bid * blockDim.x + threadIdx.x;
     const int nq = a.nItot - a.q0;
     if (idx >= nq * a.ngrp) return;
     const int g = idx / nq, T = a.q0 + (idx - g * nq);
@@ -1027,8 +1027,10 @@ __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu
                                                     const Zone *__restrict__ zones, int ntile, int nblk, double cut,
                                                     double base, const double *__restrict__ extra,
                                                     double *__restrict__ sigma, int accumulate, int2 *__restrict__ ranges,
-                                                    const IZone *__restrict__ iz, int nI, int ishift)
+                                                    const IZone *__restrict__ iz, int nI, int ishift, const int2 *__restrict__ edge)
 {
+    // edge != NULL: the window ends [W0, edge.x) and [edge.y, W1) of the tile -- the cut-off edges and the far lines no interval
+    // could take -- are summed for 16 states at a time on the matrix cores (k_voigt_edge_mx): skip them here.
     // iz != NULL: the lines [E0,Z0) U [Z1,E1) of the tile's parent interval (tile >> ishift, smallest interval size) were
     // summed by k_voigt_cheb -- skip them here.
     // S = 1: one wave per tile.  S = 2, 4: the S waves of a tile split its window of lines into S parts of equal estimated
@@ -1062,11 +1064,16 @@ __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu
             sa0 = min(max(zi.E0, w.W0), z.N0); sa1 = min(max(zi.Z0, sa0), z.N0);
             sb0 = max(min(zi.Z1, w.W1), z.N1); sb1 = max(min(zi.E1, w.W1), sb0);
         }
-        // this wave's share [q0, q1) of the window
-        int q0 = w.W0, q1 = w.W1;
+        // what is left of the window after the matrix-core pieces, [wl, wr), and this wave's share [q0, q1) of it
+        int wl = w.W0, wr = w.W1;
+        if (edge) {
+            const int2 e = edge[(size_t)(k >> 4) * ntile + tile];
+            wl = e.x; wr = e.y;
+        }
+        int q0 = wl, q1 = wr;
         if (S > 1) {
             // piecewise-constant cost per line: 14 (far), 0 (skipped), 20 (4-term), 36 (near zone)
-            const int b8[8] = {w.W0, sa0, sa1, z.N0, z.N1, sb0, sb1, w.W1};
+            const int b8[8] = {wl, max(sa0, wl), sa1, z.N0, z.N1, sb0, min(sb1, wr), wr};
             const int c7[7] = {14, 0, 20, 36, 20, 0, 14};
             int total = 0;
             for (int q = 0; q < 7; q++) total += (b8[q + 1] - b8[q]) * c7[q];
@@ -1077,12 +1084,12 @@ __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu
                     if (c7[q] > 0 && accu + seg >= target) return b8[q] + (target - accu) / c7[q];
                     accu += seg;
                 }
-                return w.W1;
+                return wr;
             };
-            q0 = part == 0 ? w.W0 : cut_at((int)((long long)total * part / S));
-            q1 = part == S - 1 ? w.W1 : cut_at((int)((long long)total * (part + 1) / S));
+            q0 = part == 0 ? wl : cut_at((int)((long long)total * part / S));
+            q1 = part == S - 1 ? wr : cut_at((int)((long long)total * (part + 1) / S));
         }
-        const int cw_lo[3] = {w.W0, sa1, sb1}, cw_hi[3] = {sa0, sb0, w.W1};
+        const int cw_lo[3] = {wl, sa1, sb1}, cw_hi[3] = {sa0, sb0, wr};
         for (int cw = 0; cw < 3; cw++) {
         const int p0 = max(q0, cw_lo[cw]), p1 = min(q1, cw_hi[cw]);
         if (p0 >= p1) continue;
@@ -1188,6 +1195,139 @@ __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu
             fl[((size_t)gridDim.y + k) * ntile + tile] = any1 ? 1u : 0u;
         }
     }
+}
+
+// ---- K2e: window ends of the per-point sum on the matrix cores -----------------------------------------------------------------
+// What no interval can take at the far ends of a tile's window -- the lines inside the cut-off of only some points of the
+// smallest interval, a third of k_voigt_far's instructions at 17 per pair -- is as far from the tile as lines get, so the same
+// state-separable series as K2d applies (sum_n C_n[state][line] w^n, w = 1/dnu^2), here with the points of the tile as columns
+// and the cut-off as a mask on w:  one wave = one 64-point tile x 16 states, 16 matrix instructions per 4 lines.
+struct EdgeArgs {
+    const double *nu, *nul, *gbound, *Tk;
+    const WaveWin *win;
+    const Zone *zones;
+    const IZone *iz;      // lowest interpolation level, or NULL
+    int2 *out;            // [ngrp][ntile]: k_voigt_far keeps [x, y) of the window
+    int64_t nnu;
+    int ntile, K, ngrp, nI, ishift;
+    double mu_min, cut;
+};
+// per (state group, tile): the window ends common to the group's states -- left of every state's first interpolated or near-zone
+// line, right of the last -- clipped to the distance at which the 4-term series holds for the widest line of the group
+__device__ __forceinline__ void edgezones_body(unsigned bid, const EdgeArgs &a)
+{
+    const int idx = bid * blockDim.x + threadIdx.x;
+    if (idx >= a.ntile * a.ngrp) return;
+    const int g = idx / a.ntile, t = idx - g * a.ntile;
+    const int64_t i0 = (int64_t)t * 64, i1 = (i0 + 63 < a.nnu ? i0 + 63 : a.nnu - 1);
+    const double vlo = a.nu[i0], vhi = a.nu[i1];
+    const WaveWin w = a.win[t];
+    int eL = w.W1, eR = w.W0;
+    double R = 0.0;
+    for (int k = g * 16; k < min(g * 16 + 16, a.K); k++) {
+        const Zone z = a.zones[(size_t)k * a.ntile + t];
+        int sa0 = z.M0, sb1 = z.M1;   // (as k_voigt_far)
+        if (a.iz) {
+            const IZone zi = a.iz[(size_t)k * a.nI + (t >> a.ishift)];
+            sa0 = min(max(zi.E0, w.W0), z.N0);
+            const int sb0 = max(min(zi.Z1, w.W1), z.N1);
+            sb1 = max(min(zi.E1, w.W1), sb0);
+        }
+        eL = min(eL, sa0);
+        eR = max(eR, sb1);
+        const double amax = ((vhi + a.cut) / kC) * sqrt(2.0 * kRgas * a.Tk[k]) / sqrt(a.mu_min);
+        const double gb = a.gbound[k];
+        R = fmax(R, 133.6 * sqrt(gb * gb + 4.33 * amax * amax) * (1.0 + 1e-6));
+    }
+    const double *__restrict__ nul = a.nul;
+    auto lower = [&](double val, int p, int q) { while (p < q) { const int m = (p + q) >> 1; if (nul[m] < val) p = m + 1; else q = m; } return p; };
+    auto upper = [&](double val, int p, int q) { while (p < q) { const int m = (p + q) >> 1; if (nul[m] <= val) p = m + 1; else q = m; } return p; };
+    eL = max(min(eL, lower(vlo - R, w.W0, w.W1)), w.W0);
+    eR = min(max(eR, upper(vhi + R, eL, w.W1)), w.W1);
+    if (eL - w.W0 < 8) eL = w.W0;   // (too short to be worth a wave's trip)
+    if (w.W1 - eR < 8) eR = w.W1;
+    a.out[idx] = make_int2(eL, eR);
+}
+// k_sepzones and the edge zones in one launch (both need the zones of k_gas_setup)
+__global__ __launch_bounds__(256) void k_mxzones(unsigned nb_sep, SepArgs sa, EdgeArgs ea)
+{
+    if (blockIdx.x < nb_sep) sepzones_body(blockIdx.x, sa);
+    else edgezones_body(blockIdx.x - nb_sep, ea);
+}
+
+__global__ __launch_bounds__(256) void k_voigt_edge_mx(const double *__restrict__ nu, int64_t nnu, int64_t L, const LineHot *__restrict__ hot,
+                                                       const WaveWin *__restrict__ win, const int2 *__restrict__ edge, int ntile, int K,
+                                                       double cut, double *__restrict__ sigma)
+{
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + wv, g = blockIdx.y;
+    if (tile >= ntile) return;
+    const WaveWin w = win[tile];
+    const int2 e = edge[(size_t)g * ntile + tile];
+    if (e.x <= w.W0 && e.y >= w.W1) return;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int kk = min(g * 16 + lr, K - 1);                       // (a group's tail states re-read the last one: never stored)
+    const LineHot *__restrict__ hk = hot + (size_t)kk * L;
+    double vn[4];
+#pragma unroll
+    for (int st = 0; st < 4; st++) {
+        const int64_t i = (int64_t)tile * 64 + st * 16 + lr;
+        vn[st] = nu[i < nnu ? i : nnu - 1];
+    }
+    v4f64_sep acc[4];
+#pragma unroll
+    for (int st = 0; st < 4; st++) acc[st] = v4f64_sep{0.0, 0.0, 0.0, 0.0};
+    // the lane's record as (state lr, line lq) gives the four coefficients (A operand) and, as (point lr, line lq), the line position
+    auto step = [&](const LineHot &h, bool valid) {
+        const double id2 = rcp_nr1(h.p1 * h.p1);
+        const double y2 = h.p2;
+        const double c2 = 1.5 - y2;
+        const double c3 = __builtin_fma(y2, y2 - 5.0, 3.75);
+        const double c4 = __builtin_fma(y2, __builtin_fma(y2, 10.5 - y2, -26.25), 13.125);
+        const double C1 = valid ? h.p3 * id2 : 0.0;
+        const double C2 = C1 * id2;
+        const double C3 = C2 * id2;
+        const double C4 = C3 * id2;
+        const double a1 = C1, a2 = C2 * c2, a3 = C3 * c3, a4 = C4 * c4;
+#pragma unroll
+        for (int st = 0; st < 4; st++) {
+            const double dv = vn[st] - h.nul;
+            const double s2 = dv * dv;
+            double wq = rcp_fast(s2);
+            wq = __builtin_fma(wq, __builtin_fma(-s2, wq, 1.0), wq);
+            wq = fabs(dv) > cut ? 0.0 : wq;                           // the cut-off of line_shapes.jl:10 as a mask
+            const double w2 = wq * wq, w3 = w2 * wq, w4 = w2 * w2;
+            acc[st] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, wq, acc[st], 0, 0, 0);
+            acc[st] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, w2, acc[st], 0, 0, 0);
+            acc[st] = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, w3, acc[st], 0, 0, 0);
+            acc[st] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4, w4, acc[st], 0, 0, 0);
+        }
+    };
+    for (int pp = 0; pp < 2; pp++) {   // left end ascending, right end descending: far lines first
+        const bool asc = pp == 0;
+        const int ja = asc ? w.W0 : e.y, jb = asc ? e.x : w.W1;
+        if (ja >= jb) continue;
+        const int nst = (jb - ja + 3) >> 2;
+        const int b0 = asc ? ja + lq : jb - 4 + lq, db = asc ? 4 : -4;
+        auto rec = [&](int t) { return hk[min(max(b0 + t * db, ja), jb - 1)]; };
+        auto ok = [&](int t) { const int j = b0 + t * db; return j >= ja && j < jb; };
+        LineHot cur = rec(0);
+        for (int t = 0; t < nst; t++) {
+            const LineHot nxt = rec(t + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            step(cur, ok(t));
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nxt;
+        }
+    }
+#pragma unroll
+    for (int st = 0; st < 4; st++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {   // D[state 4r + lq][point 16 st + lr]
+            const int k = g * 16 + 4 * r + lq;
+            const int64_t i = (int64_t)tile * 64 + st * 16 + lr;
+            if (k < K && i < nnu) sigma[(size_t)k * nnu + i] += acc[st][r];
+        }
 }
 
 // ---- PHCO2 (Perrin & Hartmann sub-Lorentzian CO2 wings, line_shapes.jl:467-540) ------------------------------------------------

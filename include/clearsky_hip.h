@@ -90,10 +90,11 @@ int cs_set_interp(cs_ctx *ctx, int on);
  * directly), -1 = chosen per gas from its line density; [size_min, size_max] restricts the interval sizes considered.
  * Results do not depend on the plan beyond rounding (tests/test_gpu_interp.py); it only moves work between kernels. */
 int cs_set_interp_plan(cs_ctx *ctx, int first_level, int size_min, int size_max);
-/* Node sums of the interpolated far wings: lines far enough for the 4-term series in 1/dnu^2 (|dnu| >= 133.6 sqrt(gamma^2 + 4.33
- * alpha^2) for every state of a group of 16) are summed as a matrix product on v_mfma_f64_16x16x4.  on = 1
- * (default): where the grid has enough (interval, state group) blocks to fill the chip; 2: always; 0: every node sum on the
- * vector unit.  Same results to rounding (tests/test_gpu_interp.py). */
+/* Far lines on the matrix cores: where the 4-term series in 1/dnu^2 holds for every state of a group of 16 (|dnu| >= 133.6
+ * sqrt(gamma^2 + 4.33 alpha^2)), the node sums of the interpolated far wings and the window ends of the
+ * per-point sum -- cut-off edges included, as a mask (K2e) -- are matrix products on v_mfma_f64_16x16x4.  on = 1 (default):
+ * where the grid has enough (interval | tile, state group) blocks to fill the chip; 2: always; 0: everything on the vector
+ * unit.  Same results to rounding (tests/test_gpu_interp.py). */
 int cs_set_matrix_cores(cs_ctx *ctx, int on);
 
 /*
@@ -212,7 +213,8 @@ int cs_column_counts(cs_ctx *ctx, int64_t *pair_evals, int64_t *lines_in_range);
  * out[2] = interpolation levels in use, out[3] = intervals over all levels; out[4..9] = the per-point evaluations by loop body
  * (2-term, 2-term + cut-off predicate, 3-term, 3-term + predicate, 4-term + predicate, near-zone pass), out[10..12] = the node
  * evaluations by body (2-, 3-, 4-term) on the vector unit -- what bench.py weights with the VALU instruction count of each
- * body -- and out[13] = the node evaluations summed on the matrix cores (cs_set_matrix_cores).  `out` holds 14 values.  cs_column_counts is the reference's count. */
+ * body -- and out[13], out[14] = the node and the per-point evaluations summed on the matrix cores (cs_set_matrix_cores;
+ * out[0] and out[4..9] do not include the latter).  `out` holds 15 values.  cs_column_counts is the reference's count. */
 int cs_column_work(cs_ctx *ctx, int64_t *out);
 /* interval sizes (descending, <= 5, each 128..2048 points) cs_set_interp(on) would use for this grid and cut-off; returns
  * their number (0: the grid is too coarse for the cut-off -- every pair is evaluated directly) */

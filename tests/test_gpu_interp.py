@@ -244,8 +244,9 @@ def test_phco2_fast_path(cs, O, lines, ctx_on):
 
 
 def test_matrix_core_node_sums_on_off(cs, O, lines):
-    """K2d: far lines inside the validity range of the 4-term series in 1/dnu^2 are summed at the nodes as a matrix product on
-    v_mfma_f64_16x16x4 (k_cheb_nodes_mx); the rest stays on the vector unit.  Same cross-sections as with every node sum on the
+    """K2d, K2e: far lines inside the validity range of the 4-term series in 1/dnu^2 are summed as matrix products on
+    v_mfma_f64_16x16x4 -- at the interpolation nodes (k_cheb_nodes_mx) and, for the window ends of the per-point sum with the
+    cut-off as a mask, at the points themselves (k_voigt_edge_mx); the rest stays on the vector unit.  Same cross-sections as with every node sum on the
     vector unit (5e-14) and as the oracle (1e-11), for state groups that mix low and high pressures, a ragged last group (K = 41),
     a dense synthetic table and the sparse fixtures, the column, shape-batch and batch paths."""
     nu = np.linspace(580.0, 780.0, 20000)
@@ -264,6 +265,8 @@ def test_matrix_core_node_sums_on_off(cs, O, lines):
         F = col.fetch(tau)
         B = col.run_batch([T, cs.AtmosphericProfile(P, np.linspace(205.0, 288.0, 21))])
         sb = cs.shape_batch(dense, "voigt", nu, [220.0, 296.0, 250.0], [50.0, 101325.0, 3e3], [0.02, 40.53, 1.2], 25.0, c)
+        wk = col.work()
+        assert (wk["node_evals_matrix"] > 0 and wk["direct_evals_matrix"] > 0) == on   # (both matrix-core kernels really ran)
         res[on] = (col.sigma_nodes(), tau, F, B, sb, col)
         if on:
             r = O.fluxes_discretized(nu, P, 9.8, 3, col.Tn, col.mun, col.Tlev, [dense, lines("H2O")], ["voigt"] * 2, [25.0] * 2, col.conc,
