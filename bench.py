@@ -58,7 +58,8 @@ def main():
     ap.add_argument("--precision", default="fp64", help="fp64 (headline) | mixed (fp32 far wings, BASELINE configs[4])")
     ap.add_argument("--no-interp", action="store_true", help="evaluate every (nu, line) pair (no far-wing interpolation)")
     ap.add_argument("--interp-first-level", type=int, default=-1, help="tuning: first interval level every gas uses (-1 = by line density)")
-    ap.add_argument("--no-matrix-nodes", action="store_true", help="tuning: every far-wing node sum on the vector unit")
+    ap.add_argument("--no-matrix-nodes", action="store_true", help="tuning: no far-line sums on the matrix cores (same as --matrix-cores 0)")
+    ap.add_argument("--matrix-cores", type=int, default=1, help="tuning: far-line sums on the matrix cores: 1 where the grid is long enough (default), 2 always, 0 never")
     ap.add_argument("--far-s", type=float, default=1e6, help="mixed precision: x^2 threshold of the fp32 region")
     ap.add_argument("--emulate-shard", default=None, help="R/N: time only shard R of an N-way split on this one GPU (rehearsal)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL, default) | gloo (rehearsal of N>1 on fewer GPUs)")
@@ -109,7 +110,7 @@ def main():
     ctx.set_precision(args.precision, args.far_s)
     ctx.set_interp(not args.no_interp)
     ctx.set_interp_plan(first_level=args.interp_first_level)
-    ctx.set_matrix_cores(not args.no_matrix_nodes)
+    ctx.set_matrix_cores(0 if args.no_matrix_nodes else args.matrix_cores)
     t_setup = time.perf_counter()
     col = cs.Column(cfg["P"], cfg["g"], cfg["T"], cfg["mu"], cfg["fS"], cfg["fa"], *cfg["absorbers"], core=cfg["core"],
                     theta_s=cfg["theta_s"], want_tau=True, want_M=True, nu_range=ranges[rank], ctx=ctx)

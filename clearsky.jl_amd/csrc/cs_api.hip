@@ -142,7 +142,7 @@ struct ChebGrid {
 };
 // per gas on that grid: windows per level, zones [K][nItot], node sums F [nItot][64][Kpad]
 struct GasInterp { int nlev = 0, l0 = 0; DevBuf iwin[CS_MAX_LEVEL], iz, F, sep, edge; };   // levels l0 .. nlev-1 of the grid are in use; sep: SepZone [K/16][nItot]
-                                                                                          // (matrix-core node sums), edge: int2 [K/16][tiles] (matrix-core window ends)
+                                                                                          // (matrix-core node sums), edge: EdgeZone [K/16][tiles] (matrix-core pieces of the per-point sum)
 
 struct ColGas {
     int slot = 0, shape = 0;
@@ -473,7 +473,7 @@ struct Interp {
     IZone *iz = nullptr;
     double *F = nullptr;
     SepZone *sep = nullptr;   // NULL: every node sum on the vector unit
-    int2 *edge = nullptr;     // NULL: the window ends of the per-point sum on the vector unit
+    EdgeZone *edge = nullptr; // NULL: all of the per-point sum on the vector unit
     bool sep_always = false;  // cs_set_matrix_cores(ctx, 2): also on grids too short to fill the chip with (interval, state group) blocks
 };
 
@@ -560,7 +560,7 @@ int gas_interp_build(const cs_ctx *ctx, GasInterp &gi, ChebGrid &g, const std::v
     }
     HIPCHK(gi.iz.reserve((size_t)K * g.nItot * sizeof(IZone)));
     HIPCHK(gi.sep.reserve((size_t)((K + 15) / 16) * g.nItot * sizeof(SepZone)));
-    HIPCHK(gi.edge.reserve((size_t)((K + 15) / 16) * (size_t)((nnu + 63) / 64) * sizeof(int2)));
+    HIPCHK(gi.edge.reserve((size_t)((K + 15) / 16) * (size_t)((nnu + 63) / 64) * sizeof(EdgeZone)));
     if (own_F && gi.F.bytes < (size_t)g.nItot * CS_NC * cheb_kpad(K) * sizeof(double)) {
         HIPCHK(gi.F.reserve((size_t)g.nItot * CS_NC * cheb_kpad(K) * sizeof(double)));
         HIPCHK(hipMemsetAsync(gi.F.p, 0, gi.F.bytes, s));   // padding states stay finite
@@ -579,7 +579,7 @@ Interp interp_view(const ChebGrid &g, const GasInterp &gi, int K, IZone *iz_over
     v.iz = iz_override ? iz_override : gi.iz.as<IZone>();
     v.F = gi.F.as<double>();
     v.sep = gi.sep.as<SepZone>();
-    v.edge = gi.edge.as<int2>();
+    v.edge = gi.edge.as<EdgeZone>();
     for (int l = 0; l < gi.nlev; l++) {
         v.itv[l] = g.itv[l]; v.nI[l] = g.nI[l]; v.ioff[l] = g.ioff[l];
         v.Cm[l] = g.Cm[l].as<double>();
@@ -636,9 +636,16 @@ bool phco2_fast_ok(const GasTable &G, int64_t nnu, double cut, int kn, PhScratch
 // matrix-core node sums (k_cheb_nodes_mx): fp64 Voigt only, and by default only where there are enough (interval, state group)
 // blocks to fill the chip -- on a short grid (a nu-shard) the one-state-per-wave vector kernel has the shorter critical path
 // (1/8 of C3: 0.17 vs 0.25 ms)
-static bool sep_in_use(bool have_sep, bool always, int nblocks_intervals, int kn, bool lor, bool mixed)
+static bool sep_in_use(bool have_sep, bool always, int nblocks_intervals, int kn, bool lor, bool mixed, int min_blocks = 2048)
 {
-    return have_sep && !lor && !mixed && (always || (int64_t)nblocks_intervals * ((kn + 15) / 16) >= 2048);
+    return have_sep && !lor && !mixed && (always || (int64_t)nblocks_intervals * ((kn + 15) / 16) >= min_blocks);
+}
+// the per-point pieces (k_voigt_edge_mx: one wave per (tile, state group), no reduction) pay on shorter grids -- 1/4 of C3 (1564
+// waves): far 0.42 -> 0.36 ms; 1/8: 0.261 -> 0.244 ms, which the extra zone launch eats -- but only on tables dense enough to give
+// a wave more than a few steps (C5's HITRAN fixtures: far 3.94 -> 4.01 ms with them)
+static bool edge_in_use(bool have_edge, bool always, int ntiles, int kn, bool lor, bool mixed, int64_t lines_in_range)
+{
+    return sep_in_use(have_edge, always, ntiles, kn, lor, mixed, 1024) && (always || lines_in_range >= (int64_t)ntiles * 8);
 }
 
 // K1 + K2 for one gas on `s`: parameters for `kn` states, then the line sum into sigma ([kn][nnu])
@@ -688,7 +695,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
             const dim3 gridn((unsigned)((kn + 3) / 4) * (unsigned)(itp.nItot - q0));
             const int ngrp = (kn + 15) / 16;
             const bool use_sep = sep_in_use(itp.sep != nullptr, itp.sep_always, itp.nItot - q0, kn, lor, hot32 != nullptr);
-            use_edge = sep_in_use(itp.edge != nullptr, itp.sep_always, nt64, kn, lor, hot32 != nullptr);
+            use_edge = edge_in_use(itp.edge != nullptr, itp.sep_always, nt64, kn, lor, hot32 != nullptr, jhi - jlo);
             if (use_sep || use_edge) {   // what the matrix cores take of the interpolated sets and of the window ends (needs the zones of k_gas_setup)
                 SepArgs sa;
                 sa.nodes = itp.nodes; sa.nul = G.nu.as<double>(); sa.gbound = gbound; sa.Tk = Tk; sa.iz = itp.iz; sa.out = itp.sep;
@@ -755,11 +762,16 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
                                                   win, zones, nt64, nblk_s, cut, base, extra, sigma, accumulate, ranges, iz, itp.nItot, ishift, edgez)
 #define CS_LOR_LAUNCH(SP) hipLaunchKernelGGL((k_voigt_far<false, SP, true>), grid_s, dim3(256), 0, s, dnu, nnu, G.L, hot, hot32, G.nu.as<double>(), \
                                                   win, zones, nt64, nblk_s, cut, base, extra, sigma, accumulate, ranges, iz, itp.nItot, ishift, edgez)
-        const int2 *edgez = use_edge ? itp.edge : nullptr;
+        const EdgeZone *edgez = use_edge ? itp.edge : nullptr;
         if (lor) {
             if (split == 1) CS_LOR_LAUNCH(1); else if (split == 2) CS_LOR_LAUNCH(2); else CS_LOR_LAUNCH(4);
         } else if (hot32) {
             if (split == 1) CS_FAR_LAUNCH(true, 1); else if (split == 2) CS_FAR_LAUNCH(true, 2); else CS_FAR_LAUNCH(true, 4);
+        } else if (use_edge) {
+#define CS_EDGE_LAUNCH(SP) hipLaunchKernelGGL((k_voigt_far<false, SP, false, true>), grid_s, dim3(256), 0, s, dnu, nnu, G.L, hot, hot32, G.nu.as<double>(), \
+                                                  win, zones, nt64, nblk_s, cut, base, extra, sigma, accumulate, ranges, iz, itp.nItot, ishift, edgez)
+            if (split == 1) CS_EDGE_LAUNCH(1); else if (split == 2) CS_EDGE_LAUNCH(2); else CS_EDGE_LAUNCH(4);
+#undef CS_EDGE_LAUNCH
         } else {
             if (split == 1) CS_FAR_LAUNCH(false, 1); else if (split == 2) CS_FAR_LAUNCH(false, 2); else CS_FAR_LAUNCH(false, 4);
         }
@@ -1730,9 +1742,9 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
             itp = interp_view(c.cheb, cg.itp, kc, dizones.as<IZone>());
             itp.F = dF2.as<double>();
             HIPCHK(dsep.reserve((size_t)((kc + 15) / 16) * c.cheb.nItot * sizeof(SepZone)));   // (the column's own buffer is sized for K states)
-            HIPCHK(dedge.reserve((size_t)((kc + 15) / 16) * nt64 * sizeof(int2)));
+            HIPCHK(dedge.reserve((size_t)((kc + 15) / 16) * nt64 * sizeof(EdgeZone)));
             itp.sep = ctx->matrix_nodes ? dsep.as<SepZone>() : nullptr;
-            itp.edge = ctx->matrix_nodes ? dedge.as<int2>() : nullptr;
+            itp.edge = ctx->matrix_nodes ? dedge.as<EdgeZone>() : nullptr;
             itp.sep_always = ctx->matrix_nodes == 2;
         }
         for (int64_t k0 = 0; k0 < BK; k0 += kc) {
@@ -2063,23 +2075,28 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
         }
         int ishift = 0;
         if (nlev > 0) for (int r = c.cheb.itv[nlev - 1] / 64; r > 1; r >>= 1) ishift++;
-        const bool use_edge = nlev > 0 && sep_in_use(ctx->matrix_nodes != 0, ctx->matrix_nodes == 2, nt64, K, g.shape != SH_VOIGT, ctx->mixed != 0);
-        std::vector<int2> ez;
+        const bool use_edge = nlev > 0 && edge_in_use(ctx->matrix_nodes != 0, ctx->matrix_nodes == 2, nt64, K, g.shape != SH_VOIGT, ctx->mixed != 0,
+                                                      std::max<int64_t>(g.jhi - g.jlo, 0));
+        std::vector<EdgeZone> ez;
         if (use_edge) {
             ez.resize((size_t)((K + 15) / 16) * nt64);
-            HIPCHK(hipMemcpy(ez.data(), g.itp.edge.p, ez.size() * sizeof(int2), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(ez.data(), g.itp.edge.p, ez.size() * sizeof(EdgeZone), hipMemcpyDeviceToHost));
         }
         for (int k = 0; k < K; k++)
             for (int t = 0; t < nt64; t++) {
                 WaveWin w = win[t];
                 const Zone &z = zn[(size_t)k * nt64 + t];
                 const int W0 = w.W0, W1 = w.W1;
-                if (use_edge) {   // the window ends k_voigt_edge_mx takes
-                    const int2 e = ez[(size_t)(k >> 4) * nt64 + t];
-                    edgen += 64 * (int64_t)((e.x - W0) + (W1 - e.y));
-                    w.W0 = e.x; w.W1 = e.y;
+                int pm[4] = {0, 0, 0, 0};   // [pL0, pL1), [pR0, pR1): the pieces between interpolated sets and near zone on the matrix cores
+                if (use_edge) {   // what k_voigt_edge_mx takes
+                    const EdgeZone e = ez[(size_t)(k >> 4) * nt64 + t];
+                    edgen += 64 * (int64_t)((e.eL - W0) + (W1 - e.eR));
+                    w.W0 = e.eL; w.W1 = e.eR;
+                    if (e.mL1 > e.mL0) { pm[0] = e.mL0; pm[1] = e.mL1; }
+                    if (e.mR1 > e.mR0) { pm[2] = e.mR0; pm[3] = e.mR1; }
+                    edgen += 64 * (int64_t)((pm[1] - pm[0]) + (pm[3] - pm[2]));
                 }
-                int64_t n = w.W1 - w.W0;
+                int64_t n = (w.W1 - w.W0) - (pm[1] - pm[0]) - (pm[3] - pm[2]);
                 int sa0 = z.M0, sa1 = z.M0, sb0 = z.M1, sb1 = z.M1;
                 if (nlev > 0) {   // same clamps as k_voigt_far
                     const IZone &zi = iz[(size_t)k * nItot + c.cheb.ioff[nlev - 1] + (t >> ishift)];
@@ -2091,8 +2108,10 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
                 // the same segments k_voigt_far runs inside its three clip windows
                 const int a = std::min(std::max(w.E0, W0), z.Q0), a1 = std::min(std::max(w.E0, z.Q0), z.M0);
                 const int b1 = std::max(std::min(w.E1, z.Q1), z.M1), bq = std::max(std::min(w.E1, W1), z.Q1);
-                const int cl[3] = {w.W0, sa1, sb1}, ch[3] = {sa0, sb0, w.W1};
-                for (int cw = 0; cw < 3; cw++) {
+                const int pL0 = pm[1] > pm[0] ? pm[0] : sa1, pL1 = pm[1] > pm[0] ? pm[1] : sa1;
+                const int pR0 = pm[3] > pm[2] ? pm[2] : sb0, pR1 = pm[3] > pm[2] ? pm[3] : sb0;
+                const int cl[5] = {w.W0, sa1, pL1, pR1, sb1}, ch[5] = {sa0, pL0, pR0, sb0, w.W1};
+                for (int cw = 0; cw < 5; cw++) {
                     const int p0 = cl[cw], p1 = ch[cw];
                     if (p0 >= p1) continue;
                     body[1] += seg(W0, a, p0, p1) + seg(bq, W1, p0, p1);

@@ -613,6 +613,9 @@ __global__ __launch_bounds__(256) void k_gas_setup(unsigned nb_prep, unsigned nb
 // on the matrix cores; per (state group, interval) their four pieces -- sub-ranges of [E0,P0), [P1,Z0), [Z1,P2), [P3,E1) common to
 // the group's states -- are what this kernel then skips.
 struct __attribute__((aligned(16))) SepZone { int32_t a[4], b[4]; };   // piece p = [a[p], b[p]); empty: a = b
+// the same for the per-point sum (k_voigt_edge_mx), per (state group, 64-point tile): the window ends [W0, eL) and [eR, W1), and the
+// pieces [mL0, mL1), [mR0, mR1) between the interpolated sets and the near zone (empty: m.1 <= m.0)
+struct __attribute__((aligned(16))) EdgeZone { int32_t eL, mL0, mL1, mR0, mR1, eR, pad0, pad1; };
 
 // vector-unit node sum of one (interval, state) at the lane's node v: own set minus the parent's -- [E0,P0) U [P1,Z0) left of the
 // interval, [Z1,P2) U [P3,E1) right of it -- each minus the piece [sa[p], sb[p]) the matrix cores take.  Both sides are summed from
@@ -1020,17 +1023,18 @@ __global__ __launch_bounds__(256, NSUB >= 4 ? 2 : 4) void k_cheb_apply_mfma(Cheb
 // line parameters arrive through scalar loads:
 //   [W0,a) left edge (cut-off predicate) | [a,M0) far | [M0,N0) mid-far | [N0,N1) near zone | [N1,M1) | [M1,b) | [b,W1)
 // In the near zone only the pairs with s >= 1e4 are summed here; the others belong to k_voigt_near.
-template <bool MIXED, int S, bool LOR>
+template <bool MIXED, int S, bool LOR, bool EDGE = false>
 __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu, int64_t nnu, int64_t L,
                                                     const LineHot *__restrict__ hot, const LineF32 *__restrict__ hot32,
                                                     const double *__restrict__ gnul, const WaveWin *__restrict__ win,
                                                     const Zone *__restrict__ zones, int ntile, int nblk, double cut,
                                                     double base, const double *__restrict__ extra,
                                                     double *__restrict__ sigma, int accumulate, int2 *__restrict__ ranges,
-                                                    const IZone *__restrict__ iz, int nI, int ishift, const int2 *__restrict__ edge)
+                                                    const IZone *__restrict__ iz, int nI, int ishift, const EdgeZone *__restrict__ edge)
 {
-    // edge != NULL: the window ends [W0, edge.x) and [edge.y, W1) of the tile -- the cut-off edges and the far lines no interval
-    // could take -- are summed for 16 states at a time on the matrix cores (k_voigt_edge_mx): skip them here.
+    // edge != NULL: the window ends [W0, eL) and [eR, W1) of the tile -- the cut-off edges and the far lines no interval could
+    // take -- and the pieces [mL0, mL1), [mR0, mR1) between the interpolated sets and the near zone where the series in 1/dnu^2 holds
+    // are summed for 16 states at a time on the matrix cores (k_voigt_edge_mx): skip them here.
     // iz != NULL: the lines [E0,Z0) U [Z1,E1) of the tile's parent interval (tile >> ishift, smallest interval size) were
     // summed by k_voigt_cheb -- skip them here.
     // S = 1: one wave per tile.  S = 2, 4: the S waves of a tile split its window of lines into S parts of equal estimated
@@ -1065,23 +1069,25 @@ __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu
             sb0 = max(min(zi.Z1, w.W1), z.N1); sb1 = max(min(zi.E1, w.W1), sb0);
         }
         // what is left of the window after the matrix-core pieces, [wl, wr), and this wave's share [q0, q1) of it
-        int wl = w.W0, wr = w.W1;
-        if (edge) {
-            const int2 e = edge[(size_t)(k >> 4) * ntile + tile];
-            wl = e.x; wr = e.y;
+        int wl = w.W0, wr = w.W1, pL0 = sa1, pL1 = sa1, pR0 = sb0, pR1 = sb0;
+        if (EDGE) {   // (its own instantiation: on sparse tables the two extra clip windows cost more than they save)
+            const EdgeZone e = edge[(size_t)(k >> 4) * ntile + tile];
+            wl = e.eL; wr = e.eR;
+            if (e.mL1 > e.mL0) { pL0 = e.mL0; pL1 = e.mL1; }
+            if (e.mR1 > e.mR0) { pR0 = e.mR0; pR1 = e.mR1; }
         }
         int q0 = wl, q1 = wr;
         if (S > 1) {
             // piecewise-constant cost per line: 14 (far), 0 (skipped), 20 (4-term), 36 (near zone)
-            const int b8[8] = {wl, max(sa0, wl), sa1, z.N0, z.N1, sb0, min(sb1, wr), wr};
-            const int c7[7] = {14, 0, 20, 36, 20, 0, 14};
+            const int b12[12] = {wl, max(sa0, wl), sa1, pL0, pL1, z.N0, z.N1, pR0, pR1, sb0, min(sb1, wr), wr};
+            const int c11[11] = {14, 0, 20, 0, 20, 36, 20, 0, 20, 0, 14};
             int total = 0;
-            for (int q = 0; q < 7; q++) total += (b8[q + 1] - b8[q]) * c7[q];
+            for (int q = 0; q < 11; q++) total += (b12[q + 1] - b12[q]) * c11[q];
             auto cut_at = [&](int target) {
                 int accu = 0;
-                for (int q = 0; q < 7; q++) {
-                    const int seg = (b8[q + 1] - b8[q]) * c7[q];
-                    if (c7[q] > 0 && accu + seg >= target) return b8[q] + (target - accu) / c7[q];
+                for (int q = 0; q < 11; q++) {
+                    const int seg = (b12[q + 1] - b12[q]) * c11[q];
+                    if (c11[q] > 0 && accu + seg >= target) return b12[q] + (target - accu) / c11[q];
                     accu += seg;
                 }
                 return wr;
@@ -1089,8 +1095,8 @@ __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu
             q0 = part == 0 ? wl : cut_at((int)((long long)total * part / S));
             q1 = part == S - 1 ? wr : cut_at((int)((long long)total * (part + 1) / S));
         }
-        const int cw_lo[3] = {wl, sa1, sb1}, cw_hi[3] = {sa0, sb0, wr};
-        for (int cw = 0; cw < 3; cw++) {
+        const int cw_lo[5] = {wl, sa1, EDGE ? pL1 : sb1, pR1, sb1}, cw_hi[5] = {sa0, EDGE ? pL0 : sb0, EDGE ? pR0 : wr, sb0, wr};
+        for (int cw = 0; cw < (EDGE ? 5 : 3); cw++) {
         const int p0 = max(q0, cw_lo[cw]), p1 = min(q1, cw_hi[cw]);
         if (p0 >= p1) continue;
 #define LO(x) max((x), p0)
@@ -1207,13 +1213,14 @@ struct EdgeArgs {
     const WaveWin *win;
     const Zone *zones;
     const IZone *iz;      // lowest interpolation level, or NULL
-    int2 *out;            // [ngrp][ntile]: k_voigt_far keeps [x, y) of the window
+    EdgeZone *out;        // [ngrp][ntile]
     int64_t nnu;
     int ntile, K, ngrp, nI, ishift;
     double mu_min, cut;
 };
-// per (state group, tile): the window ends common to the group's states -- left of every state's first interpolated or near-zone
-// line, right of the last -- clipped to the distance at which the 4-term series holds for the widest line of the group
+// per (state group, tile): the pieces common to the group's states -- the window ends left of every state's first interpolated or
+// near-zone line and right of the last; between every state's interpolated sets and near zone -- clipped to the distance at which
+// the 4-term series holds for the widest line of the group
 __device__ __forceinline__ void edgezones_body(unsigned bid, const EdgeArgs &a)
 {
     const int idx = bid * blockDim.x + threadIdx.x;
@@ -1222,19 +1229,19 @@ __device__ __forceinline__ void edgezones_body(unsigned bid, const EdgeArgs &a)
     const int64_t i0 = (int64_t)t * 64, i1 = (i0 + 63 < a.nnu ? i0 + 63 : a.nnu - 1);
     const double vlo = a.nu[i0], vhi = a.nu[i1];
     const WaveWin w = a.win[t];
-    int eL = w.W1, eR = w.W0;
+    int eL = w.W1, eR = w.W0, mL0 = w.W0, mL1 = w.W1, mR0 = w.W0, mR1 = w.W1;
     double R = 0.0;
     for (int k = g * 16; k < min(g * 16 + 16, a.K); k++) {
         const Zone z = a.zones[(size_t)k * a.ntile + t];
-        int sa0 = z.M0, sb1 = z.M1;   // (as k_voigt_far)
+        int sa0 = z.M0, sa1 = z.M0, sb0 = z.M1, sb1 = z.M1;   // (as k_voigt_far)
         if (a.iz) {
             const IZone zi = a.iz[(size_t)k * a.nI + (t >> a.ishift)];
-            sa0 = min(max(zi.E0, w.W0), z.N0);
-            const int sb0 = max(min(zi.Z1, w.W1), z.N1);
-            sb1 = max(min(zi.E1, w.W1), sb0);
+            sa0 = min(max(zi.E0, w.W0), z.N0); sa1 = min(max(zi.Z0, sa0), z.N0);
+            sb0 = max(min(zi.Z1, w.W1), z.N1); sb1 = max(min(zi.E1, w.W1), sb0);
         }
-        eL = min(eL, sa0);
-        eR = max(eR, sb1);
+        eL = min(eL, sa0); eR = max(eR, sb1);
+        mL0 = max(mL0, sa1); mL1 = min(mL1, z.N0);
+        mR0 = max(mR0, z.N1); mR1 = min(mR1, sb0);
         const double amax = ((vhi + a.cut) / kC) * sqrt(2.0 * kRgas * a.Tk[k]) / sqrt(a.mu_min);
         const double gb = a.gbound[k];
         R = fmax(R, 133.6 * sqrt(gb * gb + 4.33 * amax * amax) * (1.0 + 1e-6));
@@ -1242,11 +1249,18 @@ __device__ __forceinline__ void edgezones_body(unsigned bid, const EdgeArgs &a)
     const double *__restrict__ nul = a.nul;
     auto lower = [&](double val, int p, int q) { while (p < q) { const int m = (p + q) >> 1; if (nul[m] < val) p = m + 1; else q = m; } return p; };
     auto upper = [&](double val, int p, int q) { while (p < q) { const int m = (p + q) >> 1; if (nul[m] <= val) p = m + 1; else q = m; } return p; };
-    eL = max(min(eL, lower(vlo - R, w.W0, w.W1)), w.W0);
-    eR = min(max(eR, upper(vhi + R, eL, w.W1)), w.W1);
-    if (eL - w.W0 < 8) eL = w.W0;   // (too short to be worth a wave's trip)
-    if (w.W1 - eR < 8) eR = w.W1;
-    a.out[idx] = make_int2(eL, eR);
+    const int S0 = lower(vlo - R, w.W0, w.W1), S1 = upper(vhi + R, S0, w.W1);   // the series holds in [W0, S0) and [S1, W1)
+    EdgeZone e;
+    e.eL = max(min(eL, S0), w.W0);
+    e.eR = min(max(eR, S1), w.W1);
+    if (e.eL - w.W0 < 8) e.eL = w.W0;   // (too short to be worth a wave's trip)
+    if (w.W1 - e.eR < 8) e.eR = w.W1;
+    e.mL0 = mL0; e.mL1 = min(mL1, S0);
+    e.mR0 = max(mR0, S1); e.mR1 = mR1;
+    if (e.mL1 - e.mL0 < 8 || e.mL0 < e.eL) e.mL0 = e.mL1 = 0;
+    if (e.mR1 - e.mR0 < 8 || e.mR1 > e.eR) e.mR0 = e.mR1 = 0;
+    e.pad0 = e.pad1 = 0;
+    a.out[idx] = e;
 }
 // k_sepzones and the edge zones in one launch (both need the zones of k_gas_setup)
 __global__ __launch_bounds__(256) void k_mxzones(unsigned nb_sep, SepArgs sa, EdgeArgs ea)
@@ -1256,15 +1270,15 @@ __global__ __launch_bounds__(256) void k_mxzones(unsigned nb_sep, SepArgs sa, Ed
 }
 
 __global__ __launch_bounds__(256) void k_voigt_edge_mx(const double *__restrict__ nu, int64_t nnu, int64_t L, const LineHot *__restrict__ hot,
-                                                       const WaveWin *__restrict__ win, const int2 *__restrict__ edge, int ntile, int K,
+                                                       const WaveWin *__restrict__ win, const EdgeZone *__restrict__ edge, int ntile, int K,
                                                        double cut, double *__restrict__ sigma)
 {
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int tile = blockIdx.x * 4 + wv, g = blockIdx.y;
     if (tile >= ntile) return;
     const WaveWin w = win[tile];
-    const int2 e = edge[(size_t)g * ntile + tile];
-    if (e.x <= w.W0 && e.y >= w.W1) return;
+    const EdgeZone e = edge[(size_t)g * ntile + tile];
+    if (e.eL <= w.W0 && e.eR >= w.W1 && e.mL1 <= e.mL0 && e.mR1 <= e.mR0) return;
     const int lr = lane & 15, lq = lane >> 4;
     const int kk = min(g * 16 + lr, K - 1);                       // (a group's tail states re-read the last one: never stored)
     const LineHot *__restrict__ hk = hot + (size_t)kk * L;
@@ -1303,9 +1317,10 @@ __global__ __launch_bounds__(256) void k_voigt_edge_mx(const double *__restrict_
             acc[st] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4, w4, acc[st], 0, 0, 0);
         }
     };
-    for (int pp = 0; pp < 2; pp++) {   // left end ascending, right end descending: far lines first
-        const bool asc = pp == 0;
-        const int ja = asc ? w.W0 : e.y, jb = asc ? e.x : w.W1;
+    for (int pp = 0; pp < 4; pp++) {   // left pieces ascending, right pieces descending: far lines first
+        const bool asc = pp < 2;
+        const int ja = pp == 0 ? w.W0 : (pp == 1 ? e.mL0 : (pp == 2 ? e.eR : e.mR0));
+        const int jb = pp == 0 ? e.eL : (pp == 1 ? e.mL1 : (pp == 2 ? w.W1 : e.mR1));
         if (ja >= jb) continue;
         const int nst = (jb - ja + 3) >> 2;
         const int b0 = asc ? ja + lq : jb - 4 + lq, db = asc ? 4 : -4;

@@ -99,6 +99,26 @@ int main()
                                  which == 0 ? "" : "");
         }
     }
+    // do the two kernels overlap when launched on two streams?  (matrix pipe vs fp64 vector unit)
+    {
+        hipStream_t s1, s2; (void)hipStreamCreateWithFlags(&s1, hipStreamNonBlocking); (void)hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+        double *dF2; (void)hipMalloc(&dF2, (size_t)nI * 64 * 64 * 8);
+        hipEvent_t a0, a1, b1; (void)hipEventCreate(&a0); (void)hipEventCreate(&a1); (void)hipEventCreate(&b1);
+        for (int mode = 0; mode < 2; mode++)
+            for (int rep = 0; rep < 3; rep++) {
+                (void)hipDeviceSynchronize();
+                (void)hipEventRecord(a0, s1);
+                (void)hipStreamWaitEvent(s2, a0, 0);
+                hipStream_t sb = mode == 0 ? s1 : s2;
+                hipLaunchKernelGGL(k_sep, dim3(nI), dim3(256), 0, s1, dn, dl, dC, L, lpi, dF);
+                hipLaunchKernelGGL(k_classic, dim3(nI * (K / 4)), dim3(256), 0, sb, dn, dh, L, lpi, K, dF2);
+                (void)hipEventRecord(b1, sb);
+                (void)hipStreamWaitEvent(s1, b1, 0);
+                (void)hipEventRecord(a1, s1); (void)hipEventSynchronize(a1);
+                float ms; (void)hipEventElapsedTime(&ms, a0, a1);
+                if (rep == 2) printf("%s: %.3f ms for both\n", mode == 0 ? "one stream (back to back)" : "two streams             ", ms);
+            }
+    }
     const double mfma = (double)nI * 4 * (lpi / 4) * 16;   // matrix instructions
     printf("matrix instructions %.3e; at 47 TFLOP/s (2048 flop each): %.3f ms\n", mfma, mfma * 2048 / 47e12 * 1e3);
     return 0;
