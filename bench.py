@@ -167,10 +167,10 @@ def main():
     lines_total = sum(len(g.sl.nu) for g in col.gases)
     # k_voigt_far (one launch per gas), the longest kernel.  Algorithmic HBM bytes per launch: the 32-B
     # record of every (node, line) read once + sigma written (8 B per (nu, node)) + sigma re-read when it accumulates (a later
-    # gas, or onto the interpolated far wings) + the 16-B near-line index ranges handed to k_voigt_near per (nu, node) + nu.
+    # gas, or onto the interpolated far wings) + the 8-B near-line index words handed to k_voigt_near per (nu, node) + nu.
     work = col.work()
     interp_on = work["levels"] > 0
-    far_bytes = [32 * K * len(g.sl.nu) + 8 * col.nnu * K * (2 if (gi > 0 or interp_on) else 1) + 16 * col.nnu * K + 8 * col.nnu
+    far_bytes = [32 * K * len(g.sl.nu) + 8 * col.nnu * K * (2 if (gi > 0 or interp_on) else 1) + 8 * col.nnu * K + 8 * col.nnu
                  for gi, g in enumerate(col.gases)]
     far_ms = prof["far"] / max(ngas, 1)
     alg = float(np.mean(far_bytes)) if far_bytes else 0.0
@@ -194,9 +194,19 @@ def main():
         pass
     # fp64 VALU view of the three line kernels: evaluations actually issued (per-point ones count all 64 lanes of a wave, node
     # ones 64 nodes per (interval, line)) x 24 flops, over their time.  `reference_pair_evals` is what surf! evaluates.
-    evals = work["direct_evals"] + work["node_evals"]
+    # (node_evals counts every node sum; node_evals_matrix / direct_evals_matrix of them / besides direct_evals run on the matrix cores)
+    mx_triples = work.get("node_evals_matrix", 0) + work.get("direct_evals_matrix", 0)
+    evals = work["direct_evals"] + work["node_evals"] - work.get("node_evals_matrix", 0)
     flops = evals * FLOPS_PER_PAIR
     line_ms = prof["nodes"] + prof["far"] + prof["near"]
+    mx_ms = prof.get("nodes_mx", 0.0) + prof.get("far_mx", 0.0)
+    # matrix cores: 4 terms x (multiply + add) per (node | point, line, state); v_mfma_f64_16x16x4 = 2048 flop.  Spec peak of the fp64
+    # matrix path = the fp64 vector rate (78.6 TFLOP/s); tools/ubench/mfma_f64_rate.hip sustains 47, and a matrix and a vector
+    # kernel launched side by side on two streams take the sum of their times (tools/ubench/sep_nodes.hip): one fp64 pipe, two ways in
+    matrix_fp64 = dict(triples=mx_triples, flops=8.0 * mx_triples, ms=mx_ms,
+                       achieved=8.0 * mx_triples / (mx_ms * 1e-3) / 1e12 if mx_ms > 0 else 0.0, peak=FP64_VALU_PEAK_TFLOPS, unit="TFLOP/s",
+                       frac=8.0 * mx_triples / (mx_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS if mx_ms > 0 else 0.0,
+                       measured_mfma_f64_rate=47.0, kernels="k_cheb_nodes_mx + k_voigt_edge_mx")
     # measured instruction mix: lane-instructions each far-wing kernel issues = sum over its loop bodies of (lines x 64 lanes) x VALU
     # instructions per line (ISA), over its HIP-event time, against the fp64-rate issue peak (all 64 lanes of a wave count, also
     # those the cut-off predicate masks)
@@ -217,7 +227,7 @@ def main():
                                    evals_issued=evals, direct_evals=work["direct_evals"], node_evals=work["node_evals"],
                                    reference_pair_evals=cnt["pair_evals"], flops_per_eval=FLOPS_PER_PAIR,
                                    kernels="k_cheb_nodes + k_voigt_far + k_voigt_near"),
-                    valu_issue=valu_issue,
+                    valu_issue=valu_issue, matrix_fp64=matrix_fp64,
                     interp_levels=work["levels"], kernel_ms=prof)
 
     # the drop-in entry point (cs_fluxes_discretized: host pointers in, host arrays out, what the Julia method calls per

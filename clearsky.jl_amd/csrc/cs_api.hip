@@ -652,7 +652,7 @@ static bool edge_in_use(bool have_edge, bool always, int ntiles, int kn, bool lo
 void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, int64_t jrange1, int kn, const double *Tk, const double *Pk, const double *Ppk,
                 const double *scale, LineHot *hot, LineCold *cold, const double *dnu, int64_t nnu, int ntile256,
                 const int32_t *J0, const int32_t *J1, const WaveWin *win, int xtiles, Zone *zones, int2 *ranges, const double *gbound, double cut, double base,
-                const double *extra, double *sigma, int accumulate, hipEvent_t *evg,   // NULL or 3 events: after K1, nodes, far
+                const double *extra, double *sigma, int accumulate, hipEvent_t *evg,   // NULL or 5 events: after K1 (+ zones), nodes (vector unit), nodes (matrix cores), far (vector unit), far (matrix cores)
                 LineF32 *hot32 = nullptr, double far_s = 1e6, Interp itp = Interp(), ChebApply *defer = nullptr, PhScratch *ph = nullptr)
 {
     // only the lines some window can reach (windows are sorted: first tile's start .. last tile's end)
@@ -687,7 +687,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
             nb_iz = (unsigned)(((int64_t)(itp.nItot - itp.ioff[itp.l0]) * kn + 255) / 256);
         }
         hipLaunchKernelGGL(k_gas_setup, dim3(nb_prep + nb_zones + nb_iz), dim3(256), 0, s, nb_prep, nb_zones, pa, za, P, itp.iz);
-        if (evg) (void)hipEventRecord(evg[0], s);
+        if (evg && itp.nlev == 0) (void)hipEventRecord(evg[0], s);
         if (itp.nlev > 0) {   // sigma = base + extra + interpolated far wings; the per-point kernels add the rest
             const int q0 = itp.ioff[itp.l0];
             // deferred apply: the gases of a column add their node sums into ONE F (levels an earlier gas has written accumulate)
@@ -710,6 +710,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
                 const unsigned nb_edge = use_edge ? (unsigned)(((int64_t)nt64 * ngrp + 255) / 256) : 0u;
                 hipLaunchKernelGGL(k_mxzones, dim3(nb_sep + nb_edge), dim3(256), 0, s, nb_sep, sa, ea);
             }
+            if (evg) (void)hipEventRecord(evg[0], s);
             const SepZone *sepz = use_sep ? itp.sep : nullptr;
             if (lor)
                 hipLaunchKernelGGL((k_cheb_nodes<false, true>), gridn, dim3(256), 0, s, itp.nodes, G.L, hot, hot32, G.nu.as<double>(), itp.iz,
@@ -720,10 +721,11 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
             else
                 hipLaunchKernelGGL((k_cheb_nodes<false, false>), gridn, dim3(256), 0, s, itp.nodes, G.L, hot, hot32, G.nu.as<double>(), itp.iz,
                                    itp.nItot, q0, q_acc, kn, itp.Kpad, cut, itp.F, sepz);
+            if (evg) (void)hipEventRecord(evg[1], s);
             if (use_sep)
                 hipLaunchKernelGGL(k_cheb_nodes_mx, dim3((unsigned)(itp.nItot - q0) * (unsigned)ngrp), dim3(256), 0, s, itp.nodes, G.L, hot, itp.sep,
                                    itp.nItot, q0, kn, itp.Kpad, ngrp, itp.F);
-            if (evg) (void)hipEventRecord(evg[1], s);
+            if (evg) (void)hipEventRecord(evg[2], s);
             ChebApply A0;
             ChebApply &A = defer ? *defer : A0;
             if (!defer) A.ngas = 0;
@@ -749,6 +751,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
             ishift = A.shift[low];
         } else if (evg) {
             (void)hipEventRecord(evg[1], s);
+            (void)hipEventRecord(evg[2], s);
         }
         const int nblk = (nt64 + 3) / 4;
 
@@ -777,10 +780,11 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
         }
 #undef CS_FAR_LAUNCH
 #undef CS_LOR_LAUNCH
+        if (evg) (void)hipEventRecord(evg[3], s);
         if (use_edge)
             hipLaunchKernelGGL(k_voigt_edge_mx, dim3((unsigned)((nt64 + 3) / 4), (unsigned)((kn + 15) / 16)), dim3(256), 0, s, dnu, nnu, G.L, hot, win,
                                itp.edge, nt64, kn, cut, sigma);
-        if (evg) (void)hipEventRecord(evg[2], s);
+        if (evg) (void)hipEventRecord(evg[4], s);
         if (!lor) {
             const int ngrp = (nt64 + CS_NEAR_R - 1) / CS_NEAR_R;   // near kernels: one wave = CS_NEAR_R consecutive tiles
             const dim3 gridq((unsigned)((ngrp + 3) / 4), kn);
@@ -805,10 +809,10 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
         pw.nu = dnu; pw.nul = G.nu.as<double>(); pw.nnu = nnu; pw.ntile = nt64; pw.J0 = (int32_t)jlo; pw.J1 = (int32_t)jhi; pw.cut = cut;
         pw.out = ph->win.as<PhWin>();
         hipLaunchKernelGGL(k_phwin, dim3((unsigned)((nt64 + 255) / 256)), dim3(256), 0, s, pw);
-        if (evg) { (void)hipEventRecord(evg[0], s); (void)hipEventRecord(evg[1], s); }
+        if (evg) { (void)hipEventRecord(evg[0], s); (void)hipEventRecord(evg[1], s); (void)hipEventRecord(evg[2], s); }
         hipLaunchKernelGGL(k_phco2, dim3((unsigned)((nt64 + 3) / 4), kn), dim3(256), 0, s, dnu, nnu, G.L, hot, cold, ph->fac.as<double>(), ph->nu_c,
                            ph->win.as<PhWin>(), zones, nt64, cut, Tk, kn, base, extra, sigma, accumulate);
-        if (evg) (void)hipEventRecord(evg[2], s);
+        if (evg) { (void)hipEventRecord(evg[3], s); (void)hipEventRecord(evg[4], s); }
     } else {
         if (nb_prep > 0) {
             ZoneArgs za;
@@ -817,10 +821,10 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
             memset(&P, 0, sizeof P);
             hipLaunchKernelGGL(k_gas_setup, dim3(nb_prep), dim3(256), 0, s, nb_prep, 0u, pa, za, P, (IZone *)nullptr);
         }
-        if (evg) { (void)hipEventRecord(evg[0], s); (void)hipEventRecord(evg[1], s); }
+        if (evg) { (void)hipEventRecord(evg[0], s); (void)hipEventRecord(evg[1], s); (void)hipEventRecord(evg[2], s); }
         launch_linesum_shape(shape, dim3(ntile256, kn), s, dnu, nnu, G.L, hot, cold, J0, J1, cut, Tk, base, extra, sigma,
                              accumulate);
-        if (evg) (void)hipEventRecord(evg[2], s);
+        if (evg) { (void)hipEventRecord(evg[3], s); (void)hipEventRecord(evg[4], s); }
     }
 }
 
@@ -1850,7 +1854,7 @@ static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e)
                    cg.J1.as<int32_t>(), cg.win.as<WaveWin>(), cg.xtiles, cg.zones.as<Zone>(), c.ranges.as<int2>(), cg.gmax.as<double>(), cg.cut, c.sigma_gray, extra, sig, gi > 0,
                    ev ? ev + e : nullptr,
                    (ctx->mixed && cg.shape == SH_VOIGT) ? ctx->hot32.as<LineF32>() : nullptr, ctx->far_s, itp, &apply, &ctx->ph);
-        if (ev) { e += 3; HIPCHK(hipEventRecord(ev[e++], s)); }
+        if (ev) { e += 5; HIPCHK(hipEventRecord(ev[e++], s)); }
     }
     // interpolated far wings of all gases: sigma += sum_level C (sum_gas F)  (one pass over C and sigma)
     if (apply.ngas > 0) launch_apply(s, apply, cheb_kpad(K), c.nnu, K, 0.0, nullptr, sig, 1);
@@ -1907,26 +1911,26 @@ int cs_column_profile(cs_ctx *ctx, void *stream, int reps, double *ms)
     Column &c = ctx->col;
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     HIPCHK(hipSetDevice(ctx->device));
-    const int nev = 4 * c.ngas + 4;
+    const int nev = 6 * c.ngas + 4;
     std::vector<hipEvent_t> ev(nev);
     for (auto &e : ev) HIPCHK(hipEventCreate(&e));
-    for (int i = 0; i < 7; i++) ms[i] = 0.0;
+    for (int i = 0; i < 9; i++) ms[i] = 0.0;
     int rc = CS_OK;
     for (int r = 0; r < reps && rc == CS_OK; r++) {
         rc = run_impl(ctx, s, ev.data());
         if (rc) break;
         if (hipStreamSynchronize(s) != hipSuccess) { rc = fail(CS_EHIP, "hipStreamSynchronize failed"); break; }
         float t;
-        const int slot[4] = {0, 1, 3, 4};   // per gas: K1, nodes, far, near
+        const int slot[6] = {0, 1, 7, 3, 8, 4};   // per gas: K1 + zones, nodes, nodes on the matrix cores, far, far on the matrix cores, near
         for (int gi = 0; gi < c.ngas; gi++)
-            for (int q = 0; q < 4; q++) { (void)hipEventElapsedTime(&t, ev[4 * gi + q], ev[4 * gi + q + 1]); ms[slot[q]] += t; }
-        const int b = 4 * c.ngas;
+            for (int q = 0; q < 6; q++) { (void)hipEventElapsedTime(&t, ev[6 * gi + q], ev[6 * gi + q + 1]); ms[slot[q]] += t; }
+        const int b = 6 * c.ngas;
         (void)hipEventElapsedTime(&t, ev[b], ev[b + 1]); ms[2] += t;       // apply (+ baked tables, CIA)
         (void)hipEventElapsedTime(&t, ev[b + 1], ev[b + 2]); ms[5] += t;   // rt
         (void)hipEventElapsedTime(&t, ev[b + 2], ev[b + 3]); ms[6] += t;   // reduce
     }
     for (auto &e : ev) (void)hipEventDestroy(e);
-    for (int i = 0; i < 7; i++) ms[i] /= reps;
+    for (int i = 0; i < 9; i++) ms[i] /= reps;
     return rc;
 }
 
