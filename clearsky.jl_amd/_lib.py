@@ -72,6 +72,9 @@ SIGNATURES = {
     "cs_column_update_state": (C.c_int, [_vp, _dp, _dp, _dp, _dp, _dp]),
     "cs_par_count": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64)]),
     "cs_par_parse": (C.c_int, [C.c_char_p, C.c_int64, C.POINTER(C.c_int16), C.c_char_p, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
+    "cs_gas_upload_par": (C.c_int, [_vp, C.c_int, C.c_char_p, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_int), C.c_int, C.c_int64,
+                                    C.c_int, _dp, C.c_int, C.POINTER(C.c_int32), _dp, C.POINTER(C.c_int64)]),
+    "cs_gas_fetch": (C.c_int, [_vp, C.c_int, C.c_int64, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.POINTER(C.c_int16)]),
     "cs_streamnodes": (C.c_int, [C.c_int, _dp, _dp]),
     "cs_lobattonodes": (C.c_int, [C.c_int, _dp, _dp]),
     "cs_faddeeva_batch": (C.c_int, [_vp, C.c_int64, _dp, _dp, _dp]),

@@ -256,13 +256,7 @@ class Context:
         key = id(sl)
         if key in self._slots:
             return self._slots[key][0]
-        if len(self._slots) >= CS_MAX_GAS:
-            # evict the oldest table
-            old = next(iter(self._slots))
-            slot = self._slots.pop(old)[0]
-        else:
-            slot = self._next
-            self._next += 1
+        slot = self._take_slot()
         iso = np.ascontiguousarray(sl.I, dtype=np.int16)
         ncheb = np.ascontiguousarray(sl.ncheb, dtype=np.int32)
         cheb = as_f64(sl.cheb)
@@ -274,6 +268,42 @@ class Context:
         self._slots[key] = (slot, sl)
         return slot
 
+
+    def _take_slot(self):
+        if len(self._slots) >= CS_MAX_GAS:   # evict the oldest table
+            old = next(iter(self._slots))
+            return self._slots.pop(old)[0]
+        slot = self._next
+        self._next += 1
+        return slot
+
+    def load_par(self, filename: str, M: int, numin: float = 0.0, numax: float = np.inf, Scut: float = 0.0, I=(),
+                 maxlines: int = -1) -> SpectralLines:
+        """A HITRAN .par file straight into a gas slot of this context (cs_gas_upload_par: parse, filter, strongest-N, sort,
+        MOLPARAM lookup and upload on the native side -- hitran/par.jl:91-286 without host arrays in between).  Returns the
+        SpectralLines mirror of what was loaded (arrays copied back from the slot), already bound to the slot, so gases built
+        on it do not upload again.  `M`: the molecule the file holds (its MOLPARAM rows go along)."""
+        from .hitran import MOLPARAM, ISOINDEX
+        if not filename.endswith(".par"):
+            raise AssertionError("expected file with .par extension, downloaded from https://hitran.org/lbl/")
+        mp = MOLPARAM[M]
+        keep = np.array([ISOINDEX[c] if isinstance(c, str) else int(c) for c in I], dtype=np.int32)
+        mu = as_f64(mp.mu)
+        ncheb = np.ascontiguousarray(mp.ncheb_table(), dtype=np.int32)
+        cheb = as_f64(mp.cheb_table())
+        slot = self._take_slot()
+        L = C.c_int64()
+        check(lib().cs_gas_upload_par(self._h, slot, filename.encode(), float(numin), float(min(numax, 1e300)), float(Scut),
+                                      keep.ctypes.data_as(C.POINTER(C.c_int)), len(keep), int(maxlines), int(M), dptr(mu), len(mu),
+                                      ncheb.ctypes.data_as(C.POINTER(C.c_int32)), dptr(cheb), C.byref(L)))
+        n = L.value
+        a = {k: np.zeros(n) for k in ("nu", "S", "gamma_a", "gamma_s", "Epp", "na")}
+        iso = np.zeros(n, dtype=np.int16)
+        check(lib().cs_gas_fetch(self._h, slot, n, dptr(a["nu"]), dptr(a["S"]), dptr(a["gamma_a"]), dptr(a["gamma_s"]), dptr(a["Epp"]),
+                                 dptr(a["na"]), None, iso.ctypes.data_as(C.POINTER(C.c_int16))))
+        sl = SpectralLines(dict(M=np.full(n, M, np.int16), I=iso, **a))
+        self._slots[id(sl)] = (slot, sl)
+        return sl
 
     def cia_slot(self, x: CIATables) -> int:
         """Upload a CIATables object (once) and return its slot."""

@@ -2279,6 +2279,88 @@ int cs_par_parse(const char *filename, int64_t n, int16_t *M, char *I, double *n
     return CS_OK;
 }
 
+// ISOINDEX, par.jl:6-13: '1'..'9' -> 1..9, '0' -> 10, 'A'..'Z' -> 11..36; 0 = not an isotopologue character
+static int iso_index(char c)
+{
+    if (c >= '1' && c <= '9') return c - '0';
+    if (c == '0') return 10;
+    if (c >= 'A' && c <= 'Z') return 11 + (c - 'A');
+    return 0;
+}
+
+int cs_gas_upload_par(cs_ctx *ctx, int slot, const char *filename, double numin, double numax, double Scut, const int *iso_keep,
+                      int n_iso_keep, int64_t maxlines, int M_expected, const double *mu_table, int niso, const int32_t *ncheb,
+                      const double *cheb, int64_t *L_out)
+{
+    if (!ctx || !filename || !mu_table || !ncheb || !cheb || niso < 1) return fail(CS_EINVAL, "bad arguments");
+    int64_t n = 0;
+    int rc;
+    if ((rc = cs_par_count(filename, &n))) return rc;
+    std::vector<int16_t> M(n);
+    std::vector<char> I(n);
+    std::vector<double> nu(n), S(n), A(n), ga(n), gs(n), Epp(n), na(n), da(n);
+    if ((rc = cs_par_parse(filename, n, M.data(), I.data(), nu.data(), S.data(), A.data(), ga.data(), gs.data(), Epp.data(), na.data(), da.data())))
+        return rc;
+    // par.jl:153-175: wavenumber range, intensity cut, isotopologue list
+    std::vector<int64_t> keep;
+    keep.reserve(n);
+    for (int64_t i = 0; i < n; i++) {
+        if (!(nu[i] >= numin && nu[i] <= numax && S[i] >= Scut)) continue;
+        if (n_iso_keep > 0) {
+            const int ii = iso_index(I[i]);
+            bool ok = false;
+            for (int q = 0; q < n_iso_keep; q++) ok = ok || iso_keep[q] == ii;
+            if (!ok) continue;
+        }
+        keep.push_back(i);
+    }
+    if (keep.empty()) return fail(CS_EINVAL, "par information has been filtered to nothing!");   // par.jl:172
+    // par.jl:177-186: the `maxlines` strongest lines (N is the unfiltered count there); order of equal intensities as the host
+    // mirror produces it: ascending stable sort, reversed
+    if (maxlines > 0 && n > maxlines) {
+        std::stable_sort(keep.begin(), keep.end(), [&](int64_t a, int64_t b) { return S[a] < S[b]; });
+        std::reverse(keep.begin(), keep.end());
+        if ((int64_t)keep.size() > maxlines) keep.resize((size_t)maxlines);
+    }
+    std::stable_sort(keep.begin(), keep.end(), [&](int64_t a, int64_t b) { return nu[a] < nu[b]; });   // par.jl:188-191
+    const int64_t L = (int64_t)keep.size();
+    std::vector<double> o_nu(L), o_S(L), o_ga(L), o_gs(L), o_E(L), o_na(L), o_mu(L);
+    std::vector<int16_t> o_iso(L);
+    for (int64_t j = 0; j < L; j++) {
+        const int64_t i = keep[j];
+        if (M[i] != M_expected)   // SpectralLines holds one molecule (par.jl:239); the MOLPARAM rows handed in belong to M_expected
+            return fail(CS_EINVAL, "record %lld is molecule %d, expected %d: SpectralLines objects must contain only one molecule's lines",
+                        (long long)i, (int)M[i], M_expected);
+        const int ii = iso_index(I[i]);
+        if (ii < 1 || ii > niso) return fail(CS_EINVAL, "isotopologue '%c' of record %lld has no MOLPARAM row (%d rows)", I[i], (long long)i, niso);
+        o_nu[j] = nu[i]; o_S[j] = S[i]; o_ga[j] = ga[i]; o_gs[j] = gs[i]; o_E[j] = Epp[i]; o_na[j] = na[i];
+        o_iso[j] = (int16_t)ii;
+        o_mu[j] = mu_table[ii - 1];
+    }
+    if (L_out) *L_out = L;
+    return cs_gas_upload(ctx, slot, L, o_nu.data(), o_S.data(), o_ga.data(), o_gs.data(), o_E.data(), o_na.data(), o_mu.data(), o_iso.data(),
+                         niso, ncheb, cheb);
+}
+
+int cs_gas_fetch(cs_ctx *ctx, int slot, int64_t L, double *nu, double *S, double *gamma_a, double *gamma_s, double *Epp, double *na,
+                 double *mu_iso, int16_t *iso)
+{
+    if (!ctx || slot < 0 || slot >= CS_MAX_GAS || !ctx->gas[slot].present) return fail(CS_EINVAL, "gas slot is empty");
+    GasTable &G = ctx->gas[slot];
+    if (L != G.L) return fail(CS_EINVAL, "slot holds %lld lines, caller expects %lld", (long long)G.L, (long long)L);
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t nb = (size_t)L * sizeof(double);
+    if (nu) HIPCHK(hipMemcpy(nu, G.nu.p, nb, hipMemcpyDeviceToHost));
+    if (S) HIPCHK(hipMemcpy(S, G.S.p, nb, hipMemcpyDeviceToHost));
+    if (gamma_a) HIPCHK(hipMemcpy(gamma_a, G.ga.p, nb, hipMemcpyDeviceToHost));
+    if (gamma_s) HIPCHK(hipMemcpy(gamma_s, G.gs.p, nb, hipMemcpyDeviceToHost));
+    if (Epp) HIPCHK(hipMemcpy(Epp, G.Epp.p, nb, hipMemcpyDeviceToHost));
+    if (na) HIPCHK(hipMemcpy(na, G.na.p, nb, hipMemcpyDeviceToHost));
+    if (mu_iso) HIPCHK(hipMemcpy(mu_iso, G.mu.p, nb, hipMemcpyDeviceToHost));
+    if (iso) HIPCHK(hipMemcpy(iso, G.iso.p, (size_t)L * sizeof(int16_t), hipMemcpyDeviceToHost));
+    return CS_OK;
+}
+
 int cs_streamnodes(int n, double *m, double *W)
 {
     if (n < 1 || n > CS_MAX_STREAM) return fail(CS_EINVAL, "nstream must be in [1,%d]", CS_MAX_STREAM);

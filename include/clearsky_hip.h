@@ -234,6 +234,21 @@ int cs_column_update_state(cs_ctx *ctx, const double *T_nodes, const double *mu_
 int cs_par_count(const char *filename, int64_t *n);
 int cs_par_parse(const char *filename, int64_t n, int16_t *M, char *I, double *nu, double *S, double *A, double *gamma_a,
                  double *gamma_s, double *Epp, double *na, double *delta_a);
+/*
+ * f3 to the letter -- a HITRAN .par file straight into a gas slot, no host-language arrays in between: readpar
+ * (hitran/par.jl:91-193: parse, nu range / intensity cut / isotopologue filter :153-175, the `maxlines` strongest :177-186, stable
+ * sort by wavenumber :188-191) + SpectralLines (:224-286: one molecule only, isotopologue numbers through ISOINDEX :6-13, molar
+ * masses from MOLPARAM) + cs_gas_upload.
+ *   iso_keep[n_iso_keep] : isotopologue numbers to keep (0 entries: all);  maxlines <= 0: no limit
+ *   M_expected, mu_table[niso], ncheb[niso], cheb[niso][16] : the molecule and its MOLPARAM rows (src/hitran/molparam.jl)
+ *   *L_out : lines kept.  Errors: CS_EINVAL with the reference's messages (filtered to nothing, several molecules).
+ * cs_gas_fetch copies a slot's line arrays back (the host mirror of a table loaded this way; any pointer may be NULL).
+ */
+int cs_gas_upload_par(cs_ctx *ctx, int slot, const char *filename, double numin, double numax, double Scut, const int *iso_keep,
+                      int n_iso_keep, int64_t maxlines, int M_expected, const double *mu_table, int niso, const int32_t *ncheb,
+                      const double *cheb, int64_t *L_out);
+int cs_gas_fetch(cs_ctx *ctx, int slot, int64_t L, double *nu, double *S, double *gamma_a, double *gamma_s, double *Epp, double *na,
+                 double *mu_iso, int16_t *iso);
 
 /*
  * B thermal states of the resident column in one go: the np+1 perturbed profiles of jacobian! or the successive profiles of

@@ -226,3 +226,43 @@ def test_update_and_batch_vs_oracle(cs, O, lines):
                              sigma_gray=1e-27)
     assert np.max(np.abs(Fc[0] - r["Fup"])) < 1e-11 * r["Fup"].max()
     ctx.close()
+
+
+def test_par_file_straight_into_a_gas_slot(cs, O, ctx):
+    """f3 to the letter (hitran/par.jl:91-286): cs_gas_upload_par parses, filters (range, intensity cut, isotopologues), keeps the
+    strongest N, sorts, looks the molar masses up and uploads on the native side.  The slot's arrays are bit-equal to the Python
+    mirror's readpar + SpectralLines for several filter sets (also with isotopologue CHARACTERS, as the reference accepts), the
+    reference's error cases raise, and a column built on the natively loaded table matches the oracle."""
+    import workloads as W
+    f = W.fixture("CO2.par")
+    for kw in (dict(), dict(numin=600.0, numax=720.0), dict(Scut=1e-24, I=(1, 2)), dict(I=("1", "3")), dict(maxlines=300),
+               dict(numin=550.0, numax=800.0, Scut=1e-26, I=(1, 2, 3), maxlines=500)):
+        a = ctx.load_par(f, 2, **kw)
+        b = cs.SpectralLines(f, **kw)
+        assert a.N == b.N and a.M == b.M
+        for name in ("nu", "S", "gamma_a", "gamma_s", "Epp", "na", "mu", "A"):
+            assert np.array_equal(getattr(a, name), getattr(b, name)), (kw, name)
+        assert np.array_equal(a.I, b.I)
+        mu_dev = np.zeros(a.N)
+        cs.check(cs.lib().cs_gas_fetch(ctx.handle, ctx.slot_of(a), a.N, None, None, None, None, None, None,
+                                       mu_dev.ctypes.data_as(_dp), None))
+        assert np.array_equal(mu_dev, b.mu)                                    # (the MOLPARAM lookup happened on the native side)
+    with pytest.raises(cs.ClearSkyHIPError, match="filtered to nothing"):
+        ctx.load_par(f, 2, numin=1e5)
+    with pytest.raises(cs.ClearSkyHIPError, match="only one molecule"):
+        ctx.load_par(f, 1)                                                      # (the file holds CO2, not H2O)
+    with pytest.raises(AssertionError):
+        ctx.load_par(f + ".txt", 2)
+    sl = ctx.load_par(f, 2, numin=550.0, numax=800.0)
+    nslots = len(ctx._slots)
+    nu = np.linspace(600.0, 750.0, 3001)
+    P = cs.pressuregrid(10.0, 1e5, 13)
+    T = cs.AtmosphericProfile(P, np.linspace(210.0, 290.0, 13))
+    col = cs.Column(P, 9.8, T, 0.029, 0.0, 0.0, cs.DirectGas(sl, 400e-6, nu), core=cs.Discretized(4, 2), want_tau=True, ctx=ctx)
+    assert len(ctx._slots) == nslots                                           # bound to its slot: no second upload
+    col.run()
+    tau = np.zeros((col.nl, col.nnu), order="F")
+    Fup, Fdn = col.fetch(tau)
+    ref_sl = cs.SpectralLines(f, numin=550.0, numax=800.0)
+    r = O.fluxes_discretized(nu, P, 9.8, 2, col.Tn, col.mun, col.Tlev, [ref_sl], ["voigt"], [25.0], col.conc, nstream=4)
+    assert relerr(tau, r["tau"]) < 1e-11 and abs(Fup[0] - r["Fup"][0]) < 1e-11 * r["Fup"][0]
