@@ -131,18 +131,22 @@ def test_interp_fuzz(cs, O, seed):
     P = 10 ** rng.uniform(-1, 5.5, K)
     P[rng.random(K) < 0.1] = 0.0
     Pp = P * rng.uniform(0, 1, K)
-    on, off = cs.Context(0), cs.Context(0)
+    on, off, onv = cs.Context(0), cs.Context(0), cs.Context(0)
     off.set_interp(False)
+    on.set_matrix_cores(2)     # far lines on the matrix cores wherever the series holds (K2d, K2e), whatever the grid length
+    onv.set_matrix_cores(0)    # ... and everything on the vector unit
     a = cs.shape_batch(sl, "voigt", nu, list(T), list(P), list(Pp), cut, on)
+    av = cs.shape_batch(sl, "voigt", nu, list(T), list(P), list(Pp), cut, onv)
     b = cs.shape_batch(sl, "voigt", nu, list(T), list(P), list(Pp), cut, off)
-    assert np.array_equal(a == 0, b == 0)
+    assert np.array_equal(a == 0, b == 0) and np.array_equal(av == 0, b == 0)
     assert relerr(a, b, floor=1e-280) < 2e-13, (seed, kind, cs.interp_plan(nu, cut), relerr(a, b, floor=1e-280))
+    assert relerr(av, b, floor=1e-280) < 2e-13, (seed, kind, cs.interp_plan(nu, cut), relerr(av, b, floor=1e-280))
     idx = np.sort(rng.choice(len(nu), min(len(nu), 300), replace=False))
     for k in rng.choice(K, min(K, 3), replace=False):
         so = O.shape_bang("voigt", nu, sl, T[k], P[k], Pp[k], cut)[idx] if len(nu) <= 3000 else None
         if so is not None:
             assert relerr(a[k][idx], so, floor=1e-280) < 1e-11
-    on.close(); off.close()
+    on.close(); off.close(); onv.close()
 
 
 def test_interp_column_mixed_gases(cs, O):
@@ -159,6 +163,7 @@ def test_interp_column_mixed_gases(cs, O):
     for flag in (True, False):
         ctx = cs.Context(0)
         ctx.set_interp(flag)
+        ctx.set_matrix_cores(2)
         col = cs.Column(P, 9.8, T, 0.029, 1.0, 0.1, g1, g3, g2, cs.GrayGas(1e-27, nu), core=cs.Discretized(4, 3), theta_s=0.5, ctx=ctx)
         col.run()
         F = cs.FluxPack(len(P), len(nu))

@@ -21,6 +21,7 @@ STATES = [(220.0, 50.0, 0.02), (296.0, 101325.0, 40.53), (260.0, 3e3, 30.0), (19
 @pytest.fixture(scope="module")
 def ctx_on(cs):
     c = cs.Context(0)
+    c.set_matrix_cores(2)   # (the matrix-core kernels also on these short grids; the vector-only path: test_matrix_core_node_sums_on_off)
     yield c
     c.close()
 
