@@ -722,9 +722,13 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
                 hipLaunchKernelGGL((k_cheb_nodes<false, false>), gridn, dim3(256), 0, s, itp.nodes, G.L, hot, hot32, G.nu.as<double>(), itp.iz,
                                    itp.nItot, q0, q_acc, kn, itp.Kpad, cut, itp.F, sepz);
             if (evg) (void)hipEventRecord(evg[1], s);
-            if (use_sep)
-                hipLaunchKernelGGL(k_cheb_nodes_mx, dim3((unsigned)(itp.nItot - q0) * (unsigned)ngrp), dim3(256), 0, s, itp.nodes, G.L, hot, itp.sep,
-                                   itp.nItot, q0, kn, itp.Kpad, ngrp, itp.F);
+            if (use_sep) {
+                const int nq = itp.nItot - q0;
+                const int nsplit = itp.nlev - itp.l0 > 1 ? itp.nI[itp.l0] : nq;   // the largest interval size in use (all of them if it is the only one)
+                const unsigned nblk_mx = (unsigned)(nsplit * ngrp) + (unsigned)(((int64_t)(nq - nsplit) * ngrp + 3) / 4);
+                hipLaunchKernelGGL(k_cheb_nodes_mx, dim3(nblk_mx), dim3(256), 0, s, itp.nodes, G.L, hot, itp.sep, itp.nItot, q0, nsplit, kn,
+                                   itp.Kpad, ngrp, itp.F);
+            }
             if (evg) (void)hipEventRecord(evg[2], s);
             ChebApply A0;
             ChebApply &A = defer ? *defer : A0;
@@ -2032,7 +2036,7 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
     HIPCHK(hipDeviceSynchronize());
     const int K = c.K;
     const int nt64 = (int)((c.nnu + 63) / 64);
-    int64_t direct = 0, nodes = 0, sepn = 0, edgen = 0;   // sepn, edgen: (node | point, line, state) triples summed on the matrix cores
+    int64_t direct = 0, nodes = 0, sepn = 0, edgen = 0, mx3 = 0;   // sepn, edgen: (node | point, line, state) triples summed on the matrix cores; mx3: those with 3 terms
     int64_t body[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // per-point lines by body: 2-term, 2-term+cut-off, 3-term, 3-term+cut-off, 4-term+cut-off,
                                                      // near-zone pass; node lines: 2-, 3-, 4-term
     auto seg = [](int lo, int hi, int p0, int p1) { return (int64_t)std::max(0, std::min(hi, p1) - std::max(lo, p0)); };
@@ -2064,7 +2068,10 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
                     if (use_sep) {
                         const SepZone &s4 = sz[(size_t)(k >> 4) * nItot + q];
                         for (int p = 0; p < 4; p++)
-                            if (s4.b[p] > s4.a[p]) { sa[p] = s4.a[p]; sb[p] = s4.b[p]; sepn += (int64_t)CS_NC * (s4.b[p] - s4.a[p]); }
+                            if (s4.b[p] > s4.a[p]) {
+                                sa[p] = s4.a[p]; sb[p] = s4.b[p]; sepn += (int64_t)CS_NC * (s4.b[p] - s4.a[p]);
+                                mx3 += (int64_t)CS_NC * (p < 2 ? s4.m[p] - s4.a[p] : s4.b[p] - s4.m[p]);
+                            }
                     }
                     const int lo8[8] = {z.E0, sb[0], z.P1, sb[1], sb[3], z.P3, sb[2], z.Z1}, hi8[8] = {sa[0], z.P0, sa[1], z.Z0, z.E1, sa[3], z.P2, sa[2]};
                     for (int w8 = 0; w8 < 8; w8++) {
@@ -2095,9 +2102,10 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
                 if (use_edge) {   // what k_voigt_edge_mx takes
                     const EdgeZone e = ez[(size_t)(k >> 4) * nt64 + t];
                     edgen += 64 * (int64_t)((e.eL - W0) + (W1 - e.eR));
+                    mx3 += 64 * (int64_t)(((e.far3 & 1) ? e.eL - W0 : 0) + ((e.far3 & 2) ? W1 - e.eR : 0));
                     w.W0 = e.eL; w.W1 = e.eR;
-                    if (e.mL1 > e.mL0) { pm[0] = e.mL0; pm[1] = e.mL1; }
-                    if (e.mR1 > e.mR0) { pm[2] = e.mR0; pm[3] = e.mR1; }
+                    if (e.mL1 > e.mL0) { pm[0] = e.mL0; pm[1] = e.mL1; mx3 += 64 * (int64_t)(e.mL3 - e.mL0); }
+                    if (e.mR1 > e.mR0) { pm[2] = e.mR0; pm[3] = e.mR1; mx3 += 64 * (int64_t)(e.mR1 - e.mR3); }
                     edgen += 64 * (int64_t)((pm[1] - pm[0]) + (pm[3] - pm[2]));
                 }
                 int64_t n = (w.W1 - w.W0) - (pm[1] - pm[0]) - (pm[3] - pm[2]);
@@ -2135,6 +2143,7 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
     for (int q = 6; q < 9; q++) out[4 + q] = (int64_t)CS_NC * body[q];
     out[13] = sepn;
     out[14] = edgen;
+    out[15] = mx3;
     return CS_OK;
 }
 

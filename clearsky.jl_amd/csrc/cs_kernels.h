@@ -612,10 +612,12 @@ __global__ __launch_bounds__(256) void k_gas_setup(unsigned nb_prep, unsigned nb
 // Far lines whose 4-term series in 1/dnu^2 is exact for all 16 states of a state group (k_cheb_nodes_mx below) are summed
 // on the matrix cores; per (state group, interval) their four pieces -- sub-ranges of [E0,P0), [P1,Z0), [Z1,P2), [P3,E1) common to
 // the group's states -- are what this kernel then skips.
-struct __attribute__((aligned(16))) SepZone { int32_t a[4], b[4]; };   // piece p = [a[p], b[p]); empty: a = b
+struct __attribute__((aligned(16))) SepZone { int32_t a[4], b[4], m[4]; };   // piece p = [a[p], b[p]); empty: a = b.  m[p] splits it: the lines
+                                                                              // farther than it (below m on the left, from m on the right) need 3 terms
 // the same for the per-point sum (k_voigt_edge_mx), per (state group, 64-point tile): the window ends [W0, eL) and [eR, W1), and the
 // pieces [mL0, mL1), [mR0, mR1) between the interpolated sets and the near zone (empty: m.1 <= m.0)
-struct __attribute__((aligned(16))) EdgeZone { int32_t eL, mL0, mL1, mR0, mR1, eR, pad0, pad1; };
+// mL3, mR3 split the middle pieces like SepZone::m; far3 bit 0 / 1: the left / right window end needs 3 terms only
+struct __attribute__((aligned(16))) EdgeZone { int32_t eL, mL0, mL1, mR0, mR1, eR, mL3, mR3, far3, pad0, pad1, pad2; };
 
 // vector-unit node sum of one (interval, state) at the lane's node v: own set minus the parent's -- [E0,P0) U [P1,Z0) left of the
 // interval, [Z1,P2) U [P3,E1) right of it -- each minus the piece [sa[p], sb[p]) the matrix cores take.  Both sides are summed from
@@ -709,6 +711,83 @@ __global__ __launch_bounds__(256) void k_cheb_nodes(const double *__restrict__ n
 // of its own record; 16 matrix instructions per 4 lines x 64 nodes x 16 states.  The loop runs at the matrix pipe's rate (0.92
 // of it in tools/ubench/sep_nodes.hip: 2.5x the scalar-load VALU loop for the same triples) and leaves the vector unit to the
 // kernels beside it.  Pieces from sepzones_body (k_mxzones).
+// four binary searches over the same sorted array side by side (one thread: their dependent loads overlap instead of queueing up):
+// r[q] = first index in [p, e) whose value is >= val[q] (q < 2: lower bound) resp. > val[q] (q >= 2: upper bound)
+__device__ __forceinline__ void search4(const double *__restrict__ a, const double (&val)[4], int p, int e, int (&r)[4])
+{
+    int lo[4] = {p, p, p, p}, hi[4] = {e, e, e, e};
+    while (lo[0] < hi[0] || lo[1] < hi[1] || lo[2] < hi[2] || lo[3] < hi[3]) {
+        double x[4];
+        int m[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { m[q] = (lo[q] + hi[q]) >> 1; x[q] = lo[q] < hi[q] ? a[m[q]] : 0.0; }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (lo[q] < hi[q]) {
+                const bool right = q < 2 ? x[q] < val[q] : x[q] <= val[q];
+                if (right) lo[q] = m[q] + 1; else hi[q] = m[q];
+            }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) r[q] = lo[q];
+}
+
+// validity of the truncated series (tools/voigt_series.py): relative truncation error <= 1e-17 where
+//   4 terms: (y^2 + 3.0) / x^2 <= 5.6e-5   <=>  |dnu| >= 133.6 sqrt(gamma^2 + 4.33 alpha^2)
+//   3 terms: (y^2 + 3.5) / x^2 <= 2.15e-6  <=>  |dnu| >= 682.0 sqrt(gamma^2 + 5.05 alpha^2)
+constexpr double kSep4 = 133.6, kSep3 = 682.0;
+typedef double v4f64_sep __attribute__((ext_vector_type(4)));
+// one step of the matrix-core sums: 4 lines x 64 columns (nodes or points) x 16 states.  The lane's record as (state lr, line lq)
+// gives the NT coefficients (A operands) and, as (column lr, line lq), the line position; vn[st] = the lane's column of sub-tile
+// st.  MASK: w = 0 beyond the cut-off (line_shapes.jl:10).  4 NT matrix instructions.
+template <int NT, bool MASK>
+__device__ __forceinline__ void sep_step(v4f64_sep (&acc)[4], const double (&vn)[4], const LineHot &h, bool valid, double cut)
+{
+    const double id2 = rcp_nr1(h.p1 * h.p1);
+    const double y2 = h.p2;
+    const double c2 = 1.5 - y2;
+    const double c3 = __builtin_fma(y2, y2 - 5.0, 3.75);
+    const double C1 = valid ? h.p3 * id2 : 0.0;
+    const double C2 = C1 * id2;
+    const double C3 = C2 * id2;
+    const double a1 = C1, a2 = C2 * c2, a3 = C3 * c3;
+    double a4 = 0.0;
+    if (NT == 4) a4 = (C3 * id2) * __builtin_fma(y2, __builtin_fma(y2, 10.5 - y2, -26.25), 13.125);
+#pragma unroll
+    for (int st = 0; st < 4; st++) {
+        const double dv = vn[st] - h.nul;
+        const double s2 = dv * dv;
+        double w = rcp_fast(s2);
+        w = __builtin_fma(w, __builtin_fma(-s2, w, 1.0), w);   // second Newton step (powers up to w^4 of it are taken)
+        if (MASK) w = fabs(dv) > cut ? 0.0 : w;
+        const double w2 = w * w, w3 = w2 * w;
+        acc[st] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, w, acc[st], 0, 0, 0);
+        acc[st] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, w2, acc[st], 0, 0, 0);
+        acc[st] = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, w3, acc[st], 0, 0, 0);
+        if (NT == 4) acc[st] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4, w2 * w2, acc[st], 0, 0, 0);
+    }
+}
+// the lines [ja, jb) of one (state-row pointer hk) in steps of 4, ascending or descending; the load of step t + 1 is issued before the
+// matrix instructions of step t and waited for after them
+template <int NT, bool MASK>
+__device__ __forceinline__ void sep_run(v4f64_sep (&acc)[4], const double (&vn)[4], const LineHot *__restrict__ hk, int ja, int jb, bool asc,
+                                        int lq, double cut)
+{
+    if (ja >= jb) return;
+    const int nst = (jb - ja + 3) >> 2;
+    const int b0 = asc ? ja + lq : jb - 4 + lq, db = asc ? 4 : -4;   // line of this lane group at step t: b0 + t db
+    auto rec = [&](int t) { return hk[min(max(b0 + t * db, ja), jb - 1)]; };
+    auto ok = [&](int t) { const int j = b0 + t * db; return j >= ja && j < jb; };
+    LineHot cur = rec(0);
+    for (int t = 0; t < nst; t++) {
+        const LineHot nxt = rec(t + 1);      // (past the end: a harmless re-read of an end record, never used)
+        __builtin_amdgcn_sched_barrier(0);   // keep the load here: the scheduler would sink it behind the matrix instructions
+        sep_step<NT, MASK>(acc, vn, cur, ok(t), cut);
+        __builtin_amdgcn_sched_barrier(0);   // ... and the wait for it there
+        cur = nxt;
+    }
+}
+
 struct SepArgs {
     const double *nodes, *nul, *gbound, *Tk;
     const IZone *iz;
@@ -726,7 +805,7 @@ __device__ __forceinline__ void sepzones_body(unsigned bid, const SepArgs &a)
     const int g = idx / nq, T = a.q0 + (idx - g * nq);
     const double vhi = a.nodes[(size_t)T * CS_NC], vlo = a.nodes[(size_t)T * CS_NC + CS_NC - 1];   // nodes run from the upper end down
     int lo[4] = {0, 0, 0, 0}, hi[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
-    double R = 0.0;
+    double R = 0.0, R3 = 0.0;
     int E0 = 0, E1 = 0;
     for (int k = g * 16; k < min(g * 16 + 16, a.K); k++) {
         const IZone z = a.iz[(size_t)k * a.nItot + T];
@@ -737,23 +816,30 @@ __device__ __forceinline__ void sepzones_body(unsigned bid, const SepArgs &a)
         E0 = z.E0; E1 = z.E1;
         const double amax = ((vhi + a.cut) / kC) * sqrt(2.0 * kRgas * a.Tk[k]) / sqrt(a.mu_min);
         const double gb = a.gbound[k];
-        R = fmax(R, 133.6 * sqrt(gb * gb + 4.33 * amax * amax) * (1.0 + 1e-6));
+        R = fmax(R, kSep4 * sqrt(gb * gb + 4.33 * amax * amax) * (1.0 + 1e-6));
+        R3 = fmax(R3, kSep3 * sqrt(gb * gb + 5.05 * amax * amax) * (1.0 + 1e-6));
     }
-    const double *__restrict__ nul = a.nul;
-    auto lower = [&](double val, int p, int q) { while (p < q) { const int m = (p + q) >> 1; if (nul[m] < val) p = m + 1; else q = m; } return p; };
-    auto upper = [&](double val, int p, int q) { while (p < q) { const int m = (p + q) >> 1; if (nul[m] <= val) p = m + 1; else q = m; } return p; };
-    const int S0 = lower(vlo - R, E0, E1), S1 = upper(vhi + R, S0, E1);
+    int sr[4];
+    {
+        const double sv[4] = {vlo - R, vlo - R3, vhi + R, vhi + R3};
+        search4(a.nul, sv, E0, E1, sr);
+    }
+    const int S0 = sr[0], S1 = max(sr[2], S0);
+    const int T0 = min(sr[1], S0), T1 = max(sr[3], S1);   // three terms do in [E0, T0) and [T1, E1)
     SepZone z;
     for (int p = 0; p < 4; p++) {
         int pa = lo[p], pb = hi[p];
         if (p < 2) pb = min(pb, S0); else pa = max(pa, S1);
         if (pb - pa < 8) { pa = 0; pb = 0; }   // (too short to be worth a wave's trip)
         z.a[p] = pa; z.b[p] = pb;
+        int pm = p < 2 ? min(max(T0, pa), pb) : min(max(T1, pa), pb);
+        if (p < 2 && pm - pa < 8) pm = pa;     // (a 3-term part that short is not worth its own steps: four terms for it too)
+        if (p >= 2 && pb - pm < 8) pm = pb;
+        z.m[p] = pm;
     }
     a.out[(size_t)g * a.nItot + T] = z;
 }
 
-typedef double v4f64_sep __attribute__((ext_vector_type(4)));
 #define CS_MX_PITCH 66   // LDS row pitch (doubles) of the partial sums: rows of the four lane groups land on different banks
 // One block = one interval x one group of 16 states: every piece is cut into four runs of lines (multiples of 4), wave w takes
 // run w -- far end first on both sides -- with the next record in flight while the 16 matrix instructions of a step issue; the
@@ -762,15 +848,27 @@ typedef double v4f64_sep __attribute__((ext_vector_type(4)));
 // side -- the matrix and vector phases do overlap, but the vector loop lives on eight waves per SIMD hiding its scalar loads, and
 // this kernel's registers and LDS allow four: 0.94 ms for a quarter of the vector work, profiles/r02_notes.md.)
 __global__ __launch_bounds__(256) void k_cheb_nodes_mx(const double *__restrict__ nodes, int64_t L, const LineHot *__restrict__ hot,
-                                                       const SepZone *__restrict__ sep, int nItot, int q0, int K, int Kpad, int ngrp,
-                                                       double *__restrict__ F)
+                                                       const SepZone *__restrict__ sep, int nItot, int q0, int nsplit, int K, int Kpad,
+                                                       int ngrp, double *__restrict__ F)
 {
+    // the first nsplit intervals (the largest interval size in use: several hundred lines per piece) are shared by the four waves
+    // of a block as described; the rest (a few dozen lines, ~10 steps) go one (interval, group) per wave -- no LDS, no barrier
     __shared__ double part[4][16][CS_MX_PITCH];
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int T = q0 + (int)(blockIdx.x / ngrp);
-    const int g = (int)((blockIdx.x % ngrp + T) % ngrp);   // (rotated: the groups differ in work and would alias with the XCD round-robin)
+    const int nb_split = nsplit * ngrp;
+    const bool split = (int)blockIdx.x < nb_split;   // (block-uniform)
+    int T, g;
+    if (split) {
+        T = q0 + (int)(blockIdx.x / ngrp);
+        g = (int)((blockIdx.x % ngrp + T) % ngrp);   // (rotated: the groups differ in work and would alias with the XCD round-robin)
+    } else {
+        const int item = nb_split + ((int)blockIdx.x - nb_split) * 4 + wv;
+        if (item >= (nItot - q0) * ngrp) return;
+        T = q0 + item / ngrp;
+        g = item % ngrp;
+    }
     const SepZone z = sep[(size_t)g * nItot + T];
-    if (!(z.b[0] > z.a[0] || z.b[1] > z.a[1] || z.b[2] > z.a[2] || z.b[3] > z.a[3])) return;   // (block-uniform)
+    if (!(z.b[0] > z.a[0] || z.b[1] > z.a[1] || z.b[2] > z.a[2] || z.b[3] > z.a[3])) return;   // (uniform per block when split, else per wave)
     {
         const int lr = lane & 15, lq = lane >> 4;
         const int kk = min(g * 16 + lr, K - 1);                       // (a group's tail states re-read the last one: never stored)
@@ -781,59 +879,41 @@ __global__ __launch_bounds__(256) void k_cheb_nodes_mx(const double *__restrict_
         v4f64_sep acc[4];
 #pragma unroll
         for (int st = 0; st < 4; st++) acc[st] = v4f64_sep{0.0, 0.0, 0.0, 0.0};
-        // the lane's record as (state lr, line lq) gives the four coefficients (A operand) and, as (node lr, line lq), the line position
-        auto step = [&](const LineHot &h, bool valid) {
-            const double id2 = rcp_nr1(h.p1 * h.p1);
-            const double y2 = h.p2;
-            const double c2 = 1.5 - y2;
-            const double c3 = __builtin_fma(y2, y2 - 5.0, 3.75);
-            const double c4 = __builtin_fma(y2, __builtin_fma(y2, 10.5 - y2, -26.25), 13.125);
-            const double C1 = valid ? h.p3 * id2 : 0.0;
-            const double C2 = C1 * id2;
-            const double C3 = C2 * id2;
-            const double C4 = C3 * id2;
-            const double a1 = C1, a2 = C2 * c2, a3 = C3 * c3, a4 = C4 * c4;
-#pragma unroll
-            for (int st = 0; st < 4; st++) {
-                const double dv = vn[st] - h.nul;
-                const double s2 = dv * dv;
-                double w = rcp_fast(s2);
-                w = __builtin_fma(w, __builtin_fma(-s2, w, 1.0), w);   // second Newton step: the matrix pipe sets the pace, the VALU has slack
-                const double w2 = w * w, w3 = w2 * w, w4 = w2 * w2;
-                acc[st] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, w, acc[st], 0, 0, 0);
-                acc[st] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, w2, acc[st], 0, 0, 0);
-                acc[st] = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, w3, acc[st], 0, 0, 0);
-                acc[st] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4, w4, acc[st], 0, 0, 0);
-            }
+        // left pieces ascending, right pieces descending, the 3-term part of a piece (its far end) first: wave 0 owns the far end of
+        // every part
+        auto quarter = [&](int pa, int pb, bool asc, int &ja, int &jb) {   // this wave's run of [pa, pb): multiples of 4 lines
+            if (!split) { ja = pa; jb = pb; return; }
+            const int run = ((pb - pa + 15) >> 4) << 2;
+            ja = asc ? pa + wv * run : max(pb - (wv + 1) * run, pa);
+            jb = asc ? min(ja + run, pb) : pb - wv * run;
         };
-        // left pieces ascending, right pieces descending: wave 0 owns the far end of every piece.  The load of step t + 1 is issued
-        // before the matrix instructions of step t and waited for after them.
         for (int pp = 0; pp < 4; pp++) {
             const int p = pp < 2 ? pp : 5 - pp;          // 0, 1, 3, 2
             const bool asc = pp < 2;
-            const int n = z.b[p] - z.a[p];
-            if (n <= 0) continue;
-            const int run = ((n + 15) >> 4) << 2;
-            const int ja = asc ? z.a[p] + wv * run : max(z.b[p] - (wv + 1) * run, z.a[p]);
-            const int jb = asc ? min(ja + run, z.b[p]) : z.b[p] - wv * run;
-            if (ja >= jb) continue;
-            const int nst = (jb - ja + 3) >> 2;
-            const int b0 = asc ? ja + lq : jb - 4 + lq, db = asc ? 4 : -4;   // line of this lane group at step t: b0 + t db
-            auto rec = [&](int t) { return hk[min(max(b0 + t * db, ja), jb - 1)]; };
-            auto ok = [&](int t) { const int j = b0 + t * db; return j >= ja && j < jb; };
-            LineHot cur = rec(0);
-            for (int t = 0; t < nst; t++) {
-                const LineHot nxt = rec(t + 1);      // (past the end: a harmless re-read of an end record, never used)
-                __builtin_amdgcn_sched_barrier(0);   // keep the load here: the scheduler would sink it behind the matrix instructions
-                step(cur, ok(t));
-                __builtin_amdgcn_sched_barrier(0);   // ... and the wait for it there
-                cur = nxt;
+            if (z.b[p] <= z.a[p]) continue;
+            int ja, jb;
+            if (asc) {
+                if (z.m[p] > z.a[p]) { quarter(z.a[p], z.m[p], true, ja, jb); sep_run<3, false>(acc, vn, hk, ja, jb, true, lq, 0.0); }
+                if (z.b[p] > z.m[p]) { quarter(z.m[p], z.b[p], true, ja, jb); sep_run<4, false>(acc, vn, hk, ja, jb, true, lq, 0.0); }
+            } else {
+                if (z.b[p] > z.m[p]) { quarter(z.m[p], z.b[p], false, ja, jb); sep_run<3, false>(acc, vn, hk, ja, jb, false, lq, 0.0); }
+                if (z.m[p] > z.a[p]) { quarter(z.a[p], z.m[p], false, ja, jb); sep_run<4, false>(acc, vn, hk, ja, jb, false, lq, 0.0); }
             }
+        }
+        if (!split) {   // D[state 4r + lq][node 16 st + lr] straight into F
+#pragma unroll
+            for (int st = 0; st < 4; st++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int k = g * 16 + 4 * r + lq;
+                    if (k < K) F[((size_t)T * CS_NC + st * 16 + lr) * Kpad + k] += acc[st][r];
+                }
+            return;
         }
 #pragma unroll
         for (int st = 0; st < 4; st++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) part[wv][4 * r + lq][st * 16 + lr] = acc[st][r];   // D[state 4r + lq][node 16 st + lr]
+            for (int r = 0; r < 4; r++) part[wv][4 * r + lq][st * 16 + lr] = acc[st][r];
     }
     __syncthreads();
     for (int s4 = 0; s4 < 4; s4++) {
@@ -1230,7 +1310,7 @@ __device__ __forceinline__ void edgezones_body(unsigned bid, const EdgeArgs &a)
     const double vlo = a.nu[i0], vhi = a.nu[i1];
     const WaveWin w = a.win[t];
     int eL = w.W1, eR = w.W0, mL0 = w.W0, mL1 = w.W1, mR0 = w.W0, mR1 = w.W1;
-    double R = 0.0;
+    double R = 0.0, R3 = 0.0;
     for (int k = g * 16; k < min(g * 16 + 16, a.K); k++) {
         const Zone z = a.zones[(size_t)k * a.ntile + t];
         int sa0 = z.M0, sa1 = z.M0, sb0 = z.M1, sb1 = z.M1;   // (as k_voigt_far)
@@ -1244,12 +1324,16 @@ __device__ __forceinline__ void edgezones_body(unsigned bid, const EdgeArgs &a)
         mR0 = max(mR0, z.N1); mR1 = min(mR1, sb0);
         const double amax = ((vhi + a.cut) / kC) * sqrt(2.0 * kRgas * a.Tk[k]) / sqrt(a.mu_min);
         const double gb = a.gbound[k];
-        R = fmax(R, 133.6 * sqrt(gb * gb + 4.33 * amax * amax) * (1.0 + 1e-6));
+        R = fmax(R, kSep4 * sqrt(gb * gb + 4.33 * amax * amax) * (1.0 + 1e-6));
+        R3 = fmax(R3, kSep3 * sqrt(gb * gb + 5.05 * amax * amax) * (1.0 + 1e-6));
     }
-    const double *__restrict__ nul = a.nul;
-    auto lower = [&](double val, int p, int q) { while (p < q) { const int m = (p + q) >> 1; if (nul[m] < val) p = m + 1; else q = m; } return p; };
-    auto upper = [&](double val, int p, int q) { while (p < q) { const int m = (p + q) >> 1; if (nul[m] <= val) p = m + 1; else q = m; } return p; };
-    const int S0 = lower(vlo - R, w.W0, w.W1), S1 = upper(vhi + R, S0, w.W1);   // the series holds in [W0, S0) and [S1, W1)
+    int sr[4];
+    {
+        const double sv[4] = {vlo - R, vlo - R3, vhi + R, vhi + R3};
+        search4(a.nul, sv, w.W0, w.W1, sr);
+    }
+    const int S0 = sr[0], S1 = max(sr[2], S0);            // the series holds in [W0, S0) and [S1, W1)
+    const int T0 = min(sr[1], S0), T1 = max(sr[3], S1);   // ... with three terms in [W0, T0) and [T1, W1)
     EdgeZone e;
     e.eL = max(min(eL, S0), w.W0);
     e.eR = min(max(eR, S1), w.W1);
@@ -1259,7 +1343,12 @@ __device__ __forceinline__ void edgezones_body(unsigned bid, const EdgeArgs &a)
     e.mR0 = max(mR0, S1); e.mR1 = mR1;
     if (e.mL1 - e.mL0 < 8 || e.mL0 < e.eL) e.mL0 = e.mL1 = 0;
     if (e.mR1 - e.mR0 < 8 || e.mR1 > e.eR) e.mR0 = e.mR1 = 0;
-    e.pad0 = e.pad1 = 0;
+    e.far3 = (e.eL <= T0 ? 1 : 0) | (e.eR >= T1 ? 2 : 0);    // (a window end is 20 cm^-1 away: all of it or none)
+    e.mL3 = min(max(T0, e.mL0), e.mL1);
+    if (e.mL3 - e.mL0 < 8) e.mL3 = e.mL0;
+    e.mR3 = min(max(T1, e.mR0), e.mR1);
+    if (e.mR1 - e.mR3 < 8) e.mR3 = e.mR1;
+    e.pad0 = e.pad1 = e.pad2 = 0;
     a.out[idx] = e;
 }
 // k_sepzones and the edge zones in one launch (both need the zones of k_gas_setup)
@@ -1291,49 +1380,16 @@ __global__ __launch_bounds__(256) void k_voigt_edge_mx(const double *__restrict_
     v4f64_sep acc[4];
 #pragma unroll
     for (int st = 0; st < 4; st++) acc[st] = v4f64_sep{0.0, 0.0, 0.0, 0.0};
-    // the lane's record as (state lr, line lq) gives the four coefficients (A operand) and, as (point lr, line lq), the line position
-    auto step = [&](const LineHot &h, bool valid) {
-        const double id2 = rcp_nr1(h.p1 * h.p1);
-        const double y2 = h.p2;
-        const double c2 = 1.5 - y2;
-        const double c3 = __builtin_fma(y2, y2 - 5.0, 3.75);
-        const double c4 = __builtin_fma(y2, __builtin_fma(y2, 10.5 - y2, -26.25), 13.125);
-        const double C1 = valid ? h.p3 * id2 : 0.0;
-        const double C2 = C1 * id2;
-        const double C3 = C2 * id2;
-        const double C4 = C3 * id2;
-        const double a1 = C1, a2 = C2 * c2, a3 = C3 * c3, a4 = C4 * c4;
-#pragma unroll
-        for (int st = 0; st < 4; st++) {
-            const double dv = vn[st] - h.nul;
-            const double s2 = dv * dv;
-            double wq = rcp_fast(s2);
-            wq = __builtin_fma(wq, __builtin_fma(-s2, wq, 1.0), wq);
-            wq = fabs(dv) > cut ? 0.0 : wq;                           // the cut-off of line_shapes.jl:10 as a mask
-            const double w2 = wq * wq, w3 = w2 * wq, w4 = w2 * w2;
-            acc[st] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, wq, acc[st], 0, 0, 0);
-            acc[st] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, w2, acc[st], 0, 0, 0);
-            acc[st] = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, w3, acc[st], 0, 0, 0);
-            acc[st] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4, w4, acc[st], 0, 0, 0);
-        }
-    };
-    for (int pp = 0; pp < 4; pp++) {   // left pieces ascending, right pieces descending: far lines first
-        const bool asc = pp < 2;
-        const int ja = pp == 0 ? w.W0 : (pp == 1 ? e.mL0 : (pp == 2 ? e.eR : e.mR0));
-        const int jb = pp == 0 ? e.eL : (pp == 1 ? e.mL1 : (pp == 2 ? w.W1 : e.mR1));
-        if (ja >= jb) continue;
-        const int nst = (jb - ja + 3) >> 2;
-        const int b0 = asc ? ja + lq : jb - 4 + lq, db = asc ? 4 : -4;
-        auto rec = [&](int t) { return hk[min(max(b0 + t * db, ja), jb - 1)]; };
-        auto ok = [&](int t) { const int j = b0 + t * db; return j >= ja && j < jb; };
-        LineHot cur = rec(0);
-        for (int t = 0; t < nst; t++) {
-            const LineHot nxt = rec(t + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            step(cur, ok(t));
-            __builtin_amdgcn_sched_barrier(0);
-            cur = nxt;
-        }
+    // left pieces ascending, right pieces descending: far lines first; three terms where they do
+    if (e.far3 & 1) sep_run<3, true>(acc, vn, hk, w.W0, e.eL, true, lq, cut); else sep_run<4, true>(acc, vn, hk, w.W0, e.eL, true, lq, cut);
+    if (e.mL1 > e.mL0) {
+        sep_run<3, true>(acc, vn, hk, e.mL0, e.mL3, true, lq, cut);
+        sep_run<4, true>(acc, vn, hk, e.mL3, e.mL1, true, lq, cut);
+    }
+    if (e.far3 & 2) sep_run<3, true>(acc, vn, hk, e.eR, w.W1, false, lq, cut); else sep_run<4, true>(acc, vn, hk, e.eR, w.W1, false, lq, cut);
+    if (e.mR1 > e.mR0) {
+        sep_run<3, true>(acc, vn, hk, e.mR3, e.mR1, false, lq, cut);
+        sep_run<4, true>(acc, vn, hk, e.mR0, e.mR3, false, lq, cut);
     }
 #pragma unroll
     for (int st = 0; st < 4; st++)

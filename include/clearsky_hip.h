@@ -214,7 +214,8 @@ int cs_column_counts(cs_ctx *ctx, int64_t *pair_evals, int64_t *lines_in_range);
  * (2-term, 2-term + cut-off predicate, 3-term, 3-term + predicate, 4-term + predicate, near-zone pass), out[10..12] = the node
  * evaluations by body (2-, 3-, 4-term) on the vector unit -- what bench.py weights with the VALU instruction count of each
  * body -- and out[13], out[14] = the node and the per-point evaluations summed on the matrix cores (cs_set_matrix_cores;
- * out[0] and out[4..9] do not include the latter).  `out` holds 15 values.  cs_column_counts is the reference's count. */
+ * out[0] and out[4..9] do not include the latter), out[15] = those of out[13] + out[14] that take three series terms instead of
+ * four.  `out` holds 16 values.  cs_column_counts is the reference's count. */
 int cs_column_work(cs_ctx *ctx, int64_t *out);
 /* interval sizes (descending, <= 5, each 128..2048 points) cs_set_interp(on) would use for this grid and cut-off; returns
  * their number (0: the grid is too coarse for the cut-off -- every pair is evaluated directly) */
