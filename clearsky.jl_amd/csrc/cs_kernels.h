@@ -1103,8 +1103,11 @@ __global__ __launch_bounds__(256, NSUB >= 4 ? 2 : 4) void k_cheb_apply_mfma(Cheb
 // line parameters arrive through scalar loads:
 //   [W0,a) left edge (cut-off predicate) | [a,M0) far | [M0,N0) mid-far | [N0,N1) near zone | [N1,M1) | [M1,b) | [b,W1)
 // In the near zone only the pairs with s >= 1e4 are summed here; the others belong to k_voigt_near.
+#ifndef CS_FAR_ATTR
+#define CS_FAR_ATTR
+#endif
 template <bool MIXED, int S, bool LOR, bool EDGE = false>
-__global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu, int64_t nnu, int64_t L,
+__global__ __launch_bounds__(256) CS_FAR_ATTR void k_voigt_far(const double *__restrict__ nu, int64_t nnu, int64_t L,
                                                     const LineHot *__restrict__ hot, const LineF32 *__restrict__ hot32,
                                                     const double *__restrict__ gnul, const WaveWin *__restrict__ win,
                                                     const Zone *__restrict__ zones, int ntile, int nblk, double cut,
@@ -1221,7 +1224,12 @@ __global__ __launch_bounds__(256) void k_voigt_far(const double *__restrict__ nu
                 P = __builtin_fma(u, P, p2);
                 P = __builtin_fma(u, P, p1v);
                 P = __builtin_fma(u, P, 1.0);
-                acc += (in && s >= kSerS) ? (h.p3 * u) * P : 0.0;
+                // (the term is made opaque before the select: otherwise the compiler sinks the whole series into a branch under the
+                // lanes' exec mask -- which saves nothing on a wave that always has such lanes -- and with it the load of p3, so that
+                // every line waits twice for scalar memory instead of four lines waiting once)
+                double term = (h.p3 * u) * P;
+                asm volatile("" : "+v"(term));
+                acc += (in && s >= kSerS) ? term : 0.0;
                 if (in && s < kSerS) { bl = min(bl, j); bh = j; }
                 if (in && s < kMidS) { cl = min(cl, j); ch = j; }
             }
