@@ -198,6 +198,7 @@ struct cs_ctx {
     int interp = 1;   // far wings by Chebyshev interpolation over 128..2048-point intervals (k_cheb_nodes / k_cheb_apply)
     int itp_first = -1, itp_min = 128, itp_max = 2048;   // cs_set_interp_plan: first level per gas (-1 = by line density), size range
     int matrix_nodes = 1;   // cs_set_matrix_cores: separable far-wing node sums on v_mfma_f64 (k_cheb_nodes_mx)
+    int matrix_core = 1;    // ... and the window core on sub-tiles (k_voigt_sub + the second mask of k_voigt_edge_mx)
     double far_s = 1e6;
     DevBuf hot32;
     DevBuf tmpA, tmpB, tmpC;
@@ -475,6 +476,7 @@ struct Interp {
     SepZone *sep = nullptr;   // NULL: every node sum on the vector unit
     EdgeZone *edge = nullptr; // NULL: all of the per-point sum on the vector unit
     bool sep_always = false;  // cs_set_matrix_cores(ctx, 2): also on grids too short to fill the chip with (interval, state group) blocks
+    bool core = true;         // cs_set_matrix_cores(ctx, on | 4) switches the sub-tile treatment of the window core (k_voigt_sub) off
 };
 
 // interval sizes worth using on this grid: an interval of width W leaves lines over (2 cut - 2.3 W) to interpolate
@@ -706,6 +708,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
                 ea.nI = itp.nItot; ea.ishift = 0;
                 for (int r = itp.itv[itp.nlev - 1] / 64; r > 1; r >>= 1) ea.ishift++;
                 ea.mu_min = G.mu_min; ea.cut = cut;
+                ea.core = (use_edge && itp.core) ? 1 : 0;
                 const unsigned nb_sep = use_sep ? (unsigned)(((int64_t)(itp.nItot - q0) * ngrp + 255) / 256) : 0u;
                 const unsigned nb_edge = use_edge ? (unsigned)(((int64_t)nt64 * ngrp + 255) / 256) : 0u;
                 hipLaunchKernelGGL(k_mxzones, dim3(nb_sep + nb_edge), dim3(256), 0, s, nb_sep, sa, ea);
@@ -784,6 +787,9 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
         }
 #undef CS_FAR_LAUNCH
 #undef CS_LOR_LAUNCH
+        if (use_edge && itp.core)   // the window cores of the groups whose series radius is short: pairs inside it (the rest: k_voigt_edge_mx)
+            hipLaunchKernelGGL(k_voigt_sub, dim3((unsigned)nt64, (unsigned)((kn + 3) / 4)), dim3(256), 0, s, dnu, nnu, G.L, hot, G.nu.as<double>(), zones,
+                               itp.edge, nt64, kn, cut, sigma, reinterpret_cast<unsigned *>(ranges));
         if (evg) (void)hipEventRecord(evg[3], s);
         if (use_edge)
             hipLaunchKernelGGL(k_voigt_edge_mx, dim3((unsigned)((nt64 + 3) / 4), (unsigned)((kn + 15) / 16)), dim3(256), 0, s, dnu, nnu, G.L, hot, win,
@@ -957,7 +963,10 @@ int cs_set_interp_plan(cs_ctx *ctx, int first_level, int size_min, int size_max)
 int cs_set_matrix_cores(cs_ctx *ctx, int on)
 {
     if (!ctx) return fail(CS_EINVAL, "ctx is NULL");
-    ctx->matrix_nodes = on < 0 ? 0 : (on > 2 ? 2 : on);
+    if (on < 0) on = 0;
+    ctx->matrix_core = (on & 4) ? 0 : 1;   // (tuning / tests: | 4 keeps the tile-wide near-zone pass everywhere)
+    on &= 3;
+    ctx->matrix_nodes = on > 2 ? 2 : on;
     return CS_OK;
 }
 
@@ -1038,6 +1047,7 @@ static int shape_impl(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t 
         itp = interp_view(cheb, ginterp, kc);
         if (!ctx->matrix_nodes) itp.sep = nullptr, itp.edge = nullptr;
         itp.sep_always = ctx->matrix_nodes == 2;
+        itp.core = ctx->matrix_core != 0;
     }
     for (int k0 = 0; k0 < K; k0 += kc) {
         const int kn = std::min(kc, K - k0);
@@ -1118,6 +1128,7 @@ int cs_bake(cs_ctx *ctx, int gas_slot, int table_slot, int shape, double dnu_cut
         itp = interp_view(cheb, ginterp, kc);
         if (!ctx->matrix_nodes) itp.sep = nullptr, itp.edge = nullptr;
         itp.sep_always = ctx->matrix_nodes == 2;
+        itp.core = ctx->matrix_core != 0;
     }
     for (int k0 = 0; k0 < M; k0 += kc) {
         const int kn = std::min(kc, M - k0);
@@ -1754,6 +1765,7 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
             itp.sep = ctx->matrix_nodes ? dsep.as<SepZone>() : nullptr;
             itp.edge = ctx->matrix_nodes ? dedge.as<EdgeZone>() : nullptr;
             itp.sep_always = ctx->matrix_nodes == 2;
+            itp.core = ctx->matrix_core != 0;
         }
         for (int64_t k0 = 0; k0 < BK; k0 += kc) {
             const int kn = (int)std::min<int64_t>(kc, BK - k0);
@@ -1853,6 +1865,7 @@ static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e)
         itp.F = c.chebF.as<double>();
         if (!ctx->matrix_nodes) itp.sep = nullptr, itp.edge = nullptr;
         itp.sep_always = ctx->matrix_nodes == 2;
+        itp.core = ctx->matrix_core != 0;
         launch_gas(s, cg.shape, G, cg.jlo, cg.jhi, K, c.Tk.as<double>(), c.Pk.as<double>(), cg.Pp.as<double>(), cg.conc.as<double>(),
                    c.hot.as<LineHot>(), c.cold.as<LineCold>(), c.nu.as<double>(), c.nnu, c.ntile, cg.J0.as<int32_t>(),
                    cg.J1.as<int32_t>(), cg.win.as<WaveWin>(), cg.xtiles, cg.zones.as<Zone>(), c.ranges.as<int2>(), cg.gmax.as<double>(), cg.cut, c.sigma_gray, extra, sig, gi > 0,
@@ -2036,7 +2049,8 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
     HIPCHK(hipDeviceSynchronize());
     const int K = c.K;
     const int nt64 = (int)((c.nnu + 63) / 64);
-    int64_t direct = 0, nodes = 0, sepn = 0, edgen = 0, mx3 = 0;   // sepn, edgen: (node | point, line, state) triples summed on the matrix cores; mx3: those with 3 terms
+    int64_t direct = 0, nodes = 0, sepn = 0, edgen = 0, mx3 = 0, subn = 0;   // subn: (lane, line) evaluations of k_voigt_sub
+    //   // sepn, edgen: (node | point, line, state) triples summed on the matrix cores; mx3: those with 3 terms
     int64_t body[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // per-point lines by body: 2-term, 2-term+cut-off, 3-term, 3-term+cut-off, 4-term+cut-off,
                                                      // near-zone pass; node lines: 2-, 3-, 4-term
     auto seg = [](int lo, int hi, int p0, int p1) { return (int64_t)std::max(0, std::min(hi, p1) - std::max(lo, p0)); };
@@ -2099,6 +2113,7 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
                 const Zone &z = zn[(size_t)k * nt64 + t];
                 const int W0 = w.W0, W1 = w.W1;
                 int pm[4] = {0, 0, 0, 0};   // [pL0, pL1), [pR0, pR1): the pieces between interpolated sets and near zone on the matrix cores
+                int cc0 = 0, cc1 = 0;       // [cc0, cc1): the core that k_voigt_sub and the second mask of k_voigt_edge_mx share
                 if (use_edge) {   // what k_voigt_edge_mx takes
                     const EdgeZone e = ez[(size_t)(k >> 4) * nt64 + t];
                     edgen += 64 * (int64_t)((e.eL - W0) + (W1 - e.eR));
@@ -2107,8 +2122,19 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
                     if (e.mL1 > e.mL0) { pm[0] = e.mL0; pm[1] = e.mL1; mx3 += 64 * (int64_t)(e.mL3 - e.mL0); }
                     if (e.mR1 > e.mR0) { pm[2] = e.mR0; pm[3] = e.mR1; mx3 += 64 * (int64_t)(e.mR1 - e.mR3); }
                     edgen += 64 * (int64_t)((pm[1] - pm[0]) + (pm[3] - pm[2]));
+                    if (e.cR > e.cL) {   // the core: every pair visits the matrix cores (masked inside R), k_voigt_sub the lines within R of each sub-tile
+                        cc0 = e.cL; cc1 = e.cR;
+                        edgen += 64 * (int64_t)(e.cR - e.cL);
+                        const double *nl = ctx->gas[g.slot].h_nu.data();
+                        for (int q4 = 0; q4 < 4; q4++) {
+                            const double v0 = c.h_nu[(size_t)t * 64 + 16 * q4] - e.R, v1 = c.h_nu[(size_t)t * 64 + 16 * q4 + 15] + e.R;
+                            const int ja = (int)(std::lower_bound(nl + e.cL, nl + e.cR, v0) - nl);
+                            const int jb = (int)(std::upper_bound(nl + ja, nl + e.cR, v1) - nl);
+                            subn += 16 * (int64_t)(jb - ja);
+                        }
+                    }
                 }
-                int64_t n = (w.W1 - w.W0) - (pm[1] - pm[0]) - (pm[3] - pm[2]);
+                int64_t n = (w.W1 - w.W0) - (pm[1] - pm[0]) - (pm[3] - pm[2]) - (cc1 - cc0);
                 int sa0 = z.M0, sa1 = z.M0, sb0 = z.M1, sb1 = z.M1;
                 if (nlev > 0) {   // same clamps as k_voigt_far
                     const IZone &zi = iz[(size_t)k * nItot + c.cheb.ioff[nlev - 1] + (t >> ishift)];
@@ -2122,8 +2148,9 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
                 const int b1 = std::max(std::min(w.E1, z.Q1), z.M1), bq = std::max(std::min(w.E1, W1), z.Q1);
                 const int pL0 = pm[1] > pm[0] ? pm[0] : sa1, pL1 = pm[1] > pm[0] ? pm[1] : sa1;
                 const int pR0 = pm[3] > pm[2] ? pm[2] : sb0, pR1 = pm[3] > pm[2] ? pm[3] : sb0;
-                const int cl[5] = {w.W0, sa1, pL1, pR1, sb1}, ch[5] = {sa0, pL0, pR0, sb0, w.W1};
-                for (int cw = 0; cw < 5; cw++) {
+                const int cM0 = cc1 > cc0 ? cc0 : pR0, cM1 = cc1 > cc0 ? cc1 : pR0;
+                const int cl[6] = {w.W0, sa1, pL1, cM1, pR1, sb1}, ch[6] = {sa0, pL0, cM0, pR0, sb0, w.W1};
+                for (int cw = 0; cw < 6; cw++) {
                     const int p0 = cl[cw], p1 = ch[cw];
                     if (p0 >= p1) continue;
                     body[1] += seg(W0, a, p0, p1) + seg(bq, W1, p0, p1);
@@ -2144,6 +2171,7 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
     out[13] = sepn;
     out[14] = edgen;
     out[15] = mx3;
+    out[16] = subn;
     return CS_OK;
 }
 

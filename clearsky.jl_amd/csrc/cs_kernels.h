@@ -312,6 +312,14 @@ __device__ __forceinline__ double vgpr_const(double x)
     asm volatile("" : "+v"(x));
     return x;
 }
+// the same in a scalar register pair, for constants that meet only vector operands (a gfx950 VALU instruction reads one scalar
+// source): the higher coefficients of the near-zone series, which cost the hot kernel 22 VGPRs as vector constants and every wave
+// 11 serialised loads as volatile memory operands
+__device__ __forceinline__ double sgpr_const(double x)
+{
+    asm volatile("" : "+s"(x));
+    return x;
+}
 __device__ __forceinline__ FarK load_fark()
 {
     FarK c;
@@ -617,7 +625,10 @@ struct __attribute__((aligned(16))) SepZone { int32_t a[4], b[4], m[4]; };   // 
 // the same for the per-point sum (k_voigt_edge_mx), per (state group, 64-point tile): the window ends [W0, eL) and [eR, W1), and the
 // pieces [mL0, mL1), [mR0, mR1) between the interpolated sets and the near zone (empty: m.1 <= m.0)
 // mL3, mR3 split the middle pieces like SepZone::m; far3 bit 0 / 1: the left / right window end needs 3 terms only
-struct __attribute__((aligned(16))) EdgeZone { int32_t eL, mL0, mL1, mR0, mR1, eR, mL3, mR3, far3, pad0, pad1, pad2; };
+// [cL, cR) (empty: cR <= cL): the core of the window -- everything between the matrix-core pieces, near zone included -- when the
+// series radius R of the group is shorter than the tile: there k_voigt_sub sums the pairs with |dnu| < R on 16-point sub-tiles
+// and k_voigt_edge_mx the pairs with |dnu| >= R (a second mask), and k_voigt_far leaves the core alone
+struct __attribute__((aligned(16))) EdgeZone { int32_t eL, mL0, mL1, mR0, mR1, eR, mL3, mR3, far3, cL, cR, pad0; double R, pad1; };
 
 // vector-unit node sum of one (interval, state) at the lane's node v: own set minus the parent's -- [E0,P0) U [P1,Z0) left of the
 // interval, [Z1,P2) U [P3,E1) right of it -- each minus the piece [sa[p], sb[p]) the matrix cores take.  Both sides are summed from
@@ -740,8 +751,8 @@ typedef double v4f64_sep __attribute__((ext_vector_type(4)));
 // one step of the matrix-core sums: 4 lines x 64 columns (nodes or points) x 16 states.  The lane's record as (state lr, line lq)
 // gives the NT coefficients (A operands) and, as (column lr, line lq), the line position; vn[st] = the lane's column of sub-tile
 // st.  MASK: w = 0 beyond the cut-off (line_shapes.jl:10).  4 NT matrix instructions.
-template <int NT, bool MASK>
-__device__ __forceinline__ void sep_step(v4f64_sep (&acc)[4], const double (&vn)[4], const LineHot &h, bool valid, double cut)
+template <int NT, int MASK>   // MASK 1: w = 0 beyond the cut-off; 2: also inside the radius rin (those pairs are k_voigt_sub's)
+__device__ __forceinline__ void sep_step(v4f64_sep (&acc)[4], const double (&vn)[4], const LineHot &h, bool valid, double cut, double rin = 0.0)
 {
     const double id2 = rcp_nr1(h.p1 * h.p1);
     const double y2 = h.p2;
@@ -759,7 +770,8 @@ __device__ __forceinline__ void sep_step(v4f64_sep (&acc)[4], const double (&vn)
         const double s2 = dv * dv;
         double w = rcp_fast(s2);
         w = __builtin_fma(w, __builtin_fma(-s2, w, 1.0), w);   // second Newton step (powers up to w^4 of it are taken)
-        if (MASK) w = fabs(dv) > cut ? 0.0 : w;
+        if (MASK == 1) w = fabs(dv) > cut ? 0.0 : w;
+        if (MASK == 2) w = (fabs(dv) > cut || fabs(dv) < rin) ? 0.0 : w;
         const double w2 = w * w, w3 = w2 * w;
         acc[st] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, w, acc[st], 0, 0, 0);
         acc[st] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, w2, acc[st], 0, 0, 0);
@@ -769,9 +781,9 @@ __device__ __forceinline__ void sep_step(v4f64_sep (&acc)[4], const double (&vn)
 }
 // the lines [ja, jb) of one (state-row pointer hk) in steps of 4, ascending or descending; the load of step t + 1 is issued before the
 // matrix instructions of step t and waited for after them
-template <int NT, bool MASK>
+template <int NT, int MASK>
 __device__ __forceinline__ void sep_run(v4f64_sep (&acc)[4], const double (&vn)[4], const LineHot *__restrict__ hk, int ja, int jb, bool asc,
-                                        int lq, double cut)
+                                        int lq, double cut, double rin = 0.0)
 {
     if (ja >= jb) return;
     const int nst = (jb - ja + 3) >> 2;
@@ -782,7 +794,7 @@ __device__ __forceinline__ void sep_run(v4f64_sep (&acc)[4], const double (&vn)[
     for (int t = 0; t < nst; t++) {
         const LineHot nxt = rec(t + 1);      // (past the end: a harmless re-read of an end record, never used)
         __builtin_amdgcn_sched_barrier(0);   // keep the load here: the scheduler would sink it behind the matrix instructions
-        sep_step<NT, MASK>(acc, vn, cur, ok(t), cut);
+        sep_step<NT, MASK>(acc, vn, cur, ok(t), cut, rin);
         __builtin_amdgcn_sched_barrier(0);   // ... and the wait for it there
         cur = nxt;
     }
@@ -893,11 +905,11 @@ __global__ __launch_bounds__(256) void k_cheb_nodes_mx(const double *__restrict_
             if (z.b[p] <= z.a[p]) continue;
             int ja, jb;
             if (asc) {
-                if (z.m[p] > z.a[p]) { quarter(z.a[p], z.m[p], true, ja, jb); sep_run<3, false>(acc, vn, hk, ja, jb, true, lq, 0.0); }
-                if (z.b[p] > z.m[p]) { quarter(z.m[p], z.b[p], true, ja, jb); sep_run<4, false>(acc, vn, hk, ja, jb, true, lq, 0.0); }
+                if (z.m[p] > z.a[p]) { quarter(z.a[p], z.m[p], true, ja, jb); sep_run<3, 0>(acc, vn, hk, ja, jb, true, lq, 0.0); }
+                if (z.b[p] > z.m[p]) { quarter(z.m[p], z.b[p], true, ja, jb); sep_run<4, 0>(acc, vn, hk, ja, jb, true, lq, 0.0); }
             } else {
-                if (z.b[p] > z.m[p]) { quarter(z.m[p], z.b[p], false, ja, jb); sep_run<3, false>(acc, vn, hk, ja, jb, false, lq, 0.0); }
-                if (z.m[p] > z.a[p]) { quarter(z.a[p], z.m[p], false, ja, jb); sep_run<4, false>(acc, vn, hk, ja, jb, false, lq, 0.0); }
+                if (z.b[p] > z.m[p]) { quarter(z.m[p], z.b[p], false, ja, jb); sep_run<3, 0>(acc, vn, hk, ja, jb, false, lq, 0.0); }
+                if (z.m[p] > z.a[p]) { quarter(z.a[p], z.m[p], false, ja, jb); sep_run<4, 0>(acc, vn, hk, ja, jb, false, lq, 0.0); }
             }
         }
         if (!split) {   // D[state 4r + lq][node 16 st + lr] straight into F
@@ -1137,6 +1149,7 @@ __global__ __launch_bounds__(256) CS_FAR_ATTR void k_voigt_far(const double *__r
     double acc = 0.0;
     int bl = 0x3fffffff, bh = -1, cl = 0x3fffffff, ch = -1;
     Zone z = {};
+    bool core = false;   // (wave-uniform) the core of this (tile, state group) belongs to k_voigt_sub, the near-line hand-off with it
     if (work) {
         const LineHot *__restrict__ hk = hot + (size_t)k * L;
         const LineF32 *__restrict__ hf = MIXED ? hot32 + (size_t)k * L : nullptr;
@@ -1152,18 +1165,21 @@ __global__ __launch_bounds__(256) CS_FAR_ATTR void k_voigt_far(const double *__r
             sb0 = max(min(zi.Z1, w.W1), z.N1); sb1 = max(min(zi.E1, w.W1), sb0);
         }
         // what is left of the window after the matrix-core pieces, [wl, wr), and this wave's share [q0, q1) of it
-        int wl = w.W0, wr = w.W1, pL0 = sa1, pL1 = sa1, pR0 = sb0, pR1 = sb0;
-        if (EDGE) {   // (its own instantiation: on sparse tables the two extra clip windows cost more than they save)
+        int wl = w.W0, wr = w.W1, pL0 = sa1, pL1 = sa1, pR0 = sb0, pR1 = sb0, cL = 0, cR = 0;
+        if (EDGE) {   // (its own instantiation: on sparse tables the extra clip windows cost more than they save)
             const EdgeZone e = edge[(size_t)(k >> 4) * ntile + tile];
             wl = e.eL; wr = e.eR;
             if (e.mL1 > e.mL0) { pL0 = e.mL0; pL1 = e.mL1; }
             if (e.mR1 > e.mR0) { pR0 = e.mR0; pR1 = e.mR1; }
+            if (e.cR > e.cL) { cL = e.cL; cR = e.cR; core = true; }
         }
+        if (!core) cL = cR = pR0;   // (no core: the middle window [pL1, pR0) stays whole)
         int q0 = wl, q1 = wr;
         if (S > 1) {
             // piecewise-constant cost per line: 14 (far), 0 (skipped), 20 (4-term), 36 (near zone)
-            const int b12[12] = {wl, max(sa0, wl), sa1, pL0, pL1, z.N0, z.N1, pR0, pR1, sb0, min(sb1, wr), wr};
-            const int c11[11] = {14, 0, 20, 0, 20, 36, 20, 0, 20, 0, 14};
+            const int cc = core ? 0 : 1;   // (the core of the window is not this kernel's)
+            const int b12[12] = {wl, max(sa0, wl), sa1, pL0, pL1, core ? pL1 : z.N0, core ? pR0 : z.N1, pR0, pR1, sb0, min(sb1, wr), wr};
+            const int c11[11] = {14, 0, 20, 0, 20 * cc, 36 * cc, 20 * cc, 0, 20, 0, 14};
             int total = 0;
             for (int q = 0; q < 11; q++) total += (b12[q + 1] - b12[q]) * c11[q];
             auto cut_at = [&](int target) {
@@ -1178,8 +1194,9 @@ __global__ __launch_bounds__(256) CS_FAR_ATTR void k_voigt_far(const double *__r
             q0 = part == 0 ? wl : cut_at((int)((long long)total * part / S));
             q1 = part == S - 1 ? wr : cut_at((int)((long long)total * (part + 1) / S));
         }
-        const int cw_lo[5] = {wl, sa1, EDGE ? pL1 : sb1, pR1, sb1}, cw_hi[5] = {sa0, EDGE ? pL0 : sb0, EDGE ? pR0 : wr, sb0, wr};
-        for (int cw = 0; cw < (EDGE ? 5 : 3); cw++) {
+        const int cw_lo[6] = {wl, sa1, EDGE ? pL1 : sb1, EDGE ? cR : sb1, pR1, sb1};
+        const int cw_hi[6] = {sa0, EDGE ? pL0 : sb0, EDGE ? cL : wr, pR0, sb0, wr};
+        for (int cw = 0; cw < (EDGE ? 6 : 3); cw++) {
         const int p0 = max(q0, cw_lo[cw]), p1 = min(q1, cw_hi[cw]);
         if (p0 >= p1) continue;
 #define LO(x) max((x), p0)
@@ -1202,9 +1219,10 @@ __global__ __launch_bounds__(256) CS_FAR_ATTR void k_voigt_far(const double *__r
         // near zone: six-term series where s >= 1e3; the index ranges of this lane's s < 1e3 and s < 100 lines go to
         // k_voigt_near through `ranges` (relative to N0; empty = {0,0})
         if (HI(z.N1) > LO(z.N0)) {
-            const volatile double *tb2 = kFarTable;   // (loaded here, by the waves that have a near zone: as opaque register constants
-            const double q40 = tb2[8], q41 = tb2[9], q42 = tb2[10], q43 = tb2[11], q44 = tb2[12];   // they cost the kernel 22 VGPRs)
-            const double q50 = tb2[13], q51 = tb2[14], q52 = tb2[15], q53 = tb2[16], q54 = tb2[17], q55 = tb2[18];
+            const double q40 = sgpr_const(59.0625), q41 = sgpr_const(-787.5), q42 = sgpr_const(2835.0), q43 = sgpr_const(-3780.0),
+                         q44 = vgpr_const(1680.0);                                                            // a4 U8 in t
+            const double q50 = sgpr_const(324.84375), q51 = sgpr_const(-6496.875), q52 = sgpr_const(36382.5), q53 = sgpr_const(-83160.0),
+                         q54 = sgpr_const(83160.0), q55 = vgpr_const(-30240.0);                                // a5 U10 in t
 #pragma unroll 4
             for (int j = LO(z.N0); j < HI(z.N1); j++) {
                 const LineHot h = hk[j];
@@ -1275,7 +1293,7 @@ __global__ __launch_bounds__(256) CS_FAR_ATTR void k_voigt_far(const double *__r
     // spectral point and node in all (cs_api.hip refuses tables dense enough to overflow 20 + 12 bits: check_near_density) --
     // and per (tile, node) and tier a flag "some lane has candidates": tiles without any (most tiles of a sparse table, every
     // tile of a high-pressure state, where y^2 alone exceeds 1e3) skip the store here and the whole wave there
-    if (!LOR) {   // (a Lorentz profile has no near-line kernels to hand anything to)
+    if (!LOR && !core) {   // (a Lorentz profile has no near-line kernels to hand anything to; a core's hand-off is k_voigt_sub's)
         const unsigned r0 = (live && bh >= bl) ? ((unsigned)(bl - z.N0) << 12) | (unsigned)(bh + 1 - bl) : 0u;
         const unsigned r1 = (live && ch >= cl) ? ((unsigned)(cl - z.N0) << 12) | (unsigned)(ch + 1 - cl) : 0u;
         const bool any0 = __any(r0 != 0u), any1 = __any(r1 != 0u);
@@ -1303,7 +1321,7 @@ struct EdgeArgs {
     const IZone *iz;      // lowest interpolation level, or NULL
     EdgeZone *out;        // [ngrp][ntile]
     int64_t nnu;
-    int ntile, K, ngrp, nI, ishift;
+    int ntile, K, ngrp, nI, ishift, core;   // core: sub-tile treatment of the window core where it pays (k_voigt_sub)
     double mu_min, cut;
 };
 // per (state group, tile): the pieces common to the group's states -- the window ends left of every state's first interpolated or
@@ -1356,7 +1374,17 @@ __device__ __forceinline__ void edgezones_body(unsigned bid, const EdgeArgs &a)
     if (e.mL3 - e.mL0 < 8) e.mL3 = e.mL0;
     e.mR3 = min(max(T1, e.mR0), e.mR1);
     if (e.mR1 - e.mR3 < 8) e.mR3 = e.mR1;
-    e.pad0 = e.pad1 = e.pad2 = 0;
+    // core: from the end of the left middle piece (or of every state's interpolated set) to the start of the right one.  Worth
+    // it where a sub-tile's neighbourhood (16 points + 2 R) is well below the tile's (64 points + 2 R), and only with all 16 points
+    // of every sub-tile present (a ragged last tile keeps the tile-wide pass)
+    e.cL = e.mL1 > e.mL0 ? e.mL1 : mL0;
+    e.cR = e.mR1 > e.mR0 ? e.mR0 : mR1;
+    const bool core_ok = a.core && a.iz && i0 + 63 < a.nnu && mL0 <= mL1 && mR0 <= mR1 && e.cL <= mL1 && e.cR >= mR0 && e.cR > e.cL &&
+                         R < 0.75 * (vhi - vlo);
+    if (!core_ok) e.cL = e.cR = 0;
+    e.R = R;
+    e.pad0 = 0;
+    e.pad1 = 0.0;
     a.out[idx] = e;
 }
 // k_sepzones and the edge zones in one launch (both need the zones of k_gas_setup)
@@ -1375,7 +1403,7 @@ __global__ __launch_bounds__(256) void k_voigt_edge_mx(const double *__restrict_
     if (tile >= ntile) return;
     const WaveWin w = win[tile];
     const EdgeZone e = edge[(size_t)g * ntile + tile];
-    if (e.eL <= w.W0 && e.eR >= w.W1 && e.mL1 <= e.mL0 && e.mR1 <= e.mR0) return;
+    if (e.eL <= w.W0 && e.eR >= w.W1 && e.mL1 <= e.mL0 && e.mR1 <= e.mR0 && e.cR <= e.cL) return;
     const int lr = lane & 15, lq = lane >> 4;
     const int kk = min(g * 16 + lr, K - 1);                       // (a group's tail states re-read the last one: never stored)
     const LineHot *__restrict__ hk = hot + (size_t)kk * L;
@@ -1389,16 +1417,17 @@ __global__ __launch_bounds__(256) void k_voigt_edge_mx(const double *__restrict_
 #pragma unroll
     for (int st = 0; st < 4; st++) acc[st] = v4f64_sep{0.0, 0.0, 0.0, 0.0};
     // left pieces ascending, right pieces descending: far lines first; three terms where they do
-    if (e.far3 & 1) sep_run<3, true>(acc, vn, hk, w.W0, e.eL, true, lq, cut); else sep_run<4, true>(acc, vn, hk, w.W0, e.eL, true, lq, cut);
+    if (e.far3 & 1) sep_run<3, 1>(acc, vn, hk, w.W0, e.eL, true, lq, cut); else sep_run<4, 1>(acc, vn, hk, w.W0, e.eL, true, lq, cut);
     if (e.mL1 > e.mL0) {
-        sep_run<3, true>(acc, vn, hk, e.mL0, e.mL3, true, lq, cut);
-        sep_run<4, true>(acc, vn, hk, e.mL3, e.mL1, true, lq, cut);
+        sep_run<3, 1>(acc, vn, hk, e.mL0, e.mL3, true, lq, cut);
+        sep_run<4, 1>(acc, vn, hk, e.mL3, e.mL1, true, lq, cut);
     }
-    if (e.far3 & 2) sep_run<3, true>(acc, vn, hk, e.eR, w.W1, false, lq, cut); else sep_run<4, true>(acc, vn, hk, e.eR, w.W1, false, lq, cut);
+    if (e.far3 & 2) sep_run<3, 1>(acc, vn, hk, e.eR, w.W1, false, lq, cut); else sep_run<4, 1>(acc, vn, hk, e.eR, w.W1, false, lq, cut);
     if (e.mR1 > e.mR0) {
-        sep_run<3, true>(acc, vn, hk, e.mR3, e.mR1, false, lq, cut);
-        sep_run<4, true>(acc, vn, hk, e.mR0, e.mR3, false, lq, cut);
+        sep_run<3, 1>(acc, vn, hk, e.mR3, e.mR1, false, lq, cut);
+        sep_run<4, 1>(acc, vn, hk, e.mR0, e.mR3, false, lq, cut);
     }
+    if (e.cR > e.cL) sep_run<4, 2>(acc, vn, hk, e.cL, e.cR, true, lq, cut, e.R);   // the core: pairs at least R apart
 #pragma unroll
     for (int st = 0; st < 4; st++)
 #pragma unroll
@@ -1407,6 +1436,113 @@ __global__ __launch_bounds__(256) void k_voigt_edge_mx(const double *__restrict_
             const int64_t i = (int64_t)tile * 64 + st * 16 + lr;
             if (k < K && i < nnu) sigma[(size_t)k * nnu + i] += acc[st][r];
         }
+}
+
+// K2f: the core of the window on 16-point sub-tiles.  The tile-wide near-zone pass of k_voigt_far runs its 37 instructions for every
+// line within the TILE's reach on all 64 lanes, of which the few within 100 Doppler widths of the line need them.  Here one wave =
+// one sub-tile of 16 points x 4 states (lane = 16 s + point; the record of (state, line) through a vector load, 16 lanes per
+// address), so a line is visited by the sub-tiles within R of it only -- a third as many (lane, line) evaluations -- and only its
+// pairs with |dnu| < R are summed; the others are k_voigt_edge_mx's (same comparison, complementary mask).  Same series and
+// hand-off as the near-zone pass (six terms where s >= 1e3, index ranges of the s < 1e3 and s < 100 lines for k_voigt_near).
+// One block = the four sub-tiles of a tile x the same four states; the per-(tile, state) hand-off flags are OR-ed through LDS.
+__global__ __launch_bounds__(256) void k_voigt_sub(const double *__restrict__ nu, int64_t nnu, int64_t L, const LineHot *__restrict__ hot,
+                                                   const double *__restrict__ gnul, const Zone *__restrict__ zones,
+                                                   const EdgeZone *__restrict__ edge, int ntile, int K, double cut,
+                                                   double *__restrict__ sigma, unsigned *__restrict__ rp)
+{
+    __shared__ unsigned fl_sh[4][2];
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int tile = blockIdx.x, kq = blockIdx.y;
+    const EdgeZone e = edge[(size_t)(kq >> 2) * ntile + tile];
+    if (e.cR <= e.cL) return;   // (block-uniform)
+    const int s4 = lane >> 4, pt = lane & 15;
+    const int k = 4 * kq + s4;
+    const bool kin = k < K;
+    const LineHot *__restrict__ hk = hot + (size_t)(kin ? k : K - 1) * L;
+    const int64_t i = (int64_t)tile * 64 + wv * 16 + pt;   // (a core exists on complete tiles only)
+    const double v = nu[i];
+    const double Rg = e.R;
+    // the lines within Rg of the sub-tile (wave-uniform: first and last point of the sub-tile sit in lanes 0 and 15)
+    int ja = e.cL, jb = e.cR;
+    {
+        const double vlo = __builtin_bit_cast(double, ((uint64_t)__builtin_amdgcn_readlane((int)(__builtin_bit_cast(uint64_t, v) >> 32), 0) << 32) |
+                                                          (uint32_t)__builtin_amdgcn_readlane((int)__builtin_bit_cast(uint64_t, v), 0));
+        const double vhi = __builtin_bit_cast(double, ((uint64_t)__builtin_amdgcn_readlane((int)(__builtin_bit_cast(uint64_t, v) >> 32), 15) << 32) |
+                                                          (uint32_t)__builtin_amdgcn_readlane((int)__builtin_bit_cast(uint64_t, v), 15));
+        int p = ja, q = jb;
+        const double a0 = vlo - Rg;
+        while (p < q) { const int m = (p + q) >> 1; if (gnul[m] < a0) p = m + 1; else q = m; }
+        ja = p;
+        q = jb;
+        const double a1 = vhi + Rg;
+        while (p < q) { const int m = (p + q) >> 1; if (gnul[m] <= a1) p = m + 1; else q = m; }
+        jb = p;
+    }
+    // (every operand of the series is a vector register here -- the record is per lane -- so all its constants can be scalar)
+    const double k1p5 = sgpr_const(1.5), k3p75 = sgpr_const(3.75), k12 = vgpr_const(12.0), km15 = sgpr_const(-15.0), km105 = sgpr_const(-105.0),
+                 k13p125 = sgpr_const(13.125), k210 = sgpr_const(210.0), km120 = vgpr_const(-120.0);
+    const double q40 = sgpr_const(59.0625), q41 = sgpr_const(-787.5), q42 = sgpr_const(2835.0), q43 = sgpr_const(-3780.0), q44 = vgpr_const(1680.0);
+    const double q50 = sgpr_const(324.84375), q51 = sgpr_const(-6496.875), q52 = sgpr_const(36382.5), q53 = sgpr_const(-83160.0),
+                 q54 = sgpr_const(83160.0), q55 = vgpr_const(-30240.0);
+    struct { double k1p5, k3p75, k12, km15, km105, k13p125, k210, km120; } c = {k1p5, k3p75, k12, km15, km105, k13p125, k210, km120};
+    double acc = 0.0;
+    int bl = 0x3fffffff, bh = -1, cl = 0x3fffffff, ch = -1;
+    LineHot cur = hk[ja < jb ? ja : 0];
+    for (int j = ja; j < jb; j++) {
+        const LineHot nxt = hk[min(j + 1, jb - 1)];   // in flight while this line is evaluated
+        __builtin_amdgcn_sched_barrier(0);
+        const LineHot h = cur;
+        const double dv = v - h.nul;
+        const double x = dv * h.p1;
+        const double s = __builtin_fma(x, x, h.p2);
+        const bool in = fabs(dv) < Rg && !(fabs(dv) > cut);
+        const double u = rcp_fast(s);
+        const double t = h.p2 * u;
+        const double p5 = __builtin_fma(__builtin_fma(__builtin_fma(__builtin_fma(__builtin_fma(q55, t, q54), t, q53), t, q52), t, q51), t, q50);
+        const double p4 = __builtin_fma(__builtin_fma(__builtin_fma(__builtin_fma(q44, t, q43), t, q42), t, q41), t, q40);
+        const double p3 = __builtin_fma(__builtin_fma(__builtin_fma(c.km120, t, c.k210), t, c.km105), t, c.k13p125);
+        const double p2 = __builtin_fma(__builtin_fma(c.k12, t, c.km15), t, c.k3p75);
+        const double p1v = __builtin_fma(-2.0, t, c.k1p5);
+        double P = __builtin_fma(u, p5, p4);
+        P = __builtin_fma(u, P, p3);
+        P = __builtin_fma(u, P, p2);
+        P = __builtin_fma(u, P, p1v);
+        P = __builtin_fma(u, P, 1.0);
+        double term = (h.p3 * u) * P;
+        asm volatile("" : "+v"(term));
+        acc += (in && s >= kSerS) ? term : 0.0;
+        if (in && s < kSerS) { bl = min(bl, j); bh = j; }
+        if (in && s < kMidS) { cl = min(cl, j); ch = j; }
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+    }
+    const int N0 = zones[(size_t)(kin ? k : K - 1) * ntile + tile].N0;
+    const unsigned r0 = (kin && bh >= bl) ? ((unsigned)(bl - N0) << 12) | (unsigned)(bh + 1 - bl) : 0u;
+    const unsigned r1 = (kin && ch >= cl) ? ((unsigned)(cl - N0) << 12) | (unsigned)(ch + 1 - cl) : 0u;
+    const size_t plane = (size_t)K * nnu;
+    if (kin) {
+        const size_t o = (size_t)k * nnu + i;
+        if (acc != 0.0) sigma[o] += acc;
+        rp[o] = r0;            // (always written: whether the tile has candidates at all is known after the block's OR)
+        rp[plane + o] = r1;
+    }
+    // flags "some lane of (tile, state) has candidates", one word per tier: bit s = state 4 kq + s
+    const uint64_t b0 = __builtin_amdgcn_ballot_w64(r0 != 0u), b1 = __builtin_amdgcn_ballot_w64(r1 != 0u);
+    if (lane == 0) {
+        unsigned f0 = 0u, f1 = 0u;
+        for (int q = 0; q < 4; q++) {
+            f0 |= ((b0 >> (16 * q)) & 0xffffull) ? (1u << q) : 0u;
+            f1 |= ((b1 >> (16 * q)) & 0xffffull) ? (1u << q) : 0u;
+        }
+        fl_sh[wv][0] = f0; fl_sh[wv][1] = f1;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        const int q = threadIdx.x & 3, tier = threadIdx.x >> 2;
+        const unsigned f = fl_sh[0][tier] | fl_sh[1][tier] | fl_sh[2][tier] | fl_sh[3][tier];
+        const int kk = 4 * kq + q;
+        if (kk < K) (rp + 2 * plane)[((size_t)tier * K + kk) * ntile + tile] = (f >> q) & 1u;
+    }
 }
 
 // ---- PHCO2 (Perrin & Hartmann sub-Lorentzian CO2 wings, line_shapes.jl:467-540) ------------------------------------------------

@@ -94,7 +94,8 @@ int cs_set_interp_plan(cs_ctx *ctx, int first_level, int size_min, int size_max)
  * sqrt(gamma^2 + 4.33 alpha^2)), the node sums of the interpolated far wings and the window ends of the
  * per-point sum -- cut-off edges included, as a mask (K2e) -- are matrix products on v_mfma_f64_16x16x4.  on = 1 (default):
  * where the grid has enough (interval | tile, state group) blocks to fill the chip; 2: always; 0: everything on the vector
- * unit.  Same results to rounding (tests/test_gpu_interp.py). */
+ * unit; | 4 keeps the tile-wide near-zone pass where the default hands the core of a window to 16-point sub-tiles (k_voigt_sub).
+ * Same results to rounding (tests/test_gpu_interp.py). */
 int cs_set_matrix_cores(cs_ctx *ctx, int on);
 
 /*
@@ -215,7 +216,8 @@ int cs_column_counts(cs_ctx *ctx, int64_t *pair_evals, int64_t *lines_in_range);
  * evaluations by body (2-, 3-, 4-term) on the vector unit -- what bench.py weights with the VALU instruction count of each
  * body -- and out[13], out[14] = the node and the per-point evaluations summed on the matrix cores (cs_set_matrix_cores;
  * out[0] and out[4..9] do not include the latter), out[15] = those of out[13] + out[14] that take three series terms instead of
- * four.  `out` holds 16 values.  cs_column_counts is the reference's count. */
+ * four, out[16] = (lane, line) evaluations of k_voigt_sub (the window core on 16-point sub-tiles; 37 instructions each like the
+ * near-zone pass; not in out[0]).  `out` holds 17 values.  cs_column_counts is the reference's count. */
 int cs_column_work(cs_ctx *ctx, int64_t *out);
 /* interval sizes (descending, <= 5, each 128..2048 points) cs_set_interp(on) would use for this grid and cut-off; returns
  * their number (0: the grid is too coarse for the cut-off -- every pair is evaluated directly) */

@@ -245,7 +245,7 @@ def test_phco2_fast_path(cs, O, lines, ctx_on):
 
 
 def test_matrix_core_node_sums_on_off(cs, O, lines):
-    """K2d, K2e: far lines inside the validity range of the 4-term series in 1/dnu^2 are summed as matrix products on
+    """K2d, K2e, K2f: far lines inside the validity range of the 4-term series in 1/dnu^2 are summed as matrix products on
     v_mfma_f64_16x16x4 -- at the interpolation nodes (k_cheb_nodes_mx) and, for the window ends of the per-point sum with the
     cut-off as a mask, at the points themselves (k_voigt_edge_mx); the rest stays on the vector unit.  Same cross-sections as with every node sum on the
     vector unit (5e-14) and as the oracle (1e-11), for state groups that mix low and high pressures, a ragged last group (K = 41),
@@ -255,9 +255,10 @@ def test_matrix_core_node_sums_on_off(cs, O, lines):
     T = cs.AtmosphericProfile(P, np.linspace(200.0, 295.0, 21))
     dense = cs.SpectralLines.synthetic(2, 20000, 77, numin=500.0, numax=860.0)
     res = {}
-    for on in (True, False):
+    for on in (True, False, "tile-wide"):
         c = cs.Context(0)
-        c.set_matrix_cores(2 if on else 0)   # (2: also on this grid, too short for the default to choose the matrix path)
+        c.set_matrix_cores({True: 2, False: 0, "tile-wide": 2 | 4}[on])   # (2: also on this grid, too short for the default to choose
+                                                                            #  the matrix path; | 4: without the sub-tile cores, K2f)
         gases = [cs.DirectGas(dense, 400e-6, nu), cs.DirectGas(lines("H2O"), 5e-3, nu)]
         col = cs.Column(P, 9.8, T, 0.029, 0.0, 0.0, *gases, core=cs.Discretized(4, 3), want_tau=True, want_M=False, ctx=c)
         assert col.K == 41
@@ -267,13 +268,17 @@ def test_matrix_core_node_sums_on_off(cs, O, lines):
         B = col.run_batch([T, cs.AtmosphericProfile(P, np.linspace(205.0, 288.0, 21))])
         sb = cs.shape_batch(dense, "voigt", nu, [220.0, 296.0, 250.0], [50.0, 101325.0, 3e3], [0.02, 40.53, 1.2], 25.0, c)
         wk = col.work()
-        assert (wk["node_evals_matrix"] > 0 and wk["direct_evals_matrix"] > 0) == on   # (both matrix-core kernels really ran)
+        assert (wk["node_evals_matrix"] > 0 and wk["direct_evals_matrix"] > 0) == bool(on)   # (both matrix-core kernels really ran)
+        assert (wk["sub_evals"] > 0) == (on is True)                                              # (... and the sub-tile kernel)
         res[on] = (col.sigma_nodes(), tau, F, B, sb, col)
-        if on:
+        if on is True:
             r = O.fluxes_discretized(nu, P, 9.8, 3, col.Tn, col.mun, col.Tlev, [dense, lines("H2O")], ["voigt"] * 2, [25.0] * 2, col.conc,
                                      nstream=4, want_sigma=True)
             assert relerr(res[on][0], r["sigma"], floor=1e-300) < 1e-11 and relerr(tau, r["tau"]) < 1e-11
         c.close()
+    for a, b in ((res[True], res["tile-wide"]), (res["tile-wide"], res[False])):
+        assert relerr(a[0], b[0], floor=1e-300) < 5e-14 and relerr(a[1], b[1]) < 5e-14
+        assert not np.array_equal(a[0], b[0])
     a, b = res[True], res[False]
     assert relerr(a[0], b[0], floor=1e-300) < 5e-14 and relerr(a[1], b[1]) < 5e-14
     assert relerr(a[2][0], b[2][0]) < 1e-13
