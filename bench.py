@@ -212,11 +212,11 @@ def main():
     # instructions per line (ISA), over its HIP-event time, against the fp64-rate issue peak (all 64 lanes of a wave count, also
     # those the cut-off predicate masks)
     db, nb = work.get("direct_by_body", {}), work.get("node_by_body", {})
-    far_instr = sum(db.get(b, 0) * VALU_PER_LINE[b] for b in db)
+    far_instr = sum(db.get(b, 0) * VALU_PER_LINE[b] for b in db) + work.get("sub_evals", 0) * VALU_PER_LINE["near_zone"]   # (+ k_voigt_sub, timed with it)
     node_instr = sum(nb.get(b, 0) * VALU_PER_LINE[b] for b in nb)
     valu_issue = dict(unit="fraction of the fp64-rate VALU issue peak (256 CU x 4 SIMD x 16 lanes x 2.4 GHz)", valu_per_line=VALU_PER_LINE,
                       k_voigt_far=dict(lane_instr=far_instr, ms=prof["far"], frac=(far_instr / (prof["far"] * 1e-3) / VALU_ISSUE_PEAK) if prof["far"] > 0 else None,
-                                       lines_x_lanes_by_body=db),
+                                       lines_x_lanes_by_body=db, sub_tile_evals=work.get("sub_evals", 0)),
                       k_cheb_nodes=dict(lane_instr=node_instr, ms=prof["nodes"], frac=(node_instr / (prof["nodes"] * 1e-3) / VALU_ISSUE_PEAK) if prof["nodes"] > 0 else None,
                                         lines_x_nodes_by_body=nb))
     roofline = dict(bound="hbm", kernel="k_voigt_far", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",

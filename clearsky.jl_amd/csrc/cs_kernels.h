@@ -301,9 +301,8 @@ __device__ __forceinline__ void zones_body(unsigned bid, const ZoneArgs &a)
 // constants of the series kept in VGPRs for the whole kernel (gfx950 VALU instructions take one constant-bus operand:
 // the line parameter; a second literal would cost a v_mov per use).
 struct FarK { double k1p5, k3p75, k12, km15, km105, k13p125, k210, km120; };
-__device__ const double kFarTable[19] = {1.5, 3.75, 12.0, -15.0, -105.0, 13.125, 210.0, -120.0,
-                                         59.0625, -787.5, 2835.0, -3780.0, 1680.0,                           // a4*U8 in t
-                                         324.84375, -6496.875, 36382.5, -83160.0, 83160.0, -30240.0};       // a5*U10 in t
+// (coefficients of the higher terms, a4 U8 and a5 U10 as polynomials in t: 59.0625 -787.5 2835 -3780 1680 | 324.84375 -6496.875
+//  36382.5 -83160 83160 -30240)
 // an opaque constant in a VGPR pair: the empty asm hides the value from the optimiser, which would otherwise rematerialise it as
 // a literal (a v_mov per use) -- and costs no memory access (the first version loaded the table with eight volatile loads, i.e.
 // eight serialised round trips at the start of every wave: most of a short wave's life on a sparse line table)
