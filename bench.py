@@ -196,9 +196,9 @@ def main():
     # ones 64 nodes per (interval, line)) x 24 flops, over their time.  `reference_pair_evals` is what surf! evaluates.
     # (node_evals counts every node sum; node_evals_matrix / direct_evals_matrix of them / besides direct_evals run on the matrix cores)
     mx_triples = work.get("node_evals_matrix", 0) + work.get("direct_evals_matrix", 0)
-    evals = work["direct_evals"] + work["node_evals"] - work.get("node_evals_matrix", 0)
+    evals = work["direct_evals"] + work["node_evals"] - work.get("node_evals_matrix", 0) + work.get("sub_evals", 0)
     flops = evals * FLOPS_PER_PAIR
-    line_ms = prof["nodes"] + prof["far"] + prof["near"]
+    line_ms = prof["nodes"] + prof["far"] + prof["near"] + prof.get("sub", 0.0)
     mx_ms = prof.get("nodes_mx", 0.0) + prof.get("far_mx", 0.0)
     # matrix cores: 4 (or 3) terms x (multiply + add) per (node | point, line, state); v_mfma_f64_16x16x4 = 2048 flop.  Spec peak of the fp64
     # matrix path = the fp64 vector rate (78.6 TFLOP/s); tools/ubench/mfma_f64_rate.hip sustains 47, and a matrix and a vector
@@ -212,11 +212,14 @@ def main():
     # instructions per line (ISA), over its HIP-event time, against the fp64-rate issue peak (all 64 lanes of a wave count, also
     # those the cut-off predicate masks)
     db, nb = work.get("direct_by_body", {}), work.get("node_by_body", {})
-    far_instr = sum(db.get(b, 0) * VALU_PER_LINE[b] for b in db) + work.get("sub_evals", 0) * VALU_PER_LINE["near_zone"]   # (+ k_voigt_sub, timed with it)
+    far_instr = sum(db.get(b, 0) * VALU_PER_LINE[b] for b in db)
+    sub_instr = work.get("sub_evals", 0) * VALU_PER_LINE["near_zone"]
     node_instr = sum(nb.get(b, 0) * VALU_PER_LINE[b] for b in nb)
     valu_issue = dict(unit="fraction of the fp64-rate VALU issue peak (256 CU x 4 SIMD x 16 lanes x 2.4 GHz)", valu_per_line=VALU_PER_LINE,
                       k_voigt_far=dict(lane_instr=far_instr, ms=prof["far"], frac=(far_instr / (prof["far"] * 1e-3) / VALU_ISSUE_PEAK) if prof["far"] > 0 else None,
-                                       lines_x_lanes_by_body=db, sub_tile_evals=work.get("sub_evals", 0)),
+                                       lines_x_lanes_by_body=db),
+                      k_voigt_sub=dict(lane_instr=sub_instr, ms=prof.get("sub", 0.0), evals=work.get("sub_evals", 0),
+                                       frac=(sub_instr / (prof["sub"] * 1e-3) / VALU_ISSUE_PEAK) if prof.get("sub", 0.0) > 0 else None),
                       k_cheb_nodes=dict(lane_instr=node_instr, ms=prof["nodes"], frac=(node_instr / (prof["nodes"] * 1e-3) / VALU_ISSUE_PEAK) if prof["nodes"] > 0 else None,
                                         lines_x_nodes_by_body=nb))
     roofline = dict(bound="hbm", kernel="k_voigt_far", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
@@ -227,7 +230,7 @@ def main():
                                    unit="TFLOP/s", frac=flops / (line_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS if line_ms > 0 else 0.0,
                                    evals_issued=evals, direct_evals=work["direct_evals"], node_evals=work["node_evals"],
                                    reference_pair_evals=cnt["pair_evals"], flops_per_eval=FLOPS_PER_PAIR,
-                                   kernels="k_cheb_nodes + k_voigt_far + k_voigt_near"),
+                                   kernels="k_cheb_nodes + k_voigt_far + k_voigt_sub + k_voigt_near"),
                     valu_issue=valu_issue, matrix_fp64=matrix_fp64,
                     interp_levels=work["levels"], kernel_ms=prof)
 

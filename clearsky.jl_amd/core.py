@@ -1052,12 +1052,12 @@ class Column:
 
     def profile(self, reps: int = 3, stream: int = 0):
         """HIP-event time per kernel class, ms per evaluation, summed over gases: dict(prep, nodes, apply, far, near, rt, reduce,
-        nodes_mx, far_mx) = k_gas_setup (+ k_mxzones), k_cheb_nodes, k_cheb_apply, k_voigt_far (or k_linesum), k_voigt_near, k_rt,
-        k_freduce, k_cheb_nodes_mx, k_voigt_edge_mx."""
-        ms = np.zeros(9)
+        nodes_mx, far_mx, sub) = k_gas_setup (+ k_mxzones), k_cheb_nodes, k_cheb_apply, k_voigt_far (or k_linesum), k_voigt_near, k_rt,
+        k_freduce, k_cheb_nodes_mx, k_voigt_edge_mx, k_voigt_sub."""
+        ms = np.zeros(10)
         self._ensure_resident()
         check(lib().cs_column_profile(self.ctx.handle, C.c_void_p(stream) if stream else None, reps, dptr(ms)))
-        return dict(prep=ms[0], nodes=ms[1], apply=ms[2], far=ms[3], near=ms[4], rt=ms[5], reduce=ms[6], nodes_mx=ms[7], far_mx=ms[8])
+        return dict(prep=ms[0], nodes=ms[1], apply=ms[2], far=ms[3], near=ms[4], rt=ms[5], reduce=ms[6], nodes_mx=ms[7], far_mx=ms[8], sub=ms[9])
 
     def flux_ptr(self) -> int:
         self._require_resident("flux_ptr")

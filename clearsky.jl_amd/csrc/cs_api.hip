@@ -654,7 +654,7 @@ static bool edge_in_use(bool have_edge, bool always, int ntiles, int kn, bool lo
 void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, int64_t jrange1, int kn, const double *Tk, const double *Pk, const double *Ppk,
                 const double *scale, LineHot *hot, LineCold *cold, const double *dnu, int64_t nnu, int ntile256,
                 const int32_t *J0, const int32_t *J1, const WaveWin *win, int xtiles, Zone *zones, int2 *ranges, const double *gbound, double cut, double base,
-                const double *extra, double *sigma, int accumulate, hipEvent_t *evg,   // NULL or 5 events: after K1 (+ zones), nodes (vector unit), nodes (matrix cores), far (vector unit), far (matrix cores)
+                const double *extra, double *sigma, int accumulate, hipEvent_t *evg,   // NULL or 6 events: after K1 (+ zones), nodes (vector unit), nodes (matrix cores), far (vector unit), sub-tile cores, far (matrix cores)
                 LineF32 *hot32 = nullptr, double far_s = 1e6, Interp itp = Interp(), ChebApply *defer = nullptr, PhScratch *ph = nullptr)
 {
     // only the lines some window can reach (windows are sorted: first tile's start .. last tile's end)
@@ -787,19 +787,23 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
         }
 #undef CS_FAR_LAUNCH
 #undef CS_LOR_LAUNCH
+        if (evg) (void)hipEventRecord(evg[3], s);
         if (use_edge && itp.core)   // the window cores of the groups whose series radius is short: pairs inside it (the rest: k_voigt_edge_mx)
             hipLaunchKernelGGL(k_voigt_sub, dim3((unsigned)nt64, (unsigned)((kn + 3) / 4)), dim3(256), 0, s, dnu, nnu, G.L, hot, G.nu.as<double>(), zones,
                                itp.edge, nt64, kn, cut, sigma, reinterpret_cast<unsigned *>(ranges));
-        if (evg) (void)hipEventRecord(evg[3], s);
+        if (evg) (void)hipEventRecord(evg[4], s);
         if (use_edge)
             hipLaunchKernelGGL(k_voigt_edge_mx, dim3((unsigned)((nt64 + 3) / 4), (unsigned)((kn + 15) / 16)), dim3(256), 0, s, dnu, nnu, G.L, hot, win,
                                itp.edge, nt64, kn, cut, sigma);
-        if (evg) (void)hipEventRecord(evg[4], s);
+        if (evg) (void)hipEventRecord(evg[5], s);
         if (!lor) {
-            const int ngrp = (nt64 + CS_NEAR_R - 1) / CS_NEAR_R;   // near kernels: one wave = CS_NEAR_R consecutive tiles
-            const dim3 gridq((unsigned)((ngrp + 3) / 4), kn);
-            hipLaunchKernelGGL(k_voigt_near<0>, gridq, dim3(256), 0, s, dnu, nnu, G.L, hot, cold, zones, nt64, ngrp, cut, sigma, ranges);
-            hipLaunchKernelGGL(k_voigt_near<1>, gridq, dim3(256), 0, s, dnu, nnu, G.L, hot, cold, zones, nt64, ngrp, cut, sigma, ranges);
+            const int ngrp = (nt64 + CS_NEAR_R - 1) / CS_NEAR_R;   // near kernels: one wave = CS_NEAR_R consecutive tiles ...
+            // ... times nrep, one after the other, where the table is sparse against the grid (few tiles have candidates at all) and
+            // the grid long enough to keep the chip full with an eighth of the waves
+            const int nrep = (jhi - jlo < (int64_t)nt64 * 2 && (int64_t)ngrp * kn >= 262144) ? 8 : 1;
+            const dim3 gridq((unsigned)(((ngrp + nrep - 1) / nrep + 3) / 4), kn);
+            hipLaunchKernelGGL(k_voigt_near<0>, gridq, dim3(256), 0, s, dnu, nnu, G.L, hot, cold, zones, nt64, ngrp, nrep, cut, sigma, ranges);
+            hipLaunchKernelGGL(k_voigt_near<1>, gridq, dim3(256), 0, s, dnu, nnu, G.L, hot, cold, zones, nt64, ngrp, nrep, cut, sigma, ranges);
         }
     } else if (shape == SH_PHCO2 && ph && phco2_fast_ok(G, nnu, cut, kn, ph)) {
         // PHCO2 fast path (k_phco2): region-uniform far lines with factorised chi; needs the cut-off edges inside region 3 and the
@@ -822,7 +826,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
         if (evg) { (void)hipEventRecord(evg[0], s); (void)hipEventRecord(evg[1], s); (void)hipEventRecord(evg[2], s); }
         hipLaunchKernelGGL(k_phco2, dim3((unsigned)((nt64 + 3) / 4), kn), dim3(256), 0, s, dnu, nnu, G.L, hot, cold, ph->fac.as<double>(), ph->nu_c,
                            ph->win.as<PhWin>(), zones, nt64, cut, Tk, kn, base, extra, sigma, accumulate);
-        if (evg) { (void)hipEventRecord(evg[3], s); (void)hipEventRecord(evg[4], s); }
+        if (evg) { (void)hipEventRecord(evg[3], s); (void)hipEventRecord(evg[4], s); (void)hipEventRecord(evg[5], s); }
     } else {
         if (nb_prep > 0) {
             ZoneArgs za;
@@ -834,7 +838,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
         if (evg) { (void)hipEventRecord(evg[0], s); (void)hipEventRecord(evg[1], s); (void)hipEventRecord(evg[2], s); }
         launch_linesum_shape(shape, dim3(ntile256, kn), s, dnu, nnu, G.L, hot, cold, J0, J1, cut, Tk, base, extra, sigma,
                              accumulate);
-        if (evg) { (void)hipEventRecord(evg[3], s); (void)hipEventRecord(evg[4], s); }
+        if (evg) { (void)hipEventRecord(evg[3], s); (void)hipEventRecord(evg[4], s); (void)hipEventRecord(evg[5], s); }
     }
 }
 
@@ -1871,7 +1875,7 @@ static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e)
                    cg.J1.as<int32_t>(), cg.win.as<WaveWin>(), cg.xtiles, cg.zones.as<Zone>(), c.ranges.as<int2>(), cg.gmax.as<double>(), cg.cut, c.sigma_gray, extra, sig, gi > 0,
                    ev ? ev + e : nullptr,
                    (ctx->mixed && cg.shape == SH_VOIGT) ? ctx->hot32.as<LineF32>() : nullptr, ctx->far_s, itp, &apply, &ctx->ph);
-        if (ev) { e += 5; HIPCHK(hipEventRecord(ev[e++], s)); }
+        if (ev) { e += 6; HIPCHK(hipEventRecord(ev[e++], s)); }
     }
     // interpolated far wings of all gases: sigma += sum_level C (sum_gas F)  (one pass over C and sigma)
     if (apply.ngas > 0) launch_apply(s, apply, cheb_kpad(K), c.nnu, K, 0.0, nullptr, sig, 1);
@@ -1928,26 +1932,26 @@ int cs_column_profile(cs_ctx *ctx, void *stream, int reps, double *ms)
     Column &c = ctx->col;
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     HIPCHK(hipSetDevice(ctx->device));
-    const int nev = 6 * c.ngas + 4;
+    const int nev = 7 * c.ngas + 4;
     std::vector<hipEvent_t> ev(nev);
     for (auto &e : ev) HIPCHK(hipEventCreate(&e));
-    for (int i = 0; i < 9; i++) ms[i] = 0.0;
+    for (int i = 0; i < 10; i++) ms[i] = 0.0;
     int rc = CS_OK;
     for (int r = 0; r < reps && rc == CS_OK; r++) {
         rc = run_impl(ctx, s, ev.data());
         if (rc) break;
         if (hipStreamSynchronize(s) != hipSuccess) { rc = fail(CS_EHIP, "hipStreamSynchronize failed"); break; }
         float t;
-        const int slot[6] = {0, 1, 7, 3, 8, 4};   // per gas: K1 + zones, nodes, nodes on the matrix cores, far, far on the matrix cores, near
+        const int slot[7] = {0, 1, 7, 3, 9, 8, 4};   // per gas: K1 + zones, nodes, nodes on the matrix cores, far, sub-tile cores, far on the matrix cores, near
         for (int gi = 0; gi < c.ngas; gi++)
-            for (int q = 0; q < 6; q++) { (void)hipEventElapsedTime(&t, ev[6 * gi + q], ev[6 * gi + q + 1]); ms[slot[q]] += t; }
-        const int b = 6 * c.ngas;
+            for (int q = 0; q < 7; q++) { (void)hipEventElapsedTime(&t, ev[7 * gi + q], ev[7 * gi + q + 1]); ms[slot[q]] += t; }
+        const int b = 7 * c.ngas;
         (void)hipEventElapsedTime(&t, ev[b], ev[b + 1]); ms[2] += t;       // apply (+ baked tables, CIA)
         (void)hipEventElapsedTime(&t, ev[b + 1], ev[b + 2]); ms[5] += t;   // rt
         (void)hipEventElapsedTime(&t, ev[b + 2], ev[b + 3]); ms[6] += t;   // reduce
     }
     for (auto &e : ev) (void)hipEventDestroy(e);
-    for (int i = 0; i < 9; i++) ms[i] /= reps;
+    for (int i = 0; i < 10; i++) ms[i] /= reps;
     return rc;
 }
 

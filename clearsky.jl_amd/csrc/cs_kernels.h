@@ -1808,44 +1808,45 @@ __device__ __forceinline__ void near_pass(const double *__restrict__ nu, int64_t
 template <int TIER>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_voigt_near(const double *__restrict__ nu, int64_t nnu, int64_t L,
                                                      const LineHot *__restrict__ hot, const LineCold *__restrict__ cold,
-                                                     const Zone *__restrict__ zones, int ntile, int ngrp, double cut,
+                                                     const Zone *__restrict__ zones, int ntile, int ngrp, int nrep, double cut,
                                                      double *__restrict__ sigma, const int2 *__restrict__ ranges)
 {
+    // nrep consecutive tiles per wave, one after the other: on a sparse table nearly every (tile, state) has no candidates, and a
+    // wave that only reads its flag and exits still costs its launch -- 7.9e5 of them per kernel at C5, 0.3 ms whatever the gas
     __shared__ unsigned qidx_s[4][CS_NEAR_Q];
     __shared__ double qres_s[4][CS_NEAR_Q];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int grp = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wv);   // group of CS_NEAR_R tiles
-    if (grp >= ngrp) return;
-    const int tile0 = grp * CS_NEAR_R;
+    const int grp0 = __builtin_amdgcn_readfirstlane(((int)blockIdx.x * 4 + wv) * nrep);   // first group of CS_NEAR_R tiles
     const int k = blockIdx.y;
     const LineHot *__restrict__ hk = hot + (size_t)k * L;
     const LineCold *__restrict__ ck = cold + (size_t)k * L;
     // two planes of packed words: tier 0 ranges, then tier 1 ranges, [gridDim.y][nnu] each; behind them the per-(tile, node) flags
-    {
-        const unsigned *__restrict__ fl = reinterpret_cast<const unsigned *>(ranges) + 2 * (size_t)gridDim.y * nnu;
-        if (fl[((size_t)TIER * gridDim.y + k) * ntile + grp] == 0u) return;   // (wave-uniform: CS_NEAR_R = 1, group = tile)
-    }
+    const unsigned *__restrict__ fl = reinterpret_cast<const unsigned *>(ranges) + 2 * (size_t)gridDim.y * nnu + ((size_t)TIER * gridDim.y + k) * ntile;
     const unsigned *__restrict__ rp = reinterpret_cast<const unsigned *>(ranges) + (size_t)TIER * gridDim.y * nnu + (size_t)k * nnu;
-    int lo[CS_NEAR_R], hi[CS_NEAR_R];
-    double acc[CS_NEAR_R];
+    for (int grp = grp0; grp < min(grp0 + nrep, ngrp); grp++) {
+        if (fl[grp] == 0u) continue;   // (wave-uniform: CS_NEAR_R = 1, group = tile)
+        const int tile0 = grp * CS_NEAR_R;
+        int lo[CS_NEAR_R], hi[CS_NEAR_R];
+        double acc[CS_NEAR_R];
 #pragma unroll
-    for (int r = 0; r < CS_NEAR_R; r++) {
-        const int tile = tile0 + r;
-        const int64_t i = (int64_t)tile * 64 + lane;
-        lo[r] = hi[r] = 0;
-        acc[r] = 0.0;
-        if (tile < ntile && i < nnu) {
-            const unsigned q = rp[i];
-            const int N0 = zones[(size_t)k * ntile + tile].N0;
-            lo[r] = N0 + (int)(q >> 12);
-            hi[r] = lo[r] + (int)(q & 0xfffu);
+        for (int r = 0; r < CS_NEAR_R; r++) {
+            const int tile = tile0 + r;
+            const int64_t i = (int64_t)tile * 64 + lane;
+            lo[r] = hi[r] = 0;
+            acc[r] = 0.0;
+            if (tile < ntile && i < nnu) {
+                const unsigned q = rp[i];
+                const int N0 = zones[(size_t)k * ntile + tile].N0;
+                lo[r] = N0 + (int)(q >> 12);
+                hi[r] = lo[r] + (int)(q & 0xfffu);
+            }
         }
-    }
-    near_pass<TIER>(nu, nnu, tile0, lo, hi, acc, hk, ck, cut, qidx_s[wv], qres_s[wv]);
+        near_pass<TIER>(nu, nnu, tile0, lo, hi, acc, hk, ck, cut, qidx_s[wv], qres_s[wv]);
 #pragma unroll
-    for (int r = 0; r < CS_NEAR_R; r++) {
-        const int64_t i = (int64_t)(tile0 + r) * 64 + lane;
-        if (tile0 + r < ntile && i < nnu && acc[r] != 0.0) sigma[(size_t)k * nnu + i] += acc[r];
+        for (int r = 0; r < CS_NEAR_R; r++) {
+            const int64_t i = (int64_t)(tile0 + r) * 64 + lane;
+            if (tile0 + r < ntile && i < nnu && acc[r] != 0.0) sigma[(size_t)k * nnu + i] += acc[r];
+        }
     }
 }
 

@@ -199,9 +199,9 @@ int cs_column_run(cs_ctx *ctx, void *stream);
  * (absorbers.jl:95), left in HBM for cs_column_sigma_fetch / cs_accel_store.  Asynchronous. */
 int cs_column_sigma_run(cs_ctx *ctx, void *stream);
 int cs_column_sync(cs_ctx *ctx);
-/* run `reps` evaluations with HIP events between the kernel classes on `stream`; ms[9] = average milliseconds per
+/* run `reps` evaluations with HIP events between the kernel classes on `stream`; ms[10] = average milliseconds per
  * evaluation spent in {k_gas_setup (+ k_mxzones), k_cheb_nodes, k_cheb_apply (+ k_table_eval, k_cia), k_voigt_far (or
- * k_linesum), k_voigt_near, k_rt, k_freduce, k_cheb_nodes_mx, k_voigt_edge_mx}, summed over gases */
+ * k_linesum), k_voigt_near, k_rt, k_freduce, k_cheb_nodes_mx, k_voigt_edge_mx, k_voigt_sub}, summed over gases */
 int cs_column_profile(cs_ctx *ctx, void *stream, int reps, double *ms);
 int cs_column_flux_ptr(cs_ctx *ctx, double **dF);
 /* asynchronously copy the [2*np] band fluxes (Fup then Fdn) into caller-owned DEVICE memory on `stream` */
