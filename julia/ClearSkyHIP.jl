@@ -32,11 +32,11 @@ check(rc::Cint) = rc == 0 ? nothing : error("clearsky_hip ($rc): $(lasterror())"
 
 mutable struct Context
     handle::Ptr{Cvoid}
-    slots::IdDict{SpectralLines,Cint}
+    slots::IdDict{Any,Cint}            # SpectralLines objects (slot!) or the arguments of slotfrompar!
     function Context(device::Integer=0)
         h = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:cs_create, LIB), Cint, (Cint, Ref{Ptr{Cvoid}}), device, h))
-        c = new(h[], IdDict{SpectralLines,Cint}())
+        c = new(h[], IdDict{Any,Cint}())
         finalizer(x -> ccall((:cs_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.handle), c)
         return c
     end
@@ -66,6 +66,30 @@ function slot!(ctx::Context, sl::SpectralLines)::Cint
     ctx.slots[sl] = slot
     return slot
 end
+
+# a .par file straight into a gas slot (f3): readpar's filters + SpectralLines' constructor on the native side
+# [hitran/par.jl:91-193, 224-286]; returns the slot and the number of lines kept.  `M` is the molecule the file holds.
+function slotfrompar!(ctx::Context, filename::String, M::Integer; νmin::Real=0, νmax::Real=Inf, Scut::Real=0, I=[], maxlines::Integer=-1)
+    mp = MOLPARAM[M]
+    niso = length(mp.I)
+    ncheb = Int32[mp.hascheb[i] ? mp.ncheb[i] : 0 for i in 1:niso]
+    cheb = zeros(Float64, CHEB_LD, niso)
+    for i in 1:niso, k in 1:length(mp.cheb[i])
+        cheb[k,i] = mp.cheb[i][k]
+    end
+    keep = Cint[x isa Char ? ClearSky.ISOINDEX[x] : x for x in I]
+    slot = Cint(length(ctx.slots))
+    L = Ref{Int64}(0)
+    check(ccall((:cs_gas_upload_par, LIB), Cint,
+        (Ptr{Cvoid}, Cint, Cstring, Cdouble, Cdouble, Cdouble, Ptr{Cint}, Cint, Int64, Cint, Ptr{Float64}, Cint, Ptr{Int32},
+         Ptr{Float64}, Ref{Int64}),
+        ctx.handle, slot, filename, νmin, min(νmax, 1e300), Scut, keep, length(keep), maxlines, M, mp.μ, niso, ncheb, cheb, L))
+    ctx.slots[(filename, M, νmin, νmax, Scut, Tuple(keep), maxlines)] = slot
+    return slot, L[]
+end
+
+# far-line sums on the matrix cores: 1 where the grid is long enough (default), 2 always, 0 never
+matrixcores!(ctx::Context, on::Integer=1) = check(ccall((:cs_set_matrix_cores, LIB), Cint, (Ptr{Cvoid}, Cint), ctx.handle, on))
 
 #-------------------------------------------------------------------------------
 # B1: shape! operators [line_shapes.jl:412-424, :313-324, :200-211, :527-540]
