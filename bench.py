@@ -165,12 +165,15 @@ def main():
     ngas = len(col.gases)
     K = col.K
     lines_total = sum(len(g.sl.nu) for g in col.gases)
-    # k_voigt_far (one launch per gas), the longest kernel.  Algorithmic HBM bytes per launch: the 32-B
-    # record of every (node, line) read once + sigma written (8 B per (nu, node)) + sigma re-read when it accumulates (a later
-    # gas, or onto the interpolated far wings) + the 8-B near-line index words handed to k_voigt_near per (nu, node) + nu.
+    # k_voigt_far (one launch per gas), the longest kernel.  Algorithmic HBM bytes per launch: sigma written
+    # (8 B per (nu, node)) and re-read when it accumulates (a later gas, or onto the interpolated far wings) + nu, and for the states
+    # whose window core is not k_voigt_sub's (K_far of K on average): the 32-B record of every (node, line) read once + the 8-B near-line
+    # index words handed to k_voigt_near per (nu, node).
     work = col.work()
     interp_on = work["levels"] > 0
-    far_bytes = [32 * K * len(g.sl.nu) + 8 * col.nnu * K * (2 if (gi > 0 or interp_on) else 1) + 8 * col.nnu * K + 8 * col.nnu
+    nt64 = (col.nnu + 63) // 64
+    K_far = K - work.get("core_tile_states", 0) / max(ngas, 1) / nt64
+    far_bytes = [32 * K_far * len(g.sl.nu) + 8 * col.nnu * K * (2 if (gi > 0 or interp_on) else 1) + 8 * col.nnu * K_far + 8 * col.nnu
                  for gi, g in enumerate(col.gases)]
     far_ms = prof["far"] / max(ngas, 1)
     alg = float(np.mean(far_bytes)) if far_bytes else 0.0

@@ -2053,7 +2053,7 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
     HIPCHK(hipDeviceSynchronize());
     const int K = c.K;
     const int nt64 = (int)((c.nnu + 63) / 64);
-    int64_t direct = 0, nodes = 0, sepn = 0, edgen = 0, mx3 = 0, subn = 0;   // subn: (lane, line) evaluations of k_voigt_sub
+    int64_t direct = 0, nodes = 0, sepn = 0, edgen = 0, mx3 = 0, subn = 0, ncore = 0;   // subn: (lane, line) evaluations of k_voigt_sub
     //   // sepn, edgen: (node | point, line, state) triples summed on the matrix cores; mx3: those with 3 terms
     int64_t body[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // per-point lines by body: 2-term, 2-term+cut-off, 3-term, 3-term+cut-off, 4-term+cut-off,
                                                      // near-zone pass; node lines: 2-, 3-, 4-term
@@ -2128,6 +2128,7 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
                     edgen += 64 * (int64_t)((pm[1] - pm[0]) + (pm[3] - pm[2]));
                     if (e.cR > e.cL) {   // the core: every pair visits the matrix cores (masked inside R), k_voigt_sub the lines within R of each sub-tile
                         cc0 = e.cL; cc1 = e.cR;
+                        ncore++;
                         edgen += 64 * (int64_t)(e.cR - e.cL);
                         const double *nl = ctx->gas[g.slot].h_nu.data();
                         for (int q4 = 0; q4 < 4; q4++) {
@@ -2176,6 +2177,7 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
     out[14] = edgen;
     out[15] = mx3;
     out[16] = subn;
+    out[17] = ncore;
     return CS_OK;
 }
 
