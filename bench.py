@@ -48,8 +48,8 @@ def source_stamp():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)   # (0.55 s of timed region at C3: long enough for an outside utilisation sampler to see it)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="C3")
     ap.add_argument("--lines", default=None, help="synthetic | fixture")
     ap.add_argument("--nnu", type=int, default=None)
