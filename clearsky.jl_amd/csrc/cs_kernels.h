@@ -225,6 +225,31 @@ struct WaveWin { int32_t W0, W1, E0, E1; };  // per 64-point tile: window, first
 // needs 15 y^2/s^3 < 1e-15 (y^2 bounded per window from the largest Lorentz and smallest Doppler width); outside [Q0,Q1): 2 terms + c2
 struct __attribute__((aligned(16))) Zone { int32_t M0, N0, N1, M1, Q0, Q1, pad1, pad2; };
 
+// N binary searches over the same sorted array side by side (one thread: their dependent loads overlap instead of queueing up --
+// a zone thread is a chain of six to eight searches of ~10 loads each otherwise, and those chains are what k_gas_setup waits for).
+// Query q looks in [lo[q], hi[q]) for the first index whose value is >= val[q] (bit q of upmask clear: lower bound) resp.
+// > val[q] (set: upper bound); the answer comes back in lo[q].  lo[q] >= hi[q] on entry: query not wanted, lo[q] is returned.
+template <int N>
+__device__ __forceinline__ void search_many(const double *__restrict__ a, const double (&val)[N], unsigned upmask, int (&lo)[N], int (&hi)[N])
+{
+    for (;;) {
+        bool any = false;
+#pragma unroll
+        for (int q = 0; q < N; q++) any = any || lo[q] < hi[q];
+        if (!any) break;
+        double x[N];
+        int m[N];
+#pragma unroll
+        for (int q = 0; q < N; q++) { m[q] = (lo[q] + hi[q]) >> 1; x[q] = lo[q] < hi[q] ? a[m[q]] : 0.0; }
+#pragma unroll
+        for (int q = 0; q < N; q++)
+            if (lo[q] < hi[q]) {
+                const bool right = ((upmask >> q) & 1u) ? x[q] <= val[q] : x[q] < val[q];
+                if (right) lo[q] = m[q] + 1; else hi[q] = m[q];
+            }
+    }
+}
+
 // node-state dependent zone bounds, one thread per (state, tile)
 struct ZoneArgs {
     const double *nu, *nul, *Tk, *gbound;
@@ -269,13 +294,6 @@ __device__ __forceinline__ void zones_body(unsigned bid, const ZoneArgs &a)
     const double dA = 100.0 * amax / kSqLn2 * (1.0 + 1e-6);  // |dnu| >= dA  =>  x^2 >= 1e4 (4-term series good to 1e-14)
     const double dAA = dA * sqrt(far_s * 1e-4);               // |dnu| >= dAA =>  x^2 >= far_s (>= 1e6: u^3 terms < 1e-16)
     // (inside [N0,N1) the far kernel uses the 6-term series down to s = 1e3, the near kernel takes over below)
-    auto lower = [&](double val, int a, int b) { while (a < b) { int m = (a + b) >> 1; if (nul[m] < val) a = m + 1; else b = m; } return a; };
-    auto upper = [&](double val, int a, int b) { while (a < b) { int m = (a + b) >> 1; if (nul[m] <= val) a = m + 1; else b = m; } return a; };
-    Zone z;
-    z.M0 = lower(vlo - dAA, w.W0, w.W1);
-    z.N0 = lower(vlo - dA, z.M0, w.W1);
-    z.N1 = upper(vhi + dA, z.N0, w.W1);
-    z.M1 = upper(vhi + dAA, z.N1, w.W1);
     // y = gamma*sqrt(ln2)/alpha <= gbound[k]*sqrt(ln2)/alpha_min(window); gbound = host-side bound on gammalorentz
     const double vmin = vlo - cut;
     double y2b = 1e300;
@@ -285,12 +303,22 @@ __device__ __forceinline__ void zones_body(unsigned bid, const ZoneArgs &a)
         y2b = yb * yb;
     }
     // mode-0 body is exact to 1e-15 where s >= s0 = max(1e6, (1.5e16 y2b)^(1/3))  <=>  |dnu| >= dAA * sqrt(s0/1e6)
+    const bool wantq = y2b > 60.0 && y2b < 1e290;
+    const double dQ = wantq ? dA * sqrt(fmax(cbrt(1.5e16 * y2b), far_s) * 1e-4) : dAA;
+    // M0 <= N0 <= N1 <= M1 and Q0 <= M0, Q1 >= M1 follow from dQ >= dAA >= dA: all six over the whole window, side by side
+    const double sv[6] = {vlo - dAA, vlo - dA, vlo - dQ, vhi + dA, vhi + dAA, vhi + dQ};
+    int slo[6] = {w.W0, w.W0, w.W0, w.W0, w.W0, w.W0}, shi[6] = {w.W1, w.W1, wantq ? w.W1 : w.W0, w.W1, w.W1, wantq ? w.W1 : w.W0};
+    search_many<6>(nul, sv, 0x38u, slo, shi);
+    Zone z;
+    z.M0 = slo[0];
+    z.N0 = max(slo[1], z.M0);
+    z.N1 = max(slo[3], z.N0);
+    z.M1 = max(slo[4], z.N1);
     if (y2b <= 60.0) {
         z.Q0 = z.M0; z.Q1 = z.M1;
-    } else if (y2b < 1e290) {
-        const double dQ = dA * sqrt(fmax(cbrt(1.5e16 * y2b), far_s) * 1e-4);
-        z.Q0 = lower(vlo - dQ, w.W0, z.M0);
-        z.Q1 = upper(vhi + dQ, z.M1, w.W1);
+    } else if (wantq) {
+        z.Q0 = min(slo[2], z.M0);
+        z.Q1 = max(slo[5], z.M1);
     } else {
         z.Q0 = w.W0; z.Q1 = w.W1;
     }
@@ -520,10 +548,11 @@ struct IzParams {
     int itv[CS_MAX_LEVEL], nI[CS_MAX_LEVEL], ioff[CS_MAX_LEVEL];
     const WaveWin *iwin[CS_MAX_LEVEL];
 };
-// E0, Z0, Z1, E1 of (level l, interval T, state with thermal speed vth); false if the set is empty
-__device__ __forceinline__ bool izone_outer(const IzParams &P, int l, int T, const double *__restrict__ nu, int64_t nnu,
-                                            const double *__restrict__ nul, double vth, double mu_min, double cut, double &vlo,
-                                            double &vhi, double &dA, int &E0, int &Z0, int &Z1, int &E1, bool lorentz = false)
+// span, window and margin of (level l, interval T) for a state with thermal speed vth: E0..E1 = lines inside the cut-off of every
+// point, dZ = how far the interpolated set stays from the interval; false if the set is empty
+__device__ __forceinline__ bool izone_frame(const IzParams &P, int l, int T, const double *__restrict__ nu, int64_t nnu, double vth,
+                                            double mu_min, double cut, double &vlo, double &vhi, double &dA, double &dZ, int &E0, int &E1,
+                                            bool lorentz)
 {
     const int itv = P.itv[l];
     const int64_t i0 = (int64_t)T * itv, i1 = (i0 + itv - 1 < nnu ? i0 + itv - 1 : nnu - 1);
@@ -531,15 +560,11 @@ __device__ __forceinline__ bool izone_outer(const IzParams &P, int l, int T, con
     vhi = nu[i1];
     const WaveWin w = P.iwin[l][T];   // E0..E1: lines inside the cut-off of every point of the interval
     E0 = w.E0; E1 = w.E1;
-    if (w.E1 <= w.E0) { E0 = Z0 = Z1 = E1 = w.E0; return false; }   // (then the parent has nothing either: the sets are nested)
+    if (w.E1 <= w.E0) { E0 = E1 = w.E0; return false; }   // (then the parent has nothing either: the sets are nested)
     const double h = 0.5 * (vhi - vlo);
     const double amax = ((vhi + cut) / kC) * vth / sqrt(mu_min);
     dA = lorentz ? 0.0 : 100.0 * amax / kSqLn2 * (1.0 + 1e-6);   // (a Lorentz profile has no Doppler core to stay clear of)
-    const double dZ = fmax(dA, kChebMargin * h);
-    auto lower = [&](double val, int a, int b) { while (a < b) { int m = (a + b) >> 1; if (nul[m] < val) a = m + 1; else b = m; } return a; };
-    auto upper = [&](double val, int a, int b) { while (a < b) { int m = (a + b) >> 1; if (nul[m] <= val) a = m + 1; else b = m; } return a; };
-    Z0 = lower(vlo - dZ, w.E0, w.E1);
-    Z1 = upper(vhi + dZ, Z0, w.E1);
+    dZ = fmax(dA, kChebMargin * h);
     return true;
 }
 __device__ __forceinline__ void izones_body(unsigned bid, const IzParams &P, const ZoneArgs &a, IZone *__restrict__ iz)
@@ -558,18 +583,14 @@ __device__ __forceinline__ void izones_body(unsigned bid, const IzParams &P, con
     const int T = q - P.ioff[l];
     const size_t idx = (size_t)k * P.nItot + q;
     const double vth = sqrt(2.0 * kRgas * Tk[k]);
-    double vlo, vhi, dA;
+    double vlo, vhi, dA, dZ;
     IZone z;
-    if (!izone_outer(P, l, T, nu, nnu, nul, vth, mu_min, cut, vlo, vhi, dA, z.E0, z.Z0, z.Z1, z.E1, a.lorentz)) {
-        z.Q0 = z.M0 = z.M1 = z.Q1 = z.P0 = z.P1 = z.P2 = z.P3 = z.E0;
+    if (!izone_frame(P, l, T, nu, nnu, vth, mu_min, cut, vlo, vhi, dA, dZ, z.E0, z.E1, a.lorentz)) {
+        z.Z0 = z.Z1 = z.Q0 = z.M0 = z.M1 = z.Q1 = z.P0 = z.P1 = z.P2 = z.P3 = z.E0;
         iz[idx] = z;
         return;
     }
     const double dAA = dA * sqrt(far_s * 1e-4);
-    auto lower = [&](double val, int a, int b) { while (a < b) { int m = (a + b) >> 1; if (nul[m] < val) a = m + 1; else b = m; } return a; };
-    auto upper = [&](double val, int a, int b) { while (a < b) { int m = (a + b) >> 1; if (nul[m] <= val) a = m + 1; else b = m; } return a; };
-    z.M0 = lower(vlo - dAA, z.E0, z.Z0);
-    z.M1 = upper(vhi + dAA, z.Z1, z.E1);
     const double vmin = vlo - cut;
     double y2b = 1e300;
     if (vmin > 0.0) {
@@ -577,12 +598,31 @@ __device__ __forceinline__ void izones_body(unsigned bid, const IzParams &P, con
         const double yb = gbound[k] * kSqLn2 / amin;
         y2b = yb * yb;
     }
+    const bool wantq = y2b > 60.0 && y2b < 1e290 && !a.lorentz;
+    const double dQ = wantq ? dA * sqrt(fmax(cbrt(1.5e16 * y2b), far_s) * 1e-4) : dAA;
+    // the parent interval (next level up): its own set is [qE0, qZ0) U [qZ1, qE1)
+    bool par = false;
+    double pvlo = 0.0, pvhi = 0.0, pdA, pdZ = 0.0;
+    int qE0 = 0, qE1 = 0;
+    if (l > P.l0) {
+        int pshift = 0;
+        for (int r = P.itv[l - 1] / P.itv[l]; r > 1; r >>= 1) pshift++;
+        par = izone_frame(P, l - 1, T >> pshift, nu, nnu, vth, mu_min, cut, pvlo, pvhi, pdA, pdZ, qE0, qE1, a.lorentz);
+    }
+    // own Z0, Z1 (set stays dZ away), M0, M1 (4-term zone), Q0, Q1 (3-term zone), parent's Z0, Z1: eight searches side by side
+    const double sv[8] = {vlo - dZ, vlo - dAA, vlo - dQ, pvlo - pdZ, vhi + dZ, vhi + dAA, vhi + dQ, pvhi + pdZ};
+    int slo[8] = {z.E0, z.E0, z.E0, qE0, z.E0, z.E0, z.E0, qE0};
+    int shi[8] = {z.E1, z.E1, wantq ? z.E1 : z.E0, par ? qE1 : qE0, z.E1, z.E1, wantq ? z.E1 : z.E0, par ? qE1 : qE0};
+    search_many<8>(nul, sv, 0xf0u, slo, shi);
+    z.Z0 = slo[0];
+    z.Z1 = max(slo[4], z.Z0);
+    z.M0 = min(slo[1], z.Z0);
+    z.M1 = max(slo[5], z.Z1);
     if (y2b <= 60.0) {
         z.Q0 = z.M0; z.Q1 = z.M1;
-    } else if (y2b < 1e290) {
-        const double dQ = dA * sqrt(fmax(cbrt(1.5e16 * y2b), far_s) * 1e-4);
-        z.Q0 = lower(vlo - dQ, z.E0, z.M0);
-        z.Q1 = upper(vhi + dQ, z.M1, z.E1);
+    } else if (wantq) {
+        z.Q0 = min(slo[2], z.M0);
+        z.Q1 = max(slo[6], z.M1);
     } else {
         z.Q0 = z.E0; z.Q1 = z.E1;
     }
@@ -590,15 +630,10 @@ __device__ __forceinline__ void izones_body(unsigned bid, const IzParams &P, con
     // the parent's own set is nested in this one ([E0,E1) grows and [Z0,Z1) shrinks with the interval); clamp it anyway
     z.P0 = z.P1 = z.E0;
     z.P2 = z.P3 = z.E1;
-    if (l > P.l0) {
-        int pshift = 0;
-        for (int r = P.itv[l - 1] / P.itv[l]; r > 1; r >>= 1) pshift++;
-        double pvlo, pvhi, pdA;
-        int qE0, qZ0, qZ1, qE1;
-        if (izone_outer(P, l - 1, T >> pshift, nu, nnu, nul, vth, mu_min, cut, pvlo, pvhi, pdA, qE0, qZ0, qZ1, qE1, a.lorentz)) {
-            if (qZ0 > qE0) { z.P0 = min(max(qE0, z.E0), z.Z0); z.P1 = min(max(qZ0, z.P0), z.Z0); }
-            if (qE1 > qZ1) { z.P2 = min(max(qZ1, z.Z1), z.E1); z.P3 = min(max(qE1, z.P2), z.E1); }
-        }
+    if (par) {
+        const int qZ0 = slo[3], qZ1 = max(slo[7], qZ0);
+        if (qZ0 > qE0) { z.P0 = min(max(qE0, z.E0), z.Z0); z.P1 = min(max(qZ0, z.P0), z.Z0); }
+        if (qE1 > qZ1) { z.P2 = min(max(qZ1, z.Z1), z.E1); z.P3 = min(max(qE1, z.P2), z.E1); }
     }
     iz[idx] = z;
 }
