@@ -638,14 +638,17 @@ __device__ __forceinline__ void izones_body(unsigned bid, const IzParams &P, con
     iz[idx] = z;
 }
 
-// K1 and the zone bounds of one gas in ONE launch: the three jobs are independent of each other (blocks [0,nb_prep) prepare the
-// line records, the next nb_zones blocks the per-tile zones, the rest the interval zones), so fusing them only removes two
+// K1 and the zone bounds of one gas in ONE launch: the three jobs are independent of each other (the first nb_zones blocks find the
+// per-tile zones, the next ones the interval zones, the last nb_prep prepare the line records), so fusing them only removes two
 // dependent kernel boundaries per gas -- which is what a nu-shard of a multi-GPU run, a few hundred tiles, spends its time on.
+// The zone blocks go first: they are chains of dependent loads (binary searches) that the record blocks, a stream of stores,
+// then run beside instead of before.
 __global__ __launch_bounds__(256) void k_gas_setup(unsigned nb_prep, unsigned nb_zones, PrepArgs pa, ZoneArgs za, IzParams ip, IZone *__restrict__ iz)
 {
-    if (blockIdx.x < nb_prep) prep_body(blockIdx.x, pa);
-    else if (blockIdx.x < nb_prep + nb_zones) zones_body(blockIdx.x - nb_prep, za);
-    else izones_body(blockIdx.x - nb_prep - nb_zones, ip, za, iz);
+    const unsigned nb_iz = gridDim.x - nb_prep - nb_zones;
+    if (blockIdx.x < nb_zones) zones_body(blockIdx.x, za);
+    else if (blockIdx.x < nb_zones + nb_iz) izones_body(blockIdx.x - nb_zones, ip, za, iz);
+    else prep_body(blockIdx.x - nb_zones - nb_iz, pa);
 }
 
 // one wave = the 64 Chebyshev nodes of one interval x one node state: far-wing sums at the nodes -> F[interval][node][state].
