@@ -203,11 +203,11 @@ def main():
     flops = evals * FLOPS_PER_PAIR
     line_ms = prof["nodes"] + prof["far"] + prof["near"] + prof.get("sub", 0.0)
     mx_ms = prof.get("nodes_mx", 0.0) + prof.get("far_mx", 0.0)
-    # matrix cores: 4 (or 3) terms x (multiply + add) per (node | point, line, state); v_mfma_f64_16x16x4 = 2048 flop.  Spec peak of the fp64
+    # matrix cores: 4 (or 3, or 8) terms x (multiply + add) per (node | point, line, state); v_mfma_f64_16x16x4 = 2048 flop.  Spec peak of the fp64
     # matrix path = the fp64 vector rate (78.6 TFLOP/s); tools/ubench/mfma_f64_rate.hip sustains 47, and a matrix and a vector
     # kernel launched side by side on two streams take the sum of their times (tools/ubench/sep_nodes.hip): one fp64 pipe, two ways in
-    mx_flops = 8.0 * mx_triples - 2.0 * work.get("matrix_evals_3term", 0)   # (three terms where they reach 1e-17: 6 flop)
-    matrix_fp64 = dict(triples=mx_triples, triples_3term=work.get("matrix_evals_3term", 0), flops=mx_flops, ms=mx_ms,
+    mx_flops = 8.0 * mx_triples - 2.0 * work.get("matrix_evals_3term", 0) + 8.0 * work.get("matrix_evals_8term", 0)   # (3 terms: 6 flop; 8 terms: 16)
+    matrix_fp64 = dict(triples=mx_triples, triples_3term=work.get("matrix_evals_3term", 0), triples_8term=work.get("matrix_evals_8term", 0), flops=mx_flops, ms=mx_ms,
                        achieved=mx_flops / (mx_ms * 1e-3) / 1e12 if mx_ms > 0 else 0.0, peak=FP64_VALU_PEAK_TFLOPS, unit="TFLOP/s",
                        frac=mx_flops / (mx_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS if mx_ms > 0 else 0.0,
                        measured_mfma_f64_rate=47.0, kernels="k_cheb_nodes_mx + k_voigt_edge_mx")

@@ -477,6 +477,7 @@ struct Interp {
     EdgeZone *edge = nullptr; // NULL: all of the per-point sum on the vector unit
     bool sep_always = false;  // cs_set_matrix_cores(ctx, 2): also on grids too short to fill the chip with (interval, state group) blocks
     bool core = true;         // cs_set_matrix_cores(ctx, on | 4) switches the sub-tile treatment of the window core (k_voigt_sub) off
+    double core4 = 0.75;      // the core takes the 4-term series where its radius is below core4 x the tile's span, else the 8-term one
 };
 
 // interval sizes worth using on this grid: an interval of width W leaves lines over (2 cut - 2.3 W) to interpolate
@@ -709,6 +710,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
                 for (int r = itp.itv[itp.nlev - 1] / 64; r > 1; r >>= 1) ea.ishift++;
                 ea.mu_min = G.mu_min; ea.cut = cut;
                 ea.core = (use_edge && itp.core) ? 1 : 0;
+                ea.core4 = itp.core4;
                 const unsigned nb_sep = use_sep ? (unsigned)(((int64_t)(itp.nItot - q0) * ngrp + 255) / 256) : 0u;
                 const unsigned nb_edge = use_edge ? (unsigned)(((int64_t)nt64 * ngrp + 255) / 256) : 0u;
                 hipLaunchKernelGGL(k_mxzones, dim3(nb_sep + nb_edge), dim3(256), 0, s, nb_sep, sa, ea);
@@ -789,7 +791,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
 #undef CS_LOR_LAUNCH
         if (evg) (void)hipEventRecord(evg[3], s);
         if (use_edge && itp.core)   // the window cores of the groups whose series radius is short: pairs inside it (the rest: k_voigt_edge_mx)
-            hipLaunchKernelGGL(k_voigt_sub, dim3((unsigned)nt64, (unsigned)((kn + 3) / 4)), dim3(256), 0, s, dnu, nnu, G.L, hot, G.nu.as<double>(), zones,
+            hipLaunchKernelGGL(k_voigt_sub<8>, dim3((unsigned)nt64, (unsigned)((kn + 7) / 8)), dim3(512), 0, s, dnu, nnu, G.L, hot, G.nu.as<double>(), zones,
                                itp.edge, nt64, kn, cut, sigma, reinterpret_cast<unsigned *>(ranges));
         if (evg) (void)hipEventRecord(evg[4], s);
         if (use_edge)
@@ -2053,7 +2055,7 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
     HIPCHK(hipDeviceSynchronize());
     const int K = c.K;
     const int nt64 = (int)((c.nnu + 63) / 64);
-    int64_t direct = 0, nodes = 0, sepn = 0, edgen = 0, mx3 = 0, subn = 0, ncore = 0;   // subn: (lane, line) evaluations of k_voigt_sub
+    int64_t direct = 0, nodes = 0, sepn = 0, edgen = 0, mx3 = 0, subn = 0, ncore = 0, mx8 = 0;   // subn: (lane, line) evaluations of k_voigt_sub
     //   // sepn, edgen: (node | point, line, state) triples summed on the matrix cores; mx3: those with 3 terms
     int64_t body[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // per-point lines by body: 2-term, 2-term+cut-off, 3-term, 3-term+cut-off, 4-term+cut-off,
                                                      // near-zone pass; node lines: 2-, 3-, 4-term
@@ -2130,12 +2132,13 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
                         cc0 = e.cL; cc1 = e.cR;
                         ncore++;
                         edgen += 64 * (int64_t)(e.cR - e.cL);
+                        if (e.far3 & 4) mx8 += 64 * (int64_t)(e.cR - e.cL);
                         const double *nl = ctx->gas[g.slot].h_nu.data();
-                        for (int q4 = 0; q4 < 4; q4++) {
-                            const double v0 = c.h_nu[(size_t)t * 64 + 16 * q4] - e.R, v1 = c.h_nu[(size_t)t * 64 + 16 * q4 + 15] + e.R;
+                        for (int q4 = 0; q4 < 8; q4++) {   // (k_voigt_sub<8>)
+                            const double v0 = c.h_nu[(size_t)t * 64 + 8 * q4] - e.R, v1 = c.h_nu[(size_t)t * 64 + 8 * q4 + 7] + e.R;
                             const int ja = (int)(std::lower_bound(nl + e.cL, nl + e.cR, v0) - nl);
                             const int jb = (int)(std::upper_bound(nl + ja, nl + e.cR, v1) - nl);
-                            subn += 16 * (int64_t)(jb - ja);
+                            subn += 8 * (int64_t)(jb - ja);
                         }
                     }
                 }
@@ -2178,6 +2181,7 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
     out[15] = mx3;
     out[16] = subn;
     out[17] = ncore;
+    out[18] = mx8;
     return CS_OK;
 }
 

@@ -661,7 +661,8 @@ struct __attribute__((aligned(16))) SepZone { int32_t a[4], b[4], m[4]; };   // 
                                                                               // farther than it (below m on the left, from m on the right) need 3 terms
 // the same for the per-point sum (k_voigt_edge_mx), per (state group, 64-point tile): the window ends [W0, eL) and [eR, W1), and the
 // pieces [mL0, mL1), [mR0, mR1) between the interpolated sets and the near zone (empty: m.1 <= m.0)
-// mL3, mR3 split the middle pieces like SepZone::m; far3 bit 0 / 1: the left / right window end needs 3 terms only
+// mL3, mR3 split the middle pieces like SepZone::m; far3 bit 0 / 1: the left / right window end needs 3 terms only; bit 2: the
+// core takes 8 terms (and R is their radius, not that of 4)
 // [cL, cR) (empty: cR <= cL): the core of the window -- everything between the matrix-core pieces, near zone included -- when the
 // series radius R of the group is shorter than the tile: there k_voigt_sub sums the pairs with |dnu| < R on 16-point sub-tiles
 // and k_voigt_edge_mx the pairs with |dnu| >= R (a second mask), and k_voigt_far leaves the core alone
@@ -783,7 +784,8 @@ __device__ __forceinline__ void search4(const double *__restrict__ a, const doub
 // validity of the truncated series (tools/voigt_series.py): relative truncation error <= 1e-17 where
 //   4 terms: (y^2 + 3.0) / x^2 <= 5.6e-5   <=>  |dnu| >= 133.6 sqrt(gamma^2 + 4.33 alpha^2)
 //   3 terms: (y^2 + 3.5) / x^2 <= 2.15e-6  <=>  |dnu| >= 682.0 sqrt(gamma^2 + 5.05 alpha^2)
-constexpr double kSep4 = 133.6, kSep3 = 682.0;
+//   8 terms: (y^2 + 4.4) / x^2 <= 7.5e-3   <=>  |dnu| >= 11.55 sqrt(gamma^2 + 6.35 alpha^2)
+constexpr double kSep4 = 133.6, kSep3 = 682.0, kSep8 = 11.55;
 typedef double v4f64_sep __attribute__((ext_vector_type(4)));
 // one step of the matrix-core sums: 4 lines x 64 columns (nodes or points) x 16 states.  The lane's record as (state lr, line lq)
 // gives the NT coefficients (A operands) and, as (column lr, line lq), the line position; vn[st] = the lane's column of sub-tile
@@ -793,27 +795,36 @@ __device__ __forceinline__ void sep_step(v4f64_sep (&acc)[4], const double (&vn)
 {
     const double id2 = rcp_nr1(h.p1 * h.p1);
     const double y2 = h.p2;
-    const double c2 = 1.5 - y2;
-    const double c3 = __builtin_fma(y2, y2 - 5.0, 3.75);
-    const double C1 = valid ? h.p3 * id2 : 0.0;
-    const double C2 = C1 * id2;
-    const double C3 = C2 * id2;
-    const double a1 = C1, a2 = C2 * c2, a3 = C3 * c3;
-    double a4 = 0.0;
-    if (NT == 4) a4 = (C3 * id2) * __builtin_fma(y2, __builtin_fma(y2, 10.5 - y2, -26.25), 13.125);
+    // a_n = (A y / sqrt(pi)) c_n(y^2) / d^(2n), c_n from tools/voigt_series.py (exact rationals, all representable)
+    double a[NT];
+    double Cn = valid ? h.p3 * id2 : 0.0;
+    a[0] = Cn;
+    Cn *= id2; a[1] = Cn * (1.5 - y2);
+    Cn *= id2; a[2] = Cn * __builtin_fma(y2, y2 - 5.0, 3.75);
+    if (NT >= 4) { Cn *= id2; a[3] = Cn * __builtin_fma(y2, __builtin_fma(y2, 10.5 - y2, -26.25), 13.125); }
+    if (NT == 8) {
+        Cn *= id2; a[4] = Cn * __builtin_fma(y2, __builtin_fma(y2, __builtin_fma(y2, y2 - 18.0, 94.5), -157.5), 59.0625);
+        Cn *= id2; a[5] = Cn * __builtin_fma(y2, __builtin_fma(y2, __builtin_fma(y2, __builtin_fma(y2, 27.5 - y2, -247.5), 866.25), -1082.8125), 324.84375);
+        Cn *= id2; a[6] = Cn * __builtin_fma(y2, __builtin_fma(y2, __builtin_fma(y2, __builtin_fma(y2, __builtin_fma(y2, y2 - 39.0, 536.25), -3217.5), 8445.9375),
+                                                               -8445.9375), 2111.484375);
+        Cn *= id2; a[7] = Cn * __builtin_fma(y2, __builtin_fma(y2, __builtin_fma(y2, __builtin_fma(y2, __builtin_fma(y2, __builtin_fma(y2, 52.5 - y2, -1023.75), 9384.375),
+                                                                                          -42229.6875), 88682.34375), -73901.953125), 15836.1328125);
+    }
 #pragma unroll
     for (int st = 0; st < 4; st++) {
         const double dv = vn[st] - h.nul;
         const double s2 = dv * dv;
         double w = rcp_fast(s2);
-        w = __builtin_fma(w, __builtin_fma(-s2, w, 1.0), w);   // second Newton step (powers up to w^4 of it are taken)
+        w = __builtin_fma(w, __builtin_fma(-s2, w, 1.0), w);   // second Newton step (powers of it are taken)
         if (MASK == 1) w = fabs(dv) > cut ? 0.0 : w;
         if (MASK == 2) w = (fabs(dv) > cut || fabs(dv) < rin) ? 0.0 : w;
-        const double w2 = w * w, w3 = w2 * w;
-        acc[st] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, w, acc[st], 0, 0, 0);
-        acc[st] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, w2, acc[st], 0, 0, 0);
-        acc[st] = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, w3, acc[st], 0, 0, 0);
-        if (NT == 4) acc[st] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4, w2 * w2, acc[st], 0, 0, 0);
+        double wn = w;
+#pragma unroll
+        for (int n = 0; n < NT; n++) {
+            acc[st] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[n], wn, acc[st], 0, 0, 0);
+            if (n + 1 < NT) wn *= w;
+        }
+        if (NT == 8) __builtin_amdgcn_sched_barrier(0);   // (one sub-tile at a time: interleaving the four costs 60 more registers)
     }
 }
 // the lines [ja, jb) of one (state-row pointer hk) in steps of 4, ascending or descending; the load of step t + 1 is issued before the
@@ -1359,7 +1370,7 @@ struct EdgeArgs {
     EdgeZone *out;        // [ngrp][ntile]
     int64_t nnu;
     int ntile, K, ngrp, nI, ishift, core;   // core: sub-tile treatment of the window core where it pays (k_voigt_sub)
-    double mu_min, cut;
+    double mu_min, cut, core4;              // core4: the core takes the 4-term series where its radius is below core4 x the tile's span
 };
 // per (state group, tile): the pieces common to the group's states -- the window ends left of every state's first interpolated or
 // near-zone line and right of the last; between every state's interpolated sets and near zone -- clipped to the distance at which
@@ -1373,7 +1384,7 @@ __device__ __forceinline__ void edgezones_body(unsigned bid, const EdgeArgs &a)
     const double vlo = a.nu[i0], vhi = a.nu[i1];
     const WaveWin w = a.win[t];
     int eL = w.W1, eR = w.W0, mL0 = w.W0, mL1 = w.W1, mR0 = w.W0, mR1 = w.W1;
-    double R = 0.0, R3 = 0.0;
+    double R = 0.0, R3 = 0.0, R8 = 0.0;
     for (int k = g * 16; k < min(g * 16 + 16, a.K); k++) {
         const Zone z = a.zones[(size_t)k * a.ntile + t];
         int sa0 = z.M0, sa1 = z.M0, sb0 = z.M1, sb1 = z.M1;   // (as k_voigt_far)
@@ -1389,6 +1400,7 @@ __device__ __forceinline__ void edgezones_body(unsigned bid, const EdgeArgs &a)
         const double gb = a.gbound[k];
         R = fmax(R, kSep4 * sqrt(gb * gb + 4.33 * amax * amax) * (1.0 + 1e-6));
         R3 = fmax(R3, kSep3 * sqrt(gb * gb + 5.05 * amax * amax) * (1.0 + 1e-6));
+        R8 = fmax(R8, kSep8 * sqrt(gb * gb + 6.35 * amax * amax) * (1.0 + 1e-6));
     }
     int sr[4];
     {
@@ -1416,10 +1428,16 @@ __device__ __forceinline__ void edgezones_body(unsigned bid, const EdgeArgs &a)
     // of every sub-tile present (a ragged last tile keeps the tile-wide pass)
     e.cL = e.mL1 > e.mL0 ? e.mL1 : mL0;
     e.cR = e.mR1 > e.mR0 ? e.mR0 : mR1;
+    // the pairs of the core inside the radius are k_voigt_sub's: the radius of the 4-term series where it is short against the tile
+    // (the low-pressure groups), else that of the 8-term series -- twice the matrix instructions for the core's lines, a radius
+    // 12 times shorter (the groups whose Lorentz widths set it)
+    const bool core8 = !(R < a.core4 * (vhi - vlo));
+    const double Rc = core8 ? R8 : R;
     const bool core_ok = a.core && a.iz && i0 + 63 < a.nnu && mL0 <= mL1 && mR0 <= mR1 && e.cL <= mL1 && e.cR >= mR0 && e.cR > e.cL &&
-                         R < 0.75 * (vhi - vlo);
+                         Rc < (core8 ? 0.3 : 0.75) * (vhi - vlo);   // (an 8-term core costs twice the matrix instructions: only where the sub-tiles then see few lines)
     if (!core_ok) e.cL = e.cR = 0;
-    e.R = R;
+    else if (core8) e.far3 |= 4;
+    e.R = Rc;
     e.pad0 = 0;
     e.pad1 = 0.0;
     a.out[idx] = e;
@@ -1431,7 +1449,9 @@ __global__ __launch_bounds__(256) void k_mxzones(unsigned nb_sep, SepArgs sa, Ed
     else edgezones_body(blockIdx.x - nb_sep, ea);
 }
 
-__global__ __launch_bounds__(256) void k_voigt_edge_mx(const double *__restrict__ nu, int64_t nnu, int64_t L, const LineHot *__restrict__ hot,
+// (three waves per SIMD, with the 164 registers that allows: the 8-term step of the cores wants them -- left alone the allocator
+//  takes 148 + 32 accumulators, i.e. two waves: 0.44 vs 0.41 ms)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_voigt_edge_mx(const double *__restrict__ nu, int64_t nnu, int64_t L, const LineHot *__restrict__ hot,
                                                        const WaveWin *__restrict__ win, const EdgeZone *__restrict__ edge, int ntile, int K,
                                                        double cut, double *__restrict__ sigma)
 {
@@ -1464,7 +1484,9 @@ __global__ __launch_bounds__(256) void k_voigt_edge_mx(const double *__restrict_
         sep_run<3, 1>(acc, vn, hk, e.mR3, e.mR1, false, lq, cut);
         sep_run<4, 1>(acc, vn, hk, e.mR0, e.mR3, false, lq, cut);
     }
-    if (e.cR > e.cL) sep_run<4, 2>(acc, vn, hk, e.cL, e.cR, true, lq, cut, e.R);   // the core: pairs at least R apart
+    if (e.cR > e.cL) {   // the core: pairs at least R apart
+        if (e.far3 & 4) sep_run<8, 2>(acc, vn, hk, e.cL, e.cR, true, lq, cut, e.R); else sep_run<4, 2>(acc, vn, hk, e.cL, e.cR, true, lq, cut, e.R);
+    }
 #pragma unroll
     for (int st = 0; st < 4; st++)
 #pragma unroll
@@ -1482,30 +1504,34 @@ __global__ __launch_bounds__(256) void k_voigt_edge_mx(const double *__restrict_
 // pairs with |dnu| < R are summed; the others are k_voigt_edge_mx's (same comparison, complementary mask).  Same series and
 // hand-off as the near-zone pass (six terms where s >= 1e3, index ranges of the s < 1e3 and s < 100 lines for k_voigt_near).
 // One block = the four sub-tiles of a tile x the same four states; the per-(tile, state) hand-off flags are OR-ed through LDS.
-__global__ __launch_bounds__(256) void k_voigt_sub(const double *__restrict__ nu, int64_t nnu, int64_t L, const LineHot *__restrict__ hot,
-                                                   const double *__restrict__ gnul, const Zone *__restrict__ zones,
-                                                   const EdgeZone *__restrict__ edge, int ntile, int K, double cut,
-                                                   double *__restrict__ sigma, unsigned *__restrict__ rp)
+// SW = points per sub-tile (16: 4 states per wave, 4 waves per block; 8: 8 states per wave, 8 waves per block = the 8 sub-tiles of
+// the tile: a quarter fewer (lane, line) evaluations again, 0.38 -> 0.30 ms at C3)
+template <int SW>
+__global__ __launch_bounds__(4096 / SW) void k_voigt_sub(const double *__restrict__ nu, int64_t nnu, int64_t L, const LineHot *__restrict__ hot,
+                                                         const double *__restrict__ gnul, const Zone *__restrict__ zones,
+                                                         const EdgeZone *__restrict__ edge, int ntile, int K, double cut,
+                                                         double *__restrict__ sigma, unsigned *__restrict__ rp)
 {
-    __shared__ unsigned fl_sh[4][2];
+    constexpr int NSW = 64 / SW;     // states per wave = sub-tiles per tile = waves per block
+    __shared__ unsigned fl_sh[NSW][2];
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int tile = blockIdx.x, kq = blockIdx.y;
-    const EdgeZone e = edge[(size_t)(kq >> 2) * ntile + tile];
+    const int tile = blockIdx.x, kq = blockIdx.y;   // states NSW kq .. NSW kq + NSW - 1 (all in one group of 16)
+    const EdgeZone e = edge[(size_t)((kq * NSW) >> 4) * ntile + tile];
     if (e.cR <= e.cL) return;   // (block-uniform)
-    const int s4 = lane >> 4, pt = lane & 15;
-    const int k = 4 * kq + s4;
+    const int s4 = lane / SW, pt = lane % SW;
+    const int k = NSW * kq + s4;
     const bool kin = k < K;
     const LineHot *__restrict__ hk = hot + (size_t)(kin ? k : K - 1) * L;
-    const int64_t i = (int64_t)tile * 64 + wv * 16 + pt;   // (a core exists on complete tiles only)
+    const int64_t i = (int64_t)tile * 64 + wv * SW + pt;   // (a core exists on complete tiles only)
     const double v = nu[i];
     const double Rg = e.R;
-    // the lines within Rg of the sub-tile (wave-uniform: first and last point of the sub-tile sit in lanes 0 and 15)
+    // the lines within Rg of the sub-tile (wave-uniform: first and last point of the sub-tile sit in lanes 0 and SW - 1)
     int ja = e.cL, jb = e.cR;
     {
         const double vlo = __builtin_bit_cast(double, ((uint64_t)__builtin_amdgcn_readlane((int)(__builtin_bit_cast(uint64_t, v) >> 32), 0) << 32) |
                                                           (uint32_t)__builtin_amdgcn_readlane((int)__builtin_bit_cast(uint64_t, v), 0));
-        const double vhi = __builtin_bit_cast(double, ((uint64_t)__builtin_amdgcn_readlane((int)(__builtin_bit_cast(uint64_t, v) >> 32), 15) << 32) |
-                                                          (uint32_t)__builtin_amdgcn_readlane((int)__builtin_bit_cast(uint64_t, v), 15));
+        const double vhi = __builtin_bit_cast(double, ((uint64_t)__builtin_amdgcn_readlane((int)(__builtin_bit_cast(uint64_t, v) >> 32), SW - 1) << 32) |
+                                                          (uint32_t)__builtin_amdgcn_readlane((int)__builtin_bit_cast(uint64_t, v), SW - 1));
         int p = ja, q = jb;
         const double a0 = vlo - Rg;
         while (p < q) { const int m = (p + q) >> 1; if (gnul[m] < a0) p = m + 1; else q = m; }
@@ -1563,21 +1589,23 @@ __global__ __launch_bounds__(256) void k_voigt_sub(const double *__restrict__ nu
         rp[o] = r0;            // (always written: whether the tile has candidates at all is known after the block's OR)
         rp[plane + o] = r1;
     }
-    // flags "some lane of (tile, state) has candidates", one word per tier: bit s = state 4 kq + s
+    // flags "some lane of (tile, state) has candidates", one word per tier: bit s = state NSW kq + s
     const uint64_t b0 = __builtin_amdgcn_ballot_w64(r0 != 0u), b1 = __builtin_amdgcn_ballot_w64(r1 != 0u);
     if (lane == 0) {
         unsigned f0 = 0u, f1 = 0u;
-        for (int q = 0; q < 4; q++) {
-            f0 |= ((b0 >> (16 * q)) & 0xffffull) ? (1u << q) : 0u;
-            f1 |= ((b1 >> (16 * q)) & 0xffffull) ? (1u << q) : 0u;
+        const uint64_t m = SW == 16 ? 0xffffull : 0xffull;
+        for (int q = 0; q < NSW; q++) {
+            f0 |= ((b0 >> (SW * q)) & m) ? (1u << q) : 0u;
+            f1 |= ((b1 >> (SW * q)) & m) ? (1u << q) : 0u;
         }
         fl_sh[wv][0] = f0; fl_sh[wv][1] = f1;
     }
     __syncthreads();
-    if (threadIdx.x < 8) {
-        const int q = threadIdx.x & 3, tier = threadIdx.x >> 2;
-        const unsigned f = fl_sh[0][tier] | fl_sh[1][tier] | fl_sh[2][tier] | fl_sh[3][tier];
-        const int kk = 4 * kq + q;
+    if (threadIdx.x < 2 * NSW) {
+        const int q = threadIdx.x % NSW, tier = threadIdx.x / NSW;
+        unsigned f = 0u;
+        for (int x = 0; x < NSW; x++) f |= fl_sh[x][tier];
+        const int kk = NSW * kq + q;
         if (kk < K) (rp + 2 * plane)[((size_t)tier * K + kk) * ntile + tile] = (f >> q) & 1u;
     }
 }
