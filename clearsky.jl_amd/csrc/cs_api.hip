@@ -477,7 +477,8 @@ struct Interp {
     EdgeZone *edge = nullptr; // NULL: all of the per-point sum on the vector unit
     bool sep_always = false;  // cs_set_matrix_cores(ctx, 2): also on grids too short to fill the chip with (interval, state group) blocks
     bool core = true;         // cs_set_matrix_cores(ctx, on | 4) switches the sub-tile treatment of the window core (k_voigt_sub) off
-    double core4 = 0.75;      // the core takes the 4-term series where its radius is below core4 x the tile's span, else the 8-term one
+    double core4 = 0.0;       // the core takes the 4-term series where its radius is below core4 x the tile's span, else the 8-term one
+                              // (0: always the 8-term one -- measured at C3 with 0.75 / 0.3 / 0: 2.61 / 2.55 / 2.52 ms)
 };
 
 // interval sizes worth using on this grid: an interval of width W leaves lines over (2 cut - 2.3 W) to interpolate
@@ -636,6 +637,10 @@ bool phco2_fast_ok(const GasTable &G, int64_t nnu, double cut, int kn, PhScratch
     return true;
 }
 
+// points per sub-tile of k_voigt_sub (16: 0.34 ms at C3 with every core on the 8-term series; 8: 0.22; 4: 0.22 -- what is left is not
+// the evaluations)
+constexpr int CS_SUBW = 8;
+
 // matrix-core node sums (k_cheb_nodes_mx): fp64 Voigt only, and by default only where there are enough (interval, state group)
 // blocks to fill the chip -- on a short grid (a nu-shard) the one-state-per-wave vector kernel has the shorter critical path
 // (1/8 of C3: 0.17 vs 0.25 ms)
@@ -791,7 +796,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
 #undef CS_LOR_LAUNCH
         if (evg) (void)hipEventRecord(evg[3], s);
         if (use_edge && itp.core)   // the window cores of the groups whose series radius is short: pairs inside it (the rest: k_voigt_edge_mx)
-            hipLaunchKernelGGL(k_voigt_sub<8>, dim3((unsigned)nt64, (unsigned)((kn + 7) / 8)), dim3(512), 0, s, dnu, nnu, G.L, hot, G.nu.as<double>(), zones,
+            hipLaunchKernelGGL(k_voigt_sub<CS_SUBW>, dim3((unsigned)nt64, (unsigned)((kn + 64 / CS_SUBW - 1) / (64 / CS_SUBW))), dim3(4096 / CS_SUBW), 0, s, dnu, nnu, G.L, hot, G.nu.as<double>(), zones,
                                itp.edge, nt64, kn, cut, sigma, reinterpret_cast<unsigned *>(ranges));
         if (evg) (void)hipEventRecord(evg[4], s);
         if (use_edge)
@@ -2134,11 +2139,11 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
                         edgen += 64 * (int64_t)(e.cR - e.cL);
                         if (e.far3 & 4) mx8 += 64 * (int64_t)(e.cR - e.cL);
                         const double *nl = ctx->gas[g.slot].h_nu.data();
-                        for (int q4 = 0; q4 < 8; q4++) {   // (k_voigt_sub<8>)
-                            const double v0 = c.h_nu[(size_t)t * 64 + 8 * q4] - e.R, v1 = c.h_nu[(size_t)t * 64 + 8 * q4 + 7] + e.R;
+                        for (int q4 = 0; q4 < 64 / CS_SUBW; q4++) {   // (k_voigt_sub<CS_SUBW>)
+                            const double v0 = c.h_nu[(size_t)t * 64 + CS_SUBW * q4] - e.R, v1 = c.h_nu[(size_t)t * 64 + CS_SUBW * q4 + CS_SUBW - 1] + e.R;
                             const int ja = (int)(std::lower_bound(nl + e.cL, nl + e.cR, v0) - nl);
                             const int jb = (int)(std::upper_bound(nl + ja, nl + e.cR, v1) - nl);
-                            subn += 8 * (int64_t)(jb - ja);
+                            subn += CS_SUBW * (int64_t)(jb - ja);
                         }
                     }
                 }

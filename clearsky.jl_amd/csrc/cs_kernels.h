@@ -1593,7 +1593,7 @@ __global__ __launch_bounds__(4096 / SW) void k_voigt_sub(const double *__restric
     const uint64_t b0 = __builtin_amdgcn_ballot_w64(r0 != 0u), b1 = __builtin_amdgcn_ballot_w64(r1 != 0u);
     if (lane == 0) {
         unsigned f0 = 0u, f1 = 0u;
-        const uint64_t m = SW == 16 ? 0xffffull : 0xffull;
+        const uint64_t m = (1ull << SW) - 1ull;
         for (int q = 0; q < NSW; q++) {
             f0 |= ((b0 >> (SW * q)) & m) ? (1u << q) : 0u;
             f1 |= ((b1 >> (SW * q)) & m) ? (1u << q) : 0u;
