@@ -182,6 +182,7 @@ def main():
     # separate passes: tools/profile.sh writes profiles/pmc_traffic.json).  It is quoted only when that file was measured on the
     # kernels loaded now (same source stamp) and on this exact workload; otherwise null -- never a stale number.
     traffic, traffic_note = None, "no PMC profile of this build/workload under profiles/"
+    pm, pm_dominant = None, None
     try:
         pm = json.load(open(os.path.join(_ROOT, "profiles", "pmc_traffic.json")))
         default_wl = args.nnu is None and args.lines is None and args.shape == "voigt" and N == 1 and interp_on and args.precision == "fp64" and not args.emulate_shard
@@ -191,6 +192,7 @@ def main():
             traffic_note = "profiles/pmc_traffic.json was measured on another workload"
         else:
             kk = pm["kernels"][pm["dominant"]]
+            pm_dominant = pm["dominant"].split("<")[0]
             traffic = (kk["FETCH_SIZE_KB"] + kk["WRITE_SIZE_KB"]) * 1024.0
             traffic_note = pm.get("calibration", "")
     except Exception:
@@ -225,10 +227,37 @@ def main():
                                        frac=(sub_instr / (prof["sub"] * 1e-3) / VALU_ISSUE_PEAK) if prof.get("sub", 0.0) > 0 else None),
                       k_cheb_nodes=dict(lane_instr=node_instr, ms=prof["nodes"], frac=(node_instr / (prof["nodes"] * 1e-3) / VALU_ISSUE_PEAK) if prof["nodes"] > 0 else None,
                                         lines_x_nodes_by_body=nb))
-    roofline = dict(bound="hbm", kernel="k_voigt_far", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_note=traffic_note, launches_per_step=ngas, avg_launch_ms=far_ms,
-                    algorithmic_bytes_per_launch=alg,
-                    note="elementwise fp64 accumulate over (nu,line) pairs: VALU-bound by construction, see valu_fp64",
+    # the dominant kernel = the class with the largest time per step among the line kernels (all one launch per gas); its roof:
+    # the fp64 matrix path for the two matrix-core kernels (flops of the series terms they sum), HBM for the vector kernels
+    # (algorithmic bytes; their binding roof, the fp64 vector unit, is in valu_issue)
+    n3n = work.get("node_evals_matrix_3term", 0)
+    fl_nodes_mx = 8.0 * work.get("node_evals_matrix", 0) - 2.0 * n3n
+    fl_edge_mx = 8.0 * work.get("direct_evals_matrix", 0) - 2.0 * (work.get("matrix_evals_3term", 0) - n3n) + 8.0 * work.get("matrix_evals_8term", 0)
+    K_vec = K   # (k_cheb_nodes: the records of every state can be touched; F written once)
+    nodes_bytes = float(np.mean([32 * K_vec * len(g.sl.nu) + 8 * 64 * work["intervals"] * K for g in col.gases])) if col.gases else 0.0
+    cands = dict(k_voigt_far=("hbm", prof["far"], alg), k_cheb_nodes=("hbm", prof["nodes"], nodes_bytes),
+                 k_voigt_edge_mx=("mfma", prof.get("far_mx", 0.0), fl_edge_mx / max(ngas, 1)),
+                 k_cheb_nodes_mx=("mfma", prof.get("nodes_mx", 0.0), fl_nodes_mx / max(ngas, 1)))
+    dom = max(cands, key=lambda kname: cands[kname][1])
+    bound, dom_ms, per_launch = cands[dom]
+    dom_ms /= max(ngas, 1)
+    if bound == "mfma":
+        r_ach, r_peak, r_unit = (per_launch / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0), FP64_VALU_PEAK_TFLOPS, "TFLOP/s"
+    else:
+        r_ach, r_peak, r_unit = (per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0), HBM_PEAK_GBS, "GB/s"
+    if traffic is not None and pm_dominant != dom:
+        traffic, traffic_note = None, f"profiles/pmc_traffic.json names {pm_dominant} as the dominant kernel, this run {dom}"
+    elif traffic is not None:
+        kk = pm["kernels"][[k_ for k_ in pm["kernels"] if k_.split("<")[0] == dom][0]]
+        traffic = (kk["FETCH_SIZE_KB"] + kk["WRITE_SIZE_KB"]) * 1024.0
+    roofline = dict(bound=bound, kernel=dom, achieved=r_ach, peak=r_peak, unit=r_unit,
+                    frac=r_ach / r_peak, traffic=traffic, traffic_note=traffic_note, launches_per_step=ngas, avg_launch_ms=dom_ms,
+                    algorithmic_flops_per_launch=per_launch if bound == "mfma" else None,
+                    algorithmic_bytes_per_launch=per_launch if bound == "hbm" else None,
+                    note=("series terms x (multiply + add) per (nu | node, line, state) summed as v_mfma_f64_16x16x4 products; the fp64 matrix path of "
+                          "MI355X has the vector unit's peak (78.6 TFLOP/s; tools/ubench/mfma_f64_rate.hip sustains 47) and shares its pipe"
+                          if bound == "mfma" else "elementwise fp64 accumulate over (nu,line) pairs: VALU-bound by construction, see valu_issue"),
+                    k_voigt_far_hbm=dict(achieved=achieved, frac=achieved / HBM_PEAK_GBS, unit="GB/s", avg_launch_ms=far_ms, algorithmic_bytes_per_launch=alg),
                     valu_fp64=dict(achieved=flops / (line_ms * 1e-3) / 1e12 if line_ms > 0 else 0.0, peak=FP64_VALU_PEAK_TFLOPS,
                                    unit="TFLOP/s", frac=flops / (line_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS if line_ms > 0 else 0.0,
                                    evals_issued=evals, direct_evals=work["direct_evals"], node_evals=work["node_evals"],

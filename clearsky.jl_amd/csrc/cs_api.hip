@@ -2060,7 +2060,7 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
     HIPCHK(hipDeviceSynchronize());
     const int K = c.K;
     const int nt64 = (int)((c.nnu + 63) / 64);
-    int64_t direct = 0, nodes = 0, sepn = 0, edgen = 0, mx3 = 0, subn = 0, ncore = 0, mx8 = 0;   // subn: (lane, line) evaluations of k_voigt_sub
+    int64_t direct = 0, nodes = 0, sepn = 0, edgen = 0, mx3 = 0, subn = 0, ncore = 0, mx8 = 0, mx3n = 0;   // subn: (lane, line) evaluations of k_voigt_sub
     //   // sepn, edgen: (node | point, line, state) triples summed on the matrix cores; mx3: those with 3 terms
     int64_t body[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // per-point lines by body: 2-term, 2-term+cut-off, 3-term, 3-term+cut-off, 4-term+cut-off,
                                                      // near-zone pass; node lines: 2-, 3-, 4-term
@@ -2096,6 +2096,7 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
                             if (s4.b[p] > s4.a[p]) {
                                 sa[p] = s4.a[p]; sb[p] = s4.b[p]; sepn += (int64_t)CS_NC * (s4.b[p] - s4.a[p]);
                                 mx3 += (int64_t)CS_NC * (p < 2 ? s4.m[p] - s4.a[p] : s4.b[p] - s4.m[p]);
+                                mx3n += (int64_t)CS_NC * (p < 2 ? s4.m[p] - s4.a[p] : s4.b[p] - s4.m[p]);
                             }
                     }
                     const int lo8[8] = {z.E0, sb[0], z.P1, sb[1], sb[3], z.P3, sb[2], z.Z1}, hi8[8] = {sa[0], z.P0, sa[1], z.Z0, z.E1, sa[3], z.P2, sa[2]};
@@ -2187,6 +2188,7 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
     out[16] = subn;
     out[17] = ncore;
     out[18] = mx8;
+    out[19] = mx3n;
     return CS_OK;
 }
 

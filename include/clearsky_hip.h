@@ -218,7 +218,8 @@ int cs_column_counts(cs_ctx *ctx, int64_t *pair_evals, int64_t *lines_in_range);
  * out[0] and out[4..9] do not include the latter), out[15] = those of out[13] + out[14] that take three series terms instead of
  * four, out[16] = (lane, line) evaluations of k_voigt_sub (the window core on 16-point sub-tiles; 37 instructions each like the
  * near-zone pass; not in out[0]), out[17] = (tile, state) pairs whose window core is k_voigt_sub's, summed over the gases, out[18] =
- * those of out[14] that take eight series terms (cores of the groups whose Lorentz widths set the radius).  `out` holds 19 values.
+ * those of out[14] that take eight series terms (the sub-tile cores), out[19] = the part of out[15] that belongs to out[13].  `out`
+ * holds 20 values.
  * cs_column_counts is the reference's count. */
 int cs_column_work(cs_ctx *ctx, int64_t *out);
 /* interval sizes (descending, <= 5, each 128..2048 points) cs_set_interp(on) would use for this grid and cut-off; returns
