@@ -1532,14 +1532,20 @@ __global__ __launch_bounds__(4096 / SW) void k_voigt_sub(const double *__restric
                                                           (uint32_t)__builtin_amdgcn_readlane((int)__builtin_bit_cast(uint64_t, v), 0));
         const double vhi = __builtin_bit_cast(double, ((uint64_t)__builtin_amdgcn_readlane((int)(__builtin_bit_cast(uint64_t, v) >> 32), SW - 1) << 32) |
                                                           (uint32_t)__builtin_amdgcn_readlane((int)__builtin_bit_cast(uint64_t, v), SW - 1));
-        int p = ja, q = jb;
-        const double a0 = vlo - Rg;
-        while (p < q) { const int m = (p + q) >> 1; if (gnul[m] < a0) p = m + 1; else q = m; }
-        ja = p;
-        q = jb;
-        const double a1 = vhi + Rg;
-        while (p < q) { const int m = (p + q) >> 1; if (gnul[m] <= a1) p = m + 1; else q = m; }
-        jb = p;
+        // one vector load per 64 lines of the core and two ballots instead of two binary searches (chains of dependent scalar
+        // loads: most of what a wave with half a dozen lines to sum spent its time on)
+        const double a0 = vlo - Rg, a1 = vhi + Rg;
+        const int c0 = ja, c1 = jb;
+        int first = c1, last = c0;   // first line >= a0, one past the last line <= a1
+        for (int base = c0; base < c1; base += 64) {
+            const int j = base + lane;
+            const double x = gnul[j < c1 ? j : c1 - 1];
+            const uint64_t mlo = __builtin_amdgcn_ballot_w64(j < c1 && x >= a0), mhi = __builtin_amdgcn_ballot_w64(j < c1 && x <= a1);
+            if (mlo != 0 && first == c1) first = base + __builtin_ctzll(mlo);
+            if (mhi != 0) last = base + 64 - __builtin_clzll(mhi);
+        }
+        ja = first;
+        jb = max(last, first);
     }
     // (every operand of the series is a vector register here -- the record is per lane -- so all its constants can be scalar)
     const double k1p5 = sgpr_const(1.5), k3p75 = sgpr_const(3.75), k12 = vgpr_const(12.0), km15 = sgpr_const(-15.0), km105 = sgpr_const(-105.0),
