@@ -1334,8 +1334,8 @@ __global__ __launch_bounds__(256) CS_FAR_ATTR void k_voigt_far(const double *__r
     const bool live = i < nnu;
     if (live) {
         const size_t o = (size_t)k * nnu + i;
-        const double prev = accumulate ? sigma[o] : (base + (extra ? extra[o] : 0.0));
-        sigma[o] = prev + acc;
+        if (!accumulate) sigma[o] = (base + (extra ? extra[o] : 0.0)) + acc;
+        else if (acc != 0.0) sigma[o] += acc;   // (nothing to add -- most tiles of a sparse table: no trip to sigma at all; x + 0.0 = x bit for bit)
     }
     // hand-off to k_voigt_near<0>, <1>: per (nu, node) and tier one word, (first line - N0) << 12 | count -- 8 bytes per
     // spectral point and node in all (cs_api.hip refuses tables dense enough to overflow 20 + 12 bits: check_near_density) --
