@@ -640,6 +640,9 @@ bool phco2_fast_ok(const GasTable &G, int64_t nnu, double cut, int kn, PhScratch
 // points per sub-tile of k_voigt_sub (16: 0.34 ms at C3 with every core on the 8-term series; 8: 0.22; 4: 0.22 -- what is left is not
 // the evaluations)
 constexpr int CS_SUBW = 8;
+// per-point matrix pieces only on tables with at least this many lines per tile in range (C5: the synthetic O3 table at 6.4 per
+// tile gains 0.12 ms with them, the HITRAN fixtures at 0.4-0.7 lose)
+constexpr int CS_EDGE_DENS = 4;
 
 // matrix-core node sums (k_cheb_nodes_mx): fp64 Voigt only, and by default only where there are enough (interval, state group)
 // blocks to fill the chip -- on a short grid (a nu-shard) the one-state-per-wave vector kernel has the shorter critical path
@@ -650,10 +653,10 @@ static bool sep_in_use(bool have_sep, bool always, int nblocks_intervals, int kn
 }
 // the per-point pieces (k_voigt_edge_mx: one wave per (tile, state group), no reduction) pay on shorter grids -- 1/4 of C3 (1564
 // waves): far 0.42 -> 0.36 ms; 1/8: 0.261 -> 0.244 ms, which the extra zone launch eats -- but only on tables dense enough to give
-// a wave more than a few steps (C5's HITRAN fixtures: far 3.94 -> 4.01 ms with them)
+// a wave more than a few steps (C5's HITRAN fixtures: far 3.94 -> 4.01 ms with them; its synthetic O3 table: step 10.63 -> 10.51)
 static bool edge_in_use(bool have_edge, bool always, int ntiles, int kn, bool lor, bool mixed, int64_t lines_in_range)
 {
-    return sep_in_use(have_edge, always, ntiles, kn, lor, mixed, 1024) && (always || lines_in_range >= (int64_t)ntiles * 8);
+    return sep_in_use(have_edge, always, ntiles, kn, lor, mixed, 1024) && (always || lines_in_range >= (int64_t)ntiles * CS_EDGE_DENS);
 }
 
 // K1 + K2 for one gas on `s`: parameters for `kn` states, then the line sum into sigma ([kn][nnu])
