@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--interp-first-level", type=int, default=-1, help="tuning: first interval level every gas uses (-1 = by line density)")
     ap.add_argument("--no-matrix-nodes", action="store_true", help="tuning: no far-line sums on the matrix cores (same as --matrix-cores 0)")
     ap.add_argument("--matrix-cores", type=int, default=1, help="tuning: far-line sums on the matrix cores: 1 where the grid is long enough (default), 2 always, 0 never")
+    ap.add_argument("--no-merge", action="store_true", help="tuning: one launch set per gas instead of one merged line table per column")
     ap.add_argument("--far-s", type=float, default=1e6, help="mixed precision: x^2 threshold of the fp32 region")
     ap.add_argument("--emulate-shard", default=None, help="R/N: time only shard R of an N-way split on this one GPU (rehearsal)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL, default) | gloo (rehearsal of N>1 on fewer GPUs)")
@@ -111,6 +112,7 @@ def main():
     ctx.set_interp(not args.no_interp)
     ctx.set_interp_plan(first_level=args.interp_first_level)
     ctx.set_matrix_cores(0 if args.no_matrix_nodes else args.matrix_cores)
+    ctx.set_merge(not args.no_merge)
     t_setup = time.perf_counter()
     col = cs.Column(cfg["P"], cfg["g"], cfg["T"], cfg["mu"], cfg["fS"], cfg["fa"], *cfg["absorbers"], core=cfg["core"],
                     theta_s=cfg["theta_s"], want_tau=True, want_M=True, nu_range=ranges[rank], ctx=ctx)
@@ -162,7 +164,8 @@ def main():
     # per-kernel HIP-event timing on the launch stream (rank-local) and the roofline of the dominant kernel
     prof = col.profile(reps=max(3, min(10, args.steps)), stream=stream)
     cnt = col.counts()
-    ngas = len(col.gases)
+    info = col.info()
+    ngas = max(int(info["groups"]), 1)     # launch sets per step: the gases of a column that share a cut-off run as ONE merged table
     K = col.K
     lines_total = sum(len(g.sl.nu) for g in col.gases)
     # k_voigt_far (one launch per gas), the longest kernel.  Algorithmic HBM bytes per launch: sigma written
@@ -173,8 +176,8 @@ def main():
     interp_on = work["levels"] > 0
     nt64 = (col.nnu + 63) // 64
     K_far = K - work.get("core_tile_states", 0) / max(ngas, 1) / nt64
-    far_bytes = [32 * K_far * len(g.sl.nu) + 8 * col.nnu * K * (2 if (gi > 0 or interp_on) else 1) + 8 * col.nnu * K_far + 8 * col.nnu
-                 for gi, g in enumerate(col.gases)]
+    far_bytes = [32 * K_far * lines_total / ngas + 8 * col.nnu * K * (2 if (gi > 0 or interp_on) else 1) + 8 * col.nnu * K_far + 8 * col.nnu
+                 for gi in range(ngas)]
     far_ms = prof["far"] / max(ngas, 1)
     alg = float(np.mean(far_bytes)) if far_bytes else 0.0
     achieved = alg / (far_ms * 1e-3) / 1e9 if far_ms > 0 else 0.0
@@ -234,7 +237,7 @@ def main():
     fl_nodes_mx = 8.0 * work.get("node_evals_matrix", 0) - 2.0 * n3n
     fl_edge_mx = 8.0 * work.get("direct_evals_matrix", 0) - 2.0 * (work.get("matrix_evals_3term", 0) - n3n) + 8.0 * work.get("matrix_evals_8term", 0)
     K_vec = K   # (k_cheb_nodes: the records of every state can be touched; F written once)
-    nodes_bytes = float(np.mean([32 * K_vec * len(g.sl.nu) + 8 * 64 * work["intervals"] * K for g in col.gases])) if col.gases else 0.0
+    nodes_bytes = (32 * K_vec * lines_total / ngas + 8 * 64 * work["intervals"] * K) if col.gases else 0.0
     cands = dict(k_voigt_far=("hbm", prof["far"], alg), k_cheb_nodes=("hbm", prof["nodes"], nodes_bytes),
                  k_voigt_edge_mx=("mfma", prof.get("far_mx", 0.0), fl_edge_mx / max(ngas, 1)),
                  k_cheb_nodes_mx=("mfma", prof.get("nodes_mx", 0.0), fl_nodes_mx / max(ngas, 1)))
@@ -333,7 +336,7 @@ def main():
                                         f"{len(nu)} wavenumbers x {nl} layers, {args.shape}, {cfg['lines_kind']} lines "
                                         f"({lines_total} total), Discretized(nstream=5,nlobatto=2)",
                                nnu=len(nu), layers=nl, lines=lines_total, parallelism=f"nu-shard x{N}"),
-                   olr_wm2=olr, setup_ms=setup_ms, host_pointer_ms=host_ptr, kernel_source_sha16=source_stamp(),
+                   olr_wm2=olr, setup_ms=setup_ms, launches_per_step=int(info["launches"]), launch_groups=int(info["groups"]), host_pointer_ms=host_ptr, kernel_source_sha16=source_stamp(),
                    roofline=roofline, cpu_baseline=cpu)
         print(json.dumps(out))
     if N > 1:

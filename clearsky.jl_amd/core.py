@@ -251,6 +251,11 @@ class Context:
         False/0 every node sum on the vector unit."""
         check(lib().cs_set_matrix_cores(self._h, int(on)))
 
+    def set_merge(self, on: bool = True):
+        """One launch set per column (default): Voigt/Lorentz gases with the same cut-off share a merged line table; False = one
+        launch set per gas."""
+        check(lib().cs_set_merge(self._h, int(bool(on))))
+
     def slot_of(self, sl: SpectralLines) -> int:
         """Upload `sl` (once) and return its gas slot."""
         key = id(sl)
@@ -1075,6 +1080,13 @@ class Column:
         a, b = C.c_int64(), C.c_int64()
         check(lib().cs_column_counts(self.ctx.handle, C.byref(a), C.byref(b)))
         return dict(pair_evals=a.value, lines_in_range=b.value)
+
+    def info(self):
+        """dict(groups, launches, lines, merge, max_members): launch groups of the resident column and kernel launches of its last run"""
+        self._require_resident("info")
+        out = (C.c_int64 * 8)()
+        check(lib().cs_column_info(self.ctx.handle, out))
+        return dict(groups=out[0], launches=out[1], lines=out[2], merge=out[3], max_members=out[4])
 
     def work(self):
         """Evaluations the last run issued for its Voigt gases: per-point, at interpolation nodes; levels in use."""

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -35,15 +36,29 @@ int fail(int code, const char *fmt, ...)
     return code;
 }
 
+thread_local int g_nlaunch = 0;   // kernel launches since the last reset (cs_column_run reports its count)
+#define CS_LAUNCH(...) do { g_nlaunch++; hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
 #define HIPCHK(expr)                                                                                   \
     do {                                                                                               \
         hipError_t e_ = (expr);                                                                        \
         if (e_ != hipSuccess) return fail(CS_EHIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+// owns one device allocation; move-only, so that `x = T()` frees what x held and containers of structs with DevBuf members can
+// grow without double frees
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    DevBuf &operator=(DevBuf &&o) noexcept
+    {
+        if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; }
+        return *this;
+    }
     ~DevBuf() { release(); }
     void release()
     {
@@ -76,10 +91,13 @@ struct GasTable {
     int64_t L = 0;
     int niso = 0;
     double mu_min = 0.0, mu_max = 0.0, ga_max = 0.0, gs_max = 0.0, na_min = 0.0, na_max = 0.0;
-    std::vector<double> h_nu;
+    // host mirror of the table (58 B per line): what a column merges when several of its gases share one launch set
+    std::vector<double> h_nu, h_S, h_ga, h_gs, h_Epp, h_na, h_mu, h_cheb;
     std::vector<int16_t> h_iso;
     std::vector<int32_t> h_ncheb;
-    DevBuf nu, S, ga, gs, Epp, na, mu, iso, ncheb, cheb, sref;
+    std::vector<uint8_t> h_gid;                          // merged tables only: member index of each line
+    std::vector<std::pair<int, uint64_t>> members;       // merged tables only: (slot, generation) of each member, in member order
+    DevBuf nu, S, ga, gs, Epp, na, mu, iso, ncheb, cheb, sref, gid;
     GasDev dev() const
     {
         GasDev g;
@@ -88,6 +106,7 @@ struct GasTable {
         g.Epp = Epp.as<double>(); g.na = na.as<double>(); g.mu = mu.as<double>();
         g.iso = iso.as<int16_t>(); g.ncheb = ncheb.as<int32_t>(); g.cheb = cheb.as<double>();
         g.sref = sref.as<double>();
+        g.gid = h_gid.empty() ? nullptr : gid.as<uint8_t>();
         return g;
     }
 };
@@ -144,15 +163,27 @@ struct ChebGrid {
 struct GasInterp { int nlev = 0, l0 = 0; DevBuf iwin[CS_MAX_LEVEL], iz, F, sep, edge; };   // levels l0 .. nlev-1 of the grid are in use; sep: SepZone [K/16][nItot]
                                                                                           // (matrix-core node sums), edge: EdgeZone [K/16][tiles] (matrix-core pieces of the per-point sum)
 
-struct ColGas {
+// a gas of the column as the caller named it (conc is laid out [ngas, K] over these)
+struct UserGas {
     int slot = 0, shape = 0;
     double cut = 25.0;
-    DevBuf conc, Pp, J0, J1;  // [K], [K], [ntile], [ntile]
+    uint64_t generation = 0;
+    int64_t pairs_per_state = -1, lines_in_range = 0;
+};
+// a launch group: one gas, or all Voigt (Lorentz) gases of the column with the same cut-off merged into ONE sorted line table --
+// sigma_total = sum_g C_g sigma_g (absorbers.jl:84-95) and a per-(state, line) record carries everything gas-specific (the
+// member's concentration and partial pressure enter in k_gas_setup), so the kernels see one table: one launch set per column
+// instead of one per gas, and windows as dense as the column's lines together
+struct ColGas {
+    std::vector<int> mem;     // indices into Column::ugas
+    const GasTable *tab = nullptr;   // ctx->gas[slot], or a merged table owned by the context
+    int shape = 0;
+    double cut = 25.0;
+    DevBuf conc, Pp, J0, J1;  // [nmem][K], [nmem][K], [ntile], [ntile]
     DevBuf win, zones, gmax;  // [ntile64] WaveWin, [K][ntile64] Zone, [K] max Lorentz width (Voigt fast path)
     GasInterp itp;            // interpolated far wings (nlev = 0: off)
-    int64_t pairs_per_state = 0, lines_in_range = 0, jlo = 0, jhi = 0;
+    int64_t jlo = 0, jhi = 0;
     int xtiles = 0;           // longest XCD stretch of the far kernel's tile order, in tiles (wave_windows)
-    uint64_t generation = 0;
 };
 
 // k_rt launch geometry (rt_geometry)
@@ -169,7 +200,10 @@ struct Column {
     double g = 0, sigma_gray = 0, theta_s = 0;
     RtParams rt;
     std::vector<double> h_P, h_Pk, h_xs, h_nu;
-    std::vector<ColGas> gas;
+    std::vector<UserGas> ugas;   // the caller's gases (ngas of them)
+    std::vector<ColGas> gas;     // launch groups
+    int merge = 1;               // the context's cs_set_merge at setup time
+    int launches = 0;            // kernel launches of the last cs_column_run
     std::vector<ColTab> tab;
     std::vector<ColCia> cia;
     ColAccel accel;
@@ -199,6 +233,8 @@ struct cs_ctx {
     int itp_first = -1, itp_min = 128, itp_max = 2048;   // cs_set_interp_plan: first level per gas (-1 = by line density), size range
     int matrix_nodes = 1;   // cs_set_matrix_cores: separable far-wing node sums on v_mfma_f64 (k_cheb_nodes_mx)
     int matrix_core = 1;    // ... and the window core on sub-tiles (k_voigt_sub + the second mask of k_voigt_edge_mx)
+    int merge = 1;          // cs_set_merge: gases of a column with the same shape and cut-off share one merged line table
+    std::vector<std::unique_ptr<GasTable>> merged;   // merged tables (keyed by their members' (slot, generation)), a few kept
     double far_s = 1e6;
     DevBuf hot32;
     DevBuf tmpA, tmpB, tmpC;
@@ -285,7 +321,7 @@ void launch_linesum(dim3 grid, hipStream_t s, const double *nu, int64_t nnu, int
                     const LineCold *cold, const int32_t *J0, const int32_t *J1, double cut, const double *Tk,
                     double base, const double *extra, double *sigma, int accumulate)
 {
-    hipLaunchKernelGGL(k_linesum<SHAPE>, grid, dim3(256), 0, s, nu, nnu, L, hot, cold, J0, J1, cut, Tk, base, extra,
+    CS_LAUNCH(k_linesum<SHAPE>, grid, dim3(256), 0, s, nu, nnu, L, hot, cold, J0, J1, cut, Tk, base, extra,
                        sigma, accumulate);
 }
 
@@ -321,10 +357,10 @@ void launch_rt_ns(const RtGeom &g, int B, hipStream_t s, const RtParams &p, cons
                   const double *S, const double *alb, double *tau, double *Mup, double *Mdn, double *partial, size_t sig_bstride)
 {
     if (g.ud)
-        hipLaunchKernelGGL((k_rt<NS, true>), dim3(g.nblk, B), dim3(g.threads), g.shmem, s, p, nu, wts, nnu, sigma, muk, P, Tlev, S, alb,
+        CS_LAUNCH((k_rt<NS, true>), dim3(g.nblk, B), dim3(g.threads), g.shmem, s, p, nu, wts, nnu, sigma, muk, P, Tlev, S, alb,
                            tau, Mup, Mdn, partial, sig_bstride);
     else
-        hipLaunchKernelGGL((k_rt<NS, false>), dim3(g.nblk, B), dim3(g.threads), g.shmem, s, p, nu, wts, nnu, sigma, muk, P, Tlev, S, alb,
+        CS_LAUNCH((k_rt<NS, false>), dim3(g.nblk, B), dim3(g.threads), g.shmem, s, p, nu, wts, nnu, sigma, muk, P, Tlev, S, alb,
                            tau, Mup, Mdn, partial, sig_bstride);
 }
 
@@ -508,7 +544,7 @@ int cheb_build(const cs_ctx *ctx, ChebGrid &g, const double *h_nu, const double 
     HIPCHK(g.nodes.reserve((size_t)g.nItot * CS_NC * sizeof(double)));
     for (int l = 0; l < g.nlev; l++) {
         HIPCHK(g.Cm[l].reserve((size_t)g.nI[l] * CS_NC * g.itv[l] * sizeof(double)));
-        hipLaunchKernelGGL(k_cheb_setup, dim3(g.nI[l]), dim3(256), 0, s, dnu, nnu, g.itv[l], g.nI[l],
+        CS_LAUNCH(k_cheb_setup, dim3(g.nI[l]), dim3(256), 0, s, dnu, nnu, g.itv[l], g.nI[l],
                            g.nodes.as<double>() + (size_t)g.ioff[l] * CS_NC, g.Cm[l].as<double>());
         HIPCHK(hipGetLastError());
     }
@@ -599,11 +635,11 @@ void launch_apply(hipStream_t s, const ChebApply &A, int Kpad, int64_t nnu, int 
 #ifdef CS_APPLY_VALU   // the vector-unit version (kept for A/B builds)
     const int nsg = (kn + CS_KPAD - 1) / CS_KPAD;
     if ((int64_t)nt64 * nsg <= 1200) {   // small grid: four waves per (tile, state group), 16 nodes each (0.076 -> 0.040 ms at 784; a tie at 1564, slower beyond)
-        hipLaunchKernelGGL(k_cheb_apply_split, dim3((unsigned)(nt64 * nsg)), dim3(256), 0, s, A, Kpad, nnu, nt64, kn, base, extra, sigma,
+        CS_LAUNCH(k_cheb_apply_split, dim3((unsigned)(nt64 * nsg)), dim3(256), 0, s, A, Kpad, nnu, nt64, kn, base, extra, sigma,
                            accumulate);
         return;
     }
-    hipLaunchKernelGGL(k_cheb_apply, dim3((unsigned)(((nt64 + 3) / 4 + 7) / 8 * 8) * (unsigned)nsg), dim3(256), 0, s, A,
+    CS_LAUNCH(k_cheb_apply, dim3((unsigned)(((nt64 + 3) / 4 + 7) / 8 * 8) * (unsigned)nsg), dim3(256), 0, s, A,
                        Kpad, nnu, nt64, kn, base, extra, sigma, accumulate);
 #else
     const int kp = cheb_kpad(kn);                // sub-tiles actually in use (Kpad is the row pitch of F)
@@ -614,10 +650,10 @@ void launch_apply(hipStream_t s, const ChebApply &A, int Kpad, int64_t nnu, int 
 #define CS_APPLY_NSUB 2
 #endif
     if ((int64_t)nt64 * ((nst + CS_APPLY_NSUB - 1) / CS_APPLY_NSUB) >= 2048)   // enough (tile, state chunk) waves to fill 1024 SIMDs twice
-        hipLaunchKernelGGL(k_cheb_apply_mfma<CS_APPLY_NSUB>, dim3(tb8 * (unsigned)((nst + CS_APPLY_NSUB - 1) / CS_APPLY_NSUB)), dim3(256), 0, s, A, Kpad, nnu, nt64, kn, base,
+        CS_LAUNCH(k_cheb_apply_mfma<CS_APPLY_NSUB>, dim3(tb8 * (unsigned)((nst + CS_APPLY_NSUB - 1) / CS_APPLY_NSUB)), dim3(256), 0, s, A, Kpad, nnu, nt64, kn, base,
                            extra, sigma, accumulate);
     else
-        hipLaunchKernelGGL(k_cheb_apply_mfma<1>, dim3(tb8 * (unsigned)nst), dim3(256), 0, s, A, Kpad, nnu, nt64, kn, base, extra, sigma,
+        CS_LAUNCH(k_cheb_apply_mfma<1>, dim3(tb8 * (unsigned)nst), dim3(256), 0, s, A, Kpad, nnu, nt64, kn, base, extra, sigma,
                            accumulate);
 #endif
 }
@@ -661,7 +697,7 @@ static bool edge_in_use(bool have_edge, bool always, int ntiles, int kn, bool lo
 
 // K1 + K2 for one gas on `s`: parameters for `kn` states, then the line sum into sigma ([kn][nnu])
 void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, int64_t jrange1, int kn, const double *Tk, const double *Pk, const double *Ppk,
-                const double *scale, LineHot *hot, LineCold *cold, const double *dnu, int64_t nnu, int ntile256,
+                const double *scale, int mstride /* members of a merged table: element (m, k) of Ppk / scale at m * mstride + k */, LineHot *hot, LineCold *cold, const double *dnu, int64_t nnu, int ntile256,
                 const int32_t *J0, const int32_t *J1, const WaveWin *win, int xtiles, Zone *zones, int2 *ranges, const double *gbound, double cut, double base,
                 const double *extra, double *sigma, int accumulate, hipEvent_t *evg,   // NULL or 6 events: after K1 (+ zones), nodes (vector unit), nodes (matrix cores), far (vector unit), sub-tile cores, far (matrix cores)
                 LineF32 *hot32 = nullptr, double far_s = 1e6, Interp itp = Interp(), ChebApply *defer = nullptr, PhScratch *ph = nullptr)
@@ -671,7 +707,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
     const int64_t tot = (int64_t)kn * (jhi - jlo);
     PrepArgs pa;
     pa.shape = shape; pa.K = kn; pa.g = G.dev(); pa.jlo = jlo; pa.jhi = jhi;
-    pa.Tk = Tk; pa.Pk = Pk; pa.Ppk = Ppk; pa.scale = scale; pa.hot = hot; pa.cold = cold; pa.hot32 = shape == SH_VOIGT ? hot32 : nullptr;
+    pa.Tk = Tk; pa.Pk = Pk; pa.Ppk = Ppk; pa.scale = scale; pa.mstride = mstride; pa.hot = hot; pa.cold = cold; pa.hot32 = shape == SH_VOIGT ? hot32 : nullptr;
     pa.phfac = nullptr;
     pa.nu_c = 0.0;
     const unsigned nb_prep = (unsigned)((tot + 255) / 256);
@@ -697,7 +733,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
             for (int l = 0; l < itp.nlev; l++) { P.itv[l] = itp.itv[l]; P.nI[l] = itp.nI[l]; P.ioff[l] = itp.ioff[l]; P.iwin[l] = itp.iwin[l]; }
             nb_iz = (unsigned)(((int64_t)(itp.nItot - itp.ioff[itp.l0]) * kn + 255) / 256);
         }
-        hipLaunchKernelGGL(k_gas_setup, dim3(nb_prep + nb_zones + nb_iz), dim3(256), 0, s, nb_prep, nb_zones, pa, za, P, itp.iz);
+        CS_LAUNCH(k_gas_setup, dim3(nb_prep + nb_zones + nb_iz), dim3(256), 0, s, nb_prep, nb_zones, pa, za, P, itp.iz);
         if (evg && itp.nlev == 0) (void)hipEventRecord(evg[0], s);
         if (itp.nlev > 0) {   // sigma = base + extra + interpolated far wings; the per-point kernels add the rest
             const int q0 = itp.ioff[itp.l0];
@@ -721,25 +757,25 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
                 ea.core4 = itp.core4;
                 const unsigned nb_sep = use_sep ? (unsigned)(((int64_t)(itp.nItot - q0) * ngrp + 255) / 256) : 0u;
                 const unsigned nb_edge = use_edge ? (unsigned)(((int64_t)nt64 * ngrp + 255) / 256) : 0u;
-                hipLaunchKernelGGL(k_mxzones, dim3(nb_sep + nb_edge), dim3(256), 0, s, nb_sep, sa, ea);
+                CS_LAUNCH(k_mxzones, dim3(nb_sep + nb_edge), dim3(256), 0, s, nb_sep, sa, ea);
             }
             if (evg) (void)hipEventRecord(evg[0], s);
             const SepZone *sepz = use_sep ? itp.sep : nullptr;
             if (lor)
-                hipLaunchKernelGGL((k_cheb_nodes<false, true>), gridn, dim3(256), 0, s, itp.nodes, G.L, hot, hot32, G.nu.as<double>(), itp.iz,
+                CS_LAUNCH((k_cheb_nodes<false, true>), gridn, dim3(256), 0, s, itp.nodes, G.L, hot, hot32, G.nu.as<double>(), itp.iz,
                                    itp.nItot, q0, q_acc, kn, itp.Kpad, cut, itp.F, sepz);
             else if (hot32)
-                hipLaunchKernelGGL((k_cheb_nodes<true, false>), gridn, dim3(256), 0, s, itp.nodes, G.L, hot, hot32, G.nu.as<double>(), itp.iz,
+                CS_LAUNCH((k_cheb_nodes<true, false>), gridn, dim3(256), 0, s, itp.nodes, G.L, hot, hot32, G.nu.as<double>(), itp.iz,
                                    itp.nItot, q0, q_acc, kn, itp.Kpad, cut, itp.F, sepz);
             else
-                hipLaunchKernelGGL((k_cheb_nodes<false, false>), gridn, dim3(256), 0, s, itp.nodes, G.L, hot, hot32, G.nu.as<double>(), itp.iz,
+                CS_LAUNCH((k_cheb_nodes<false, false>), gridn, dim3(256), 0, s, itp.nodes, G.L, hot, hot32, G.nu.as<double>(), itp.iz,
                                    itp.nItot, q0, q_acc, kn, itp.Kpad, cut, itp.F, sepz);
             if (evg) (void)hipEventRecord(evg[1], s);
             if (use_sep) {
                 const int nq = itp.nItot - q0;
                 const int nsplit = itp.nlev - itp.l0 > 1 ? itp.nI[itp.l0] : nq;   // the largest interval size in use (all of them if it is the only one)
                 const unsigned nblk_mx = (unsigned)(nsplit * ngrp) + (unsigned)(((int64_t)(nq - nsplit) * ngrp + 3) / 4);
-                hipLaunchKernelGGL(k_cheb_nodes_mx, dim3(nblk_mx), dim3(256), 0, s, itp.nodes, G.L, hot, itp.sep, itp.nItot, q0, nsplit, kn,
+                CS_LAUNCH(k_cheb_nodes_mx, dim3(nblk_mx), dim3(256), 0, s, itp.nodes, G.L, hot, itp.sep, itp.nItot, q0, nsplit, kn,
                                    itp.Kpad, ngrp, itp.F);
             }
             if (evg) (void)hipEventRecord(evg[2], s);
@@ -778,9 +814,9 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
         const int nblk_s = (nt64 * split + 3) / 4;
         // 8 x (blocks of the longest XCD stretch): XCD-aware tile mapping (tile_block); xtiles is a multiple of 4 tiles
         const dim3 grid_s((unsigned)(8 * (xtiles * split / 4)), kn);
-#define CS_FAR_LAUNCH(MIX, SP) hipLaunchKernelGGL((k_voigt_far<MIX, SP, false>), grid_s, dim3(256), 0, s, dnu, nnu, G.L, hot, hot32, G.nu.as<double>(), \
+#define CS_FAR_LAUNCH(MIX, SP) CS_LAUNCH((k_voigt_far<MIX, SP, false>), grid_s, dim3(256), 0, s, dnu, nnu, G.L, hot, hot32, G.nu.as<double>(), \
                                                   win, zones, nt64, nblk_s, cut, base, extra, sigma, accumulate, ranges, iz, itp.nItot, ishift, edgez)
-#define CS_LOR_LAUNCH(SP) hipLaunchKernelGGL((k_voigt_far<false, SP, true>), grid_s, dim3(256), 0, s, dnu, nnu, G.L, hot, hot32, G.nu.as<double>(), \
+#define CS_LOR_LAUNCH(SP) CS_LAUNCH((k_voigt_far<false, SP, true>), grid_s, dim3(256), 0, s, dnu, nnu, G.L, hot, hot32, G.nu.as<double>(), \
                                                   win, zones, nt64, nblk_s, cut, base, extra, sigma, accumulate, ranges, iz, itp.nItot, ishift, edgez)
         const EdgeZone *edgez = use_edge ? itp.edge : nullptr;
         if (lor) {
@@ -788,7 +824,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
         } else if (hot32) {
             if (split == 1) CS_FAR_LAUNCH(true, 1); else if (split == 2) CS_FAR_LAUNCH(true, 2); else CS_FAR_LAUNCH(true, 4);
         } else if (use_edge) {
-#define CS_EDGE_LAUNCH(SP) hipLaunchKernelGGL((k_voigt_far<false, SP, false, true>), grid_s, dim3(256), 0, s, dnu, nnu, G.L, hot, hot32, G.nu.as<double>(), \
+#define CS_EDGE_LAUNCH(SP) CS_LAUNCH((k_voigt_far<false, SP, false, true>), grid_s, dim3(256), 0, s, dnu, nnu, G.L, hot, hot32, G.nu.as<double>(), \
                                                   win, zones, nt64, nblk_s, cut, base, extra, sigma, accumulate, ranges, iz, itp.nItot, ishift, edgez)
             if (split == 1) CS_EDGE_LAUNCH(1); else if (split == 2) CS_EDGE_LAUNCH(2); else CS_EDGE_LAUNCH(4);
 #undef CS_EDGE_LAUNCH
@@ -799,11 +835,11 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
 #undef CS_LOR_LAUNCH
         if (evg) (void)hipEventRecord(evg[3], s);
         if (use_edge && itp.core)   // the window cores of the groups whose series radius is short: pairs inside it (the rest: k_voigt_edge_mx)
-            hipLaunchKernelGGL(k_voigt_sub<CS_SUBW>, dim3((unsigned)nt64, (unsigned)((kn + 64 / CS_SUBW - 1) / (64 / CS_SUBW))), dim3(4096 / CS_SUBW), 0, s, dnu, nnu, G.L, hot, G.nu.as<double>(), zones,
+            CS_LAUNCH(k_voigt_sub<CS_SUBW>, dim3((unsigned)nt64, (unsigned)((kn + 64 / CS_SUBW - 1) / (64 / CS_SUBW))), dim3(4096 / CS_SUBW), 0, s, dnu, nnu, G.L, hot, G.nu.as<double>(), zones,
                                itp.edge, nt64, kn, cut, sigma, reinterpret_cast<unsigned *>(ranges));
         if (evg) (void)hipEventRecord(evg[4], s);
         if (use_edge)
-            hipLaunchKernelGGL(k_voigt_edge_mx, dim3((unsigned)((nt64 + 3) / 4), (unsigned)((kn + 15) / 16)), dim3(256), 0, s, dnu, nnu, G.L, hot, win,
+            CS_LAUNCH(k_voigt_edge_mx, dim3((unsigned)((nt64 + 3) / 4), (unsigned)((kn + 15) / 16)), dim3(256), 0, s, dnu, nnu, G.L, hot, win,
                                itp.edge, nt64, kn, cut, sigma);
         if (evg) (void)hipEventRecord(evg[5], s);
         if (!lor) {
@@ -812,8 +848,8 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
             // the grid long enough to keep the chip full with an eighth of the waves
             const int nrep = (jhi - jlo < (int64_t)nt64 * 2 && (int64_t)ngrp * kn >= 262144) ? 8 : 1;
             const dim3 gridq((unsigned)(((ngrp + nrep - 1) / nrep + 3) / 4), kn);
-            hipLaunchKernelGGL(k_voigt_near<0>, gridq, dim3(256), 0, s, dnu, nnu, G.L, hot, cold, zones, nt64, ngrp, nrep, cut, sigma, ranges);
-            hipLaunchKernelGGL(k_voigt_near<1>, gridq, dim3(256), 0, s, dnu, nnu, G.L, hot, cold, zones, nt64, ngrp, nrep, cut, sigma, ranges);
+            CS_LAUNCH(k_voigt_near<0>, gridq, dim3(256), 0, s, dnu, nnu, G.L, hot, cold, zones, nt64, ngrp, nrep, cut, sigma, ranges);
+            CS_LAUNCH(k_voigt_near<1>, gridq, dim3(256), 0, s, dnu, nnu, G.L, hot, cold, zones, nt64, ngrp, nrep, cut, sigma, ranges);
         }
     } else if (shape == SH_PHCO2 && ph && phco2_fast_ok(G, nnu, cut, kn, ph)) {
         // PHCO2 fast path (k_phco2): region-uniform far lines with factorised chi; needs the cut-off edges inside region 3 and the
@@ -828,13 +864,13 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
         const unsigned nb_zones = (unsigned)(((int64_t)nt64 * kn + 255) / 256);
         IzParams P;
         memset(&P, 0, sizeof P);
-        hipLaunchKernelGGL(k_gas_setup, dim3(nb_prep + nb_zones), dim3(256), 0, s, nb_prep, nb_zones, pa, za, P, (IZone *)nullptr);
+        CS_LAUNCH(k_gas_setup, dim3(nb_prep + nb_zones), dim3(256), 0, s, nb_prep, nb_zones, pa, za, P, (IZone *)nullptr);
         PhArgs pw;
         pw.nu = dnu; pw.nul = G.nu.as<double>(); pw.nnu = nnu; pw.ntile = nt64; pw.J0 = (int32_t)jlo; pw.J1 = (int32_t)jhi; pw.cut = cut;
         pw.out = ph->win.as<PhWin>();
-        hipLaunchKernelGGL(k_phwin, dim3((unsigned)((nt64 + 255) / 256)), dim3(256), 0, s, pw);
+        CS_LAUNCH(k_phwin, dim3((unsigned)((nt64 + 255) / 256)), dim3(256), 0, s, pw);
         if (evg) { (void)hipEventRecord(evg[0], s); (void)hipEventRecord(evg[1], s); (void)hipEventRecord(evg[2], s); }
-        hipLaunchKernelGGL(k_phco2, dim3((unsigned)((nt64 + 3) / 4), kn), dim3(256), 0, s, dnu, nnu, G.L, hot, cold, ph->fac.as<double>(), ph->nu_c,
+        CS_LAUNCH(k_phco2, dim3((unsigned)((nt64 + 3) / 4), kn), dim3(256), 0, s, dnu, nnu, G.L, hot, cold, ph->fac.as<double>(), ph->nu_c,
                            ph->win.as<PhWin>(), zones, nt64, cut, Tk, kn, base, extra, sigma, accumulate);
         if (evg) { (void)hipEventRecord(evg[3], s); (void)hipEventRecord(evg[4], s); (void)hipEventRecord(evg[5], s); }
     } else {
@@ -843,7 +879,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
             IzParams P;
             memset(&za, 0, sizeof za);
             memset(&P, 0, sizeof P);
-            hipLaunchKernelGGL(k_gas_setup, dim3(nb_prep), dim3(256), 0, s, nb_prep, 0u, pa, za, P, (IZone *)nullptr);
+            CS_LAUNCH(k_gas_setup, dim3(nb_prep), dim3(256), 0, s, nb_prep, 0u, pa, za, P, (IZone *)nullptr);
         }
         if (evg) { (void)hipEventRecord(evg[0], s); (void)hipEventRecord(evg[1], s); (void)hipEventRecord(evg[2], s); }
         launch_linesum_shape(shape, dim3(ntile256, kn), s, dnu, nnu, G.L, hot, cold, J0, J1, cut, Tk, base, extra, sigma,
@@ -904,6 +940,38 @@ void cs_destroy(cs_ctx *ctx)
     delete ctx;
 }
 
+// host mirror -> statistics + device arrays
+static int table_to_device(GasTable &G, hipStream_t s)
+{
+    const int64_t L = G.L;
+    G.mu_min = *std::min_element(G.h_mu.begin(), G.h_mu.end());
+    G.mu_max = *std::max_element(G.h_mu.begin(), G.h_mu.end());
+    G.ga_max = *std::max_element(G.h_ga.begin(), G.h_ga.end());
+    G.gs_max = *std::max_element(G.h_gs.begin(), G.h_gs.end());
+    G.na_min = *std::min_element(G.h_na.begin(), G.h_na.end());
+    G.na_max = *std::max_element(G.h_na.begin(), G.h_na.end());
+    if (!(G.mu_min > 0)) return fail(CS_EINVAL, "isotopologue molar masses must be positive");
+    std::vector<double> sref(L);   // scaleintensity, line_shapes.jl:107-123: the denominator at Tref does not depend on the state
+    for (int64_t j = 0; j < L; j++) sref[j] = G.h_S[j] / (std::exp(-kC2 * G.h_Epp[j] / kTref) * (1.0 - std::exp(-kC2 * G.h_nu[j] / kTref)));
+    int rc;
+    if ((rc = upload(G.sref, sref.data(), L, s))) return rc;
+    if ((rc = upload(G.nu, G.h_nu.data(), L, s)) || (rc = upload(G.S, G.h_S.data(), L, s)) || (rc = upload(G.ga, G.h_ga.data(), L, s)) ||
+        (rc = upload(G.gs, G.h_gs.data(), L, s)) || (rc = upload(G.Epp, G.h_Epp.data(), L, s)) || (rc = upload(G.na, G.h_na.data(), L, s)) ||
+        (rc = upload(G.mu, G.h_mu.data(), L, s)) || (rc = upload(G.iso, G.h_iso.data(), L, s)) || (rc = upload(G.ncheb, G.h_ncheb.data(), G.niso, s)) ||
+        (rc = upload(G.cheb, G.h_cheb.data(), (size_t)G.niso * CS_CHEB_LD, s)))
+        return rc;
+    if (!G.h_gid.empty() && (rc = upload(G.gid, G.h_gid.data(), L, s))) return rc;
+    HIPCHK(hipStreamSynchronize(s));   // (sref is a local)
+    G.present = true;
+    return CS_OK;
+}
+
+static uint64_t next_generation()
+{
+    static uint64_t g = 0;
+    return ++g;
+}
+
 int cs_gas_upload(cs_ctx *ctx, int slot, int64_t L, const double *nu, const double *S, const double *gamma_a,
                   const double *gamma_s, const double *Epp, const double *na, const double *mu_iso,
                   const int16_t *iso, int niso, const int32_t *ncheb, const double *cheb)
@@ -917,32 +985,71 @@ int cs_gas_upload(cs_ctx *ctx, int slot, int64_t L, const double *nu, const doub
     if (L >= ((int64_t)1 << 26)) return fail(CS_EINVAL, "line table too long (%lld lines; the limit is 2^26 - 1 per gas)", (long long)L);
     HIPCHK(hipSetDevice(ctx->device));
     GasTable &G = ctx->gas[slot];
-    hipStream_t s = ctx->stream;
+    G.present = false;
     G.L = L;
     G.niso = niso;
-    G.h_nu.assign(nu, nu + L);
+    G.h_nu.assign(nu, nu + L); G.h_S.assign(S, S + L); G.h_ga.assign(gamma_a, gamma_a + L); G.h_gs.assign(gamma_s, gamma_s + L);
+    G.h_Epp.assign(Epp, Epp + L); G.h_na.assign(na, na + L); G.h_mu.assign(mu_iso, mu_iso + L);
     G.h_iso.assign(iso, iso + L);
     G.h_ncheb.assign(ncheb, ncheb + niso);
-    G.mu_min = *std::min_element(mu_iso, mu_iso + L);
-    G.mu_max = *std::max_element(mu_iso, mu_iso + L);
-    G.ga_max = *std::max_element(gamma_a, gamma_a + L);
-    G.gs_max = *std::max_element(gamma_s, gamma_s + L);
-    G.na_min = *std::min_element(na, na + L);
-    G.na_max = *std::max_element(na, na + L);
-    if (!(G.mu_min > 0)) return fail(CS_EINVAL, "isotopologue molar masses must be positive");
-    std::vector<double> sref(L);   // scaleintensity, line_shapes.jl:107-123: the denominator at Tref does not depend on the state
-    for (int64_t j = 0; j < L; j++) sref[j] = S[j] / (std::exp(-kC2 * Epp[j] / kTref) * (1.0 - std::exp(-kC2 * nu[j] / kTref)));
+    G.h_cheb.assign(cheb, cheb + (size_t)niso * CS_CHEB_LD);
+    G.h_gid.clear();
+    G.members.clear();
     int rc;
-    if ((rc = upload(G.sref, sref.data(), L, s))) return rc;
-    if ((rc = upload(G.nu, nu, L, s)) || (rc = upload(G.S, S, L, s)) || (rc = upload(G.ga, gamma_a, L, s)) ||
-        (rc = upload(G.gs, gamma_s, L, s)) || (rc = upload(G.Epp, Epp, L, s)) || (rc = upload(G.na, na, L, s)) ||
-        (rc = upload(G.mu, mu_iso, L, s)) || (rc = upload(G.iso, iso, L, s)) || (rc = upload(G.ncheb, ncheb, niso, s)) ||
-        (rc = upload(G.cheb, cheb, (size_t)niso * CS_CHEB_LD, s)))
-        return rc;
-    HIPCHK(hipStreamSynchronize(s));
-    G.present = true;
-    static uint64_t next_generation = 0;
-    G.generation = ++next_generation;
+    if ((rc = table_to_device(G, ctx->stream))) return rc;
+    G.generation = next_generation();
+    return CS_OK;
+}
+
+// One sorted table out of the tables of `slots` (stable merge by wavenumber: lines of equal position keep member order), each
+// line tagged with its member index; isotopologue numbers are offset into the concatenated Chebyshev tables.  Kept by the context
+// (a handful, keyed by the members' upload generations) so that re-setting a column up does not merge again.
+static int merged_table(cs_ctx *ctx, const std::vector<int> &slots, const GasTable **out)
+{
+    std::vector<std::pair<int, uint64_t>> key;
+    for (int sl : slots) key.emplace_back(sl, ctx->gas[sl].generation);
+    for (auto &m : ctx->merged)
+        if (m->members == key) { *out = m.get(); return CS_OK; }
+    if (ctx->merged.size() >= 4) ctx->merged.erase(ctx->merged.begin());   // (no column is resident while one is being set up)
+    int64_t L = 0;
+    int niso = 0;
+    for (int sl : slots) { L += ctx->gas[sl].L; niso += ctx->gas[sl].niso; }
+    if (L >= ((int64_t)1 << 26)) return fail(CS_EINVAL, "merged line table too long (%lld lines; the limit is 2^26 - 1)", (long long)L);
+    std::unique_ptr<GasTable> M(new GasTable());
+    GasTable &G = *M;
+    G.L = L;
+    G.niso = niso;
+    G.members = key;
+    struct Src { uint8_t m; int32_t j; };
+    std::vector<Src> order;
+    order.reserve(L);
+    std::vector<int> iso_off(slots.size());
+    int off = 0;
+    for (size_t m = 0; m < slots.size(); m++) {
+        const GasTable &g = ctx->gas[slots[m]];
+        iso_off[m] = off;
+        off += g.niso;
+        for (int64_t j = 0; j < g.L; j++) order.push_back(Src{(uint8_t)m, (int32_t)j});
+        G.h_ncheb.insert(G.h_ncheb.end(), g.h_ncheb.begin(), g.h_ncheb.end());
+        G.h_cheb.insert(G.h_cheb.end(), g.h_cheb.begin(), g.h_cheb.end());
+    }
+    // (each member is sorted: a stable sort of the concatenation is the stable merge)
+    std::stable_sort(order.begin(), order.end(), [&](const Src &a, const Src &b) { return ctx->gas[slots[a.m]].h_nu[a.j] < ctx->gas[slots[b.m]].h_nu[b.j]; });
+    G.h_nu.resize(L); G.h_S.resize(L); G.h_ga.resize(L); G.h_gs.resize(L); G.h_Epp.resize(L); G.h_na.resize(L); G.h_mu.resize(L);
+    G.h_iso.resize(L); G.h_gid.resize(L);
+    for (int64_t i = 0; i < L; i++) {
+        const Src q = order[i];
+        const GasTable &g = ctx->gas[slots[q.m]];
+        G.h_nu[i] = g.h_nu[q.j]; G.h_S[i] = g.h_S[q.j]; G.h_ga[i] = g.h_ga[q.j]; G.h_gs[i] = g.h_gs[q.j];
+        G.h_Epp[i] = g.h_Epp[q.j]; G.h_na[i] = g.h_na[q.j]; G.h_mu[i] = g.h_mu[q.j];
+        G.h_iso[i] = (int16_t)(g.h_iso[q.j] + iso_off[q.m]);
+        G.h_gid[i] = q.m;
+    }
+    int rc;
+    if ((rc = table_to_device(G, ctx->stream))) return rc;
+    G.generation = next_generation();
+    *out = M.get();
+    ctx->merged.push_back(std::move(M));
     return CS_OK;
 }
 
@@ -984,9 +1091,18 @@ int cs_set_matrix_cores(cs_ctx *ctx, int on)
     return CS_OK;
 }
 
+int cs_set_merge(cs_ctx *ctx, int on)
+{
+    if (!ctx) return fail(CS_EINVAL, "ctx is NULL");
+    ctx->merge = on ? 1 : 0;
+    return CS_OK;
+}
+
 int cs_gas_clear(cs_ctx *ctx, int slot)
 {
     if (!ctx || slot < 0 || slot >= CS_MAX_GAS) return fail(CS_EINVAL, "bad slot");
+    for (auto &g : ctx->col.ugas)
+        if (g.slot == slot) ctx->col.ready = false;   // (the resident column's windows belong to the table that goes away)
     ctx->gas[slot] = GasTable();
     return CS_OK;
 }
@@ -1065,7 +1181,7 @@ static int shape_impl(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t 
     }
     for (int k0 = 0; k0 < K; k0 += kc) {
         const int kn = std::min(kc, K - k0);
-        launch_gas(s, shape, G, J0.front(), J1.back(), kn, dT.as<double>() + k0, dP.as<double>() + k0, dPp.as<double>() + k0, nullptr,
+        launch_gas(s, shape, G, J0.front(), J1.back(), kn, dT.as<double>() + k0, dP.as<double>() + k0, dPp.as<double>() + k0, nullptr, 0,
                    hot.as<LineHot>(), cold.as<LineCold>(), dnu.as<double>(), nnu, ntile, dJ0.as<int32_t>(), dJ1.as<int32_t>(),
                    dwin.as<WaveWin>(), xtiles, dzones.as<Zone>(), dranges.as<int2>(), dgmax.as<double>() + k0, dnu_cut, 0.0, nullptr, dsig.as<double>(), 0, nullptr,
                    mix32, ctx->far_s, itp, nullptr, &ctx->ph);
@@ -1146,14 +1262,14 @@ int cs_bake(cs_ctx *ctx, int gas_slot, int table_slot, int shape, double dnu_cut
     }
     for (int k0 = 0; k0 < M; k0 += kc) {
         const int kn = std::min(kc, M - k0);
-        launch_gas(s, shape, G, J0.front(), J1.back(), kn, dT.as<double>() + k0, dP.as<double>() + k0, dPp.as<double>() + k0, nullptr, hot.as<LineHot>(),
+        launch_gas(s, shape, G, J0.front(), J1.back(), kn, dT.as<double>() + k0, dP.as<double>() + k0, dPp.as<double>() + k0, nullptr, 0, hot.as<LineHot>(),
                    cold.as<LineCold>(), dnu.as<double>(), nnu, ntile, dJ0.as<int32_t>(), dJ1.as<int32_t>(), dwin.as<WaveWin>(), xtiles,
                    dzones.as<Zone>(), dranges.as<int2>(), dgb.as<double>() + k0, dnu_cut, 0.0, nullptr, tb.Z.as<double>() + (size_t)k0 * nnu, 0, nullptr,
                    mix32, ctx->far_s, itp, nullptr, &ctx->ph);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(s));
     }
-    hipLaunchKernelGGL(k_table_log, dim3((unsigned)((nnu + 255) / 256)), dim3(256), 0, s, tb.Z.as<double>(), M, nnu);
+    CS_LAUNCH(k_table_log, dim3((unsigned)((nnu + 255) / 256)), dim3(256), 0, s, tb.Z.as<double>(), M, nnu);
     HIPCHK(hipGetLastError());
     if (lnsigma_out) HIPCHK(hipMemcpyAsync(lnsigma_out, tb.Z.p, (size_t)M * nnu * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -1183,14 +1299,14 @@ static int launch_table_eval(hipStream_t s, const double *Z, int M, int64_t nnu,
     const int ntile = (int)((nnu + 255) / 256);
     if ((size_t)M * CS_TAB_KC * sizeof(double) > 65536)
         HIPCHK(hipFuncSetAttribute((const void *)k_table_eval, hipFuncAttributeMaxDynamicSharedMemorySize, M * CS_TAB_KC * (int)sizeof(double)));
-    hipLaunchKernelGGL(k_table_eval, dim3((unsigned)ntile, (unsigned)((K + CS_TAB_KC - 1) / CS_TAB_KC)), dim3(256),
+    CS_LAUNCH(k_table_eval, dim3((unsigned)ntile, (unsigned)((K + CS_TAB_KC - 1) / CS_TAB_KC)), dim3(256),
                        (size_t)M * CS_TAB_KC * sizeof(double), s, Z, M, nnu, W, K, conc, sigma);
 #else
     const int nt64 = (int)((nnu + 63) / 64);
     const int nst = (K + 15) / 16, nsg = (nst + CS_TABLE_NSUB - 1) / CS_TABLE_NSUB;
     const int64_t nblk = (int64_t)((nt64 + 3) / 4) * nsg;
     if (nblk > 0x7fffffffLL) return fail(CS_EINVAL, "too many (tile, state) blocks for the opacity-table kernel");
-    hipLaunchKernelGGL(k_table_eval_mfma<CS_TABLE_NSUB>, dim3((unsigned)nblk), dim3(256), 0, s, Z, M, nnu, nt64, W, K, conc, sigma);
+    CS_LAUNCH(k_table_eval_mfma<CS_TABLE_NSUB>, dim3((unsigned)nblk), dim3(256), 0, s, Z, M, nnu, nt64, W, K, conc, sigma);
 #endif
     return CS_OK;
 }
@@ -1420,7 +1536,7 @@ int cs_accel_store(cs_ctx *ctx, int accel_slot)
     AccelDev &ad = ctx->accel[accel_slot];
     const int64_t n = (int64_t)c.K * c.nnu;
     HIPCHK(ad.L.reserve((size_t)n * sizeof(double)));
-    hipLaunchKernelGGL(k_accel_store, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, c.sigma.as<double>(), ad.L.as<double>());
+    CS_LAUNCH(k_accel_store, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, c.sigma.as<double>(), ad.L.as<double>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s));
     ad.nnu = c.nnu;
@@ -1472,7 +1588,7 @@ int cs_accel_eval(cs_ctx *ctx, int accel_slot, double P, int64_t i0, int64_t n, 
         (rc = upload(db, xb.data(), 1, s)))
         return rc;
     HIPCHK(ctx->tmpC.reserve((size_t)ad.nnu * sizeof(double)));
-    hipLaunchKernelGGL(k_accel_eval, dim3((unsigned)((ad.nnu + 255) / 256), 1), dim3(256), 0, s, ad.L.as<double>(), ad.nnu, 1, dc.as<int32_t>(),
+    CS_LAUNCH(k_accel_eval, dim3((unsigned)((ad.nnu + 255) / 256), 1), dim3(256), 0, s, ad.L.as<double>(), ad.nnu, 1, dc.as<int32_t>(),
                        dx.as<double>(), da.as<double>(), db.as<double>(), 0.0, (const double *)nullptr, ctx->tmpC.as<double>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(sigma_out, ctx->tmpC.as<double>() + i0, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -1574,9 +1690,11 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
     if (c.has_extra && (rc = upload(c.extra, sigma_extra, (size_t)nnu * K, s))) return rc;
     if (c.has_S && (rc = upload(c.S_toa, S_toa, nnu, s))) return rc;
     if (c.has_alb && (rc = upload(c.albedo, albedo, nnu, s))) return rc;
-    // gases: tile windows and workspace
+    // gases: launch groups, tile windows and workspace
     c.gas.clear();
-    c.gas.resize(ngas);
+    c.ugas.clear();
+    c.ugas.resize(ngas);
+    c.merge = ctx->merge;
     c.cheb.nlev = 0;
     if (ctx->interp) {   // interval sizes from the narrowest Voigt cut-off of the column
         double cmin = 0.0;
@@ -1587,24 +1705,52 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
             }
         if (cmin > 0.0 && (rc = cheb_build(ctx, c.cheb, nu, c.nu.as<double>(), nnu, cmin, s))) return rc;
     }
-    size_t maxL = 0;
+    std::vector<std::vector<int>> groups;
     for (int gi = 0; gi < ngas; gi++) {
-        ColGas &cg = c.gas[gi];
-        cg.slot = gas_slots[gi];
-        cg.shape = shapes ? shapes[gi] : CS_SHAPE_VOIGT;
-        cg.cut = dnu_cuts ? dnu_cuts[gi] : 25.0;
-        if (cg.slot < 0 || cg.slot >= CS_MAX_GAS || !ctx->gas[cg.slot].present)
-            return fail(CS_EINVAL, "gas slot %d is empty", cg.slot);
-        cg.generation = ctx->gas[cg.slot].generation;
-        if (cg.shape < 0 || cg.shape > 3) return fail(CS_EINVAL, "unknown shape %d", cg.shape);
-        GasTable &G = ctx->gas[cg.slot];
+        UserGas &ug = c.ugas[gi];
+        ug.slot = gas_slots[gi];
+        ug.shape = shapes ? shapes[gi] : CS_SHAPE_VOIGT;
+        ug.cut = dnu_cuts ? dnu_cuts[gi] : 25.0;
+        if (ug.slot < 0 || ug.slot >= CS_MAX_GAS || !ctx->gas[ug.slot].present)
+            return fail(CS_EINVAL, "gas slot %d is empty", ug.slot);
+        ug.generation = ctx->gas[ug.slot].generation;
+        if (ug.shape < 0 || ug.shape > 3) return fail(CS_EINVAL, "unknown shape %d", ug.shape);
+        const GasTable &G = ctx->gas[ug.slot];
+        ug.pairs_per_state = -1;   // counted on demand (cs_column_counts): O(nnu log L) on the host
+        ug.lines_in_range = std::upper_bound(G.h_nu.begin(), G.h_nu.end(), nu[nnu - 1] + ug.cut) -
+                            std::lower_bound(G.h_nu.begin(), G.h_nu.end(), nu[0] - ug.cut);   // (the reference's count: inside the cut-off)
+        // Voigt (Lorentz) gases with the same cut-off go into one group; a slot named twice stays apart (a merged table tags a
+        // line with ONE member)
+        bool placed = false;
+        if (ctx->merge && (ug.shape == SH_VOIGT || ug.shape == SH_LORENTZ))
+            for (auto &grp : groups) {
+                const UserGas &h = c.ugas[grp[0]];
+                bool dup = false;
+                for (int m : grp) dup = dup || c.ugas[m].slot == ug.slot;
+                if (h.shape == ug.shape && h.cut == ug.cut && !dup && grp.size() < 255) { grp.push_back(gi); placed = true; break; }
+            }
+        if (!placed) groups.push_back(std::vector<int>{gi});
+    }
+    c.gas.resize(groups.size());
+    size_t maxL = 0;
+    for (size_t qi = 0; qi < groups.size(); qi++) {
+        ColGas &cg = c.gas[qi];
+        cg.mem = groups[qi];
+        cg.shape = c.ugas[cg.mem[0]].shape;
+        cg.cut = c.ugas[cg.mem[0]].cut;
+        if (cg.mem.size() == 1) {
+            cg.tab = &ctx->gas[c.ugas[cg.mem[0]].slot];
+        } else {
+            std::vector<int> slots;
+            for (int m : cg.mem) slots.push_back(c.ugas[m].slot);
+            if ((rc = merged_table(ctx, slots, &cg.tab))) return rc;
+        }
+        const GasTable &G = *cg.tab;
         if (cg.shape == SH_VOIGT && (rc = check_near_density(G, nu, nnu, cg.cut))) return rc;
-        int64_t g0, g1;
+        int64_t g0, g1, pairs_unused, inr_unused;
         included_range(G.h_nu, nu[0], nu[nnu - 1], cg.cut, false, g0, g1);
         std::vector<int32_t> J0, J1;
-        tile_windows(G.h_nu, g0, g1, nu, nnu, window_reach(cg.shape, G, nu[nnu - 1], cg.cut), J0, J1, cg.pairs_per_state, cg.lines_in_range);
-        cg.lines_in_range = std::upper_bound(G.h_nu.begin() + g0, G.h_nu.begin() + g1, nu[nnu - 1] + cg.cut) -
-                            std::lower_bound(G.h_nu.begin() + g0, G.h_nu.begin() + g1, nu[0] - cg.cut);   // (the reference's count: inside the cut-off)
+        tile_windows(G.h_nu, g0, g1, nu, nnu, window_reach(cg.shape, G, nu[nnu - 1], cg.cut), J0, J1, pairs_unused, inr_unused);
         cg.jlo = J0.front();
         cg.jhi = J1.back();
         std::vector<WaveWin> win;
@@ -1617,6 +1763,7 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
         if (c.cheb.nlev > 0 && (cg.shape == SH_VOIGT || cg.shape == SH_LORENTZ) &&
             (rc = gas_interp_build(ctx, cg.itp, c.cheb, G.h_nu, g0, g1, nu, nnu, cg.cut, c.K, s, false)))
             return rc;
+        HIPCHK(hipStreamSynchronize(s));   // J0, J1, win are locals
         maxL = std::max(maxL, (size_t)G.L);
     }
     if (c.cheb.nlev > 0) {
@@ -1665,22 +1812,29 @@ int cs_column_update_state(cs_ctx *ctx, const double *T_nodes, const double *mu_
     int rc;
     c.h_Tk = Tk;
     for (int gi = 0; gi < c.ngas; gi++)
-        if ((rc = check_gas_states(ctx->gas[c.gas[gi].slot], K, Tk.data()))) return rc;
+        if ((rc = check_gas_states(ctx->gas[c.ugas[gi].slot], K, Tk.data()))) return rc;
     if ((rc = upload(c.Tk, Tk.data(), K, s)) || (rc = upload(c.muk, muk.data(), K, s)) ||
         (rc = upload(c.Tlev, T_levels, c.np, s)))
         return rc;
-    std::vector<double> cc(K), pp(K);
-    for (int gi = 0; gi < c.ngas; gi++) {
-        for (int k = 0; k < K; k++) {
-            cc[k] = conc[gi + (size_t)c.ngas * k];
-            if (!(cc[k] >= 0 && cc[k] <= 1))
-                return fail(CS_EINVAL, "gas molar concentrations must be in [0,1], not %g", cc[k]);
-            pp[k] = cc[k] * c.h_Pk[k];  // Pp = C*P, gases.jl:126
+    for (auto &cg : c.gas) {   // per group: concentration and partial pressure of every member [nmem][K], Lorentz-width bound over the members
+        const int nm = (int)cg.mem.size();
+        std::vector<double> cc((size_t)nm * K), pp((size_t)nm * K), gb(K, 0.0);
+        for (int m = 0; m < nm; m++) {
+            const int gi = cg.mem[m];
+            for (int k = 0; k < K; k++) {
+                const double v = conc[gi + (size_t)c.ngas * k];
+                if (!(v >= 0 && v <= 1))
+                    return fail(CS_EINVAL, "gas molar concentrations must be in [0,1], not %g", v);
+                cc[(size_t)m * K + k] = v;
+                pp[(size_t)m * K + k] = v * c.h_Pk[k];  // Pp = C*P, gases.jl:126
+            }
+            const std::vector<double> gm = gamma_bound(ctx->gas[c.ugas[gi].slot], K, Tk.data(), c.h_Pk.data(), pp.data() + (size_t)m * K);
+            for (int k = 0; k < K; k++) gb[k] = std::max(gb[k], gm[k]);
         }
-        std::vector<double> gb = gamma_bound(ctx->gas[c.gas[gi].slot], K, Tk.data(), c.h_Pk.data(), pp.data());
-        if ((rc = upload(c.gas[gi].conc, cc.data(), K, s)) || (rc = upload(c.gas[gi].Pp, pp.data(), K, s)) ||
-            (rc = upload(c.gas[gi].gmax, gb.data(), K, s)))
+        if ((rc = upload(cg.conc, cc.data(), cc.size(), s)) || (rc = upload(cg.Pp, pp.data(), pp.size(), s)) ||
+            (rc = upload(cg.gmax, gb.data(), K, s)))
             return rc;
+        HIPCHK(hipStreamSynchronize(s));   // (locals)
     }
     HIPCHK(hipStreamSynchronize(s));
     if (!c.tab.empty()) {
@@ -1718,7 +1872,7 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
     }
     int rc;
     for (int gi = 0; gi < c.ngas; gi++)
-        if ((rc = check_gas_states(ctx->gas[c.gas[gi].slot], (int)BK, Tk.data()))) return rc;
+        if ((rc = check_gas_states(ctx->gas[c.ugas[gi].slot], (int)BK, Tk.data()))) return rc;
     const double *extra = c.has_extra ? c.extra.as<double>() : nullptr;
     if (extra) return fail(CS_EINVAL, "host-evaluated sigma(nu,T,P) terms are not supported in batch mode");
     const bool shared_sigma = c.accel.slot >= 0;   // AcceleratedAbsorber: cross-sections do not depend on the thermal state (absorbers.jl:203)
@@ -1736,10 +1890,10 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
         if ((rc = sigma_impl(ctx, s, nullptr, e))) return rc;
     } else if (c.ngas == 0) {
         const int64_t tot = BK * c.nnu;
-        hipLaunchKernelGGL(k_fill, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, tot, c.sigma_gray, (const double *)nullptr, sig);
+        CS_LAUNCH(k_fill, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, tot, c.sigma_gray, (const double *)nullptr, sig);
     }
     size_t maxL = 0;
-    for (auto &g : c.gas) maxL = std::max(maxL, (size_t)ctx->gas[g.slot].L);
+    for (auto &g : c.gas) maxL = std::max(maxL, (size_t)g.tab->L);
     const size_t per_state = maxL * (sizeof(LineHot) + sizeof(LineCold) + (ctx->mixed ? sizeof(LineF32) : 0)) + (size_t)c.nnu * sizeof(int2);
     const int kc = (int)std::max<size_t>(1, std::min<size_t>({(size_t)BK, ((size_t)8 << 30) / std::max<size_t>(per_state, 1), (size_t)65535}));
     if (c.ngas > 0) {
@@ -1748,21 +1902,27 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
         HIPCHK(dranges.reserve((size_t)kc * c.nnu * sizeof(int2) + (size_t)2 * kc * ((c.nnu + 63) / 64) * sizeof(int)));
         if (ctx->mixed) HIPCHK(ctx->hot32.reserve(((size_t)kc * maxL + 4) * sizeof(LineF32)));
     }
-    std::vector<double> cc(BK), pp(BK);
     ctx->ph.nu_lo = c.h_nu.front(); ctx->ph.nu_hi = c.h_nu.back();
-    for (int gi = 0; gi < c.ngas; gi++) {
-        ColGas &cg = c.gas[gi];
-        GasTable &G = ctx->gas[cg.slot];
-        for (int b = 0; b < B; b++)
-            for (int k = 0; k < K; k++) {
-                const double v = conc[(size_t)b * c.ngas * K + gi + (size_t)c.ngas * k];
-                if (!(v >= 0 && v <= 1)) return fail(CS_EINVAL, "gas molar concentrations must be in [0,1], not %g", v);
-                cc[(size_t)b * K + k] = v;
-                pp[(size_t)b * K + k] = v * c.h_Pk[k];
-            }
-        std::vector<double> gb = gamma_bound(G, (int)BK, Tk.data(), Pk.data(), pp.data());
+    for (size_t qi = 0; qi < c.gas.size(); qi++) {
+        ColGas &cg = c.gas[qi];
+        const GasTable &G = *cg.tab;
+        const int nm = (int)cg.mem.size();
+        std::vector<double> cc((size_t)nm * BK), pp((size_t)nm * BK), gb(BK, 0.0);
+        for (int m = 0; m < nm; m++) {
+            const int gi = cg.mem[m];
+            double *cm = cc.data() + (size_t)m * BK, *pm = pp.data() + (size_t)m * BK;
+            for (int b = 0; b < B; b++)
+                for (int k = 0; k < K; k++) {
+                    const double v = conc[(size_t)b * c.ngas * K + gi + (size_t)c.ngas * k];
+                    if (!(v >= 0 && v <= 1)) return fail(CS_EINVAL, "gas molar concentrations must be in [0,1], not %g", v);
+                    cm[(size_t)b * K + k] = v;
+                    pm[(size_t)b * K + k] = v * c.h_Pk[k];
+                }
+            const std::vector<double> gm = gamma_bound(ctx->gas[c.ugas[gi].slot], (int)BK, Tk.data(), Pk.data(), pm);
+            for (int64_t k = 0; k < BK; k++) gb[k] = std::max(gb[k], gm[k]);
+        }
         const size_t nt64 = (size_t)((c.nnu + 63) / 64);
-        if ((rc = upload(dconc, cc.data(), BK, s)) || (rc = upload(dPp, pp.data(), BK, s)) || (rc = upload(dgb, gb.data(), BK, s))) return rc;
+        if ((rc = upload(dconc, cc.data(), cc.size(), s)) || (rc = upload(dPp, pp.data(), pp.size(), s)) || (rc = upload(dgb, gb.data(), BK, s))) return rc;
         HIPCHK(dzones.reserve((size_t)kc * nt64 * sizeof(Zone)));
         Interp itp;
         if (cg.itp.nlev > 0) {
@@ -1784,13 +1944,13 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
         for (int64_t k0 = 0; k0 < BK; k0 += kc) {
             const int kn = (int)std::min<int64_t>(kc, BK - k0);
             launch_gas(s, cg.shape, G, cg.jlo, cg.jhi, kn, dTk.as<double>() + k0, dPk.as<double>() + k0, dPp.as<double>() + k0,
-                       dconc.as<double>() + k0, hot.as<LineHot>(), cold.as<LineCold>(), c.nu.as<double>(), c.nnu, c.ntile,
+                       dconc.as<double>() + k0, (int)BK, hot.as<LineHot>(), cold.as<LineCold>(), c.nu.as<double>(), c.nnu, c.ntile,
                        cg.J0.as<int32_t>(), cg.J1.as<int32_t>(), cg.win.as<WaveWin>(), cg.xtiles, dzones.as<Zone>(), dranges.as<int2>(),
-                       dgb.as<double>() + k0, cg.cut, c.sigma_gray, nullptr, sig + (size_t)k0 * c.nnu, gi > 0, nullptr,
+                       dgb.as<double>() + k0, cg.cut, c.sigma_gray, nullptr, sig + (size_t)k0 * c.nnu, qi > 0, nullptr,
                        (ctx->mixed && cg.shape == SH_VOIGT) ? ctx->hot32.as<LineF32>() : nullptr, ctx->far_s, itp, nullptr, &ctx->ph);
             HIPCHK(hipGetLastError());
         }
-        HIPCHK(hipStreamSynchronize(s));   // cc/pp/gb host buffers are reused by the next gas
+        HIPCHK(hipStreamSynchronize(s));   // cc/pp/gb are locals; the device buffers are reused by the next group
     }
     // baked gases of the column at all B*K states: the Gas functor fC(T,P)*exp(Phi(T, ln P)) (gases.jl:85,278) -- what RCM holds
     // inside its AcceleratedAbsorber (radiative_convective.jl:6-103)
@@ -1826,7 +1986,7 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
                     p2[(size_t)b * K + k] = cia_P2[(size_t)b * nc * K + t + (size_t)nc * k];
                 }
             if ((rc = upload_cia_states(ctx, ci.slot, ci.flags, (int)BK, Tk.data(), Pk.data(), p1.data(), p2.data(), 1, 0, dst, d1, d2, da))) return rc;
-            hipLaunchKernelGGL(k_cia, dim3((unsigned)c.ntile), dim3(256), 0, s, ci.nband, ci.bands.as<CiaBand>(), dst.as<CiaState>(),
+            CS_LAUNCH(k_cia, dim3((unsigned)c.ntile), dim3(256), 0, s, ci.nband, ci.bands.as<CiaBand>(), dst.as<CiaState>(),
                                c.nu.as<double>(), c.nnu, (int)BK, d1.as<double>(), d2.as<double>(), da.as<double>(), sig);
             HIPCHK(hipGetLastError());
             HIPCHK(hipStreamSynchronize(s));
@@ -1836,7 +1996,7 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
                     c.wts.as<double>(), c.nnu, sig, dmuk.as<double>(), c.P.as<double>(), dTlev.as<double>(),
                     c.has_S ? c.S_toa.as<double>() : nullptr, c.has_alb ? c.albedo.as<double>() : nullptr, (double *)nullptr, nullptr,
                     nullptr, dpart.as<double>(), shared_sigma ? 0 : (size_t)K * c.nnu);   // batches return band fluxes only: no tau stored
-    hipLaunchKernelGGL(k_freduce, dim3(2 * np, B), dim3(256), 0, s, dpart.as<double>(), bg.nblk, 2 * np, dF.as<double>());
+    CS_LAUNCH(k_freduce, dim3(2 * np, B), dim3(256), 0, s, dpart.as<double>(), bg.nblk, 2 * np, dF.as<double>());
     HIPCHK(hipGetLastError());
     std::vector<double> F((size_t)B * 2 * np);
     HIPCHK(hipMemcpyAsync(F.data(), dF.p, F.size() * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -1858,29 +2018,29 @@ static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e)
     const double *extra = c.has_extra ? c.extra.as<double>() : nullptr;
     if (c.accel.slot >= 0) {   // AcceleratedAbsorber: exp of the ln P-interpolated ln sigma (absorbers.jl:203)
         AccelDev &ad = ctx->accel[c.accel.slot];
-        hipLaunchKernelGGL(k_accel_eval, dim3((unsigned)c.ntile, K), dim3(256), 0, s, ad.L.as<double>(), c.nnu, K, c.accel.cell.as<int32_t>(),
+        CS_LAUNCH(k_accel_eval, dim3((unsigned)c.ntile, K), dim3(256), 0, s, ad.L.as<double>(), c.nnu, K, c.accel.cell.as<int32_t>(),
                            c.accel.x.as<double>(), c.accel.xa.as<double>(), c.accel.xb.as<double>(), c.sigma_gray, extra, sig);
-    } else if (c.ngas == 0) {
+    } else if (c.gas.empty()) {
         const int64_t tot = (int64_t)K * c.nnu;
-        hipLaunchKernelGGL(k_fill, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, tot, c.sigma_gray, extra, sig);
+        CS_LAUNCH(k_fill, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, tot, c.sigma_gray, extra, sig);
     }
     if (ctx->mixed) {
         size_t maxL = 0;
-        for (auto &g : c.gas) maxL = std::max(maxL, (size_t)ctx->gas[g.slot].L);
+        for (auto &g : c.gas) maxL = std::max(maxL, (size_t)g.tab->L);
         HIPCHK(ctx->hot32.reserve(((size_t)K * maxL + 4) * sizeof(LineF32)));   // no-op once sized (not capturable the first time)
     }
     ChebApply apply;
     apply.ngas = 0;
     ctx->ph.nu_lo = c.h_nu.front(); ctx->ph.nu_hi = c.h_nu.back();
-    for (int gi = 0; gi < c.ngas; gi++) {
+    for (int gi = 0; gi < (int)c.gas.size(); gi++) {
         ColGas &cg = c.gas[gi];
-        GasTable &G = ctx->gas[cg.slot];
+        const GasTable &G = *cg.tab;
         Interp itp = cg.itp.nlev > 0 ? interp_view(c.cheb, cg.itp, K) : Interp();
         itp.F = c.chebF.as<double>();
         if (!ctx->matrix_nodes) itp.sep = nullptr, itp.edge = nullptr;
         itp.sep_always = ctx->matrix_nodes == 2;
         itp.core = ctx->matrix_core != 0;
-        launch_gas(s, cg.shape, G, cg.jlo, cg.jhi, K, c.Tk.as<double>(), c.Pk.as<double>(), cg.Pp.as<double>(), cg.conc.as<double>(),
+        launch_gas(s, cg.shape, G, cg.jlo, cg.jhi, K, c.Tk.as<double>(), c.Pk.as<double>(), cg.Pp.as<double>(), cg.conc.as<double>(), K,
                    c.hot.as<LineHot>(), c.cold.as<LineCold>(), c.nu.as<double>(), c.nnu, c.ntile, cg.J0.as<int32_t>(),
                    cg.J1.as<int32_t>(), cg.win.as<WaveWin>(), cg.xtiles, cg.zones.as<Zone>(), c.ranges.as<int2>(), cg.gmax.as<double>(), cg.cut, c.sigma_gray, extra, sig, gi > 0,
                    ev ? ev + e : nullptr,
@@ -1895,18 +2055,24 @@ static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e)
         if ((rc2 = launch_table_eval(s, tb.Z.as<double>(), tb.nT * tb.nP, c.nnu, t.W.as<double>(), K, t.conc.as<double>(), sig))) return rc2;
     }
     for (auto &cc : c.cia)  // CIA pairs
-        hipLaunchKernelGGL(k_cia, dim3((unsigned)c.ntile), dim3(256), 0, s, cc.nband, cc.bands.as<CiaBand>(), cc.st.as<CiaState>(),
+        CS_LAUNCH(k_cia, dim3((unsigned)c.ntile), dim3(256), 0, s, cc.nband, cc.bands.as<CiaBand>(), cc.st.as<CiaState>(),
                            c.nu.as<double>(), c.nnu, K, cc.rho1.as<double>(), cc.rho2.as<double>(), cc.rhoa.as<double>(), sig);
     HIPCHK(hipGetLastError());
     return CS_OK;
 }
 
-// enqueue one evaluation; when ev != NULL an event is recorded between the kernel classes (ev must hold 4*ngas+4)
+// enqueue one evaluation; when ev != NULL an event is recorded between the kernel classes (ev must hold 7 * (launch groups) + 4)
 static int run_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev)
 {
     Column &c = ctx->col;
     double *sig = c.sigma.as<double>();
     int e = 0, rc;
+    for (auto &ug : c.ugas)   // (a table re-uploaded into a slot of the resident column: its windows are stale)
+        if (!ctx->gas[ug.slot].present || ctx->gas[ug.slot].generation != ug.generation) {
+            c.ready = false;
+            return fail(CS_ESTATE, "gas slot %d was re-uploaded or cleared after cs_column_setup", ug.slot);
+        }
+    g_nlaunch = 0;
     if (ev) HIPCHK(hipEventRecord(ev[e++], s));
     if ((rc = sigma_impl(ctx, s, ev, e))) return rc;
     if (ev) HIPCHK(hipEventRecord(ev[e++], s));
@@ -1915,9 +2081,10 @@ static int run_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev)
               c.has_S ? c.S_toa.as<double>() : nullptr, c.has_alb ? c.albedo.as<double>() : nullptr, c.want_tau ? c.tau.as<double>() : nullptr,
               c.want_M ? c.Mup.as<double>() : nullptr, c.want_M ? c.Mdn.as<double>() : nullptr, c.partial.as<double>());
     if (ev) HIPCHK(hipEventRecord(ev[e++], s));
-    hipLaunchKernelGGL(k_freduce, dim3(2 * c.np), dim3(256), 0, s, c.partial.as<double>(), c.rtg.nblk, 2 * c.np,
+    CS_LAUNCH(k_freduce, dim3(2 * c.np), dim3(256), 0, s, c.partial.as<double>(), c.rtg.nblk, 2 * c.np,
                        c.F.as<double>());
     if (ev) HIPCHK(hipEventRecord(ev[e++], s));
+    c.launches = g_nlaunch;
     HIPCHK(hipGetLastError());
     return CS_OK;
 }
@@ -1942,7 +2109,8 @@ int cs_column_profile(cs_ctx *ctx, void *stream, int reps, double *ms)
     Column &c = ctx->col;
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     HIPCHK(hipSetDevice(ctx->device));
-    const int nev = 7 * c.ngas + 4;
+    const int ngrp = (int)c.gas.size();
+    const int nev = 7 * ngrp + 4;
     std::vector<hipEvent_t> ev(nev);
     for (auto &e : ev) HIPCHK(hipEventCreate(&e));
     for (int i = 0; i < 10; i++) ms[i] = 0.0;
@@ -1953,9 +2121,9 @@ int cs_column_profile(cs_ctx *ctx, void *stream, int reps, double *ms)
         if (hipStreamSynchronize(s) != hipSuccess) { rc = fail(CS_EHIP, "hipStreamSynchronize failed"); break; }
         float t;
         const int slot[7] = {0, 1, 7, 3, 9, 8, 4};   // per gas: K1 + zones, nodes, nodes on the matrix cores, far, sub-tile cores, far on the matrix cores, near
-        for (int gi = 0; gi < c.ngas; gi++)
+        for (int gi = 0; gi < ngrp; gi++)
             for (int q = 0; q < 7; q++) { (void)hipEventElapsedTime(&t, ev[7 * gi + q], ev[7 * gi + q + 1]); ms[slot[q]] += t; }
-        const int b = 7 * c.ngas;
+        const int b = 7 * ngrp;
         (void)hipEventElapsedTime(&t, ev[b], ev[b + 1]); ms[2] += t;       // apply (+ baked tables, CIA)
         (void)hipEventElapsedTime(&t, ev[b + 1], ev[b + 2]); ms[5] += t;   // rt
         (void)hipEventElapsedTime(&t, ev[b + 2], ev[b + 3]); ms[6] += t;   // reduce
@@ -1994,7 +2162,7 @@ static int fetch_transposed(cs_ctx *ctx, const double *dsrc, int R, int64_t Cn, 
     hipStream_t s = ctx->stream;
     HIPCHK(c.stage.reserve((size_t)R * Cn * sizeof(double)));
     dim3 grid((unsigned)((Cn + 31) / 32), (unsigned)((R + 31) / 32));
-    hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, s, dsrc, R, Cn, c.stage.as<double>());
+    CS_LAUNCH(k_transpose, grid, dim3(256), 0, s, dsrc, R, Cn, c.stage.as<double>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(hdst, c.stage.p, (size_t)R * Cn * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -2039,13 +2207,25 @@ int cs_column_counts(cs_ctx *ctx, int64_t *pair_evals, int64_t *lines_in_range)
     if (!ctx || !ctx->col.ready) return fail(CS_ESTATE, "no resident column");
     Column &c = ctx->col;
     int64_t p = 0, l = 0;
-    for (auto &g : c.gas) {
+    for (auto &g : c.ugas) {
         if (g.pairs_per_state < 0) g.pairs_per_state = count_pairs(ctx->gas[g.slot].h_nu, c.h_nu.data(), c.nnu, g.cut);
         p += g.pairs_per_state * c.K;
         l += g.lines_in_range;
     }
     if (pair_evals) *pair_evals = p;
     if (lines_in_range) *lines_in_range = l;
+    return CS_OK;
+}
+
+int cs_column_info(cs_ctx *ctx, int64_t *out)
+{
+    if (!ctx || !ctx->col.ready || !out) return fail(CS_ESTATE, "no resident column");
+    const Column &c = ctx->col;
+    for (int i = 0; i < 8; i++) out[i] = 0;
+    out[0] = (int64_t)c.gas.size();
+    out[1] = c.launches;
+    for (auto &g : c.gas) { out[2] += g.tab->L; out[4] = std::max<int64_t>(out[4], (int64_t)g.mem.size()); }
+    out[3] = c.merge;
     return CS_OK;
 }
 
@@ -2142,7 +2322,7 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
                         ncore++;
                         edgen += 64 * (int64_t)(e.cR - e.cL);
                         if (e.far3 & 4) mx8 += 64 * (int64_t)(e.cR - e.cL);
-                        const double *nl = ctx->gas[g.slot].h_nu.data();
+                        const double *nl = g.tab->h_nu.data();
                         for (int q4 = 0; q4 < 64 / CS_SUBW; q4++) {   // (k_voigt_sub<CS_SUBW>)
                             const double v0 = c.h_nu[(size_t)t * 64 + CS_SUBW * q4] - e.R, v1 = c.h_nu[(size_t)t * 64 + CS_SUBW * q4 + CS_SUBW - 1] + e.R;
                             const int ja = (int)(std::lower_bound(nl + e.cL, nl + e.cR, v0) - nl);
@@ -2206,8 +2386,9 @@ static bool column_matches(cs_ctx *ctx, int64_t nnu, const double *nu, int np, c
     if (c.nnu != nnu || c.np != np || c.nlob != nlobatto || c.nstream != nstream || c.ngas != ngas) return false;
     if (c.g != g || c.sigma_gray != sigma_gray || c.theta_s != theta_s) return false;
     if (c.want_tau != want_tau || c.want_M != want_M) return false;
+    if (c.merge != ctx->merge) return false;
     for (int gi = 0; gi < ngas; gi++) {
-        const ColGas &cg = c.gas[gi];
+        const UserGas &cg = c.ugas[gi];
         if (cg.slot != gas_slots[gi] || cg.shape != (shapes ? shapes[gi] : CS_SHAPE_VOIGT) || cg.cut != (dnu_cuts ? dnu_cuts[gi] : 25.0)) return false;
         if (gas_slots[gi] < 0 || gas_slots[gi] >= CS_MAX_GAS || !ctx->gas[cg.slot].present || ctx->gas[cg.slot].generation != cg.generation) return false;
     }
@@ -2453,7 +2634,7 @@ int cs_faddeeva_batch(cs_ctx *ctx, int64_t n, const double *x, const double *y, 
     int rc;
     if ((rc = upload(ctx->tmpA, x, n, s)) || (rc = upload(ctx->tmpB, y, n, s))) return rc;
     HIPCHK(ctx->tmpC.reserve(n * sizeof(double)));
-    hipLaunchKernelGGL(k_faddeeva, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, ctx->tmpA.as<double>(),
+    CS_LAUNCH(k_faddeeva, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, ctx->tmpA.as<double>(),
                        ctx->tmpB.as<double>(), ctx->tmpC.as<double>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, ctx->tmpC.p, n * sizeof(double), hipMemcpyDeviceToHost, s));

@@ -50,6 +50,8 @@ struct GasDev {
     const int16_t *iso;
     const int32_t *ncheb;
     const double *cheb;  // [niso][16]
+    const uint8_t *gid;  // merged table of several gases of a column: member index of each line (NULL: one gas) -- selects the
+                         // member's partial pressure and concentration in k_gas_setup; everything else of a record is per line
 };
 
 // line_shapes.jl:27-48
@@ -73,7 +75,8 @@ struct PrepArgs {
     int shape, K;
     GasDev g;
     int64_t jlo, jhi;
-    const double *Tk, *Pk, *Ppk, *scale;
+    const double *Tk, *Pk, *Ppk, *scale;   // Ppk, scale: [members][mstride], element (m, k) at m * mstride + k
+    int mstride;
     LineHot *hot;
     LineCold *cold;
     LineF32 *hot32;
@@ -95,7 +98,8 @@ __device__ __forceinline__ void prep_body(unsigned bid, const PrepArgs &pa)
     int k = (int)(idx / nj);
     int64_t j = jlo + (idx - (int64_t)k * nj);
     idx = (int64_t)k * g.L + j;   // records are addressed by the line's index in the full table
-    double T = Tk[k], P = Pk[k], Pp = Ppk[k], C = scale ? scale[k] : 1.0;
+    const size_t mk = (g.gid ? (size_t)g.gid[j] * pa.mstride : 0) + k;
+    double T = Tk[k], P = Pk[k], Pp = Ppk[mk], C = scale ? scale[mk] : 1.0;
     double nul = g.nu[j];
     // scaleintensity, line_shapes.jl:107-123
     double a = -kC2 * g.Epp[j];

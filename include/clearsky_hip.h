@@ -98,6 +98,13 @@ int cs_set_interp_plan(cs_ctx *ctx, int first_level, int size_min, int size_max)
  * Same results to rounding (tests/test_gpu_interp.py). */
 int cs_set_matrix_cores(cs_ctx *ctx, int on);
 
+/* One launch set per column (on by default): the Voigt (Lorentz) gases of a column that share a cut-off are merged into one sorted
+ * line table when the column is set up -- sigma_total = sum_g C_g sigma_g (absorbers.jl:84-95), and a per-(state, line) record
+ * carries its gas's concentration and partial pressure, so the kernels run once per column instead of once per gas, on windows as
+ * dense as all the column's lines together.  on = 0: one launch set per gas.  Same results to rounding (the order of the sum over
+ * lines changes).  Applies to every later cs_column_setup / cs_fluxes_discretized of the context. */
+int cs_set_merge(cs_ctx *ctx, int on);
+
 /*
  * B1: batched in-place line shape.  For every state k:  sigma[k*ld_state + i] = shape(nu[i]; T[k], P[k], Pp[k]).
  * Replaces: shape!(sigma, nu, sl, T, P, Pp, dnu_cut) -- voigt!/lorentz!/doppler!/PHCO2!, line_shapes.jl:412-424,
@@ -209,6 +216,9 @@ int cs_column_flux_to(cs_ctx *ctx, double *dst_device, void *stream);
 int cs_column_fetch(cs_ctx *ctx, int64_t nnu, int np, double *tau, double *Mup, double *Mdn, double *Fup, double *Fdn);
 int cs_column_sigma_fetch(cs_ctx *ctx, int64_t nnu, int K, double *sigma);
 int cs_column_counts(cs_ctx *ctx, int64_t *pair_evals, int64_t *lines_in_range);
+/* measurement hook, out[8]: out[0] = launch groups of the resident column (merged gases count once), out[1] = kernel launches of
+ * the last cs_column_run, out[2] = lines of all groups, out[3] = cs_set_merge at setup time, out[4] = gases in the largest group */
+int cs_column_info(cs_ctx *ctx, int64_t *out);
 /* line-shape evaluations the last cs_column_run actually issued for its Voigt gases (measurement hook): out[0] = per-point
  * evaluations of k_voigt_far/k_voigt_near (64 lanes x lines per wave), out[1] = node evaluations of k_cheb_nodes,
  * out[2] = interpolation levels in use, out[3] = intervals over all levels; out[4..9] = the per-point evaluations by loop body
