@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--no-matrix-nodes", action="store_true", help="tuning: no far-line sums on the matrix cores (same as --matrix-cores 0)")
     ap.add_argument("--matrix-cores", type=int, default=1, help="tuning: far-line sums on the matrix cores: 1 where the grid is long enough (default), 2 always, 0 never")
     ap.add_argument("--no-merge", action="store_true", help="tuning: one launch set per gas instead of one merged line table per column")
+    ap.add_argument("--tune", default="", help="tuning switches k=v[,k=v...] (cs_set_tuning)")
     ap.add_argument("--far-s", type=float, default=1e6, help="mixed precision: x^2 threshold of the fp32 region")
     ap.add_argument("--emulate-shard", default=None, help="R/N: time only shard R of an N-way split on this one GPU (rehearsal)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL, default) | gloo (rehearsal of N>1 on fewer GPUs)")
@@ -113,6 +114,8 @@ def main():
     ctx.set_interp_plan(first_level=args.interp_first_level)
     ctx.set_matrix_cores(0 if args.no_matrix_nodes else args.matrix_cores)
     ctx.set_merge(not args.no_merge)
+    for kv in filter(None, args.tune.split(",")):
+        ctx.set_tuning(*map(int, kv.split("=")))
     t_setup = time.perf_counter()
     col = cs.Column(cfg["P"], cfg["g"], cfg["T"], cfg["mu"], cfg["fS"], cfg["fa"], *cfg["absorbers"], core=cfg["core"],
                     theta_s=cfg["theta_s"], want_tau=True, want_M=True, nu_range=ranges[rank], ctx=ctx)

@@ -9,7 +9,7 @@ from ._lib import ClearSkyHIPError, build_native, lib, check, dptr, as_f64, SHAP
 from .hitran import MOLPARAM, TMIN, TMAX, ISOINDEX, MolParam, SpectralLines, readpar
 from .cia import CIATables, cia, readcia
 from .core import (interp_plan, CIA, AcceleratedAbsorber, Sigma, update_, checkpressures, pressurelimits, temperaturelimits, shape_points, AtmosphericDomain, AtmosphericProfile, Column, Gas, reconcentrate, Context, DirectGas, Discretized, FluxPack, GrayGas, UnifiedAbsorber,
-                   PHCO2, PHCO2_, chebygrid, default_context, doppler, doppler_, dtaudP, faddeeva, fluxes, formprofile,
+                   PHCO2, PHCO2_, chebygrid, default_context, doppler, doppler_, dtaudP, faddeeva, device_function, fluxes, formprofile,
                    lobattoevaluations, lobattonodes, logrange, lorentz, lorentz_, monochromaticfluxes,
                    monochromaticfluxes_, netfluxes, nodepressures, nodevalues, opticaldepth, ozonelayer, planck,
                    pressuregrid, psatH2O, radiate, radiate_, shape_batch, stefanboltzmann, streamnodes, transmittance,

@@ -38,6 +38,7 @@ SIGNATURES = {
     "cs_set_interp_plan": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int]),
     "cs_set_matrix_cores": (C.c_int, [_vp, C.c_int]),
     "cs_set_merge": (C.c_int, [_vp, C.c_int]),
+    "cs_set_tuning": (C.c_int, [_vp, C.c_int, C.c_int]),
     "cs_column_info": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
     "cs_shape_batch": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_int64, _dp, C.c_int, _dp, _dp, _dp, _dp,
                                  C.c_int64]),
@@ -80,6 +81,7 @@ SIGNATURES = {
     "cs_streamnodes": (C.c_int, [C.c_int, _dp, _dp]),
     "cs_lobattonodes": (C.c_int, [C.c_int, _dp, _dp]),
     "cs_faddeeva_batch": (C.c_int, [_vp, C.c_int64, _dp, _dp, _dp]),
+    "cs_devfn_batch": (C.c_int, [_vp, C.c_int, C.c_int64, _dp, _dp, _dp, _dp]),
 }
 
 

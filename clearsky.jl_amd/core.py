@@ -256,6 +256,11 @@ class Context:
         launch set per gas."""
         check(lib().cs_set_merge(self._h, int(bool(on))))
 
+    def set_tuning(self, key: int, value: int):
+        """A/B switches (cs_set_tuning): 0 = XCD-contiguous block order of the node kernels, 1 = interpolated wings applied inside
+        k_voigt_edge_mx"""
+        check(lib().cs_set_tuning(self._h, int(key), int(value)))
+
     def slot_of(self, sl: SpectralLines) -> int:
         """Upload `sl` (once) and return its gas slot."""
         key = id(sl)
@@ -417,6 +422,18 @@ def faddeeva(x, y, ctx: Optional[Context] = None):
     y = as_f64(np.atleast_1d(y))
     out = np.zeros_like(x)
     check(lib().cs_faddeeva_batch(ctx.handle, len(x), dptr(x), dptr(y), dptr(out)))
+    return out
+
+
+def device_function(which: str, x, y=None, z=None, ctx: Optional[Context] = None):
+    """The flux kernel's device functions point by point (test hook, cs_devfn_batch): "exp" (its own exp), "planck" (x = nu,
+    y = T; radiation.jl:48-54), "layerplanck" (x = B1, y = B2, z = tau; discretized.jl:85-87)."""
+    ctx = ctx or default_context()
+    x = as_f64(np.atleast_1d(x))
+    y = None if y is None else as_f64(np.broadcast_to(y, x.shape))
+    z = None if z is None else as_f64(np.broadcast_to(z, x.shape))
+    out = np.zeros_like(x)
+    check(lib().cs_devfn_batch(ctx.handle, {"exp": 0, "planck": 1, "layerplanck": 2}[which], len(x), dptr(x), dptr(y), dptr(z), dptr(out)))
     return out
 
 
@@ -674,12 +691,18 @@ class AcceleratedAbsorber:
     linearly in ln P.  The knots' cross-sections Sigma(U, i, T_k, P_k) are evaluated by the line kernels for every wavenumber and
     knot at once and stay in HBM (cs_accel_store); `update_(A, T)` = update!(A, T) (:173-200) re-evaluates them."""
 
-    def __init__(self, T, P, *absorbers, ctx: Optional[Context] = None):
-        if len(absorbers) == 1 and isinstance(absorbers[0], AcceleratedAbsorber):   # absorbers.jl:161-164
+    def __new__(cls, T=None, P=None, *absorbers, ctx: Optional[Context] = None):
+        # AcceleratedAbsorber(T, P, A::AcceleratedAbsorber) hands A itself back (absorbers.jl:161-164): the SAME object, so that the
+        # device slot has exactly one owner
+        if len(absorbers) == 1 and isinstance(absorbers[0], AcceleratedAbsorber):
             A = absorbers[0]
             assert np.all(np.asarray(P, float)[np.argsort(P)] == A.P), \
                 "cannot change AcceleratedAbsorber's pressure coordinates after construction"
-            self.__dict__ = A.__dict__
+            return A
+        return super().__new__(cls)
+
+    def __init__(self, T, P, *absorbers, ctx: Optional[Context] = None):
+        if len(absorbers) == 1 and absorbers[0] is self:   # the alias form: __new__ returned the existing object, nothing to build
             return
         self.ctx = ctx or default_context()
         U = absorbers[0] if (len(absorbers) == 1 and isinstance(absorbers[0], UnifiedAbsorber)) else UnifiedAbsorber(*absorbers)
@@ -702,6 +725,9 @@ class AcceleratedAbsorber:
     def __del__(self):
         try:
             if getattr(self.ctx, "_h", None) and self.ctx._h.value and hasattr(self, "slot"):
+                res = getattr(self.ctx, "_resident", None)
+                if res is not None and getattr(res, "accel", None) is self:
+                    self.ctx._resident = None      # (cs_accel_clear drops a resident column that reads this slot)
                 lib().cs_accel_clear(self.ctx._h, self.slot)
                 self.ctx._accel_used.discard(self.slot)
         except Exception:
@@ -1091,12 +1117,14 @@ class Column:
     def work(self):
         """Evaluations the last run issued for its Voigt gases: per-point, at interpolation nodes; levels in use."""
         self._require_resident("work")
-        out = (C.c_int64 * 20)()
+        out = (C.c_int64 * 32)()
         check(lib().cs_column_work(self.ctx.handle, out))
         return dict(direct_evals=out[0], node_evals=out[1], levels=out[2], intervals=out[3],
                     direct_by_body=dict(zip(("t2", "t2_cut", "t3", "t3_cut", "t4_cut", "near_zone"), [out[4 + q] for q in range(6)])),
                     node_by_body=dict(zip(("t2", "t3", "t4"), [out[10 + q] for q in range(3)])), node_evals_matrix=out[13],
-                    direct_evals_matrix=out[14], matrix_evals_3term=out[15], sub_evals=out[16], core_tile_states=out[17], matrix_evals_8term=out[18], node_evals_matrix_3term=out[19])
+                    direct_evals_matrix=out[14], matrix_evals_3term=out[15], sub_evals=out[16], core_tile_states=out[17], matrix_evals_8term=out[18], node_evals_matrix_3term=out[19],
+                    near_pairs_tier0=out[20], near_pairs_tier1=out[21], edge_mx_flops_useful=out[22], edge_mx_flops_issued=out[23],
+                    nodes_mx_flops_useful=out[24], nodes_mx_flops_issued=out[25], apply_flops=out[26])
 
     def fetch(self, tau=None, Mup=None, Mdn=None):
         """Copy results to host.  Returns (Fup, Fdn); fills the optional Fortran-order matrices in place."""

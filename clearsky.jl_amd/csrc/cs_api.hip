@@ -160,7 +160,7 @@ struct ChebGrid {
     DevBuf Cm[CS_MAX_LEVEL];    // [nI][64][itv]
 };
 // per gas on that grid: windows per level, zones [K][nItot], node sums F [nItot][64][Kpad]
-struct GasInterp { int nlev = 0, l0 = 0; DevBuf iwin[CS_MAX_LEVEL], iz, F, sep, edge; };   // levels l0 .. nlev-1 of the grid are in use; sep: SepZone [K/16][nItot]
+struct GasInterp { int nlev = 0, l0 = 0; DevBuf iwin[CS_MAX_LEVEL], iz, F, sep, edge; XMap xm = {}; };   // levels l0 .. nlev-1 of the grid are in use; sep: SepZone [K/16][nItot]
                                                                                           // (matrix-core node sums), edge: EdgeZone [K/16][tiles] (matrix-core pieces of the per-point sum)
 
 // a gas of the column as the caller named it (conc is laid out [ngas, K] over these)
@@ -217,6 +217,7 @@ struct Column {
 }  // namespace
 
 // workspace of the PHCO2 fast path (k_phco2): per-(state, line) chi factors and per-tile region windows
+constexpr int CS_NTUNE = 8;
 struct PhScratch { DevBuf fac, win; double nu_lo = 0.0, nu_hi = 0.0, nu_c = 0.0; };   // nu_lo/nu_hi: ends of the grid, set by the caller
 
 struct cs_ctx {
@@ -234,6 +235,8 @@ struct cs_ctx {
     int matrix_nodes = 1;   // cs_set_matrix_cores: separable far-wing node sums on v_mfma_f64 (k_cheb_nodes_mx)
     int matrix_core = 1;    // ... and the window core on sub-tiles (k_voigt_sub + the second mask of k_voigt_edge_mx)
     int merge = 1;          // cs_set_merge: gases of a column with the same shape and cut-off share one merged line table
+    int tune[CS_NTUNE] = {1, 1, 0, 0, 0, 0, 0, 0};   // cs_set_tuning: [0] XCD-contiguous block order of the node kernels, [1] interpolated wings
+                                                     // applied inside k_voigt_edge_mx where one launch group has them
     std::vector<std::unique_ptr<GasTable>> merged;   // merged tables (keyed by their members' (slot, generation)), a few kept
     double far_s = 1e6;
     DevBuf hot32;
@@ -513,6 +516,9 @@ struct Interp {
     EdgeZone *edge = nullptr; // NULL: all of the per-point sum on the vector unit
     bool sep_always = false;  // cs_set_matrix_cores(ctx, 2): also on grids too short to fill the chip with (interval, state group) blocks
     bool core = true;         // cs_set_matrix_cores(ctx, on | 4) switches the sub-tile treatment of the window core (k_voigt_sub) off
+    XMap xm = {};             // block order of the node kernels (xm.on = 0: interval-major)
+    bool small_mx = false;    // cs_set_tuning key 2: the matrix-core kernels on short grids too (their four-waves-per-item variants)
+    bool fuse_apply = false;  // the column's only interpolating group: k_voigt_edge_mx may carry the node sums to the grid itself
     double core4 = 0.0;       // the core takes the 4-term series where its radius is below core4 x the tile's span, else the 8-term one
                               // (0: always the 8-term one -- measured at C3 with 0.75 / 0.3 / 0: 2.61 / 2.55 / 2.52 ms)
 };
@@ -592,11 +598,29 @@ int gas_interp_build(const cs_ctx *ctx, GasInterp &gi, ChebGrid &g, const std::v
         if (ctx->itp_first >= 0) gi.l0 = std::min(ctx->itp_first, g.nlev);
         if (gi.l0 >= g.nlev) { gi.nlev = 0; gi.l0 = 0; return CS_OK; }   // too few lines: every pair directly
     }
+    memset(&gi.xm, 0, sizeof gi.xm);
+    gi.xm.on = ctx->tune[0] ? 1 : 0;
+    gi.xm.l0 = gi.l0;
+    gi.xm.nlev = g.nlev;
     for (int l = 0; l < g.nlev; l++) {
         std::vector<WaveWin> iwin;
         wave_windows(nul, g0, g1, nu, nnu, cut, iwin, g.itv[l]);
         if ((rc = upload(gi.iwin[l], iwin.data(), iwin.size(), s))) return rc;
         HIPCHK(hipStreamSynchronize(s));   // iwin is a local
+        // one contiguous stretch of the level's intervals per XCD, cut at equal sums of (lines inside every point's cut-off + 8)
+        const int nI = g.nI[l];
+        std::vector<int64_t> cum(nI + 1, 0);
+        for (int T = 0; T < nI; T++) cum[T + 1] = cum[T] + (iwin[T].E1 - iwin[T].E0) + 8;
+        gi.xm.ioff[l] = g.ioff[l];
+        gi.xm.cnt[l] = 0;
+        for (int x = 0; x <= 8; x++) {
+            const int64_t target = cum[nI] * x / 8;
+            gi.xm.xb[l][x] = x == 8 ? nI : (int)(std::lower_bound(cum.begin(), cum.end(), target) - cum.begin());
+            if (x > 0) {
+                gi.xm.xb[l][x] = std::max(gi.xm.xb[l][x], gi.xm.xb[l][x - 1]);
+                gi.xm.cnt[l] = std::max(gi.xm.cnt[l], gi.xm.xb[l][x] - gi.xm.xb[l][x - 1]);
+            }
+        }
     }
     HIPCHK(gi.iz.reserve((size_t)K * g.nItot * sizeof(IZone)));
     HIPCHK(gi.sep.reserve((size_t)((K + 15) / 16) * g.nItot * sizeof(SepZone)));
@@ -620,6 +644,7 @@ Interp interp_view(const ChebGrid &g, const GasInterp &gi, int K, IZone *iz_over
     v.F = gi.F.as<double>();
     v.sep = gi.sep.as<SepZone>();
     v.edge = gi.edge.as<EdgeZone>();
+    v.xm = gi.xm;
     for (int l = 0; l < gi.nlev; l++) {
         v.itv[l] = g.itv[l]; v.nI[l] = g.nI[l]; v.ioff[l] = g.ioff[l];
         v.Cm[l] = g.Cm[l].as<double>();
@@ -683,16 +708,19 @@ constexpr int CS_EDGE_DENS = 4;
 // matrix-core node sums (k_cheb_nodes_mx): fp64 Voigt only, and by default only where there are enough (interval, state group)
 // blocks to fill the chip -- on a short grid (a nu-shard) the one-state-per-wave vector kernel has the shorter critical path
 // (1/8 of C3: 0.17 vs 0.25 ms)
-static bool sep_in_use(bool have_sep, bool always, int nblocks_intervals, int kn, bool lor, bool mixed, int min_blocks = 2048)
+static bool mx_big(int nblocks, int kn, int min_blocks) { return (int64_t)nblocks * ((kn + 15) / 16) >= min_blocks; }
+// `small`: cs_set_tuning key 2 -- short grids too, through the variants that share one (interval | tile, group) between the four
+// waves of a block (k_cheb_nodes_mx with every level split, k_voigt_edge_mx<4>)
+static bool sep_in_use(bool have_sep, bool always, int nblocks_intervals, int kn, bool lor, bool mixed, bool small = false)
 {
-    return have_sep && !lor && !mixed && (always || (int64_t)nblocks_intervals * ((kn + 15) / 16) >= min_blocks);
+    return have_sep && !lor && !mixed && (always || small || mx_big(nblocks_intervals, kn, 2048));
 }
 // the per-point pieces (k_voigt_edge_mx: one wave per (tile, state group), no reduction) pay on shorter grids -- 1/4 of C3 (1564
 // waves): far 0.42 -> 0.36 ms; 1/8: 0.261 -> 0.244 ms, which the extra zone launch eats -- but only on tables dense enough to give
 // a wave more than a few steps (C5's HITRAN fixtures: far 3.94 -> 4.01 ms with them; its synthetic O3 table: step 10.63 -> 10.51)
-static bool edge_in_use(bool have_edge, bool always, int ntiles, int kn, bool lor, bool mixed, int64_t lines_in_range)
+static bool edge_in_use(bool have_edge, bool always, int ntiles, int kn, bool lor, bool mixed, int64_t lines_in_range, bool small = false)
 {
-    return sep_in_use(have_edge, always, ntiles, kn, lor, mixed, 1024) && (always || lines_in_range >= (int64_t)ntiles * CS_EDGE_DENS);
+    return have_edge && !lor && !mixed && (always || ((small || mx_big(ntiles, kn, 1024)) && lines_in_range >= (int64_t)ntiles * CS_EDGE_DENS));
 }
 
 // K1 + K2 for one gas on `s`: parameters for `kn` states, then the line sum into sigma ([kn][nnu])
@@ -726,6 +754,9 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
         const IZone *iz = nullptr;
         int ishift = 0;
         bool use_edge = false;   // window ends of the per-point sum on the matrix cores (k_voigt_edge_mx; with the far wings interpolated only)
+        bool fuse = false;       // ... which then also applies the interpolated wings (no k_cheb_apply launch for this group)
+        ChebApply Afuse;
+        memset(&Afuse, 0, sizeof Afuse);
         if (itp.nlev > 0) {
             P.nlev = itp.nlev;
             P.nItot = itp.nItot;
@@ -739,10 +770,12 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
             const int q0 = itp.ioff[itp.l0];
             // deferred apply: the gases of a column add their node sums into ONE F (levels an earlier gas has written accumulate)
             const int q_acc = (defer && defer->ngas > 0 && defer->l0[0] < itp.nlev) ? itp.ioff[defer->l0[0]] : itp.nItot;
-            const dim3 gridn((unsigned)((kn + 3) / 4) * (unsigned)(itp.nItot - q0));
+            int xcnt = 0;   // XCD-contiguous block order: intervals per XCD, summed over the levels in use
+            for (int l = itp.l0; l < itp.nlev; l++) xcnt += itp.xm.cnt[l];
+            const dim3 gridn(itp.xm.on ? (unsigned)((kn + 3) / 4) * 8u * (unsigned)xcnt : (unsigned)((kn + 3) / 4) * (unsigned)(itp.nItot - q0));
             const int ngrp = (kn + 15) / 16;
-            const bool use_sep = sep_in_use(itp.sep != nullptr, itp.sep_always, itp.nItot - q0, kn, lor, hot32 != nullptr);
-            use_edge = edge_in_use(itp.edge != nullptr, itp.sep_always, nt64, kn, lor, hot32 != nullptr, jhi - jlo);
+            const bool use_sep = sep_in_use(itp.sep != nullptr, itp.sep_always, itp.nItot - q0, kn, lor, hot32 != nullptr, itp.small_mx);
+            use_edge = edge_in_use(itp.edge != nullptr, itp.sep_always, nt64, kn, lor, hot32 != nullptr, jhi - jlo, itp.small_mx);
             if (use_sep || use_edge) {   // what the matrix cores take of the interpolated sets and of the window ends (needs the zones of k_gas_setup)
                 SepArgs sa;
                 sa.nodes = itp.nodes; sa.nul = G.nu.as<double>(); sa.gbound = gbound; sa.Tk = Tk; sa.iz = itp.iz; sa.out = itp.sep;
@@ -763,20 +796,26 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
             const SepZone *sepz = use_sep ? itp.sep : nullptr;
             if (lor)
                 CS_LAUNCH((k_cheb_nodes<false, true>), gridn, dim3(256), 0, s, itp.nodes, G.L, hot, hot32, G.nu.as<double>(), itp.iz,
-                                   itp.nItot, q0, q_acc, kn, itp.Kpad, cut, itp.F, sepz);
+                                   itp.nItot, q0, q_acc, kn, itp.Kpad, cut, itp.F, sepz, itp.xm);
             else if (hot32)
                 CS_LAUNCH((k_cheb_nodes<true, false>), gridn, dim3(256), 0, s, itp.nodes, G.L, hot, hot32, G.nu.as<double>(), itp.iz,
-                                   itp.nItot, q0, q_acc, kn, itp.Kpad, cut, itp.F, sepz);
+                                   itp.nItot, q0, q_acc, kn, itp.Kpad, cut, itp.F, sepz, itp.xm);
             else
                 CS_LAUNCH((k_cheb_nodes<false, false>), gridn, dim3(256), 0, s, itp.nodes, G.L, hot, hot32, G.nu.as<double>(), itp.iz,
-                                   itp.nItot, q0, q_acc, kn, itp.Kpad, cut, itp.F, sepz);
+                                   itp.nItot, q0, q_acc, kn, itp.Kpad, cut, itp.F, sepz, itp.xm);
             if (evg) (void)hipEventRecord(evg[1], s);
             if (use_sep) {
                 const int nq = itp.nItot - q0;
-                const int nsplit = itp.nlev - itp.l0 > 1 ? itp.nI[itp.l0] : nq;   // the largest interval size in use (all of them if it is the only one)
-                const unsigned nblk_mx = (unsigned)(nsplit * ngrp) + (unsigned)(((int64_t)(nq - nsplit) * ngrp + 3) / 4);
+                // the largest interval size in use is shared by the four waves of a block (all sizes if it is the only one, or on a grid
+                // too short to fill the chip with one (interval, group) per wave)
+                const int nsplit = (itp.nlev - itp.l0 > 1 && mx_big(nq, kn, 2048)) ? itp.nI[itp.l0] : nq;
+                unsigned nblk_mx = (unsigned)(nsplit * ngrp) + (unsigned)(((int64_t)(nq - nsplit) * ngrp + 3) / 4);
+                if (itp.xm.on) {
+                    const int c0 = nsplit == nq ? xcnt : itp.xm.cnt[itp.l0];
+                    nblk_mx = 8u * (unsigned)(c0 * ngrp) + 8u * (unsigned)(((int64_t)(xcnt - c0) * ngrp + 3) / 4);
+                }
                 CS_LAUNCH(k_cheb_nodes_mx, dim3(nblk_mx), dim3(256), 0, s, itp.nodes, G.L, hot, itp.sep, itp.nItot, q0, nsplit, kn,
-                                   itp.Kpad, ngrp, itp.F);
+                                   itp.Kpad, ngrp, itp.F, itp.xm);
             }
             if (evg) (void)hipEventRecord(evg[2], s);
             ChebApply A0;
@@ -789,7 +828,13 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
                 A.ioff[l] = itp.ioff[l];
                 A.Cm[l] = itp.Cm[l];
             }
-            if (defer && A.ngas > 0) {
+            fuse = defer && itp.fuse_apply && use_edge && defer->ngas == 0;   // (then k_voigt_edge_mx below carries this group's node sums to the grid)
+            if (fuse) {
+                Afuse = A;
+                Afuse.ngas = 1;
+                Afuse.l0[0] = itp.l0;
+                Afuse.F[0] = itp.F;
+            } else if (defer && A.ngas > 0) {
                 A.l0[0] = std::min(A.l0[0], itp.l0);   // same F: the sum over the gases so far
             } else {
                 A.l0[A.ngas] = itp.l0;
@@ -839,8 +884,14 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
                                itp.edge, nt64, kn, cut, sigma, reinterpret_cast<unsigned *>(ranges));
         if (evg) (void)hipEventRecord(evg[4], s);
         if (use_edge)
-            CS_LAUNCH(k_voigt_edge_mx, dim3((unsigned)((nt64 + 3) / 4), (unsigned)((kn + 15) / 16)), dim3(256), 0, s, dnu, nnu, G.L, hot, win,
-                               itp.edge, nt64, kn, cut, sigma);
+        {
+            if (mx_big(nt64, kn, 1024))
+                CS_LAUNCH(k_voigt_edge_mx<1>, dim3((unsigned)((nt64 + 3) / 4), (unsigned)((kn + 15) / 16)), dim3(256), 0, s, dnu, nnu, G.L, hot, win,
+                          itp.edge, nt64, kn, cut, sigma, fuse ? 1 : 0, Afuse, itp.Kpad);
+            else   // short grid: four waves per (tile, group)
+                CS_LAUNCH(k_voigt_edge_mx<4>, dim3((unsigned)nt64, (unsigned)((kn + 15) / 16)), dim3(256), 0, s, dnu, nnu, G.L, hot, win,
+                          itp.edge, nt64, kn, cut, sigma, fuse ? 1 : 0, Afuse, itp.Kpad);
+        }
         if (evg) (void)hipEventRecord(evg[5], s);
         if (!lor) {
             const int ngrp = (nt64 + CS_NEAR_R - 1) / CS_NEAR_R;   // near kernels: one wave = CS_NEAR_R consecutive tiles ...
@@ -1098,6 +1149,19 @@ int cs_set_merge(cs_ctx *ctx, int on)
     return CS_OK;
 }
 
+static int interp_key(const cs_ctx *ctx)
+{
+    return (ctx->tune[0] ? 65536 : 0) + ctx->interp * 4096 + (ctx->itp_first + 1) * 256 + (ctx->itp_min >> 7) * 16 + (ctx->itp_max >> 7);
+}
+
+int cs_set_tuning(cs_ctx *ctx, int key, int value)
+{
+    if (!ctx) return fail(CS_EINVAL, "ctx is NULL");
+    if (key < 0 || key >= CS_NTUNE) return fail(CS_EINVAL, "tuning key %d out of range", key);
+    ctx->tune[key] = value;
+    return CS_OK;
+}
+
 int cs_gas_clear(cs_ctx *ctx, int slot)
 {
     if (!ctx || slot < 0 || slot >= CS_MAX_GAS) return fail(CS_EINVAL, "bad slot");
@@ -1177,6 +1241,7 @@ static int shape_impl(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t 
         itp = interp_view(cheb, ginterp, kc);
         if (!ctx->matrix_nodes) itp.sep = nullptr, itp.edge = nullptr;
         itp.sep_always = ctx->matrix_nodes == 2;
+        itp.small_mx = ctx->tune[2] != 0;
         itp.core = ctx->matrix_core != 0;
     }
     for (int k0 = 0; k0 < K; k0 += kc) {
@@ -1258,6 +1323,7 @@ int cs_bake(cs_ctx *ctx, int gas_slot, int table_slot, int shape, double dnu_cut
         itp = interp_view(cheb, ginterp, kc);
         if (!ctx->matrix_nodes) itp.sep = nullptr, itp.edge = nullptr;
         itp.sep_always = ctx->matrix_nodes == 2;
+        itp.small_mx = ctx->tune[2] != 0;
         itp.core = ctx->matrix_core != 0;
     }
     for (int k0 = 0; k0 < M; k0 += kc) {
@@ -1681,7 +1747,7 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
         (rc = upload(c.Pk, c.h_Pk.data(), K, s)))
         return rc;
     c.default_wts = wts == nullptr;
-    c.interp = ctx->interp * 4096 + (ctx->itp_first + 1) * 256 + (ctx->itp_min >> 7) * 16 + (ctx->itp_max >> 7);   // every interpolation setting of the context
+    c.interp = interp_key(ctx);   // every setting of the context that shapes what setup builds
     c.has_extra = sigma_extra != nullptr;
     // an all-zero stellar spectrum / albedo is the same as none (0*exp(..) and M*0/pi are exact zeros): skip their work, and let
     // the upward sweep start without waiting for the downward one (k_rt<.., UD>)
@@ -1939,6 +2005,7 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
             itp.sep = ctx->matrix_nodes ? dsep.as<SepZone>() : nullptr;
             itp.edge = ctx->matrix_nodes ? dedge.as<EdgeZone>() : nullptr;
             itp.sep_always = ctx->matrix_nodes == 2;
+            itp.small_mx = ctx->tune[2] != 0;
             itp.core = ctx->matrix_core != 0;
         }
         for (int64_t k0 = 0; k0 < BK; k0 += kc) {
@@ -2032,6 +2099,8 @@ static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e)
     ChebApply apply;
     apply.ngas = 0;
     ctx->ph.nu_lo = c.h_nu.front(); ctx->ph.nu_hi = c.h_nu.back();
+    int n_itp = 0;
+    for (auto &cg : c.gas) n_itp += cg.itp.nlev > 0 ? 1 : 0;
     for (int gi = 0; gi < (int)c.gas.size(); gi++) {
         ColGas &cg = c.gas[gi];
         const GasTable &G = *cg.tab;
@@ -2039,7 +2108,9 @@ static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e)
         itp.F = c.chebF.as<double>();
         if (!ctx->matrix_nodes) itp.sep = nullptr, itp.edge = nullptr;
         itp.sep_always = ctx->matrix_nodes == 2;
+        itp.small_mx = ctx->tune[2] != 0;
         itp.core = ctx->matrix_core != 0;
+        itp.fuse_apply = ctx->tune[1] != 0 && n_itp == 1;
         launch_gas(s, cg.shape, G, cg.jlo, cg.jhi, K, c.Tk.as<double>(), c.Pk.as<double>(), cg.Pp.as<double>(), cg.conc.as<double>(), K,
                    c.hot.as<LineHot>(), c.cold.as<LineCold>(), c.nu.as<double>(), c.nnu, c.ntile, cg.J0.as<int32_t>(),
                    cg.J1.as<int32_t>(), cg.win.as<WaveWin>(), cg.xtiles, cg.zones.as<Zone>(), c.ranges.as<int2>(), cg.gmax.as<double>(), cg.cut, c.sigma_gray, extra, sig, gi > 0,
@@ -2245,6 +2316,10 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
     const int nt64 = (int)((c.nnu + 63) / 64);
     int64_t direct = 0, nodes = 0, sepn = 0, edgen = 0, mx3 = 0, subn = 0, ncore = 0, mx8 = 0, mx3n = 0;   // subn: (lane, line) evaluations of k_voigt_sub
     //   // sepn, edgen: (node | point, line, state) triples summed on the matrix cores; mx3: those with 3 terms
+    // flops of the two matrix-core kernels: issued = every matrix instruction's 2048; useful = 2 x terms per (column, line, state) with
+    // the column inside the cut-off, outside the core radius, and the state a real one (a group's tail rows are padding)
+    double fl_edge_useful = 0.0, fl_edge_issued = 0.0, fl_nodes_useful = 0.0, fl_nodes_issued = 0.0, fl_apply = 0.0;
+    int64_t near0 = 0, near1 = 0;
     int64_t body[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // per-point lines by body: 2-term, 2-term+cut-off, 3-term, 3-term+cut-off, 4-term+cut-off,
                                                      // near-zone pass; node lines: 2-, 3-, 4-term
     auto seg = [](int lo, int hi, int p0, int p1) { return (int64_t)std::max(0, std::min(hi, p1) - std::max(lo, p0)); };
@@ -2260,7 +2335,7 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
             iz.resize((size_t)K * nItot);
             HIPCHK(hipMemcpy(iz.data(), g.itp.iz.p, iz.size() * sizeof(IZone), hipMemcpyDeviceToHost));
             const int q0 = c.cheb.ioff[g.itp.l0];
-            const bool use_sep = sep_in_use(ctx->matrix_nodes != 0, ctx->matrix_nodes == 2, nItot - q0, K, g.shape != SH_VOIGT, ctx->mixed != 0);
+            const bool use_sep = sep_in_use(ctx->matrix_nodes != 0, ctx->matrix_nodes == 2, nItot - q0, K, g.shape != SH_VOIGT, ctx->mixed != 0, ctx->tune[2] != 0);
             std::vector<SepZone> sz;
             if (use_sep) {
                 sz.resize((size_t)((K + 15) / 16) * nItot);
@@ -2293,15 +2368,64 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
                     }
                 }
         }
+        if (nlev > 0) {
+            const int q0 = c.cheb.ioff[g.itp.l0];
+            if (sep_in_use(ctx->matrix_nodes != 0, ctx->matrix_nodes == 2, nItot - q0, K, g.shape != SH_VOIGT, ctx->mixed != 0, ctx->tune[2] != 0)) {
+                std::vector<SepZone> sz((size_t)((K + 15) / 16) * nItot);
+                HIPCHK(hipMemcpy(sz.data(), g.itp.sep.p, sz.size() * sizeof(SepZone), hipMemcpyDeviceToHost));
+                for (int gq = 0; gq < (K + 15) / 16; gq++) {
+                    const int ns = std::min(16, K - 16 * gq);
+                    for (int q = q0; q < nItot; q++) {
+                        const SepZone &z = sz[(size_t)gq * nItot + q];
+                        for (int p = 0; p < 4; p++) {
+                            if (z.b[p] <= z.a[p]) continue;
+                            const int n3 = p < 2 ? z.m[p] - z.a[p] : z.b[p] - z.m[p], n4 = (z.b[p] - z.a[p]) - n3;
+                            fl_nodes_useful += 2.0 * CS_NC * ns * (3.0 * n3 + 4.0 * n4);
+                            fl_nodes_issued += 2.0 * CS_NC * 16 * (3.0 * ((n3 + 3) / 4 * 4) + 4.0 * ((n4 + 3) / 4 * 4));
+                        }
+                    }
+                }
+            }
+        }
         int ishift = 0;
         if (nlev > 0) for (int r = c.cheb.itv[nlev - 1] / 64; r > 1; r >>= 1) ishift++;
         const bool use_edge = nlev > 0 && edge_in_use(ctx->matrix_nodes != 0, ctx->matrix_nodes == 2, nt64, K, g.shape != SH_VOIGT, ctx->mixed != 0,
-                                                      std::max<int64_t>(g.jhi - g.jlo, 0));
+                                                      std::max<int64_t>(g.jhi - g.jlo, 0), ctx->tune[2] != 0);
         std::vector<EdgeZone> ez;
         if (use_edge) {
             ez.resize((size_t)((K + 15) / 16) * nt64);
             HIPCHK(hipMemcpy(ez.data(), g.itp.edge.p, ez.size() * sizeof(EdgeZone), hipMemcpyDeviceToHost));
         }
+        if (use_edge) {
+            const double *nl = g.tab->h_nu.data(), *vv = c.h_nu.data();
+            for (int gq = 0; gq < (K + 15) / 16; gq++) {
+                const int ns = std::min(16, K - 16 * gq);
+                for (int t = 0; t < nt64; t++) {
+                    const WaveWin w = win[t];
+                    const EdgeZone e = ez[(size_t)gq * nt64 + t];
+                    const double *v0 = vv + (size_t)t * 64, *v1 = vv + std::min<int64_t>((int64_t)t * 64 + 64, c.nnu);
+                    auto piece = [&](int ja, int jb, int nt, int mask) {   // mask 0: every point counts; 1: |dnu| <= cut; 2: also |dnu| >= R
+                        if (jb <= ja) return;
+                        fl_edge_issued += 2.0 * nt * 64.0 * 16.0 * ((jb - ja + 3) / 4 * 4);
+                        double cols = 0.0;
+                        for (int j = ja; j < jb; j++) {
+                            if (mask == 0) { cols += (double)(v1 - v0); continue; }
+                            int n = (int)(std::upper_bound(v0, v1, nl[j] + g.cut) - std::lower_bound(v0, v1, nl[j] - g.cut));
+                            if (mask == 2) n -= (int)(std::lower_bound(v0, v1, nl[j] + e.R) - std::upper_bound(v0, v1, nl[j] - e.R));   // (|dnu| < R: k_voigt_sub's)
+                            cols += std::max(n, 0);
+                        }
+                        fl_edge_useful += 2.0 * nt * cols * ns;
+                    };
+                    piece(w.W0, e.eL, (e.far3 & 1) ? 3 : 4, 1);
+                    piece(e.eR, w.W1, (e.far3 & 2) ? 3 : 4, 1);
+                    if (e.mL1 > e.mL0) { piece(e.mL0, e.mL3, 3, 1); piece(e.mL3, e.mL1, 4, 1); }
+                    if (e.mR1 > e.mR0) { piece(e.mR3, e.mR1, 3, 1); piece(e.mR0, e.mR3, 4, 1); }
+                    if (e.cR > e.cL) piece(e.cL, e.cR, (e.far3 & 4) ? 8 : 4, 2);
+                }
+            }
+        }
+        if (nlev > 0)   // the contraction that carries the node sums to the grid (k_cheb_apply_mfma, or fused into k_voigt_edge_mx)
+            fl_apply += 2.0 * CS_NC * 64.0 * 16.0 * ((K + 15) / 16) * (double)nt64 * (nlev - g.itp.l0);
         for (int k = 0; k < K; k++)
             for (int t = 0; t < nt64; t++) {
                 WaveWin w = win[t];
@@ -2359,6 +2483,37 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
                 }
             }
     }
+    // near-line pairs by tier (k_voigt_near<0>: 100 <= s < 1e3, <1>: s < 100), counted from the records of the launch group whose
+    // per-(state, line) records are still in HBM -- the last Voigt group of the column (the only one when its gases are merged)
+    if (!c.gas.empty() && c.gas.back().shape == SH_VOIGT && c.gas.back().jhi > c.gas.back().jlo) {
+        const ColGas &g = c.gas.back();
+        const int64_t L = g.tab->L, nj = g.jhi - g.jlo;
+        std::vector<LineHot> rec((size_t)nj);
+        const double *vv = c.h_nu.data();
+        const int64_t nnu = c.nnu;
+        for (int k = 0; k < K; k++) {
+            HIPCHK(hipMemcpy(rec.data(), c.hot.as<LineHot>() + (size_t)k * L + g.jlo, rec.size() * sizeof(LineHot), hipMemcpyDeviceToHost));
+            for (int64_t j = 0; j < nj; j++) {
+                const LineHot &h = rec[j];
+                auto within = [&](double smax) -> int64_t {   // points with x^2 + y^2 < smax and |dnu| <= cut
+                    if (!(h.p2 < smax)) return 0;
+                    const double r = std::min(std::sqrt(smax - h.p2) / h.p1, g.cut);
+                    return (std::lower_bound(vv, vv + nnu, h.nul + r) - std::upper_bound(vv, vv + nnu, h.nul - r));
+                };
+                const int64_t n1 = within(kMidS), n0 = within(kSerS);
+                near1 += n1;
+                near0 += n0 - n1;
+            }
+        }
+    }
+    out[20] = near0;
+    out[21] = near1;
+    out[22] = (int64_t)fl_edge_useful;
+    out[23] = (int64_t)fl_edge_issued;
+    out[24] = (int64_t)fl_nodes_useful;
+    out[25] = (int64_t)fl_nodes_issued;
+    out[26] = (int64_t)fl_apply;
+    for (int q = 27; q < 32; q++) out[q] = 0;
     out[0] = direct;
     out[1] = nodes;
     out[2] = c.cheb.nlev;
@@ -2382,7 +2537,7 @@ static bool column_matches(cs_ctx *ctx, int64_t nnu, const double *nu, int np, c
                            int nstream, bool want_tau, bool want_M)
 {
     const Column &c = ctx->col;
-    if (!c.ready || c.accel.slot >= 0 || !c.default_wts || c.interp != ctx->interp * 4096 + (ctx->itp_first + 1) * 256 + (ctx->itp_min >> 7) * 16 + (ctx->itp_max >> 7) || !c.tab.empty() || !c.cia.empty()) return false;
+    if (!c.ready || c.accel.slot >= 0 || !c.default_wts || c.interp != interp_key(ctx) || !c.tab.empty() || !c.cia.empty()) return false;
     if (c.nnu != nnu || c.np != np || c.nlob != nlobatto || c.nstream != nstream || c.ngas != ngas) return false;
     if (c.g != g || c.sigma_gray != sigma_gray || c.theta_s != theta_s) return false;
     if (c.want_tau != want_tau || c.want_M != want_M) return false;
@@ -2622,6 +2777,24 @@ int cs_lobattonodes(int n, double *xs, double *ws)
         xs[i] = (x[i] + 1) / 2;
         ws[i] = w[i] / 2;
     }
+    return CS_OK;
+}
+
+int cs_devfn_batch(cs_ctx *ctx, int which, int64_t n, const double *x, const double *y, const double *z, double *out)
+{
+    if (!ctx || n < 0 || which < 0 || which > 2 || !x || !out) return fail(CS_EINVAL, "bad arguments");
+    if ((which >= 1 && !y) || (which == 2 && !z)) return fail(CS_EINVAL, "this function takes more arguments");
+    if (n == 0) return CS_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    DevBuf dx, dy, dz, dout;
+    int rc;
+    if ((rc = upload(dx, x, n, s)) || (y && (rc = upload(dy, y, n, s))) || (z && (rc = upload(dz, z, n, s)))) return rc;
+    HIPCHK(dout.reserve(n * sizeof(double)));
+    CS_LAUNCH(k_devfn, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, which, n, dx.as<double>(), dy.as<double>(), dz.as<double>(), dout.as<double>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, dout.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
     return CS_OK;
 }
 

@@ -91,7 +91,9 @@ __device__ __forceinline__ double fad_near(double x, double y)
         double c = shift ? c1[k] : c0[k + 1];
         double a = x - t, b = x + t;
         double da = __builtin_fma(a, a, y2), db = __builtin_fma(b, b, y2);
-        acc = __builtin_fma(c * (da + db), rcp_nr(da * db), acc);
+        acc = __builtin_fma(c * (da + db), rcp_fast(da * db), acc);   // (|x -+ t| >= 1/8 by the choice of grid: 2e-4 <= da db <= 2e5, inside the
+                                                                       // f32 range of the seed; 3.6e-15 per term against 1e-16 -- 24 terms of
+                                                                       // one sign -- for 3.5 of the 12 FMA-equivalents a term costs)
     }
     double res = (0.5 / kPi) * y * acc;
     if (y < 2.0 * kPi) {

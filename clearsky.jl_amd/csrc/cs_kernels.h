@@ -496,6 +496,7 @@ __device__ __forceinline__ int tile_block(const int32_t *__restrict__ xc, int ti
 // max(dA, 0.3 h) and the cut-off edges are left to the next smaller interval size, and finally to the per-point kernels.
 #define CS_NC 64
 #define CS_MAX_LEVEL 5
+#define CS_MAX_LEVEL_ 5
 constexpr double kChebMargin = 0.3;
 // per (state, interval): own set = [E0,Z0) U [Z1,E1), cut into the 2-/3-/4-term zones of the far body; [P0,P1) and [P2,P3)
 // is the part of it the parent interval (next level up) has already summed.
@@ -655,6 +656,29 @@ __global__ __launch_bounds__(256) void k_gas_setup(unsigned nb_prep, unsigned nb
     else prep_body(blockIdx.x - nb_zones - nb_iz, pa);
 }
 
+// Block order of the node kernels.  Workgroups are dealt round-robin to the 8 XCDs (private L2 each), and neighbouring intervals
+// of a level share most of their lines (a window of +-cut against an interval a quarter of that wide): with interval-major block
+// order the ~5 intervals that read a record sit on 5 different XCDs and each fetches it from the fabric (FETCH_SIZE 2.2-2.5x the
+// unique records, profiles/r02_pmc_*).  XMap gives XCD x one contiguous stretch of every level's intervals, [xb[l][x], xb[l][x+1]),
+// cut on the host at equal sums of window sizes (line density varies along a spectrum); cnt[l] = the longest stretch of level l
+// (grid size).  Speed/traffic only: any placement is correct.
+struct XMap {
+    int on, l0, nlev;
+    int cnt[CS_MAX_LEVEL_], ioff[CS_MAX_LEVEL_], xb[CS_MAX_LEVEL_][9];
+};
+// item `it` of XCD x among the levels lfirst .. llast-1 -> index in the concatenated interval list, or -1 (past the XCD's stretch)
+__device__ __forceinline__ int xmap_interval(const XMap &m, int lfirst, int llast, int x, int it)
+{
+    for (int l = lfirst; l < llast; l++) {
+        if (it < m.cnt[l]) {
+            const int T = m.xb[l][x] + it;
+            return T < m.xb[l][x + 1] ? m.ioff[l] + T : -1;
+        }
+        it -= m.cnt[l];
+    }
+    return -1;
+}
+
 // one wave = the 64 Chebyshev nodes of one interval x one node state: far-wing sums at the nodes -> F[interval][node][state].
 // All levels run in one launch over the concatenated interval list (largest intervals, i.e. longest waves, first).
 #define CS_KPAD 16   // F rows are padded to a multiple of 16 states (k_cheb_apply reads 16 at a time with scalar loads)
@@ -723,7 +747,7 @@ template <bool MIXED, bool LOR>
 __global__ __launch_bounds__(256) void k_cheb_nodes(const double *__restrict__ nodes, int64_t L, const LineHot *__restrict__ hot,
                                                      const LineF32 *__restrict__ hot32, const double *__restrict__ gnul,
                                                      const IZone *__restrict__ iz, int nItot, int q0, int q_acc, int K, int Kpad, double cut,
-                                                     double *__restrict__ F, const SepZone *__restrict__ sep)
+                                                     double *__restrict__ F, const SepZone *__restrict__ sep, XMap xm)
 {
     // q_acc: intervals >= q_acc already hold the node sums of earlier gases of the column -- add to them.  The interpolation
     // is linear, so k_cheb_apply then carries the SUM over gases to the grid in one pass per level instead of one per (gas, level).
@@ -731,10 +755,18 @@ __global__ __launch_bounds__(256) void k_cheb_nodes(const double *__restrict__ n
     // intervals q0 .. nItot-1 (the levels this gas uses)
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int nsb = (K + 3) >> 2;
-    const int T = q0 + (int)(blockIdx.x / nsb);
-    // state block rotated by the interval: workgroups go round-robin to the 8 XCDs, and with the matrix cores taking most far lines
-    // of the low-pressure states the work left here sits in the last state blocks -- unrotated, on half of the XCDs
-    const int k = (int)((blockIdx.x % nsb + (sep ? T : 0)) % nsb) * 4 + wv;   // (unrotated, a state block stays on one XCD: its records stay in that L2)
+    int T, k;
+    if (xm.on) {   // XCD x walks its own stretch of every level, all state blocks of an interval back to back
+        const int x = blockIdx.x & 7, r = blockIdx.x >> 3;
+        T = xmap_interval(xm, xm.l0, xm.nlev, x, r / nsb);
+        if (T < 0) return;
+        k = (r % nsb) * 4 + wv;
+    } else {
+        T = q0 + (int)(blockIdx.x / nsb);
+        // state block rotated by the interval: workgroups go round-robin to the 8 XCDs, and with the matrix cores taking most far lines
+        // of the low-pressure states the work left here sits in the last state blocks -- unrotated, on half of the XCDs
+        k = (int)((blockIdx.x % nsb + (sep ? T : 0)) % nsb) * 4 + wv;   // (unrotated, a state block stays on one XCD: its records stay in that L2)
+    }
     if (k >= K) return;
     const LineHot *__restrict__ hk = hot + (size_t)k * L;
     const LineF32 *__restrict__ hf = MIXED ? hot32 + (size_t)k * L : nullptr;
@@ -913,16 +945,33 @@ __device__ __forceinline__ void sepzones_body(unsigned bid, const SepArgs &a)
 // this kernel's registers and LDS allow four: 0.94 ms for a quarter of the vector work, profiles/r02_notes.md.)
 __global__ __launch_bounds__(256) void k_cheb_nodes_mx(const double *__restrict__ nodes, int64_t L, const LineHot *__restrict__ hot,
                                                        const SepZone *__restrict__ sep, int nItot, int q0, int nsplit, int K, int Kpad,
-                                                       int ngrp, double *__restrict__ F)
+                                                       int ngrp, double *__restrict__ F, XMap xm)
 {
     // the first nsplit intervals (the largest interval size in use: several hundred lines per piece) are shared by the four waves
     // of a block as described; the rest (a few dozen lines, ~10 steps) go one (interval, group) per wave -- no LDS, no barrier
     __shared__ double part[4][16][CS_MX_PITCH];
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int nb_split = nsplit * ngrp;
-    const bool split = (int)blockIdx.x < nb_split;   // (block-uniform)
+    const int nb_split = xm.on ? 8 * (nsplit == nItot - q0 ? 0 : xm.cnt[xm.l0]) * ngrp : nsplit * ngrp;   // (xm: nsplit = the first level in use, or everything)
+    int nb_split_all = nb_split;
+    if (xm.on && nsplit == nItot - q0) {   // one level only, or every level shared by four waves: all blocks are "split" blocks
+        int c = 0;
+        for (int l = xm.l0; l < xm.nlev; l++) c += xm.cnt[l];
+        nb_split_all = 8 * c * ngrp;
+    }
+    const bool split = (int)blockIdx.x < nb_split_all;   // (block-uniform)
     int T, g;
-    if (split) {
+    if (xm.on) {
+        if (split) {
+            const int x = blockIdx.x & 7, r = blockIdx.x >> 3;
+            T = xmap_interval(xm, xm.l0, nsplit == nItot - q0 ? xm.nlev : xm.l0 + 1, x, r / ngrp);
+            g = r % ngrp;
+        } else {
+            const int b = (int)blockIdx.x - nb_split_all;
+            const int x = b & 7, item = (b >> 3) * 4 + wv;
+            T = xmap_interval(xm, xm.l0 + 1, xm.nlev, x, item / ngrp);
+            g = item % ngrp;
+        }
+    } else if (split) {
         T = q0 + (int)(blockIdx.x / ngrp);
         g = (int)((blockIdx.x % ngrp + T) % ngrp);   // (rotated: the groups differ in work and would alias with the XCD round-robin)
     } else {
@@ -931,6 +980,7 @@ __global__ __launch_bounds__(256) void k_cheb_nodes_mx(const double *__restrict_
         T = q0 + item / ngrp;
         g = item % ngrp;
     }
+    if (T < 0) return;   // past the XCD's stretch (block-uniform for split blocks: no wave is left waiting at the barrier below)
     const SepZone z = sep[(size_t)g * nItot + T];
     if (!(z.b[0] > z.a[0] || z.b[1] > z.a[1] || z.b[2] > z.a[2] || z.b[3] > z.a[3])) return;   // (uniform per block when split, else per wave)
     {
@@ -1455,16 +1505,25 @@ __global__ __launch_bounds__(256) void k_mxzones(unsigned nb_sep, SepArgs sa, Ed
 
 // (three waves per SIMD, with the 164 registers that allows: the 8-term step of the cores wants them -- left alone the allocator
 //  takes 148 + 32 accumulators, i.e. two waves: 0.44 vs 0.41 ms)
+// fuse != 0: the interpolated far wings of the tile come along -- sigma += sum_level C_l[interval][:, point] . F[interval][:, state]
+// (k_cheb_apply_mfma's product, same operand and accumulator layout: states are the rows of D here too), added into the same
+// accumulators, so that sigma makes one round trip less and the step one launch less.  The host fuses when the column has ONE
+// launch group with interpolated wings and that group runs this kernel.
+// SPLIT = 4 (short grids: a nu-shard of a multi-GPU run has a few hundred tiles, i.e. fewer (tile, group) waves than the chip has
+// SIMDs, each a chain of a hundred dependent load -> matrix steps): the four waves of a block share ONE (tile, group), every piece
+// cut into four runs of lines as in k_cheb_nodes_mx, partial sums added through LDS in wave order (bitwise repeatable).
+template <int SPLIT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_voigt_edge_mx(const double *__restrict__ nu, int64_t nnu, int64_t L, const LineHot *__restrict__ hot,
                                                        const WaveWin *__restrict__ win, const EdgeZone *__restrict__ edge, int ntile, int K,
-                                                       double cut, double *__restrict__ sigma)
+                                                       double cut, double *__restrict__ sigma, int fuse, ChebApply A, int Kpad)
 {
+    __shared__ double part[SPLIT > 1 ? 4 : 1][SPLIT > 1 ? 16 : 1][SPLIT > 1 ? CS_MX_PITCH : 1];
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * 4 + wv, g = blockIdx.y;
-    if (tile >= ntile) return;
+    const int tile = SPLIT > 1 ? (int)blockIdx.x : (int)blockIdx.x * 4 + wv, g = blockIdx.y;
+    if (tile >= ntile) return;   // (block-uniform when SPLIT > 1)
     const WaveWin w = win[tile];
     const EdgeZone e = edge[(size_t)g * ntile + tile];
-    if (e.eL <= w.W0 && e.eR >= w.W1 && e.mL1 <= e.mL0 && e.mR1 <= e.mR0 && e.cR <= e.cL) return;
+    if (!fuse && e.eL <= w.W0 && e.eR >= w.W1 && e.mL1 <= e.mL0 && e.mR1 <= e.mR0 && e.cR <= e.cL) return;   // (block-uniform when SPLIT > 1)
     const int lr = lane & 15, lq = lane >> 4;
     const int kk = min(g * 16 + lr, K - 1);                       // (a group's tail states re-read the last one: never stored)
     const LineHot *__restrict__ hk = hot + (size_t)kk * L;
@@ -1477,28 +1536,73 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     v4f64_sep acc[4];
 #pragma unroll
     for (int st = 0; st < 4; st++) acc[st] = v4f64_sep{0.0, 0.0, 0.0, 0.0};
-    // left pieces ascending, right pieces descending: far lines first; three terms where they do
-    if (e.far3 & 1) sep_run<3, 1>(acc, vn, hk, w.W0, e.eL, true, lq, cut); else sep_run<4, 1>(acc, vn, hk, w.W0, e.eL, true, lq, cut);
-    if (e.mL1 > e.mL0) {
-        sep_run<3, 1>(acc, vn, hk, e.mL0, e.mL3, true, lq, cut);
-        sep_run<4, 1>(acc, vn, hk, e.mL3, e.mL1, true, lq, cut);
+    if (fuse) {
+        const double *__restrict__ Fg = A.F[0];
+        const int m0 = SPLIT > 1 ? wv * (CS_NC / 4) : 0, m1 = SPLIT > 1 ? m0 + CS_NC / 4 : CS_NC;   // (split: a quarter of the nodes per wave)
+        for (int l = A.l0[0]; l < A.nlev; l++) {
+            const int sh = A.shift[l];
+            const int T = tile >> sh, sub = tile & ((1 << sh) - 1);
+            const size_t itv = (size_t)64 << sh;
+            const double *__restrict__ Cp = A.Cm[l] + ((size_t)T * CS_NC + lq) * itv + (size_t)sub * 64 + lr;        // node lq, point lr
+            const double *__restrict__ Fp = Fg + ((size_t)(A.ioff[l] + T) * CS_NC + lq) * Kpad + (size_t)g * 16 + lr;  // node lq, state lr
+#pragma unroll 2
+            for (int m = m0; m < m1; m += 4) {
+                double b[4];
+#pragma unroll
+                for (int st = 0; st < 4; st++) b[st] = Cp[(size_t)m * itv + st * 16];
+                const double a = Fp[(size_t)m * Kpad];
+#pragma unroll
+                for (int st = 0; st < 4; st++) acc[st] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[st], acc[st], 0, 0, 0);
+            }
+        }
     }
-    if (e.far3 & 2) sep_run<3, 1>(acc, vn, hk, e.eR, w.W1, false, lq, cut); else sep_run<4, 1>(acc, vn, hk, e.eR, w.W1, false, lq, cut);
+    // this wave's run of the piece [pa, pb): all of it, or (SPLIT) one of four runs of a multiple of 4 lines, wave 0 at the far end
+    auto run = [&](int pa, int pb, bool asc, int &ja, int &jb) {
+        if (SPLIT == 1) { ja = pa; jb = pb; return; }
+        const int len = ((max(pb - pa, 0) + 15) >> 4) << 2;
+        ja = asc ? min(pa + wv * len, pb) : max(pb - (wv + 1) * len, pa);
+        jb = asc ? min(ja + len, pb) : max(pb - wv * len, pa);
+    };
+    int ja, jb;
+    // left pieces ascending, right pieces descending: far lines first; three terms where they do
+    run(w.W0, e.eL, true, ja, jb);
+    if (e.far3 & 1) sep_run<3, 1>(acc, vn, hk, ja, jb, true, lq, cut); else sep_run<4, 1>(acc, vn, hk, ja, jb, true, lq, cut);
+    if (e.mL1 > e.mL0) {
+        run(e.mL0, e.mL3, true, ja, jb); sep_run<3, 1>(acc, vn, hk, ja, jb, true, lq, cut);
+        run(e.mL3, e.mL1, true, ja, jb); sep_run<4, 1>(acc, vn, hk, ja, jb, true, lq, cut);
+    }
+    run(e.eR, w.W1, false, ja, jb);
+    if (e.far3 & 2) sep_run<3, 1>(acc, vn, hk, ja, jb, false, lq, cut); else sep_run<4, 1>(acc, vn, hk, ja, jb, false, lq, cut);
     if (e.mR1 > e.mR0) {
-        sep_run<3, 1>(acc, vn, hk, e.mR3, e.mR1, false, lq, cut);
-        sep_run<4, 1>(acc, vn, hk, e.mR0, e.mR3, false, lq, cut);
+        run(e.mR3, e.mR1, false, ja, jb); sep_run<3, 1>(acc, vn, hk, ja, jb, false, lq, cut);
+        run(e.mR0, e.mR3, false, ja, jb); sep_run<4, 1>(acc, vn, hk, ja, jb, false, lq, cut);
     }
     if (e.cR > e.cL) {   // the core: pairs at least R apart
-        if (e.far3 & 4) sep_run<8, 2>(acc, vn, hk, e.cL, e.cR, true, lq, cut, e.R); else sep_run<4, 2>(acc, vn, hk, e.cL, e.cR, true, lq, cut, e.R);
+        run(e.cL, e.cR, true, ja, jb);
+        if (e.far3 & 4) sep_run<8, 2>(acc, vn, hk, ja, jb, true, lq, cut, e.R); else sep_run<4, 2>(acc, vn, hk, ja, jb, true, lq, cut, e.R);
+    }
+    if (SPLIT == 1) {
+#pragma unroll
+        for (int st = 0; st < 4; st++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {   // D[state 4r + lq][point 16 st + lr]
+                const int k = g * 16 + 4 * r + lq;
+                const int64_t i = (int64_t)tile * 64 + st * 16 + lr;
+                if (k < K && i < nnu) sigma[(size_t)k * nnu + i] += acc[st][r];
+            }
+        return;
     }
 #pragma unroll
     for (int st = 0; st < 4; st++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) {   // D[state 4r + lq][point 16 st + lr]
-            const int k = g * 16 + 4 * r + lq;
-            const int64_t i = (int64_t)tile * 64 + st * 16 + lr;
-            if (k < K && i < nnu) sigma[(size_t)k * nnu + i] += acc[st][r];
-        }
+        for (int r = 0; r < 4; r++) part[wv][4 * r + lq][st * 16 + lr] = acc[st][r];
+    __syncthreads();
+    const int64_t i = (int64_t)tile * 64 + lane;
+    for (int s4 = 0; s4 < 4; s4++) {
+        const int ks = 4 * wv + s4, k = g * 16 + ks;
+        if (k >= K || i >= nnu) break;
+        sigma[(size_t)k * nnu + i] += ((part[0][ks][lane] + part[1][ks][lane]) + part[2][ks][lane]) + part[3][ks][lane];
+    }
 }
 
 // K2f: the core of the window on 16-point sub-tiles.  The tile-wide near-zone pass of k_voigt_far runs its 37 instructions for every
@@ -2394,6 +2498,18 @@ __global__ __launch_bounds__(256) void k_accel_eval(const double *__restrict__ L
     const double ya = L[(size_t)c * nnu + i], yb = L[(size_t)(c + 1) * nnu + i];
     const size_t o = (size_t)k * nnu + i;
     sigma[o] = (base + (extra ? extra[o] : 0.0)) + exp((x[k] - xa[k]) * (yb - ya) / (xb[k] - xa[k]) + ya);
+}
+
+// test hook: the device functions the flux kernel is built from, evaluated point by point (0: exp_rt(x), 1: planck(x = nu, y = T),
+// 2: layerplanck_inv(B1 = x, B2 = y, 1/tau = 1/z, t = exp_rt(-z)) with z > 0)
+__global__ void k_devfn(int which, int64_t n, const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
+                        double *__restrict__ out)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (which == 0) out[i] = exp_rt(x[i]);
+    else if (which == 1) out[i] = planck(x[i], y[i]);
+    else out[i] = layerplanck_inv(x[i], y[i], 1.0 / z[i], exp_rt(-z[i]));
 }
 
 __global__ void k_faddeeva(int64_t n, const double *__restrict__ x, const double *__restrict__ y, double *__restrict__ out)

@@ -105,6 +105,12 @@ int cs_set_matrix_cores(cs_ctx *ctx, int on);
  * lines changes).  Applies to every later cs_column_setup / cs_fluxes_discretized of the context. */
 int cs_set_merge(cs_ctx *ctx, int on);
 
+/* Tuning switches for A/B measurements (results do not depend on them beyond rounding): key 0 = block order of the node kernels
+ * (1, default: one contiguous stretch of every interval level per XCD; 0: interval-major), key 1 = the interpolated far wings are
+ * carried to the grid inside k_voigt_edge_mx where the column has one launch group (1, default; 0: always their own launch).
+ * Applies to every later cs_column_setup of the context. */
+int cs_set_tuning(cs_ctx *ctx, int key, int value);
+
 /*
  * B1: batched in-place line shape.  For every state k:  sigma[k*ld_state + i] = shape(nu[i]; T[k], P[k], Pp[k]).
  * Replaces: shape!(sigma, nu, sl, T, P, Pp, dnu_cut) -- voigt!/lorentz!/doppler!/PHCO2!, line_shapes.jl:412-424,
@@ -228,8 +234,13 @@ int cs_column_info(cs_ctx *ctx, int64_t *out);
  * out[0] and out[4..9] do not include the latter), out[15] = those of out[13] + out[14] that take three series terms instead of
  * four, out[16] = (lane, line) evaluations of k_voigt_sub (the window core on 16-point sub-tiles; 37 instructions each like the
  * near-zone pass; not in out[0]), out[17] = (tile, state) pairs whose window core is k_voigt_sub's, summed over the gases, out[18] =
- * those of out[14] that take eight series terms (the sub-tile cores), out[19] = the part of out[15] that belongs to out[13].  `out`
- * holds 20 values.
+ * those of out[14] that take eight series terms (the sub-tile cores), out[19] = the part of out[15] that belongs to out[13];
+ * out[20], out[21] = (nu, line, state) pairs of k_voigt_near<0> (100 <= x^2+y^2 < 1e3) and <1> (< 100), counted on the host from the
+ * records of the last Voigt launch group; out[22], out[23] = flops of k_voigt_edge_mx: useful (2 x series terms for every (point,
+ * line, state) with the point inside the cut-off and outside the core radius, real states only) and issued (2048 per matrix
+ * instruction: masked columns, padded states and the fill of the last 4-line step included); out[24], out[25] = the same for
+ * k_cheb_nodes_mx; out[26] = flops of the node-sum -> grid contraction (k_cheb_apply_mfma, or fused into k_voigt_edge_mx).  `out`
+ * holds 32 values.
  * cs_column_counts is the reference's count. */
 int cs_column_work(cs_ctx *ctx, int64_t *out);
 /* interval sizes (descending, <= 5, each 128..2048 points) cs_set_interp(on) would use for this grid and cut-off; returns
@@ -303,6 +314,10 @@ int cs_lobattonodes(int n, double *x, double *w);   /* core/discretized.jl:2-9 *
 /* Re w(x+iy) evaluated on the device for n points (host pointers): the kernels' Faddeeva, test hook for
  * Faddeyeva985.faddeyeva (call site line_shapes.jl:375). */
 int cs_faddeeva_batch(cs_ctx *ctx, int64_t n, const double *x, const double *y, double *out);
+/* The device functions of the flux kernel, point by point (host pointers; test hook): which = 0: its own exp (Cody-Waite reduction +
+ * degree-13 polynomial, replaces libm's in every transmission and Planck value) at x; 1: planck(nu = x, T = y) radiation.jl:48-54;
+ * 2: layerplanck (discretized.jl:85-87) for B1 = x, B2 = y, tau = z > 0 with t = exp(-tau).  y, z may be NULL where unused. */
+int cs_devfn_batch(cs_ctx *ctx, int which, int64_t n, const double *x, const double *y, const double *z, double *out);
 
 #ifdef __cplusplus
 }

@@ -136,6 +136,25 @@ def test_accelerated_absorber_vs_oracle(cs, O, lines):
     with pytest.raises(TypeError):                              # (the reference throws its "absorbers must only be ..." string)
         cs.Column(Pr, 9.8, Tr, 0.029, 0.0, 0.0, A, g1)
     assert cs.temperaturelimits(A) == (0.0, float("inf"))
+    # AcceleratedAbsorber(T, P, A) hands A itself back (absorbers.jl:161-164): one object, one owner of the device slot -- dropping
+    # the alias must leave A usable, and dropping an absorber whose column is resident must not leave that column half-alive
+    import gc
+    before = A(4321.0).copy()
+    B = cs.AcceleratedAbsorber(T3, Pe, A)
+    assert B is A
+    del B
+    gc.collect()
+    assert np.array_equal(A(4321.0), before)
+    F1 = cs.radiate(Pr, 9.8, Tr, 0.029, 0.0, 0.2, A, core=cs.Discretized(5, 2))
+    with pytest.raises(AssertionError):
+        cs.AcceleratedAbsorber(T3, Pe * 1.01, A)                # "cannot change ... pressure coordinates after construction"
+    A2 = cs.AcceleratedAbsorber(Te, Pe, g1, ctx=ctx)            # a second absorber on the same context, then gone again
+    col2 = cs.Column(Pr, 9.8, Tr, 0.029, 0.0, 0.2, A2, core=cs.Discretized(5, 2))
+    col2.run()
+    del A2, col2
+    gc.collect()
+    F2 = cs.radiate(Pr, 9.8, Tr, 0.029, 0.0, 0.2, A, core=cs.Discretized(5, 2))
+    assert np.array_equal(F1.Fup, F2.Fup)
     ctx.close()
 
 

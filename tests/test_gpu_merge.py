@@ -158,3 +158,34 @@ def test_merged_shards_add_up(cs, O, lines):
         assert relerr(part["tau"], whole["tau"][:, r[0]:r[1]]) < 5e-13
     assert np.max(np.abs(Fup - whole["Fup"])) < 1e-12 * np.max(whole["Fup"])
     ctx.close()
+
+
+@pytest.mark.parametrize("tune", [{0: 0}, {1: 0}, {0: 0, 1: 0}, {2: 1}])
+def test_tuning_switches_same_results(cs, O, lines, tune):
+    """cs_set_tuning: block order of the node kernels (0), interpolated wings applied inside k_voigt_edge_mx (1), matrix-core kernels
+    on short grids through their four-waves-per-item variants (2) -- none of them may change a result beyond rounding"""
+    nu = np.linspace(580.0, 780.0, 20000)
+    P = cs.pressuregrid(10.0, 1e5, 21)
+    T = W.earth_temperature(P)
+    gases = [cs.DirectGas(lines("H2O"), W.fC_h2o, nu), cs.DirectGas(lines("CO2"), 400e-6, nu)]
+    res = []
+    for t in ({}, tune):
+        for mc in ((2,) if 2 not in tune else (1,)):     # key 2 only matters where the grid-length rule would say "vector unit"
+            ctx = cs.Context(0)
+            ctx.set_matrix_cores(mc)
+            for k, v in t.items():
+                ctx.set_tuning(k, v)
+            col = _column(cs, ctx, gases, P, T)
+            res.append(_results(col))
+            res[-1]["work"] = col.work()
+            res[-1]["launches"] = col.info()["launches"]
+            ctx.close()
+    _close(res[1], res[0], 5e-13, 1e-12)
+    if tune == {1: 0}:
+        assert res[1]["launches"] == res[0]["launches"] + 1          # the wings' own launch
+    if 2 in tune:
+        assert res[1]["work"]["direct_evals_matrix"] > 0 and res[0]["work"]["direct_evals_matrix"] == 0
+        assert res[1]["work"]["node_evals_matrix"] > 0 and res[0]["work"]["node_evals_matrix"] == 0
+    ref = _oracle(O, _column(cs, cs.Context(0), gases, P, T, _setup=False), cs)
+    assert relerr(res[1]["tau"], ref["tau"]) < 1e-11
+    assert np.max(np.abs(res[1]["Fup"] - ref["Fup"])) < 1e-11 * np.max(ref["Fup"])
