@@ -224,6 +224,8 @@ struct cs_ctx {
     PhScratch ph;
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;            // side stream of short grids: node sums beside the per-point kernels (cs_set_tuning key 3)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     GasTable gas[CS_MAX_GAS];
     TableDev tab[CS_MAX_TABLE];
     CiaDev cia[CS_MAX_CIA];
@@ -235,8 +237,9 @@ struct cs_ctx {
     int matrix_nodes = 1;   // cs_set_matrix_cores: separable far-wing node sums on v_mfma_f64 (k_cheb_nodes_mx)
     int matrix_core = 1;    // ... and the window core on sub-tiles (k_voigt_sub + the second mask of k_voigt_edge_mx)
     int merge = 1;          // cs_set_merge: gases of a column with the same shape and cut-off share one merged line table
-    int tune[CS_NTUNE] = {1, 1, 0, 0, 0, 0, 0, 0};   // cs_set_tuning: [0] XCD-contiguous block order of the node kernels, [1] interpolated wings
-                                                     // applied inside k_voigt_edge_mx where one launch group has them
+    // cs_set_tuning: [0] XCD-contiguous block order of the node kernels, [1] interpolated wings applied inside k_voigt_edge_mx where one
+    // launch group has them, [2] matrix-core kernels on short grids (four waves per item), [3] node sums on a side stream (1: short grids)
+    int tune[CS_NTUNE] = {0, 0, 1, 1, 0, 0, 0, 0};
     std::vector<std::unique_ptr<GasTable>> merged;   // merged tables (keyed by their members' (slot, generation)), a few kept
     double far_s = 1e6;
     DevBuf hot32;
@@ -723,13 +726,25 @@ static bool edge_in_use(bool have_edge, bool always, int ntiles, int kn, bool lo
     return have_edge && !lor && !mixed && (always || ((small || mx_big(ntiles, kn, 1024)) && lines_in_range >= (int64_t)ntiles * CS_EDGE_DENS));
 }
 
+// Short grids (a nu-shard): the kernels no longer fill the chip, a step is a chain of launch tails -- and the node sums (F) and the
+// per-point kernels (sigma) of a group are independent until the interpolation carries F to the grid.  With a Fork the node kernels
+// go to a side stream behind an event recorded after k_gas_setup / k_mxzones; `pending` says the main stream has not yet waited
+// for them (it must before anything reads F or overwrites the records).
+struct Fork { hipStream_t s2; hipEvent_t ev_fork, ev_join; bool pending; };
+static void fork_join(Fork *f, hipStream_t s)
+{
+    if (f && f->pending) { (void)hipStreamWaitEvent(s, f->ev_join, 0); f->pending = false; }
+}
+
 // K1 + K2 for one gas on `s`: parameters for `kn` states, then the line sum into sigma ([kn][nnu])
 void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, int64_t jrange1, int kn, const double *Tk, const double *Pk, const double *Ppk,
                 const double *scale, int mstride /* members of a merged table: element (m, k) of Ppk / scale at m * mstride + k */, LineHot *hot, LineCold *cold, const double *dnu, int64_t nnu, int ntile256,
                 const int32_t *J0, const int32_t *J1, const WaveWin *win, int xtiles, Zone *zones, int2 *ranges, const double *gbound, double cut, double base,
                 const double *extra, double *sigma, int accumulate, hipEvent_t *evg,   // NULL or 6 events: after K1 (+ zones), nodes (vector unit), nodes (matrix cores), far (vector unit), sub-tile cores, far (matrix cores)
-                LineF32 *hot32 = nullptr, double far_s = 1e6, Interp itp = Interp(), ChebApply *defer = nullptr, PhScratch *ph = nullptr)
+                LineF32 *hot32 = nullptr, double far_s = 1e6, Interp itp = Interp(), ChebApply *defer = nullptr, PhScratch *ph = nullptr,
+                Fork *fork = nullptr)
 {
+    fork_join(fork, s);   // (an earlier group's node kernels may still read the records this launch overwrites)
     // only the lines some window can reach (windows are sorted: first tile's start .. last tile's end)
     const int64_t jlo = jrange0, jhi = std::max(jrange1, jrange0);
     const int64_t tot = (int64_t)kn * (jhi - jlo);
@@ -794,6 +809,12 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
             }
             if (evg) (void)hipEventRecord(evg[0], s);
             const SepZone *sepz = use_sep ? itp.sep : nullptr;
+            hipStream_t sm = s;   // main stream
+            if (fork && defer && !evg) {
+                (void)hipEventRecord(fork->ev_fork, s);
+                (void)hipStreamWaitEvent(fork->s2, fork->ev_fork, 0);
+                s = fork->s2;     // the two node kernels below run beside what follows them on the main stream
+            }
             if (lor)
                 CS_LAUNCH((k_cheb_nodes<false, true>), gridn, dim3(256), 0, s, itp.nodes, G.L, hot, hot32, G.nu.as<double>(), itp.iz,
                                    itp.nItot, q0, q_acc, kn, itp.Kpad, cut, itp.F, sepz, itp.xm);
@@ -816,6 +837,11 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
                 }
                 CS_LAUNCH(k_cheb_nodes_mx, dim3(nblk_mx), dim3(256), 0, s, itp.nodes, G.L, hot, itp.sep, itp.nItot, q0, nsplit, kn,
                                    itp.Kpad, ngrp, itp.F, itp.xm);
+            }
+            if (s != sm) {
+                (void)hipEventRecord(fork->ev_join, s);
+                fork->pending = true;
+                s = sm;
             }
             if (evg) (void)hipEventRecord(evg[2], s);
             ChebApply A0;
@@ -885,8 +911,9 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
         if (evg) (void)hipEventRecord(evg[4], s);
         if (use_edge)
         {
+            if (fuse) fork_join(fork, s);   // (it reads F)
             if (mx_big(nt64, kn, 1024))
-                CS_LAUNCH(k_voigt_edge_mx<1>, dim3((unsigned)((nt64 + 3) / 4), (unsigned)((kn + 15) / 16)), dim3(256), 0, s, dnu, nnu, G.L, hot, win,
+                CS_LAUNCH(k_voigt_edge_mx<1>, dim3((unsigned)(((nt64 + 3) / 4 + 7) / 8 * 8) * (unsigned)((kn + 15) / 16)), dim3(256), 0, s, dnu, nnu, G.L, hot, win,
                           itp.edge, nt64, kn, cut, sigma, fuse ? 1 : 0, Afuse, itp.Kpad);
             else   // short grid: four waves per (tile, group)
                 CS_LAUNCH(k_voigt_edge_mx<4>, dim3((unsigned)nt64, (unsigned)((kn + 15) / 16)), dim3(256), 0, s, dnu, nnu, G.L, hot, win,
@@ -977,7 +1004,10 @@ int cs_create(int device, cs_ctx **out)
     cs_ctx *c = new cs_ctx();
     c->device = device;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) { delete c; return fail(CS_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+    if (e != hipSuccess) { cs_destroy(c); return fail(CS_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     *out = c;
     return CS_OK;
 }
@@ -986,8 +1016,12 @@ void cs_destroy(cs_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipStreamDestroy(ctx->stream);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
@@ -2101,6 +2135,9 @@ static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e)
     ctx->ph.nu_lo = c.h_nu.front(); ctx->ph.nu_hi = c.h_nu.back();
     int n_itp = 0;
     for (auto &cg : c.gas) n_itp += cg.itp.nlev > 0 ? 1 : 0;
+    // cs_set_tuning key 3: node sums on a side stream -- 1: where the grid is short (fewer than 16384 (tile, state) waves), 2: always
+    Fork fk = {ctx->stream2, ctx->ev_fork, ctx->ev_join, false};
+    const bool use_fork = !ev && (ctx->tune[3] == 2 || (ctx->tune[3] == 1 && (c.nnu + 63) / 64 * (int64_t)K < 16384));
     for (int gi = 0; gi < (int)c.gas.size(); gi++) {
         ColGas &cg = c.gas[gi];
         const GasTable &G = *cg.tab;
@@ -2115,9 +2152,11 @@ static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e)
                    c.hot.as<LineHot>(), c.cold.as<LineCold>(), c.nu.as<double>(), c.nnu, c.ntile, cg.J0.as<int32_t>(),
                    cg.J1.as<int32_t>(), cg.win.as<WaveWin>(), cg.xtiles, cg.zones.as<Zone>(), c.ranges.as<int2>(), cg.gmax.as<double>(), cg.cut, c.sigma_gray, extra, sig, gi > 0,
                    ev ? ev + e : nullptr,
-                   (ctx->mixed && cg.shape == SH_VOIGT) ? ctx->hot32.as<LineF32>() : nullptr, ctx->far_s, itp, &apply, &ctx->ph);
+                   (ctx->mixed && cg.shape == SH_VOIGT) ? ctx->hot32.as<LineF32>() : nullptr, ctx->far_s, itp, &apply, &ctx->ph,
+                   use_fork ? &fk : nullptr);
         if (ev) { e += 6; HIPCHK(hipEventRecord(ev[e++], s)); }
     }
+    fork_join(&fk, s);
     // interpolated far wings of all gases: sigma += sum_level C (sum_gas F)  (one pass over C and sigma)
     if (apply.ngas > 0) launch_apply(s, apply, cheb_kpad(K), c.nnu, K, 0.0, nullptr, sig, 1);
     for (auto &t : c.tab) {  // baked gases: sigma += fC * exp(Phi(T, ln P))

@@ -1519,7 +1519,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 {
     __shared__ double part[SPLIT > 1 ? 4 : 1][SPLIT > 1 ? 16 : 1][SPLIT > 1 ? CS_MX_PITCH : 1];
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int tile = SPLIT > 1 ? (int)blockIdx.x : (int)blockIdx.x * 4 + wv, g = blockIdx.y;
+    // SPLIT == 1: 1-D grid, XCD-aware as k_cheb_apply_mfma -- the state groups of a block of four tiles go to the same XCD back to
+    // back (workgroups are dealt round-robin to the 8 XCDs), so that the block of C they all multiply by (fuse) leaves HBM once
+    int tile, g;
+    if (SPLIT > 1) {
+        tile = (int)blockIdx.x; g = (int)blockIdx.y;
+    } else {
+        const int ngrp = (K + 15) >> 4;
+        const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+        tile = ((q / ngrp) * 8 + xcd) * 4 + wv;
+        g = q % ngrp;
+    }
     if (tile >= ntile) return;   // (block-uniform when SPLIT > 1)
     const WaveWin w = win[tile];
     const EdgeZone e = edge[(size_t)g * ntile + tile];

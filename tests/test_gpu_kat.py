@@ -52,22 +52,26 @@ def test_exp_rt_vs_libm(cs, ctx):
 
 def test_planck_device_small_and_large_x(cs, O, ctx):
     rng = np.random.default_rng(12)
-    nu = 10.0 ** rng.uniform(-6, 6, 200000)
-    T = rng.uniform(25.0, 1000.0, nu.size)
-    got = cs.device_function("planck", nu, T, ctx=ctx)
-    with np.errstate(over="ignore"):
-        ref = np.array([O.planck(np.array([v]), t)[0] for v, t in zip(nu[:2000], T[:2000])])
-        K = cs.constants
+    K = cs.constants
+    worst_small = 0.0
+    nsmall = 0
+    for T in np.concatenate([[25.0, 1000.0], rng.uniform(25.0, 1000.0, 48)]):
+        nu = 10.0 ** rng.uniform(-6, 6, 4000)
+        got = cs.device_function("planck", nu, T, ctx=ctx)
+        with np.errstate(over="ignore"):
+            ref = O.planck(nu, float(T))                       # the oracle: libm exp, the reference's formula (radiation.jl:48-54)
         x = K.h * K.c * 100.0 * nu / (K.k * T)
-        formula = 100.0 * (2 * K.h * K.c ** 2 * (100.0 * nu) ** 3) / (np.exp(x) - 1.0)
-    assert np.allclose(formula[:2000], ref, rtol=1e-13, atol=0.0)       # the numpy form used below IS the oracle's
-    # exp(x) - 1 at small x: a 2-ulp difference of exp is 2 * 2^-52 / x relative in the difference; elsewhere 1e-15
-    tol = 4.0 * 2.0 ** -52 / np.minimum(x, 1.0) + 2e-15
-    ok = formula > 0
-    assert np.all(np.abs(got[ok] - formula[ok]) <= tol[ok] * formula[ok])
-    assert np.all(got[~ok] == 0.0)                                       # exp overflow: B = 0 on both sides
-    small = x < 1e-6
-    assert small.sum() > 1000 and np.max(np.abs(got[small] / formula[small] - 1)) < 1e-8
+        # exp(x) - 1 at small x: a 2-ulp difference of exp is 2 * 2^-52 / x relative in the difference (both sides form it the
+        # reference's way); elsewhere a few ulp
+        tol = 4.0 * 2.0 ** -52 / np.minimum(x, 1.0) + 2e-15
+        ok = ref > 0
+        assert np.all(np.abs(got[ok] - ref[ok]) <= tol[ok] * ref[ok])
+        assert np.all(got[~ok] == 0.0)                         # exp overflow: B = 0 on both sides
+        small = x < 1e-6
+        nsmall += int(small.sum())
+        if small.any():
+            worst_small = max(worst_small, float(np.max(np.abs(got[small] / ref[small] - 1))))
+    assert nsmall > 1000 and worst_small < 1e-8                # Rayleigh-Jeans end: still 8 digits, as the reference's own form gives
 
 
 def test_layerplanck_device(cs, ctx):
