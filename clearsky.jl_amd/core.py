@@ -257,8 +257,8 @@ class Context:
         check(lib().cs_set_merge(self._h, int(bool(on))))
 
     def set_tuning(self, key: int, value: int):
-        """A/B switches (cs_set_tuning): 0 = XCD-contiguous block order of the node kernels, 1 = interpolated wings applied inside
-        k_voigt_edge_mx"""
+        """A/B switches (cs_set_tuning): 0 = interpolated wings applied inside k_voigt_edge_mx, 1 = matrix-core kernels on short
+        grids, 2 = node sums on a side stream (include/clearsky_hip.h)"""
         check(lib().cs_set_tuning(self._h, int(key), int(value)))
 
     def slot_of(self, sl: SpectralLines) -> int:

@@ -160,7 +160,7 @@ struct ChebGrid {
     DevBuf Cm[CS_MAX_LEVEL];    // [nI][64][itv]
 };
 // per gas on that grid: windows per level, zones [K][nItot], node sums F [nItot][64][Kpad]
-struct GasInterp { int nlev = 0, l0 = 0; DevBuf iwin[CS_MAX_LEVEL], iz, F, sep, edge; XMap xm = {}; };   // levels l0 .. nlev-1 of the grid are in use; sep: SepZone [K/16][nItot]
+struct GasInterp { int nlev = 0, l0 = 0; DevBuf iwin[CS_MAX_LEVEL], iz, F, sep, edge; };   // levels l0 .. nlev-1 of the grid are in use; sep: SepZone [K/16][nItot]
                                                                                           // (matrix-core node sums), edge: EdgeZone [K/16][tiles] (matrix-core pieces of the per-point sum)
 
 // a gas of the column as the caller named it (conc is laid out [ngas, K] over these)
@@ -224,7 +224,7 @@ struct cs_ctx {
     PhScratch ph;
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;            // side stream of short grids: node sums beside the per-point kernels (cs_set_tuning key 3)
+    hipStream_t stream2 = nullptr;            // side stream of short grids: node sums beside the per-point kernels (cs_set_tuning key 2)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     GasTable gas[CS_MAX_GAS];
     TableDev tab[CS_MAX_TABLE];
@@ -237,9 +237,9 @@ struct cs_ctx {
     int matrix_nodes = 1;   // cs_set_matrix_cores: separable far-wing node sums on v_mfma_f64 (k_cheb_nodes_mx)
     int matrix_core = 1;    // ... and the window core on sub-tiles (k_voigt_sub + the second mask of k_voigt_edge_mx)
     int merge = 1;          // cs_set_merge: gases of a column with the same shape and cut-off share one merged line table
-    // cs_set_tuning: [0] XCD-contiguous block order of the node kernels, [1] interpolated wings applied inside k_voigt_edge_mx where one
-    // launch group has them, [2] matrix-core kernels on short grids (four waves per item), [3] node sums on a side stream (1: short grids)
-    int tune[CS_NTUNE] = {0, 0, 1, 1, 0, 0, 0, 0};
+    // cs_set_tuning: [0] interpolated wings applied inside k_voigt_edge_mx where one launch group has them, [1] matrix-core kernels on
+    // short grids (four waves per item), [2] node sums on a side stream (1: short grids only, 2: always)
+    int tune[CS_NTUNE] = {0, 1, 2, 0, 0, 0, 0, 0};
     std::vector<std::unique_ptr<GasTable>> merged;   // merged tables (keyed by their members' (slot, generation)), a few kept
     double far_s = 1e6;
     DevBuf hot32;
@@ -519,8 +519,7 @@ struct Interp {
     EdgeZone *edge = nullptr; // NULL: all of the per-point sum on the vector unit
     bool sep_always = false;  // cs_set_matrix_cores(ctx, 2): also on grids too short to fill the chip with (interval, state group) blocks
     bool core = true;         // cs_set_matrix_cores(ctx, on | 4) switches the sub-tile treatment of the window core (k_voigt_sub) off
-    XMap xm = {};             // block order of the node kernels (xm.on = 0: interval-major)
-    bool small_mx = false;    // cs_set_tuning key 2: the matrix-core kernels on short grids too (their four-waves-per-item variants)
+    bool small_mx = false;    // cs_set_tuning key 1: the matrix-core kernels on short grids too (their four-waves-per-item variants)
     bool fuse_apply = false;  // the column's only interpolating group: k_voigt_edge_mx may carry the node sums to the grid itself
     double core4 = 0.0;       // the core takes the 4-term series where its radius is below core4 x the tile's span, else the 8-term one
                               // (0: always the 8-term one -- measured at C3 with 0.75 / 0.3 / 0: 2.61 / 2.55 / 2.52 ms)
@@ -601,29 +600,11 @@ int gas_interp_build(const cs_ctx *ctx, GasInterp &gi, ChebGrid &g, const std::v
         if (ctx->itp_first >= 0) gi.l0 = std::min(ctx->itp_first, g.nlev);
         if (gi.l0 >= g.nlev) { gi.nlev = 0; gi.l0 = 0; return CS_OK; }   // too few lines: every pair directly
     }
-    memset(&gi.xm, 0, sizeof gi.xm);
-    gi.xm.on = ctx->tune[0] ? 1 : 0;
-    gi.xm.l0 = gi.l0;
-    gi.xm.nlev = g.nlev;
     for (int l = 0; l < g.nlev; l++) {
         std::vector<WaveWin> iwin;
         wave_windows(nul, g0, g1, nu, nnu, cut, iwin, g.itv[l]);
         if ((rc = upload(gi.iwin[l], iwin.data(), iwin.size(), s))) return rc;
         HIPCHK(hipStreamSynchronize(s));   // iwin is a local
-        // one contiguous stretch of the level's intervals per XCD, cut at equal sums of (lines inside every point's cut-off + 8)
-        const int nI = g.nI[l];
-        std::vector<int64_t> cum(nI + 1, 0);
-        for (int T = 0; T < nI; T++) cum[T + 1] = cum[T] + (iwin[T].E1 - iwin[T].E0) + 8;
-        gi.xm.ioff[l] = g.ioff[l];
-        gi.xm.cnt[l] = 0;
-        for (int x = 0; x <= 8; x++) {
-            const int64_t target = cum[nI] * x / 8;
-            gi.xm.xb[l][x] = x == 8 ? nI : (int)(std::lower_bound(cum.begin(), cum.end(), target) - cum.begin());
-            if (x > 0) {
-                gi.xm.xb[l][x] = std::max(gi.xm.xb[l][x], gi.xm.xb[l][x - 1]);
-                gi.xm.cnt[l] = std::max(gi.xm.cnt[l], gi.xm.xb[l][x] - gi.xm.xb[l][x - 1]);
-            }
-        }
     }
     HIPCHK(gi.iz.reserve((size_t)K * g.nItot * sizeof(IZone)));
     HIPCHK(gi.sep.reserve((size_t)((K + 15) / 16) * g.nItot * sizeof(SepZone)));
@@ -647,7 +628,6 @@ Interp interp_view(const ChebGrid &g, const GasInterp &gi, int K, IZone *iz_over
     v.F = gi.F.as<double>();
     v.sep = gi.sep.as<SepZone>();
     v.edge = gi.edge.as<EdgeZone>();
-    v.xm = gi.xm;
     for (int l = 0; l < gi.nlev; l++) {
         v.itv[l] = g.itv[l]; v.nI[l] = g.nI[l]; v.ioff[l] = g.ioff[l];
         v.Cm[l] = g.Cm[l].as<double>();
@@ -712,7 +692,7 @@ constexpr int CS_EDGE_DENS = 4;
 // blocks to fill the chip -- on a short grid (a nu-shard) the one-state-per-wave vector kernel has the shorter critical path
 // (1/8 of C3: 0.17 vs 0.25 ms)
 static bool mx_big(int nblocks, int kn, int min_blocks) { return (int64_t)nblocks * ((kn + 15) / 16) >= min_blocks; }
-// `small`: cs_set_tuning key 2 -- short grids too, through the variants that share one (interval | tile, group) between the four
+// `small`: cs_set_tuning key 1 -- short grids too, through the variants that share one (interval | tile, group) between the four
 // waves of a block (k_cheb_nodes_mx with every level split, k_voigt_edge_mx<4>)
 static bool sep_in_use(bool have_sep, bool always, int nblocks_intervals, int kn, bool lor, bool mixed, bool small = false)
 {
@@ -785,9 +765,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
             const int q0 = itp.ioff[itp.l0];
             // deferred apply: the gases of a column add their node sums into ONE F (levels an earlier gas has written accumulate)
             const int q_acc = (defer && defer->ngas > 0 && defer->l0[0] < itp.nlev) ? itp.ioff[defer->l0[0]] : itp.nItot;
-            int xcnt = 0;   // XCD-contiguous block order: intervals per XCD, summed over the levels in use
-            for (int l = itp.l0; l < itp.nlev; l++) xcnt += itp.xm.cnt[l];
-            const dim3 gridn(itp.xm.on ? (unsigned)((kn + 3) / 4) * 8u * (unsigned)xcnt : (unsigned)((kn + 3) / 4) * (unsigned)(itp.nItot - q0));
+            const dim3 gridn((unsigned)((kn + 3) / 4) * (unsigned)(itp.nItot - q0));
             const int ngrp = (kn + 15) / 16;
             const bool use_sep = sep_in_use(itp.sep != nullptr, itp.sep_always, itp.nItot - q0, kn, lor, hot32 != nullptr, itp.small_mx);
             use_edge = edge_in_use(itp.edge != nullptr, itp.sep_always, nt64, kn, lor, hot32 != nullptr, jhi - jlo, itp.small_mx);
@@ -817,26 +795,22 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
             }
             if (lor)
                 CS_LAUNCH((k_cheb_nodes<false, true>), gridn, dim3(256), 0, s, itp.nodes, G.L, hot, hot32, G.nu.as<double>(), itp.iz,
-                                   itp.nItot, q0, q_acc, kn, itp.Kpad, cut, itp.F, sepz, itp.xm);
+                                   itp.nItot, q0, q_acc, kn, itp.Kpad, cut, itp.F, sepz);
             else if (hot32)
                 CS_LAUNCH((k_cheb_nodes<true, false>), gridn, dim3(256), 0, s, itp.nodes, G.L, hot, hot32, G.nu.as<double>(), itp.iz,
-                                   itp.nItot, q0, q_acc, kn, itp.Kpad, cut, itp.F, sepz, itp.xm);
+                                   itp.nItot, q0, q_acc, kn, itp.Kpad, cut, itp.F, sepz);
             else
                 CS_LAUNCH((k_cheb_nodes<false, false>), gridn, dim3(256), 0, s, itp.nodes, G.L, hot, hot32, G.nu.as<double>(), itp.iz,
-                                   itp.nItot, q0, q_acc, kn, itp.Kpad, cut, itp.F, sepz, itp.xm);
+                                   itp.nItot, q0, q_acc, kn, itp.Kpad, cut, itp.F, sepz);
             if (evg) (void)hipEventRecord(evg[1], s);
             if (use_sep) {
                 const int nq = itp.nItot - q0;
                 // the largest interval size in use is shared by the four waves of a block (all sizes if it is the only one, or on a grid
                 // too short to fill the chip with one (interval, group) per wave)
                 const int nsplit = (itp.nlev - itp.l0 > 1 && mx_big(nq, kn, 2048)) ? itp.nI[itp.l0] : nq;
-                unsigned nblk_mx = (unsigned)(nsplit * ngrp) + (unsigned)(((int64_t)(nq - nsplit) * ngrp + 3) / 4);
-                if (itp.xm.on) {
-                    const int c0 = nsplit == nq ? xcnt : itp.xm.cnt[itp.l0];
-                    nblk_mx = 8u * (unsigned)(c0 * ngrp) + 8u * (unsigned)(((int64_t)(xcnt - c0) * ngrp + 3) / 4);
-                }
+                const unsigned nblk_mx = (unsigned)(nsplit * ngrp) + (unsigned)(((int64_t)(nq - nsplit) * ngrp + 3) / 4);
                 CS_LAUNCH(k_cheb_nodes_mx, dim3(nblk_mx), dim3(256), 0, s, itp.nodes, G.L, hot, itp.sep, itp.nItot, q0, nsplit, kn,
-                                   itp.Kpad, ngrp, itp.F, itp.xm);
+                                   itp.Kpad, ngrp, itp.F);
             }
             if (s != sm) {
                 (void)hipEventRecord(fork->ev_join, s);
@@ -913,7 +887,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
         {
             if (fuse) fork_join(fork, s);   // (it reads F)
             if (mx_big(nt64, kn, 1024))
-                CS_LAUNCH(k_voigt_edge_mx<1>, dim3((unsigned)(((nt64 + 3) / 4 + 7) / 8 * 8) * (unsigned)((kn + 15) / 16)), dim3(256), 0, s, dnu, nnu, G.L, hot, win,
+                CS_LAUNCH(k_voigt_edge_mx<1>, dim3((unsigned)((nt64 + 3) / 4), (unsigned)((kn + 15) / 16)), dim3(256), 0, s, dnu, nnu, G.L, hot, win,
                           itp.edge, nt64, kn, cut, sigma, fuse ? 1 : 0, Afuse, itp.Kpad);
             else   // short grid: four waves per (tile, group)
                 CS_LAUNCH(k_voigt_edge_mx<4>, dim3((unsigned)nt64, (unsigned)((kn + 15) / 16)), dim3(256), 0, s, dnu, nnu, G.L, hot, win,
@@ -1185,7 +1159,7 @@ int cs_set_merge(cs_ctx *ctx, int on)
 
 static int interp_key(const cs_ctx *ctx)
 {
-    return (ctx->tune[0] ? 65536 : 0) + ctx->interp * 4096 + (ctx->itp_first + 1) * 256 + (ctx->itp_min >> 7) * 16 + (ctx->itp_max >> 7);
+    return ctx->interp * 4096 + (ctx->itp_first + 1) * 256 + (ctx->itp_min >> 7) * 16 + (ctx->itp_max >> 7);
 }
 
 int cs_set_tuning(cs_ctx *ctx, int key, int value)
@@ -1275,7 +1249,7 @@ static int shape_impl(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t 
         itp = interp_view(cheb, ginterp, kc);
         if (!ctx->matrix_nodes) itp.sep = nullptr, itp.edge = nullptr;
         itp.sep_always = ctx->matrix_nodes == 2;
-        itp.small_mx = ctx->tune[2] != 0;
+        itp.small_mx = ctx->tune[1] != 0;
         itp.core = ctx->matrix_core != 0;
     }
     for (int k0 = 0; k0 < K; k0 += kc) {
@@ -1357,7 +1331,7 @@ int cs_bake(cs_ctx *ctx, int gas_slot, int table_slot, int shape, double dnu_cut
         itp = interp_view(cheb, ginterp, kc);
         if (!ctx->matrix_nodes) itp.sep = nullptr, itp.edge = nullptr;
         itp.sep_always = ctx->matrix_nodes == 2;
-        itp.small_mx = ctx->tune[2] != 0;
+        itp.small_mx = ctx->tune[1] != 0;
         itp.core = ctx->matrix_core != 0;
     }
     for (int k0 = 0; k0 < M; k0 += kc) {
@@ -2039,7 +2013,7 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
             itp.sep = ctx->matrix_nodes ? dsep.as<SepZone>() : nullptr;
             itp.edge = ctx->matrix_nodes ? dedge.as<EdgeZone>() : nullptr;
             itp.sep_always = ctx->matrix_nodes == 2;
-            itp.small_mx = ctx->tune[2] != 0;
+            itp.small_mx = ctx->tune[1] != 0;
             itp.core = ctx->matrix_core != 0;
         }
         for (int64_t k0 = 0; k0 < BK; k0 += kc) {
@@ -2135,9 +2109,9 @@ static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e)
     ctx->ph.nu_lo = c.h_nu.front(); ctx->ph.nu_hi = c.h_nu.back();
     int n_itp = 0;
     for (auto &cg : c.gas) n_itp += cg.itp.nlev > 0 ? 1 : 0;
-    // cs_set_tuning key 3: node sums on a side stream -- 1: where the grid is short (fewer than 16384 (tile, state) waves), 2: always
+    // cs_set_tuning key 2: node sums on a side stream -- 1: where the grid is short (fewer than 16384 (tile, state) waves), 2: always
     Fork fk = {ctx->stream2, ctx->ev_fork, ctx->ev_join, false};
-    const bool use_fork = !ev && (ctx->tune[3] == 2 || (ctx->tune[3] == 1 && (c.nnu + 63) / 64 * (int64_t)K < 16384));
+    const bool use_fork = !ev && (ctx->tune[2] == 2 || (ctx->tune[2] == 1 && (c.nnu + 63) / 64 * (int64_t)K < 16384));
     for (int gi = 0; gi < (int)c.gas.size(); gi++) {
         ColGas &cg = c.gas[gi];
         const GasTable &G = *cg.tab;
@@ -2145,9 +2119,9 @@ static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e)
         itp.F = c.chebF.as<double>();
         if (!ctx->matrix_nodes) itp.sep = nullptr, itp.edge = nullptr;
         itp.sep_always = ctx->matrix_nodes == 2;
-        itp.small_mx = ctx->tune[2] != 0;
+        itp.small_mx = ctx->tune[1] != 0;
         itp.core = ctx->matrix_core != 0;
-        itp.fuse_apply = ctx->tune[1] != 0 && n_itp == 1;
+        itp.fuse_apply = ctx->tune[0] != 0 && n_itp == 1;
         launch_gas(s, cg.shape, G, cg.jlo, cg.jhi, K, c.Tk.as<double>(), c.Pk.as<double>(), cg.Pp.as<double>(), cg.conc.as<double>(), K,
                    c.hot.as<LineHot>(), c.cold.as<LineCold>(), c.nu.as<double>(), c.nnu, c.ntile, cg.J0.as<int32_t>(),
                    cg.J1.as<int32_t>(), cg.win.as<WaveWin>(), cg.xtiles, cg.zones.as<Zone>(), c.ranges.as<int2>(), cg.gmax.as<double>(), cg.cut, c.sigma_gray, extra, sig, gi > 0,
@@ -2374,7 +2348,7 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
             iz.resize((size_t)K * nItot);
             HIPCHK(hipMemcpy(iz.data(), g.itp.iz.p, iz.size() * sizeof(IZone), hipMemcpyDeviceToHost));
             const int q0 = c.cheb.ioff[g.itp.l0];
-            const bool use_sep = sep_in_use(ctx->matrix_nodes != 0, ctx->matrix_nodes == 2, nItot - q0, K, g.shape != SH_VOIGT, ctx->mixed != 0, ctx->tune[2] != 0);
+            const bool use_sep = sep_in_use(ctx->matrix_nodes != 0, ctx->matrix_nodes == 2, nItot - q0, K, g.shape != SH_VOIGT, ctx->mixed != 0, ctx->tune[1] != 0);
             std::vector<SepZone> sz;
             if (use_sep) {
                 sz.resize((size_t)((K + 15) / 16) * nItot);
@@ -2409,7 +2383,7 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
         }
         if (nlev > 0) {
             const int q0 = c.cheb.ioff[g.itp.l0];
-            if (sep_in_use(ctx->matrix_nodes != 0, ctx->matrix_nodes == 2, nItot - q0, K, g.shape != SH_VOIGT, ctx->mixed != 0, ctx->tune[2] != 0)) {
+            if (sep_in_use(ctx->matrix_nodes != 0, ctx->matrix_nodes == 2, nItot - q0, K, g.shape != SH_VOIGT, ctx->mixed != 0, ctx->tune[1] != 0)) {
                 std::vector<SepZone> sz((size_t)((K + 15) / 16) * nItot);
                 HIPCHK(hipMemcpy(sz.data(), g.itp.sep.p, sz.size() * sizeof(SepZone), hipMemcpyDeviceToHost));
                 for (int gq = 0; gq < (K + 15) / 16; gq++) {
@@ -2429,7 +2403,7 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
         int ishift = 0;
         if (nlev > 0) for (int r = c.cheb.itv[nlev - 1] / 64; r > 1; r >>= 1) ishift++;
         const bool use_edge = nlev > 0 && edge_in_use(ctx->matrix_nodes != 0, ctx->matrix_nodes == 2, nt64, K, g.shape != SH_VOIGT, ctx->mixed != 0,
-                                                      std::max<int64_t>(g.jhi - g.jlo, 0), ctx->tune[2] != 0);
+                                                      std::max<int64_t>(g.jhi - g.jlo, 0), ctx->tune[1] != 0);
         std::vector<EdgeZone> ez;
         if (use_edge) {
             ez.resize((size_t)((K + 15) / 16) * nt64);

@@ -496,7 +496,6 @@ __device__ __forceinline__ int tile_block(const int32_t *__restrict__ xc, int ti
 // max(dA, 0.3 h) and the cut-off edges are left to the next smaller interval size, and finally to the per-point kernels.
 #define CS_NC 64
 #define CS_MAX_LEVEL 5
-#define CS_MAX_LEVEL_ 5
 constexpr double kChebMargin = 0.3;
 // per (state, interval): own set = [E0,Z0) U [Z1,E1), cut into the 2-/3-/4-term zones of the far body; [P0,P1) and [P2,P3)
 // is the part of it the parent interval (next level up) has already summed.
@@ -656,29 +655,6 @@ __global__ __launch_bounds__(256) void k_gas_setup(unsigned nb_prep, unsigned nb
     else prep_body(blockIdx.x - nb_zones - nb_iz, pa);
 }
 
-// Block order of the node kernels.  Workgroups are dealt round-robin to the 8 XCDs (private L2 each), and neighbouring intervals
-// of a level share most of their lines (a window of +-cut against an interval a quarter of that wide): with interval-major block
-// order the ~5 intervals that read a record sit on 5 different XCDs and each fetches it from the fabric (FETCH_SIZE 2.2-2.5x the
-// unique records, profiles/r02_pmc_*).  XMap gives XCD x one contiguous stretch of every level's intervals, [xb[l][x], xb[l][x+1]),
-// cut on the host at equal sums of window sizes (line density varies along a spectrum); cnt[l] = the longest stretch of level l
-// (grid size).  Speed/traffic only: any placement is correct.
-struct XMap {
-    int on, l0, nlev;
-    int cnt[CS_MAX_LEVEL_], ioff[CS_MAX_LEVEL_], xb[CS_MAX_LEVEL_][9];
-};
-// item `it` of XCD x among the levels lfirst .. llast-1 -> index in the concatenated interval list, or -1 (past the XCD's stretch)
-__device__ __forceinline__ int xmap_interval(const XMap &m, int lfirst, int llast, int x, int it)
-{
-    for (int l = lfirst; l < llast; l++) {
-        if (it < m.cnt[l]) {
-            const int T = m.xb[l][x] + it;
-            return T < m.xb[l][x + 1] ? m.ioff[l] + T : -1;
-        }
-        it -= m.cnt[l];
-    }
-    return -1;
-}
-
 // one wave = the 64 Chebyshev nodes of one interval x one node state: far-wing sums at the nodes -> F[interval][node][state].
 // All levels run in one launch over the concatenated interval list (largest intervals, i.e. longest waves, first).
 #define CS_KPAD 16   // F rows are padded to a multiple of 16 states (k_cheb_apply reads 16 at a time with scalar loads)
@@ -747,7 +723,7 @@ template <bool MIXED, bool LOR>
 __global__ __launch_bounds__(256) void k_cheb_nodes(const double *__restrict__ nodes, int64_t L, const LineHot *__restrict__ hot,
                                                      const LineF32 *__restrict__ hot32, const double *__restrict__ gnul,
                                                      const IZone *__restrict__ iz, int nItot, int q0, int q_acc, int K, int Kpad, double cut,
-                                                     double *__restrict__ F, const SepZone *__restrict__ sep, XMap xm)
+                                                     double *__restrict__ F, const SepZone *__restrict__ sep)
 {
     // q_acc: intervals >= q_acc already hold the node sums of earlier gases of the column -- add to them.  The interpolation
     // is linear, so k_cheb_apply then carries the SUM over gases to the grid in one pass per level instead of one per (gas, level).
@@ -755,18 +731,13 @@ __global__ __launch_bounds__(256) void k_cheb_nodes(const double *__restrict__ n
     // intervals q0 .. nItot-1 (the levels this gas uses)
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int nsb = (K + 3) >> 2;
-    int T, k;
-    if (xm.on) {   // XCD x walks its own stretch of every level, all state blocks of an interval back to back
-        const int x = blockIdx.x & 7, r = blockIdx.x >> 3;
-        T = xmap_interval(xm, xm.l0, xm.nlev, x, r / nsb);
-        if (T < 0) return;
-        k = (r % nsb) * 4 + wv;
-    } else {
-        T = q0 + (int)(blockIdx.x / nsb);
-        // state block rotated by the interval: workgroups go round-robin to the 8 XCDs, and with the matrix cores taking most far lines
-        // of the low-pressure states the work left here sits in the last state blocks -- unrotated, on half of the XCDs
-        k = (int)((blockIdx.x % nsb + (sep ? T : 0)) % nsb) * 4 + wv;   // (unrotated, a state block stays on one XCD: its records stay in that L2)
-    }
+    const int T = q0 + (int)(blockIdx.x / nsb);
+    // state block rotated by the interval: workgroups go round-robin to the 8 XCDs, and with the matrix cores taking most far lines
+    // of the low-pressure states the work left here sits in the last state blocks -- unrotated, on half of the XCDs.
+    // (Tried in round 3: one contiguous stretch of every level's intervals per XCD, cut at equal sums of window sizes, so that the ~5
+    // neighbouring intervals that read a record share an L2 -- FETCH_SIZE 336 -> 291 MB here, 470 -> 448 MB in k_cheb_nodes_mx, but
+    // 0.37 -> 0.43 ms: the in-flight footprint of an XCD's blocks is several times its 4 MB L2 either way, profiles/r03_notes.md.)
+    const int k = (int)((blockIdx.x % nsb + (sep ? T : 0)) % nsb) * 4 + wv;   // (unrotated, a state block stays on one XCD: its records stay in that L2)
     if (k >= K) return;
     const LineHot *__restrict__ hk = hot + (size_t)k * L;
     const LineF32 *__restrict__ hf = MIXED ? hot32 + (size_t)k * L : nullptr;
@@ -945,33 +916,16 @@ __device__ __forceinline__ void sepzones_body(unsigned bid, const SepArgs &a)
 // this kernel's registers and LDS allow four: 0.94 ms for a quarter of the vector work, profiles/r02_notes.md.)
 __global__ __launch_bounds__(256) void k_cheb_nodes_mx(const double *__restrict__ nodes, int64_t L, const LineHot *__restrict__ hot,
                                                        const SepZone *__restrict__ sep, int nItot, int q0, int nsplit, int K, int Kpad,
-                                                       int ngrp, double *__restrict__ F, XMap xm)
+                                                       int ngrp, double *__restrict__ F)
 {
     // the first nsplit intervals (the largest interval size in use: several hundred lines per piece) are shared by the four waves
     // of a block as described; the rest (a few dozen lines, ~10 steps) go one (interval, group) per wave -- no LDS, no barrier
     __shared__ double part[4][16][CS_MX_PITCH];
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int nb_split = xm.on ? 8 * (nsplit == nItot - q0 ? 0 : xm.cnt[xm.l0]) * ngrp : nsplit * ngrp;   // (xm: nsplit = the first level in use, or everything)
-    int nb_split_all = nb_split;
-    if (xm.on && nsplit == nItot - q0) {   // one level only, or every level shared by four waves: all blocks are "split" blocks
-        int c = 0;
-        for (int l = xm.l0; l < xm.nlev; l++) c += xm.cnt[l];
-        nb_split_all = 8 * c * ngrp;
-    }
-    const bool split = (int)blockIdx.x < nb_split_all;   // (block-uniform)
+    const int nb_split = nsplit * ngrp;
+    const bool split = (int)blockIdx.x < nb_split;   // (block-uniform)
     int T, g;
-    if (xm.on) {
-        if (split) {
-            const int x = blockIdx.x & 7, r = blockIdx.x >> 3;
-            T = xmap_interval(xm, xm.l0, nsplit == nItot - q0 ? xm.nlev : xm.l0 + 1, x, r / ngrp);
-            g = r % ngrp;
-        } else {
-            const int b = (int)blockIdx.x - nb_split_all;
-            const int x = b & 7, item = (b >> 3) * 4 + wv;
-            T = xmap_interval(xm, xm.l0 + 1, xm.nlev, x, item / ngrp);
-            g = item % ngrp;
-        }
-    } else if (split) {
+    if (split) {
         T = q0 + (int)(blockIdx.x / ngrp);
         g = (int)((blockIdx.x % ngrp + T) % ngrp);   // (rotated: the groups differ in work and would alias with the XCD round-robin)
     } else {
@@ -980,7 +934,6 @@ __global__ __launch_bounds__(256) void k_cheb_nodes_mx(const double *__restrict_
         T = q0 + item / ngrp;
         g = item % ngrp;
     }
-    if (T < 0) return;   // past the XCD's stretch (block-uniform for split blocks: no wave is left waiting at the barrier below)
     const SepZone z = sep[(size_t)g * nItot + T];
     if (!(z.b[0] > z.a[0] || z.b[1] > z.a[1] || z.b[2] > z.a[2] || z.b[3] > z.a[3])) return;   // (uniform per block when split, else per wave)
     {
@@ -1519,17 +1472,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 {
     __shared__ double part[SPLIT > 1 ? 4 : 1][SPLIT > 1 ? 16 : 1][SPLIT > 1 ? CS_MX_PITCH : 1];
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    // SPLIT == 1: 1-D grid, XCD-aware as k_cheb_apply_mfma -- the state groups of a block of four tiles go to the same XCD back to
-    // back (workgroups are dealt round-robin to the 8 XCDs), so that the block of C they all multiply by (fuse) leaves HBM once
-    int tile, g;
-    if (SPLIT > 1) {
-        tile = (int)blockIdx.x; g = (int)blockIdx.y;
-    } else {
-        const int ngrp = (K + 15) >> 4;
-        const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-        tile = ((q / ngrp) * 8 + xcd) * 4 + wv;
-        g = q % ngrp;
-    }
+    // (2-D grid, tile blocks fastest: consecutive blocks are neighbouring tiles of ONE state group, whose pieces overlap by half --
+    // the XCD-aware 1-D order of k_cheb_apply_mfma, all groups of a tile block back to back on one XCD, costs 0.43 -> 0.57 ms at C3)
+    const int tile = SPLIT > 1 ? (int)blockIdx.x : (int)blockIdx.x * 4 + wv, g = blockIdx.y;
     if (tile >= ntile) return;   // (block-uniform when SPLIT > 1)
     const WaveWin w = win[tile];
     const EdgeZone e = edge[(size_t)g * ntile + tile];

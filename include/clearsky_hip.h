@@ -106,14 +106,12 @@ int cs_set_matrix_cores(cs_ctx *ctx, int on);
 int cs_set_merge(cs_ctx *ctx, int on);
 
 /* Tuning switches for A/B measurements (results do not depend on them beyond rounding; defaults from profiles/r03_notes.md):
- *   key 0: block order of the node kernels -- 0 (default) interval-major, 1 one contiguous stretch of every interval level per XCD
- *          (fewer record fetches, but slower);
- *   key 1: the interpolated far wings are carried to the grid inside k_voigt_edge_mx where the column has one launch group
- *          (1), or always by their own launch (0, default);
- *   key 2: the matrix-core kernels also on grids too short to fill the chip with one (interval | tile, state group) per wave, through
+ *   key 0: the interpolated far wings are carried to the grid inside k_voigt_edge_mx where the column has one launch group (1), or
+ *          by their own launch (0, default: one launch more, the same time at C3, less with five interval levels);
+ *   key 1: the matrix-core kernels also on grids too short to fill the chip with one (interval | tile, state group) per wave, through
  *          their four-waves-per-item variants (1, default; 0: such grids stay on the vector unit);
- *   key 3: the node sums of a launch group run on a side stream beside its per-point kernels -- 1 (default) on short grids (fewer
- *          than 16384 (tile, state) waves: a nu-shard), 2 always, 0 never.
+ *   key 2: the node sums of a launch group run on a side stream beside its per-point kernels -- 2 (default) always, 1 on short
+ *          grids only (fewer than 16384 (tile, state) waves: a nu-shard), 0 never.
  * Applies to every later cs_column_setup / cs_column_run of the context. */
 int cs_set_tuning(cs_ctx *ctx, int key, int value);
 
