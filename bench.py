@@ -23,15 +23,17 @@ import numpy as np
 _ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, _ROOT)
 
-# flops of one far-wing Voigt term in k_voigt_far: 14 fp64 VALU instructions (ISA count, mode 0/1 mix), FMAs = 2 flops
-FLOPS_PER_PAIR = 24.0
 # VALU instructions per (lane, line) of each loop body, counted in the gfx950 ISA of k_voigt_far / k_cheb_nodes (hipcc -S, loops
 # unrolled by 4: 52/68/64/80/96/148 per four lines; profiles/r02_notes.md).  The 2-/3-/4-term far-wing bodies are the same
 # instructions in both kernels; "_cut" adds the cut-off compare + select (and |dnu|).
 VALU_PER_LINE = dict(t2=13, t2_cut=17, t3=16, t3_cut=20, t4=20, t4_cut=24, near_zone=37)
+# k_voigt_near, per (nu, line, state) pair: the evaluation block of the ISA (basic block of the trip loop: 64 VALU in tier 0, 407 in
+# tier 1) + 41 for the queue write, the record fetch of the next trip and the ordered per-lane sum (profiles/r03_notes.md)
+VALU_NEAR = dict(tier0_eval=64, tier1_eval=407, per_candidate=41)
 VALU_ISSUE_PEAK = 256 * 4 * 16 * 2.4e9     # fp64-rate lane-instructions per second: 256 CU x 4 SIMD x 16 lanes x 2.4 GHz
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md: the fp64 matrix path has the vector unit's peak on this part
 
 
 def source_stamp():
@@ -164,113 +166,125 @@ def main():
     Fh = F.cpu().numpy()
     olr = float(Fh[0])
 
-    # per-kernel HIP-event timing on the launch stream (rank-local) and the roofline of the dominant kernel
+    # per-kernel HIP-event timing on the launch stream (rank-local) and the roofline of every line-stage kernel class
+    # (cs_column_profile runs the step on ONE stream with events between the classes; the timed loop above overlaps the node
+    # kernels with the per-point ones on a side stream, so the classes add up to a little more than ms_per_step)
     prof = col.profile(reps=max(3, min(10, args.steps)), stream=stream)
     cnt = col.counts()
     info = col.info()
-    ngas = max(int(info["groups"]), 1)     # launch sets per step: the gases of a column that share a cut-off run as ONE merged table
+    ngrp = max(int(info["groups"]), 1)     # launch sets per step: the gases of a column that share a cut-off run as ONE merged table
     K = col.K
     lines_total = sum(len(g.sl.nu) for g in col.gases)
-    # k_voigt_far (one launch per gas), the longest kernel.  Algorithmic HBM bytes per launch: sigma written
-    # (8 B per (nu, node)) and re-read when it accumulates (a later gas, or onto the interpolated far wings) + nu, and for the states
-    # whose window core is not k_voigt_sub's (K_far of K on average): the 32-B record of every (node, line) read once + the 8-B near-line
-    # index words handed to k_voigt_near per (nu, node).
     work = col.work()
     interp_on = work["levels"] > 0
     nt64 = (col.nnu + 63) // 64
-    K_far = K - work.get("core_tile_states", 0) / max(ngas, 1) / nt64
-    far_bytes = [32 * K_far * lines_total / ngas + 8 * col.nnu * K * (2 if (gi > 0 or interp_on) else 1) + 8 * col.nnu * K_far + 8 * col.nnu
-                 for gi in range(ngas)]
-    far_ms = prof["far"] / max(ngas, 1)
-    alg = float(np.mean(far_bytes)) if far_bytes else 0.0
-    achieved = alg / (far_ms * 1e-3) / 1e9 if far_ms > 0 else 0.0
+    sec = lambda name: prof.get(name, 0.0) * 1e-3 / ngrp      # seconds per launch of a class
+
+    def mfma_entry(name, useful, issued, note):
+        t = sec(name)
+        return dict(bound="mfma", ms_per_launch=t * 1e3, launches_per_step=ngrp, useful_flops_per_launch=useful / ngrp,
+                    issued_flops_per_launch=issued / ngrp, achieved=(useful / ngrp / t / 1e12) if t > 0 else 0.0,
+                    achieved_issued=(issued / ngrp / t / 1e12) if t > 0 else 0.0, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=(useful / ngrp / t / 1e12 / FP64_MFMA_PEAK_TFLOPS) if t > 0 else 0.0,
+                    frac_issued=(issued / ngrp / t / 1e12 / FP64_MFMA_PEAK_TFLOPS) if t > 0 else 0.0, note=note)
+
+    def valu_entry(name, lane_instr, extra):
+        t = sec(name)
+        d = dict(bound="valu_issue", ms_per_launch=t * 1e3, launches_per_step=ngrp, lane_instructions_per_launch=lane_instr / ngrp,
+                 achieved=(lane_instr / ngrp / t) if t > 0 else 0.0, peak=VALU_ISSUE_PEAK, unit="fp64-rate lane-instructions/s",
+                 frac=(lane_instr / ngrp / t / VALU_ISSUE_PEAK) if t > 0 else None)
+        d.update(extra)
+        return d
+
+    kern = {}
+    # matrix-core kernels: USEFUL flops = 2 x series terms per (point | node, line, state) with the point inside the cut-off and outside
+    # the core radius and the state a real one (cs_column_work counts them on the host from the zone tables and the grid); ISSUED = 2048
+    # per matrix instruction, i.e. masked columns, padded states and the fill of the last 4-line step included
+    kern["k_voigt_edge_mx"] = mfma_entry("far_mx", work["edge_mx_flops_useful"], work["edge_mx_flops_issued"],
+                                         "window ends, pieces between interpolated sets and near zone, window cores beyond the series radius")
+    kern["k_cheb_nodes_mx"] = mfma_entry("nodes_mx", work["nodes_mx_flops_useful"], work["nodes_mx_flops_issued"],
+                                         "node sums of the interpolated far wings, 3- / 4-term series in 1/dnu^2")
+    if prof.get("apply", 0.0) > 0 and not col.baked and not col.U.cia:
+        t = prof["apply"] * 1e-3
+        kern["k_cheb_apply_mfma"] = dict(bound="mfma", ms_per_launch=t * 1e3, launches_per_step=1, useful_flops_per_launch=work["apply_flops"],
+                                         achieved=work["apply_flops"] / t / 1e12 if t > 0 else 0.0, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                                         frac=work["apply_flops"] / t / 1e12 / FP64_MFMA_PEAK_TFLOPS if t > 0 else 0.0,
+                                         note="node sums -> grid: C[level](64 nodes x points) . F(64 nodes x states), once per step for all gases")
+    # vector kernels: lane-instructions = sum over loop bodies of (lines x 64 lanes) x VALU instructions per line, read off the ISA
+    # (hipcc -S, gfx950; all 64 lanes of a wave count, also those the cut-off predicate masks), against the fp64-rate issue peak
+    db, nb = work.get("direct_by_body", {}), work.get("node_by_body", {})
+    kern["k_voigt_far"] = valu_entry("far", sum(db.get(b_, 0) * VALU_PER_LINE[b_] for b_ in db), dict(lines_x_lanes_by_body=db))
+    kern["k_cheb_nodes"] = valu_entry("nodes", sum(nb.get(b_, 0) * VALU_PER_LINE[b_] for b_ in nb), dict(lines_x_nodes_by_body=nb))
+    kern["k_voigt_sub"] = valu_entry("sub", work.get("sub_evals", 0) * VALU_PER_LINE["near_zone"], dict(lane_line_evals=work.get("sub_evals", 0)))
+    p0, p1 = work.get("near_pairs_tier0", 0), work.get("near_pairs_tier1", 0)
+    kern["k_voigt_near"] = valu_entry("near", p0 * (VALU_NEAR["tier0_eval"] + VALU_NEAR["per_candidate"]) + p1 * (VALU_NEAR["tier1_eval"] + VALU_NEAR["per_candidate"]),
+                                      dict(pairs_tier0=p0, pairs_tier1=p1, valu_per_pair=VALU_NEAR, launches_per_step=2 * ngrp,
+                                           note="k_voigt_near<0> (100 <= x^2+y^2 < 1e3: continued fraction) + <1> (< 100: trapezoid + pole); (nu, line, "
+                                                "state) pairs counted on the host from the device's per-(state, line) records; both tiers in one time"))
+    # HBM-bound kernels: algorithmic bytes = what must cross HBM once
+    L_range = work.get("lines_in_windows", lines_total)
+    setup_bytes = (58.0 * lines_total + 48.0 * K * lines_total + 32.0 * K * nt64 + 48.0 * K * work["intervals"]) / ngrp
+    t = sec("prep")
+    kern["k_gas_setup"] = dict(bound="hbm", ms_per_launch=t * 1e3, launches_per_step=ngrp, algorithmic_bytes_per_launch=setup_bytes,
+                               achieved=setup_bytes / t / 1e9 if t > 0 else 0.0, peak=HBM_PEAK_GBS, unit="GB/s",
+                               frac=setup_bytes / t / 1e9 / HBM_PEAK_GBS if t > 0 else 0.0,
+                               note="58 B per line read + 48 B per (state, line) record written + zone tables; the time includes k_mxzones")
+    rt_bytes = 8.0 * col.nnu * (K + (col.nl if col.want_tau else 0) + (2 * col.np if col.want_M else 0) + 2)
+    t = prof["rt"] * 1e-3
+    kern["k_rt"] = dict(bound="hbm", ms_per_launch=t * 1e3, launches_per_step=1, algorithmic_bytes_per_launch=rt_bytes,
+                        achieved=rt_bytes / t / 1e9 if t > 0 else 0.0, peak=HBM_PEAK_GBS, unit="GB/s", frac=rt_bytes / t / 1e9 / HBM_PEAK_GBS if t > 0 else 0.0,
+                        note="reads sigma [K][nnu], writes tau, M+, M- when asked for; 2 ns + 1 exponentials per (nu, layer) make it VALU-bound on full grids")
+    # the dominant kernel = the class with the largest time per step
+    cls = dict(k_voigt_edge_mx="far_mx", k_cheb_nodes_mx="nodes_mx", k_voigt_far="far", k_cheb_nodes="nodes", k_voigt_sub="sub",
+               k_voigt_near="near", k_gas_setup="prep", k_rt="rt")
+    dom = max(cls, key=lambda kname: prof.get(cls[kname], 0.0))
+    D = kern[dom]
     # PMC traffic cannot be collected inside this process (rocprofv3 --pmc wraps the program, FETCH_SIZE and WRITE_SIZE in
     # separate passes: tools/profile.sh writes profiles/pmc_traffic.json).  It is quoted only when that file was measured on the
-    # kernels loaded now (same source stamp) and on this exact workload; otherwise null -- never a stale number.
-    traffic, traffic_note = None, "no PMC profile of this build/workload under profiles/"
-    pm, pm_dominant = None, None
+    # library loaded now (same build id) and on this exact workload; otherwise null -- never a stale number.
+    traffic, traffic_note, traffic_step = None, "no PMC profile of this build/workload under profiles/", None
     try:
         pm = json.load(open(os.path.join(_ROOT, "profiles", "pmc_traffic.json")))
-        default_wl = args.nnu is None and args.lines is None and args.shape == "voigt" and N == 1 and interp_on and args.precision == "fp64" and not args.emulate_shard
+        default_wl = (args.nnu is None and args.lines is None and args.shape == "voigt" and N == 1 and interp_on and args.precision == "fp64"
+                      and not args.emulate_shard and not args.tune and not args.no_merge)
         if pm.get("source_sha16") != source_stamp():
-            traffic_note = f"profiles/pmc_traffic.json belongs to build {pm.get('source_sha16')}, loaded kernels are {source_stamp()}"
+            traffic_note = f"profiles/pmc_traffic.json belongs to build {pm.get('source_sha16')}, the loaded library is {source_stamp()}"
         elif pm.get("config") != args.config or not default_wl:
             traffic_note = "profiles/pmc_traffic.json was measured on another workload"
         else:
-            kk = pm["kernels"][pm["dominant"]]
-            pm_dominant = pm["dominant"].split("<")[0]
-            traffic = (kk["FETCH_SIZE_KB"] + kk["WRITE_SIZE_KB"]) * 1024.0
-            traffic_note = pm.get("calibration", "")
+            match = [k_ for k_ in pm["kernels"] if k_.split("<")[0] == dom]
+            if match:
+                kk = pm["kernels"][match[0]]
+                traffic = (kk["FETCH_SIZE_KB"] + kk["WRITE_SIZE_KB"]) * 1024.0
+                traffic_note = pm.get("calibration", "FETCH_SIZE + WRITE_SIZE per dispatch, separate rocprofv3 --pmc passes")
+            traffic_step = pm.get("bytes_per_step")
     except Exception:
         pass
-    # fp64 VALU view of the three line kernels: evaluations actually issued (per-point ones count all 64 lanes of a wave, node
-    # ones 64 nodes per (interval, line)) x 24 flops, over their time.  `reference_pair_evals` is what surf! evaluates.
-    # (node_evals counts every node sum; node_evals_matrix / direct_evals_matrix of them / besides direct_evals run on the matrix cores)
-    mx_triples = work.get("node_evals_matrix", 0) + work.get("direct_evals_matrix", 0)
-    evals = work["direct_evals"] + work["node_evals"] - work.get("node_evals_matrix", 0) + work.get("sub_evals", 0)
-    flops = evals * FLOPS_PER_PAIR
-    line_ms = prof["nodes"] + prof["far"] + prof["near"] + prof.get("sub", 0.0)
-    mx_ms = prof.get("nodes_mx", 0.0) + prof.get("far_mx", 0.0)
-    # matrix cores: 4 (or 3, or 8) terms x (multiply + add) per (node | point, line, state); v_mfma_f64_16x16x4 = 2048 flop.  Spec peak of the fp64
-    # matrix path = the fp64 vector rate (78.6 TFLOP/s); tools/ubench/mfma_f64_rate.hip sustains 47, and a matrix and a vector
-    # kernel launched side by side on two streams take the sum of their times (tools/ubench/sep_nodes.hip): one fp64 pipe, two ways in
-    mx_flops = 8.0 * mx_triples - 2.0 * work.get("matrix_evals_3term", 0) + 8.0 * work.get("matrix_evals_8term", 0)   # (3 terms: 6 flop; 8 terms: 16)
-    matrix_fp64 = dict(triples=mx_triples, triples_3term=work.get("matrix_evals_3term", 0), triples_8term=work.get("matrix_evals_8term", 0), flops=mx_flops, ms=mx_ms,
-                       achieved=mx_flops / (mx_ms * 1e-3) / 1e12 if mx_ms > 0 else 0.0, peak=FP64_VALU_PEAK_TFLOPS, unit="TFLOP/s",
-                       frac=mx_flops / (mx_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS if mx_ms > 0 else 0.0,
-                       measured_mfma_f64_rate=47.0, kernels="k_cheb_nodes_mx + k_voigt_edge_mx")
-    # measured instruction mix: lane-instructions each far-wing kernel issues = sum over its loop bodies of (lines x 64 lanes) x VALU
-    # instructions per line (ISA), over its HIP-event time, against the fp64-rate issue peak (all 64 lanes of a wave count, also
-    # those the cut-off predicate masks)
-    db, nb = work.get("direct_by_body", {}), work.get("node_by_body", {})
-    far_instr = sum(db.get(b, 0) * VALU_PER_LINE[b] for b in db)
-    sub_instr = work.get("sub_evals", 0) * VALU_PER_LINE["near_zone"]
-    node_instr = sum(nb.get(b, 0) * VALU_PER_LINE[b] for b in nb)
-    valu_issue = dict(unit="fraction of the fp64-rate VALU issue peak (256 CU x 4 SIMD x 16 lanes x 2.4 GHz)", valu_per_line=VALU_PER_LINE,
-                      k_voigt_far=dict(lane_instr=far_instr, ms=prof["far"], frac=(far_instr / (prof["far"] * 1e-3) / VALU_ISSUE_PEAK) if prof["far"] > 0 else None,
-                                       lines_x_lanes_by_body=db),
-                      k_voigt_sub=dict(lane_instr=sub_instr, ms=prof.get("sub", 0.0), evals=work.get("sub_evals", 0),
-                                       frac=(sub_instr / (prof["sub"] * 1e-3) / VALU_ISSUE_PEAK) if prof.get("sub", 0.0) > 0 else None),
-                      k_cheb_nodes=dict(lane_instr=node_instr, ms=prof["nodes"], frac=(node_instr / (prof["nodes"] * 1e-3) / VALU_ISSUE_PEAK) if prof["nodes"] > 0 else None,
-                                        lines_x_nodes_by_body=nb))
-    # the dominant kernel = the class with the largest time per step among the line kernels (all one launch per gas); its roof:
-    # the fp64 matrix path for the two matrix-core kernels (flops of the series terms they sum), HBM for the vector kernels
-    # (algorithmic bytes; their binding roof, the fp64 vector unit, is in valu_issue)
-    n3n = work.get("node_evals_matrix_3term", 0)
-    fl_nodes_mx = 8.0 * work.get("node_evals_matrix", 0) - 2.0 * n3n
-    fl_edge_mx = 8.0 * work.get("direct_evals_matrix", 0) - 2.0 * (work.get("matrix_evals_3term", 0) - n3n) + 8.0 * work.get("matrix_evals_8term", 0)
-    K_vec = K   # (k_cheb_nodes: the records of every state can be touched; F written once)
-    nodes_bytes = (32 * K_vec * lines_total / ngas + 8 * 64 * work["intervals"] * K) if col.gases else 0.0
-    cands = dict(k_voigt_far=("hbm", prof["far"], alg), k_cheb_nodes=("hbm", prof["nodes"], nodes_bytes),
-                 k_voigt_edge_mx=("mfma", prof.get("far_mx", 0.0), fl_edge_mx / max(ngas, 1)),
-                 k_cheb_nodes_mx=("mfma", prof.get("nodes_mx", 0.0), fl_nodes_mx / max(ngas, 1)))
-    dom = max(cands, key=lambda kname: cands[kname][1])
-    bound, dom_ms, per_launch = cands[dom]
-    dom_ms /= max(ngas, 1)
-    if bound == "mfma":
-        r_ach, r_peak, r_unit = (per_launch / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0), FP64_VALU_PEAK_TFLOPS, "TFLOP/s"
-    else:
-        r_ach, r_peak, r_unit = (per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0), HBM_PEAK_GBS, "GB/s"
-    if traffic is not None and pm_dominant != dom:
-        traffic, traffic_note = None, f"profiles/pmc_traffic.json names {pm_dominant} as the dominant kernel, this run {dom}"
-    elif traffic is not None:
-        kk = pm["kernels"][[k_ for k_ in pm["kernels"] if k_.split("<")[0] == dom][0]]
-        traffic = (kk["FETCH_SIZE_KB"] + kk["WRITE_SIZE_KB"]) * 1024.0
-    roofline = dict(bound=bound, kernel=dom, achieved=r_ach, peak=r_peak, unit=r_unit,
-                    frac=r_ach / r_peak, traffic=traffic, traffic_note=traffic_note, launches_per_step=ngas, avg_launch_ms=dom_ms,
-                    algorithmic_flops_per_launch=per_launch if bound == "mfma" else None,
-                    algorithmic_bytes_per_launch=per_launch if bound == "hbm" else None,
-                    note=("series terms x (multiply + add) per (nu | node, line, state) summed as v_mfma_f64_16x16x4 products; the fp64 matrix path of "
-                          "MI355X has the vector unit's peak (78.6 TFLOP/s; tools/ubench/mfma_f64_rate.hip sustains 47) and shares its pipe"
-                          if bound == "mfma" else "elementwise fp64 accumulate over (nu,line) pairs: VALU-bound by construction, see valu_issue"),
-                    k_voigt_far_hbm=dict(achieved=achieved, frac=achieved / HBM_PEAK_GBS, unit="GB/s", avg_launch_ms=far_ms, algorithmic_bytes_per_launch=alg),
-                    valu_fp64=dict(achieved=flops / (line_ms * 1e-3) / 1e12 if line_ms > 0 else 0.0, peak=FP64_VALU_PEAK_TFLOPS,
-                                   unit="TFLOP/s", frac=flops / (line_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS if line_ms > 0 else 0.0,
-                                   evals_issued=evals, direct_evals=work["direct_evals"], node_evals=work["node_evals"],
-                                   reference_pair_evals=cnt["pair_evals"], flops_per_eval=FLOPS_PER_PAIR,
-                                   kernels="k_cheb_nodes + k_voigt_far + k_voigt_sub + k_voigt_near"),
-                    valu_issue=valu_issue, matrix_fp64=matrix_fp64,
-                    interp_levels=work["levels"], kernel_ms=prof)
+    if D["bound"] == "mfma":
+        r_ach, r_peak, r_unit = D["achieved"], D["peak"], D["unit"]
+    elif D["bound"] == "hbm":
+        r_ach, r_peak, r_unit = D["achieved"], D["peak"], D["unit"]
+    else:   # a vector kernel: price it in TFLOP/s-equivalents of the fp64 vector peak through its issue fraction
+        r_ach, r_peak, r_unit = (D["frac"] or 0.0) * FP64_VALU_PEAK_TFLOPS, FP64_VALU_PEAK_TFLOPS, "TFLOP/s (issue fraction x fp64 vector peak)"
+    ub = None
+    try:
+        ub = json.load(open(os.path.join(_ROOT, "profiles", "r03_ubench.json")))
+    except Exception:
+        pass
+    roofline = dict(bound="mfma" if D["bound"] == "mfma" else ("hbm" if D["bound"] == "hbm" else "mfma"), kernel=dom, achieved=r_ach, peak=r_peak,
+                    unit=r_unit, frac=r_ach / r_peak if r_peak else None, traffic=traffic, traffic_note=traffic_note,
+                    traffic_bytes_per_step=traffic_step, launches_per_step=D["launches_per_step"], avg_launch_ms=D["ms_per_launch"],
+                    algorithmic_flops_per_launch=D.get("useful_flops_per_launch"), issued_flops_per_launch=D.get("issued_flops_per_launch"),
+                    frac_issued=D.get("frac_issued"), algorithmic_bytes_per_launch=D.get("algorithmic_bytes_per_launch"),
+                    note=("useful flops only: 2 x series terms for every (point | node, line, state) the reference sums there (inside the cut-off, "
+                          "outside the core radius, real states); masked columns, padded states and step fill are in issued_flops.  The fp64 "
+                          "matrix path of MI355X has the vector unit's peak (78.6 TFLOP/s) and shares its pipe; measured_rates holds what "
+                          "tools/ubench sustains"),
+                    measured_rates=ub, kernels=kern, kernel_ms=prof, reference_pair_evals=cnt["pair_evals"], interp_levels=work["levels"],
+                    whole_step=dict(algorithmic_bytes=24.0 * col.nnu * col.nl + 58.0 * lines_total + 8.0 * col.nnu,
+                                    hbm_frac=(24.0 * col.nnu * col.nl + 58.0 * lines_total + 8.0 * col.nnu) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    note="SURVEY 8d: 24 B per spectral point + 58 B per line + 8 B per nu over the whole step, against 8 TB/s -- "
+                                         "small by construction: the path is fp64-issue-bound"))
 
     # the drop-in entry point (cs_fluxes_discretized: host pointers in, host arrays out, what the Julia method calls per
     # radiate!), PCIe-inclusive -- reported beside ms_per_step, never as `value`

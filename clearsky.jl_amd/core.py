@@ -352,6 +352,45 @@ class Context:
             self._free_tables.append(slot)
 
 
+class MultiContext:
+    """N contexts on N devices of one node (several may share a device: rehearsal), holding the same gas tables in the same slots
+    -- the `ctxs` of cs_fluxes_discretized_multi, i.e. radiate!/fluxes with `ngpu` GPUs behind them: contiguous
+    cost-balanced wavenumber ranges, one per context, band fluxes added on the host in context order.  Line-by-line, gray and
+    function absorbers only (baked gases, CIA pairs and accelerated absorbers live on one context)."""
+
+    def __init__(self, devices):
+        self.ctxs = [Context(int(d)) for d in devices]
+        assert len(self.ctxs) >= 1
+
+    def slot_of(self, sl: SpectralLines) -> int:
+        slots = [c.slot_of(sl) for c in self.ctxs]
+        assert all(s_ == slots[0] for s_ in slots), "contexts of a MultiContext must be used together from the start"
+        return slots[0]
+
+    def handles(self):
+        return (C.c_void_p * len(self.ctxs))(*[c.handle.value for c in self.ctxs])
+
+    def set_merge(self, on=True):
+        for c in self.ctxs:
+            c.set_merge(on)
+
+    def close(self):
+        for c in self.ctxs:
+            c.close()
+
+
+def balanced_ranges(nu, line_positions, nparts: int):
+    """cs_balanced_ranges: `nparts` contiguous ranges (start, stop) of the grid `nu` with equal estimated device time -- the multi-GPU
+    partition of SURVEY.md 8e.  line_positions: one sorted array of line wavenumbers per gas.  Host only."""
+    nu = as_f64(nu)
+    tabs = [as_f64(a) for a in line_positions]
+    n = (C.c_int64 * max(len(tabs), 1))(*[len(a) for a in tabs])
+    ptrs = (C.POINTER(C.c_double) * max(len(tabs), 1))(*[dptr(a) for a in tabs])
+    out = (C.c_int64 * (2 * nparts))()
+    check(lib().cs_balanced_ranges(len(nu), dptr(nu), len(tabs), n, ptrs, int(nparts), out))
+    return [(int(out[2 * r]), int(out[2 * r + 1])) for r in range(nparts)]
+
+
 _default_ctx = {}
 
 
@@ -1167,6 +1206,17 @@ def _fluxes_discretized(col: "Column", tau, Mup, Mdn):
             assert a.shape == (rows, col.nnu) and a.flags["F_CONTIGUOUS"] and a.dtype == np.float64, \
                 f"expected a Fortran-order float64 array of shape {(rows, col.nnu)}"
     Fup, Fdn = np.zeros(col.np), np.zeros(col.np)
+    if isinstance(col.ctx, MultiContext):      # `ngpu` contexts: cs_fluxes_discretized_multi, same arguments behind the context list
+        for c_ in col.ctx.ctxs:
+            c_._resident = None
+        check(lib().cs_fluxes_discretized_multi(
+            col.ctx.handles(), len(col.ctx.ctxs), col.nnu, dptr(col.nu), col.np, dptr(col.P), col.g, col.core.nlobatto,
+            dptr(np.asfortranarray(col.Tn).ravel(order="F").copy()), dptr(np.asfortranarray(col.mun).ravel(order="F").copy()),
+            dptr(col.Tlev), len(col.gases), ip(col.slots), ip(col.shapes), dptr(col.cuts) if len(col.cuts) else None,
+            dptr(col.conc.ravel(order="F").copy()) if col.conc.size else None, col.sigma_gray,
+            dptr(col.sigma_extra) if col.sigma_extra is not None else None, dptr(col.S_toa), dptr(col.albedo), col.theta_s,
+            col.core.nstream, fp(tau), fp(Mup), fp(Mdn), dptr(Fup), dptr(Fdn)))
+        return Fup, Fdn
     col.ctx._resident = None           # the call replaces (or re-uses) the context's resident column on the C side
     check(lib().cs_fluxes_discretized(
         col.ctx.handle, col.nnu, dptr(col.nu), col.np, dptr(col.P), col.g, col.core.nlobatto,
@@ -1192,6 +1242,9 @@ def _b3(P, g, T, mu, fS, fa, absorbers, core, theta_s, ctx, tau, Mup, Mdn):
             if a is not None and b is not a:
                 a[...] = b
         return F
+    if isinstance(direct.ctx, MultiContext):
+        raise TypeError("baked Gas objects, CIA pairs and accelerated absorbers live on ONE context: a MultiContext takes line-by-line, "
+                        "gray and function absorbers")
     direct._setup()
     direct.run()
     return direct.fetch(tau, Mup, Mdn)

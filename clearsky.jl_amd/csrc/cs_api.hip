@@ -180,6 +180,7 @@ struct ColGas {
     int shape = 0;
     double cut = 25.0;
     DevBuf conc, Pp, J0, J1;  // [nmem][K], [nmem][K], [ntile], [ntile]
+    DevBuf lrt, qref;         // state_tables(): [K], [K][niso]
     DevBuf win, zones, gmax;  // [ntile64] WaveWin, [K][ntile64] Zone, [K] max Lorentz width (Voigt fast path)
     GasInterp itp;            // interpolated far wings (nlev = 0: off)
     int64_t jlo = 0, jhi = 0;
@@ -196,6 +197,8 @@ struct Column {
     RtGeom rtg = {};
     bool want_tau = false, want_M = false, has_extra = false, has_S = false, has_alb = false;
     bool default_wts = false;  // trapezoid weights of the column's own grid (not a shard of a larger one)
+    int64_t g_nnu = 0, g_start = 0;      // set by cs_fluxes_discretized_multi: this column is points [g_start, g_start + nnu) of a grid of
+    double g_left = 0.0, g_right = 0.0;  // g_nnu points, with these neighbours left and right (what its trapezoid weights depend on)
     int interp = 0;            // the context's interpolation settings at setup time (packed)
     double g = 0, sigma_gray = 0, theta_s = 0;
     RtParams rt;
@@ -507,6 +510,18 @@ std::vector<double> gamma_bound(const GasTable &G, int K, const double *T, const
     return g;
 }
 
+// what k_gas_setup needs per state alone: ln(Tref/T) and Qref/Q(T) of every isotopologue of the table (line_shapes.jl:27-48)
+void state_tables(const GasTable &G, int K, const double *T, std::vector<double> &lrt, std::vector<double> &qrefq)
+{
+    lrt.resize(K);
+    qrefq.assign((size_t)K * G.niso, 0.0);
+    for (int k = 0; k < K; k++) {
+        lrt[k] = std::log(kTref / T[k]);
+        for (int i = 0; i < G.niso; i++)
+            if (G.h_ncheb[i] > 0) qrefq[(size_t)k * G.niso + i] = cheby_qrefq(T[k], G.h_ncheb[i], G.h_cheb.data() + (size_t)i * CS_CHEB_LD);
+    }
+}
+
 // far wings by interpolation (k_cheb_nodes + k_cheb_apply), view handed to launch_gas; nlev = 0: off
 struct Interp {
     int nlev = 0, nItot = 0, Kpad = 0, l0 = 0;
@@ -718,7 +733,8 @@ static void fork_join(Fork *f, hipStream_t s)
 
 // K1 + K2 for one gas on `s`: parameters for `kn` states, then the line sum into sigma ([kn][nnu])
 void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, int64_t jrange1, int kn, const double *Tk, const double *Pk, const double *Ppk,
-                const double *scale, int mstride /* members of a merged table: element (m, k) of Ppk / scale at m * mstride + k */, LineHot *hot, LineCold *cold, const double *dnu, int64_t nnu, int ntile256,
+                const double *scale, int mstride /* members of a merged table: element (m, k) of Ppk / scale at m * mstride + k */,
+                const double *lrt, const double *qrefq /* state_tables(): [kn], [kn][niso] */, LineHot *hot, LineCold *cold, const double *dnu, int64_t nnu, int ntile256,
                 const int32_t *J0, const int32_t *J1, const WaveWin *win, int xtiles, Zone *zones, int2 *ranges, const double *gbound, double cut, double base,
                 const double *extra, double *sigma, int accumulate, hipEvent_t *evg,   // NULL or 6 events: after K1 (+ zones), nodes (vector unit), nodes (matrix cores), far (vector unit), sub-tile cores, far (matrix cores)
                 LineF32 *hot32 = nullptr, double far_s = 1e6, Interp itp = Interp(), ChebApply *defer = nullptr, PhScratch *ph = nullptr,
@@ -727,13 +743,12 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
     fork_join(fork, s);   // (an earlier group's node kernels may still read the records this launch overwrites)
     // only the lines some window can reach (windows are sorted: first tile's start .. last tile's end)
     const int64_t jlo = jrange0, jhi = std::max(jrange1, jrange0);
-    const int64_t tot = (int64_t)kn * (jhi - jlo);
     PrepArgs pa;
     pa.shape = shape; pa.K = kn; pa.g = G.dev(); pa.jlo = jlo; pa.jhi = jhi;
-    pa.Tk = Tk; pa.Pk = Pk; pa.Ppk = Ppk; pa.scale = scale; pa.mstride = mstride; pa.hot = hot; pa.cold = cold; pa.hot32 = shape == SH_VOIGT ? hot32 : nullptr;
+    pa.Tk = Tk; pa.Pk = Pk; pa.Ppk = Ppk; pa.scale = scale; pa.mstride = mstride; pa.lrt = lrt; pa.qrefq = qrefq; pa.niso = G.niso; pa.hot = hot; pa.cold = cold; pa.hot32 = shape == SH_VOIGT ? hot32 : nullptr;
     pa.phfac = nullptr;
     pa.nu_c = 0.0;
-    const unsigned nb_prep = (unsigned)((tot + 255) / 256);
+    const unsigned nb_prep = (unsigned)((jhi - jlo + 255) / 256) * (unsigned)((kn + CS_PREP_KC - 1) / CS_PREP_KC);   // (line block, chunk of states)
     const bool lor = shape == SH_LORENTZ;   // lorentz! runs on the same far-wing machinery with its own (exact) body
     if (shape == SH_VOIGT || lor) {
         if (lor) hot32 = nullptr;           // (no fp32 variant of the Lorentz body)
@@ -1214,7 +1229,13 @@ static int shape_impl(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t 
     std::vector<int32_t> J0, J1;
     tile_windows(G.h_nu, g0, g1, nu, nnu, window_reach(shape, G, nu[nnu - 1], dnu_cut), J0, J1, pairs, inr);
     const int ntile = (int)J0.size();
-    DevBuf dnu, dT, dP, dPp, dJ0, dJ1, hot, cold, dsig, dwin, dzones, dgmax, dranges;
+    DevBuf dnu, dT, dP, dPp, dJ0, dJ1, hot, cold, dsig, dwin, dzones, dgmax, dranges, dlrt, dqref;
+    {
+        std::vector<double> lrt, qr;
+        state_tables(G, K, T, lrt, qr);
+        if ((rc = upload(dlrt, lrt.data(), lrt.size(), s)) || (rc = upload(dqref, qr.data(), qr.size(), s))) return rc;
+        HIPCHK(hipStreamSynchronize(s));
+    }
     std::vector<WaveWin> win;
     const int xtiles = wave_windows(G.h_nu, g0, g1, nu, nnu, dnu_cut, win);
     if ((rc = upload(dnu, nu, nnu, s)) || (rc = upload(dT, T, K, s)) || (rc = upload(dP, P, K, s)) ||
@@ -1255,7 +1276,7 @@ static int shape_impl(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t 
     for (int k0 = 0; k0 < K; k0 += kc) {
         const int kn = std::min(kc, K - k0);
         launch_gas(s, shape, G, J0.front(), J1.back(), kn, dT.as<double>() + k0, dP.as<double>() + k0, dPp.as<double>() + k0, nullptr, 0,
-                   hot.as<LineHot>(), cold.as<LineCold>(), dnu.as<double>(), nnu, ntile, dJ0.as<int32_t>(), dJ1.as<int32_t>(),
+                   dlrt.as<double>() + k0, dqref.as<double>() + (size_t)k0 * G.niso, hot.as<LineHot>(), cold.as<LineCold>(), dnu.as<double>(), nnu, ntile, dJ0.as<int32_t>(), dJ1.as<int32_t>(),
                    dwin.as<WaveWin>(), xtiles, dzones.as<Zone>(), dranges.as<int2>(), dgmax.as<double>() + k0, dnu_cut, 0.0, nullptr, dsig.as<double>(), 0, nullptr,
                    mix32, ctx->far_s, itp, nullptr, &ctx->ph);
         HIPCHK(hipGetLastError());
@@ -1303,7 +1324,13 @@ int cs_bake(cs_ctx *ctx, int gas_slot, int table_slot, int shape, double dnu_cut
     std::vector<WaveWin> win;
     const int xtiles = wave_windows(G.h_nu, g0, g1, nu, nnu, dnu_cut, win);
     const int ntile = (int)J0.size();
-    DevBuf dnu, dT, dP, dPp, dJ0, dJ1, hot, cold, dwin, dzones, dgb, dranges;
+    DevBuf dnu, dT, dP, dPp, dJ0, dJ1, hot, cold, dwin, dzones, dgb, dranges, dlrt, dqref;
+    {
+        std::vector<double> lrt, qr;
+        state_tables(G, M, Ts.data(), lrt, qr);
+        if ((rc = upload(dlrt, lrt.data(), lrt.size(), s)) || (rc = upload(dqref, qr.data(), qr.size(), s))) return rc;
+        HIPCHK(hipStreamSynchronize(s));
+    }
     std::vector<double> gb = gamma_bound(G, M, Ts.data(), Ps.data(), Pp.data());
     if ((rc = upload(dnu, nu, nnu, s)) || (rc = upload(dT, Ts.data(), M, s)) || (rc = upload(dP, Ps.data(), M, s)) ||
         (rc = upload(dPp, Pp.data(), M, s)) || (rc = upload(dJ0, J0.data(), ntile, s)) || (rc = upload(dJ1, J1.data(), ntile, s)) ||
@@ -1336,8 +1363,8 @@ int cs_bake(cs_ctx *ctx, int gas_slot, int table_slot, int shape, double dnu_cut
     }
     for (int k0 = 0; k0 < M; k0 += kc) {
         const int kn = std::min(kc, M - k0);
-        launch_gas(s, shape, G, J0.front(), J1.back(), kn, dT.as<double>() + k0, dP.as<double>() + k0, dPp.as<double>() + k0, nullptr, 0, hot.as<LineHot>(),
-                   cold.as<LineCold>(), dnu.as<double>(), nnu, ntile, dJ0.as<int32_t>(), dJ1.as<int32_t>(), dwin.as<WaveWin>(), xtiles,
+        launch_gas(s, shape, G, J0.front(), J1.back(), kn, dT.as<double>() + k0, dP.as<double>() + k0, dPp.as<double>() + k0, nullptr, 0, dlrt.as<double>() + k0,
+                   dqref.as<double>() + (size_t)k0 * G.niso, hot.as<LineHot>(), cold.as<LineCold>(), dnu.as<double>(), nnu, ntile, dJ0.as<int32_t>(), dJ1.as<int32_t>(), dwin.as<WaveWin>(), xtiles,
                    dzones.as<Zone>(), dranges.as<int2>(), dgb.as<double>() + k0, dnu_cut, 0.0, nullptr, tb.Z.as<double>() + (size_t)k0 * nnu, 0, nullptr,
                    mix32, ctx->far_s, itp, nullptr, &ctx->ph);
         HIPCHK(hipGetLastError());
@@ -1755,6 +1782,7 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
         (rc = upload(c.Pk, c.h_Pk.data(), K, s)))
         return rc;
     c.default_wts = wts == nullptr;
+    c.g_nnu = 0; c.g_start = 0; c.g_left = c.g_right = 0.0;   // (cs_fluxes_discretized_multi marks its shards after a successful setup)
     c.interp = interp_key(ctx);   // every setting of the context that shapes what setup builds
     c.has_extra = sigma_extra != nullptr;
     // an all-zero stellar spectrum / albedo is the same as none (0*exp(..) and M*0/pi are exact zeros): skip their work, and let
@@ -1905,8 +1933,10 @@ int cs_column_update_state(cs_ctx *ctx, const double *T_nodes, const double *mu_
             const std::vector<double> gm = gamma_bound(ctx->gas[c.ugas[gi].slot], K, Tk.data(), c.h_Pk.data(), pp.data() + (size_t)m * K);
             for (int k = 0; k < K; k++) gb[k] = std::max(gb[k], gm[k]);
         }
+        std::vector<double> lrt, qr;
+        state_tables(*cg.tab, K, Tk.data(), lrt, qr);
         if ((rc = upload(cg.conc, cc.data(), cc.size(), s)) || (rc = upload(cg.Pp, pp.data(), pp.size(), s)) ||
-            (rc = upload(cg.gmax, gb.data(), K, s)))
+            (rc = upload(cg.gmax, gb.data(), K, s)) || (rc = upload(cg.lrt, lrt.data(), lrt.size(), s)) || (rc = upload(cg.qref, qr.data(), qr.size(), s)))
             return rc;
         HIPCHK(hipStreamSynchronize(s));   // (locals)
     }
@@ -1950,7 +1980,7 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
     const double *extra = c.has_extra ? c.extra.as<double>() : nullptr;
     if (extra) return fail(CS_EINVAL, "host-evaluated sigma(nu,T,P) terms are not supported in batch mode");
     const bool shared_sigma = c.accel.slot >= 0;   // AcceleratedAbsorber: cross-sections do not depend on the thermal state (absorbers.jl:203)
-    DevBuf dTk, dPk, dmuk, dTlev, dsig, dtau, dpart, dF, dranges, dconc, dPp, dgb, dzones, dizones, dF2, dsep, dedge, hot, cold;
+    DevBuf dTk, dPk, dmuk, dTlev, dsig, dtau, dpart, dF, dranges, dconc, dPp, dgb, dzones, dizones, dF2, dsep, dedge, hot, cold, dlrt, dqref;
     if ((rc = upload(dTk, Tk.data(), BK, s)) || (rc = upload(dPk, Pk.data(), BK, s)) || (rc = upload(dmuk, muk.data(), BK, s)) ||
         (rc = upload(dTlev, T_levels, (size_t)B * np, s)))
         return rc;
@@ -1996,7 +2026,11 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
             for (int64_t k = 0; k < BK; k++) gb[k] = std::max(gb[k], gm[k]);
         }
         const size_t nt64 = (size_t)((c.nnu + 63) / 64);
-        if ((rc = upload(dconc, cc.data(), cc.size(), s)) || (rc = upload(dPp, pp.data(), pp.size(), s)) || (rc = upload(dgb, gb.data(), BK, s))) return rc;
+        std::vector<double> lrt, qr;
+        state_tables(G, (int)BK, Tk.data(), lrt, qr);
+        if ((rc = upload(dconc, cc.data(), cc.size(), s)) || (rc = upload(dPp, pp.data(), pp.size(), s)) || (rc = upload(dgb, gb.data(), BK, s)) ||
+            (rc = upload(dlrt, lrt.data(), lrt.size(), s)) || (rc = upload(dqref, qr.data(), qr.size(), s)))
+            return rc;
         HIPCHK(dzones.reserve((size_t)kc * nt64 * sizeof(Zone)));
         Interp itp;
         if (cg.itp.nlev > 0) {
@@ -2019,7 +2053,7 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
         for (int64_t k0 = 0; k0 < BK; k0 += kc) {
             const int kn = (int)std::min<int64_t>(kc, BK - k0);
             launch_gas(s, cg.shape, G, cg.jlo, cg.jhi, kn, dTk.as<double>() + k0, dPk.as<double>() + k0, dPp.as<double>() + k0,
-                       dconc.as<double>() + k0, (int)BK, hot.as<LineHot>(), cold.as<LineCold>(), c.nu.as<double>(), c.nnu, c.ntile,
+                       dconc.as<double>() + k0, (int)BK, dlrt.as<double>() + k0, dqref.as<double>() + (size_t)k0 * G.niso, hot.as<LineHot>(), cold.as<LineCold>(), c.nu.as<double>(), c.nnu, c.ntile,
                        cg.J0.as<int32_t>(), cg.J1.as<int32_t>(), cg.win.as<WaveWin>(), cg.xtiles, dzones.as<Zone>(), dranges.as<int2>(),
                        dgb.as<double>() + k0, cg.cut, c.sigma_gray, nullptr, sig + (size_t)k0 * c.nnu, qi > 0, nullptr,
                        (ctx->mixed && cg.shape == SH_VOIGT) ? ctx->hot32.as<LineF32>() : nullptr, ctx->far_s, itp, nullptr, &ctx->ph);
@@ -2123,7 +2157,7 @@ static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e)
         itp.core = ctx->matrix_core != 0;
         itp.fuse_apply = ctx->tune[0] != 0 && n_itp == 1;
         launch_gas(s, cg.shape, G, cg.jlo, cg.jhi, K, c.Tk.as<double>(), c.Pk.as<double>(), cg.Pp.as<double>(), cg.conc.as<double>(), K,
-                   c.hot.as<LineHot>(), c.cold.as<LineCold>(), c.nu.as<double>(), c.nnu, c.ntile, cg.J0.as<int32_t>(),
+                   cg.lrt.as<double>(), cg.qref.as<double>(), c.hot.as<LineHot>(), c.cold.as<LineCold>(), c.nu.as<double>(), c.nnu, c.ntile, cg.J0.as<int32_t>(),
                    cg.J1.as<int32_t>(), cg.win.as<WaveWin>(), cg.xtiles, cg.zones.as<Zone>(), c.ranges.as<int2>(), cg.gmax.as<double>(), cg.cut, c.sigma_gray, extra, sig, gi > 0,
                    ev ? ev + e : nullptr,
                    (ctx->mixed && cg.shape == SH_VOIGT) ? ctx->hot32.as<LineF32>() : nullptr, ctx->far_s, itp, &apply, &ctx->ph,
@@ -2176,6 +2210,7 @@ static int run_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev)
 int cs_column_sigma_run(cs_ctx *ctx, void *stream)
 {
     if (!ctx || !ctx->col.ready) return fail(CS_ESTATE, "cs_column_setup has not been called");
+    HIPCHK(hipSetDevice(ctx->device));
     int e = 0;
     return sigma_impl(ctx, stream ? (hipStream_t)stream : ctx->stream, nullptr, e);
 }
@@ -2183,6 +2218,7 @@ int cs_column_sigma_run(cs_ctx *ctx, void *stream)
 int cs_column_run(cs_ctx *ctx, void *stream)
 {
     if (!ctx || !ctx->col.ready) return fail(CS_ESTATE, "cs_column_setup has not been called");
+    HIPCHK(hipSetDevice(ctx->device));   // (a process may drive several contexts on several devices: cs_fluxes_discretized_multi)
     return run_impl(ctx, stream ? (hipStream_t)stream : ctx->stream, nullptr);
 }
 
@@ -2547,10 +2583,12 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
 // thermal state and the per-call spectra differ, so a call can skip the window / interpolation-matrix / workspace setup
 static bool column_matches(cs_ctx *ctx, int64_t nnu, const double *nu, int np, const double *P, double g, int nlobatto, int ngas,
                            const int *gas_slots, const int *shapes, const double *dnu_cuts, double sigma_gray, double theta_s,
-                           int nstream, bool want_tau, bool want_M)
+                           int nstream, bool want_tau, bool want_M, int64_t g_nnu = 0, int64_t g_start = 0, double g_left = 0.0, double g_right = 0.0)
 {
     const Column &c = ctx->col;
-    if (!c.ready || c.accel.slot >= 0 || !c.default_wts || c.interp != interp_key(ctx) || !c.tab.empty() || !c.cia.empty()) return false;
+    const bool shard_ok = g_nnu > 0 ? (!c.default_wts && c.g_nnu == g_nnu && c.g_start == g_start && c.g_left == g_left && c.g_right == g_right)
+                                    : c.default_wts;
+    if (!c.ready || c.accel.slot >= 0 || !shard_ok || c.interp != interp_key(ctx) || !c.tab.empty() || !c.cia.empty()) return false;
     if (c.nnu != nnu || c.np != np || c.nlob != nlobatto || c.nstream != nstream || c.ngas != ngas) return false;
     if (c.g != g || c.sigma_gray != sigma_gray || c.theta_s != theta_s) return false;
     if (c.want_tau != want_tau || c.want_M != want_M) return false;
@@ -2764,6 +2802,133 @@ int cs_gas_fetch(cs_ctx *ctx, int slot, int64_t L, double *nu, double *S, double
     if (na) HIPCHK(hipMemcpy(na, G.na.p, nb, hipMemcpyDeviceToHost));
     if (mu_iso) HIPCHK(hipMemcpy(mu_iso, G.mu.p, nb, hipMemcpyDeviceToHost));
     if (iso) HIPCHK(hipMemcpy(iso, G.iso.p, (size_t)L * sizeof(int16_t), hipMemcpyDeviceToHost));
+    return CS_OK;
+}
+
+// ---- multi-GPU --------------------------------------------------------------------------------------------
+int cs_balanced_ranges(int64_t nnu, const double *nu, int ngas, const int64_t *nlines, const double *const *line_nu, int nparts, int64_t *ranges)
+{
+    if (!nu || nnu < 1 || nparts < 1 || !ranges || ngas < 0 || (ngas > 0 && (!nlines || !line_nu))) return fail(CS_EINVAL, "bad arguments");
+    if (nparts > nnu) return fail(CS_EINVAL, "more parts (%d) than wavenumbers (%lld)", nparts, (long long)nnu);
+    // cost per wavenumber, fitted to the per-class kernel times of the eight 1/8 shards of BASELINE configs[2] (profiles/r02_notes.md;
+    // re-checked on the merged kernels, profiles/r03_notes.md): a fixed part (flux sweeps, interpolation apply, setup) + per gas its
+    // local line density rho [lines per cm^-1 within +-2 cm^-1] x (0.011 + 1.1e-6 nu) -- near-line pairs grow with the Doppler width
+    std::vector<double> cum((size_t)nnu + 1, 0.0);
+    for (int64_t i = 0; i < nnu; i++) {
+        double w = 0.19;
+        for (int gq = 0; gq < ngas; gq++) {
+            const double *b = line_nu[gq], *e = b + nlines[gq];
+            const double rho = (double)(std::upper_bound(b, e, nu[i] + 2.0) - std::lower_bound(b, e, nu[i] - 2.0)) / 4.0;
+            w += rho * (0.011 + 1.1e-6 * nu[i]);
+        }
+        cum[i + 1] = cum[i] + w;
+    }
+    std::vector<int64_t> edge(nparts + 1);
+    const bool tiles = nnu >= (int64_t)64 * 4 * nparts;   // range edges on multiples of 64 points (the kernels' tile) where the grid allows
+    for (int r = 0; r <= nparts; r++) {
+        int64_t e = std::lower_bound(cum.begin(), cum.end(), cum[nnu] * r / nparts) - cum.begin();
+        if (tiles) e = (e + 32) / 64 * 64;
+        edge[r] = e;
+    }
+    edge[0] = 0;
+    edge[nparts] = nnu;
+    // every part keeps at least one point (one tile where edges sit on tiles): push edges up from the left, then down from the right
+    const int64_t step = tiles ? 64 : 1;
+    for (int r = 1; r < nparts; r++) edge[r] = std::max(edge[r], edge[r - 1] + step);
+    for (int r = nparts - 1; r >= 1; r--) edge[r] = std::min(edge[r], edge[r + 1] - (r == nparts - 1 ? 1 : step));
+    for (int r = 1; r < nparts; r++) edge[r] = std::max(edge[r], edge[r - 1] + 1);
+    for (int r = 0; r < nparts; r++) {
+        if (!(edge[r] >= 0 && edge[r] < edge[r + 1] && edge[r + 1] <= nnu)) return fail(CS_EINVAL, "could not cut %lld wavenumbers into %d non-empty ranges", (long long)nnu, nparts);
+        ranges[2 * r] = edge[r];
+        ranges[2 * r + 1] = edge[r + 1];
+    }
+    return CS_OK;
+}
+
+int cs_fluxes_discretized_multi(cs_ctx *const *ctxs, int nctx, int64_t nnu, const double *nu, int np, const double *P, double g, int nlobatto,
+                                const double *T_nodes, const double *mu_nodes, const double *T_levels, int ngas, const int *gas_slots,
+                                const int *shapes, const double *dnu_cuts, const double *conc, double sigma_gray, const double *sigma_extra,
+                                const double *S_toa, const double *albedo, double theta_s, int nstream, double *tau, double *Mup,
+                                double *Mdn, double *Fup, double *Fdn)
+{
+    if (!ctxs || nctx < 1) return fail(CS_EINVAL, "no contexts");
+    for (int i = 0; i < nctx; i++)
+        if (!ctxs[i]) return fail(CS_EINVAL, "context %d is NULL", i);
+    if (!nu || !P || nnu < 1 || np < 2 || !Fup || !Fdn) return fail(CS_EINVAL, "bad grid arguments");
+    if (nctx == 1)
+        return cs_fluxes_discretized(ctxs[0], nnu, nu, np, P, g, nlobatto, T_nodes, mu_nodes, T_levels, ngas, gas_slots, shapes, dnu_cuts, conc,
+                                     sigma_gray, sigma_extra, S_toa, albedo, theta_s, nstream, tau, Mup, Mdn, Fup, Fdn);
+    int rc;
+    if ((rc = check_ascending(nu, nnu))) return rc;
+    if (nlobatto < 2 || nlobatto > CS_MAX_LOBATTO) return fail(CS_EINVAL, "nlobatto must be in [2,%d]", CS_MAX_LOBATTO);
+    // the partition: equal estimated device time per context, from the line tables the first context holds (every context must hold
+    // the same tables in the same slots)
+    std::vector<int64_t> nl_(ngas), ranges(2 * (size_t)nctx);
+    std::vector<const double *> ln_(ngas);
+    for (int gi = 0; gi < ngas; gi++) {
+        const int sl = gas_slots[gi];
+        if (sl < 0 || sl >= CS_MAX_GAS) return fail(CS_EINVAL, "gas slot %d out of range", sl);
+        for (int i = 0; i < nctx; i++)
+            if (!ctxs[i]->gas[sl].present || ctxs[i]->gas[sl].L != ctxs[0]->gas[sl].L)
+                return fail(CS_EINVAL, "gas slot %d must hold the same table on every context (context %d differs)", sl, i);
+        nl_[gi] = ctxs[0]->gas[sl].L;
+        ln_[gi] = ctxs[0]->gas[sl].h_nu.data();
+    }
+    if ((rc = cs_balanced_ranges(nnu, nu, ngas, nl_.data(), ln_.data(), nctx, ranges.data()))) return rc;
+    std::vector<double> wt(nnu);   // trapezoid weights of the WHOLE grid (util.jl:26-33): shards use slices, so their band fluxes simply add
+    for (int64_t j = 0; j < nnu; j++) wt[j] = ((j > 0 ? nu[j] - nu[j - 1] : 0.0) + (j + 1 < nnu ? nu[j + 1] - nu[j] : 0.0)) / 2;
+    const int K = (np - 1) * (nlobatto - 1) + 1, nl = np - 1;
+    std::vector<int> rcs(nctx, CS_OK);
+    std::vector<std::string> msgs(nctx);
+    std::vector<double> Fpart((size_t)nctx * 2 * np, 0.0);
+    // one host thread per context: its uploads, kernels and copy-backs run beside the others' (a context is not re-entrant, but
+    // different contexts are independent; HIP calls carry their device through hipSetDevice per thread)
+    auto work = [&](int i) {
+        cs_ctx *ctx = ctxs[i];
+        const int64_t a = ranges[2 * i], n = ranges[2 * i + 1] - a;
+        std::vector<double> ex;
+        if (sigma_extra) {   // [nnu, K] nu-fastest -> this shard's columns
+            ex.resize((size_t)n * K);
+            for (int k = 0; k < K; k++) std::copy(sigma_extra + (size_t)k * nnu + a, sigma_extra + (size_t)k * nnu + a + n, ex.begin() + (size_t)k * n);
+        }
+        const double gl = a > 0 ? nu[a - 1] : 0.0, gr = a + n < nnu ? nu[a + n] : 0.0;
+        int r;
+        if (column_matches(ctx, n, nu + a, np, P, g, nlobatto, ngas, gas_slots, shapes, dnu_cuts, sigma_gray, theta_s, nstream, tau != nullptr,
+                           Mup || Mdn, nnu, a, gl, gr)) {
+            Column &c = ctx->col;
+            hipStream_t s = ctx->stream;
+            r = hipSetDevice(ctx->device) == hipSuccess ? CS_OK : fail(CS_EHIP, "hipSetDevice(%d) failed", ctx->device);
+            c.has_extra = sigma_extra != nullptr;
+            c.has_S = S_toa != nullptr && std::any_of(S_toa + a, S_toa + a + n, [](double x) { return x != 0.0; });
+            c.has_alb = albedo != nullptr && std::any_of(albedo + a, albedo + a + n, [](double x) { return x != 0.0; });
+            if (!r && c.has_extra) r = upload(c.extra, ex.data(), ex.size(), s);
+            if (!r && c.has_S) r = upload(c.S_toa, S_toa + a, n, s);
+            if (!r && c.has_alb) r = upload(c.albedo, albedo + a, n, s);
+            if (!r) r = cs_column_update_state(ctx, T_nodes, mu_nodes, T_levels, conc, nullptr);
+        } else {
+            r = cs_column_setup(ctx, n, nu + a, wt.data() + a, np, P, g, nlobatto, T_nodes, mu_nodes, T_levels, ngas, gas_slots, shapes, dnu_cuts,
+                                conc, sigma_gray, sigma_extra ? ex.data() : nullptr, S_toa ? S_toa + a : nullptr, albedo ? albedo + a : nullptr,
+                                theta_s, nstream, tau != nullptr, (Mup || Mdn) ? 1 : 0);
+            if (!r) { ctx->col.g_nnu = nnu; ctx->col.g_start = a; ctx->col.g_left = gl; ctx->col.g_right = gr; }
+        }
+        if (!r) r = cs_column_run(ctx, nullptr);
+        if (!r) r = cs_column_fetch(ctx, n, np, tau ? tau + (size_t)a * nl : nullptr, Mup ? Mup + (size_t)a * np : nullptr,
+                                    Mdn ? Mdn + (size_t)a * np : nullptr, Fpart.data() + (size_t)i * 2 * np, Fpart.data() + (size_t)i * 2 * np + np);
+        rcs[i] = r;
+        if (r) msgs[i] = g_err;   // (thread-local: carry it to the caller's thread)
+    };
+    std::vector<std::thread> th;
+    for (int i = 1; i < nctx; i++) th.emplace_back(work, i);
+    work(0);
+    for (auto &t : th) t.join();
+    for (int i = 0; i < nctx; i++)
+        if (rcs[i]) return fail(rcs[i], "context %d (device %d): %s", i, ctxs[i]->device, msgs[i].c_str());
+    for (int l = 0; l < np; l++) {   // fixed-order host sum: bitwise repeatable (SURVEY 8e's deterministic alternative to an all-reduce)
+        double u = 0.0, d = 0.0;
+        for (int i = 0; i < nctx; i++) { u += Fpart[(size_t)i * 2 * np + l]; d += Fpart[(size_t)i * 2 * np + np + l]; }
+        Fup[l] = u;
+        Fdn[l] = d;
+    }
     return CS_OK;
 }
 

@@ -55,7 +55,7 @@ struct GasDev {
 };
 
 // line_shapes.jl:27-48
-__device__ __forceinline__ double cheby_qrefq(double T, int n, const double *__restrict__ a)
+__host__ __device__ __forceinline__ double cheby_qrefq(double T, int n, const double *__restrict__ a)
 {
     double tau = 2.0 * (T - kTmin) / (kTmax - kTmin) - 1.0;
     double c1 = 1.0, c2 = tau;
@@ -69,14 +69,21 @@ __device__ __forceinline__ double cheby_qrefq(double T, int n, const double *__r
     return 1.0 / y;
 }
 
-// K1: one thread per (state k, line j), j in [jlo, jhi) = the lines some window of this wavenumber grid can reach (a nu-shard
-// of a multi-GPU run needs only its part of the table); j fastest so the SoA line table is read coalesced.
+// K1: one thread per (line j, chunk of CS_PREP_KC states), j in [jlo, jhi) = the lines some window of this wavenumber grid can
+// reach (a nu-shard of a multi-GPU run needs only its part of the table); j fastest so the SoA line table is read coalesced -- once
+// per chunk instead of once per state (round 2: one thread per (state, line), 184 MB of line-table fetches per launch at C3 for a
+// 6 MB table) -- and the records of a state are written in 2 KB runs.  What depends on the state alone comes from the host:
+// ln(Tref/T) and Qref/Q(T) of every isotopologue (line_shapes.jl:27-48), K x niso values.
+#define CS_PREP_KC 8
 struct PrepArgs {
     int shape, K;
     GasDev g;
     int64_t jlo, jhi;
     const double *Tk, *Pk, *Ppk, *scale;   // Ppk, scale: [members][mstride], element (m, k) at m * mstride + k
     int mstride;
+    const double *lrt;     // [K] ln(Tref / T_k)
+    const double *qrefq;   // [K][niso] Qref/Q(T_k) per isotopologue of the table (0 where there is no fit: refused on the host)
+    int niso;
     LineHot *hot;
     LineCold *cold;
     LineF32 *hot32;
@@ -92,57 +99,60 @@ __device__ __forceinline__ void prep_body(unsigned bid, const PrepArgs &pa)
     LineHot *__restrict__ hot = pa.hot;
     LineCold *__restrict__ cold = pa.cold;
     LineF32 *__restrict__ hot32 = pa.hot32;
-    const int64_t nj = jhi - jlo;
-    int64_t idx = (int64_t)bid * blockDim.x + threadIdx.x;
-    if (idx >= (int64_t)K * nj) return;
-    int k = (int)(idx / nj);
-    int64_t j = jlo + (idx - (int64_t)k * nj);
-    idx = (int64_t)k * g.L + j;   // records are addressed by the line's index in the full table
-    const size_t mk = (g.gid ? (size_t)g.gid[j] * pa.mstride : 0) + k;
-    double T = Tk[k], P = Pk[k], Pp = Ppk[mk], C = scale ? scale[mk] : 1.0;
-    double nul = g.nu[j];
+    const unsigned njb = (unsigned)((jhi - jlo + 255) / 256);   // blocks per chunk of states
+    const int chunk = (int)(bid / njb);
+    const int64_t j = jlo + (int64_t)(bid % njb) * 256 + threadIdx.x;
+    if (j >= jhi) return;
+    const int k0 = chunk * CS_PREP_KC, k1 = min(k0 + CS_PREP_KC, K);
+    const double nul = g.nu[j];
     // scaleintensity, line_shapes.jl:107-123
-    double a = -kC2 * g.Epp[j];
-    double b = -kC2 * nul;
-    double n = exp(a / T) * (1.0 - exp(b / T));
-    int I = g.iso[j];
-    double QrefQ = cheby_qrefq(T, g.ncheb[I - 1], g.cheb + (size_t)(I - 1) * 16);
-    double S = g.sref[j] * QrefQ * n;   // the factor at Tref is folded into sref at upload (two exp and a divide less per record)
-    // alphadoppler :144, gammalorentz :255-257; (Tref/T)^na as exp(na ln(Tref/T)): a third of the instructions of pow()
-    double alpha = (nul / kC) * sqrt(2.0 * kRgas * T / g.mu[j]);
-    double gamma = exp(g.na[j] * log(kTref / T)) * (g.ga[j] * (P - Pp) + g.gs[j] * Pp) / kAtm;
-    LineHot h;
-    LineCold c;
-    h.nul = nul;
-    if (shape == SH_LORENTZ) {
-        h.p1 = gamma * gamma; h.p2 = C * S * gamma / kPi; h.p3 = 0.0;
-        c.y = gamma; c.A = C * S;
-    } else if (shape == SH_DOPPLER) {
-        h.p1 = 1.0 / (alpha * alpha); h.p2 = C * S / (alpha * 1.7724538509055159); h.p3 = 0.0;
-        c.y = alpha; c.A = C * S;
-    } else {
-        double beta = 1.0 / alpha;
-        double dd = kSqLn2 * beta;
-        double y = gamma * dd;
-        double A = C * (S * (kOSqPiLn2 * beta));
-        const double y2 = y * y;
-        h.p1 = dd; h.p2 = y2; h.p3 = A * y * kIsqPi;
-        c.y = y; c.A = A;
-    }
-    hot[idx] = h;
-    cold[idx] = c;
-    if (pa.phfac) {   // chi(dnu) = exp(a_r - b_r |nu - nul|) in region r (line_shapes.jl:467-481) factorises into a per-lane and a per-line part
-        const double B1 = 0.0888 - 0.16 * exp(-0.0041 * T), B2 = 0.0526 * exp(-0.00152 * T);
-        const double dl = nul - pa.nu_c;
-        const size_t KL = (size_t)K * g.L;
-        pa.phfac[0 * KL + idx] = exp(B1 * dl);      pa.phfac[3 * KL + idx] = exp(-B1 * dl);
-        pa.phfac[1 * KL + idx] = exp(B2 * dl);      pa.phfac[4 * KL + idx] = exp(-B2 * dl);
-        pa.phfac[2 * KL + idx] = exp(0.0232 * dl);  pa.phfac[5 * KL + idx] = exp(-0.0232 * dl);
-    }
-    if (hot32) {
-        LineF32 f;
-        f.d = (float)h.p1; f.y2 = (float)h.p2; f.ay = (float)(h.p3 * kMixScale); f.c2 = (float)(3.75 - 2.0 * h.p2);
-        hot32[idx] = f;
+    const double a = -kC2 * g.Epp[j];
+    const double b = -kC2 * nul;
+    const int I = g.iso[j];
+    const double sref = g.sref[j], mu = g.mu[j], na = g.na[j], ga = g.ga[j], gs = g.gs[j];
+    const size_t mo = g.gid ? (size_t)g.gid[j] * pa.mstride : 0;
+    for (int k = k0; k < k1; k++) {
+        const size_t idx = (size_t)k * g.L + j;   // records are addressed by the line's index in the full table
+        const double T = Tk[k], P = Pk[k], Pp = Ppk[mo + k], C = scale ? scale[mo + k] : 1.0;
+        const double n = exp(a / T) * (1.0 - exp(b / T));
+        const double QrefQ = pa.qrefq[(size_t)k * pa.niso + (I - 1)];
+        const double S = sref * QrefQ * n;   // the factor at Tref is folded into sref at upload (two exp and a divide less per record)
+        // alphadoppler :144, gammalorentz :255-257; (Tref/T)^na as exp(na ln(Tref/T)): a third of the instructions of pow()
+        const double alpha = (nul / kC) * sqrt(2.0 * kRgas * T / mu);
+        const double gamma = exp(na * pa.lrt[k]) * (ga * (P - Pp) + gs * Pp) / kAtm;
+        LineHot h;
+        LineCold c;
+        h.nul = nul;
+        if (shape == SH_LORENTZ) {
+            h.p1 = gamma * gamma; h.p2 = C * S * gamma / kPi; h.p3 = 0.0;
+            c.y = gamma; c.A = C * S;
+        } else if (shape == SH_DOPPLER) {
+            h.p1 = 1.0 / (alpha * alpha); h.p2 = C * S / (alpha * 1.7724538509055159); h.p3 = 0.0;
+            c.y = alpha; c.A = C * S;
+        } else {
+            const double beta = 1.0 / alpha;
+            const double dd = kSqLn2 * beta;
+            const double y = gamma * dd;
+            const double A = C * (S * (kOSqPiLn2 * beta));
+            const double y2 = y * y;
+            h.p1 = dd; h.p2 = y2; h.p3 = A * y * kIsqPi;
+            c.y = y; c.A = A;
+        }
+        hot[idx] = h;
+        cold[idx] = c;
+        if (pa.phfac) {   // chi(dnu) = exp(a_r - b_r |nu - nul|) in region r (line_shapes.jl:467-481) factorises into a per-lane and a per-line part
+            const double B1 = 0.0888 - 0.16 * exp(-0.0041 * T), B2 = 0.0526 * exp(-0.00152 * T);
+            const double dl = nul - pa.nu_c;
+            const size_t KL = (size_t)K * g.L;
+            pa.phfac[0 * KL + idx] = exp(B1 * dl);      pa.phfac[3 * KL + idx] = exp(-B1 * dl);
+            pa.phfac[1 * KL + idx] = exp(B2 * dl);      pa.phfac[4 * KL + idx] = exp(-B2 * dl);
+            pa.phfac[2 * KL + idx] = exp(0.0232 * dl);  pa.phfac[5 * KL + idx] = exp(-0.0232 * dl);
+        }
+        if (hot32) {
+            LineF32 f;
+            f.d = (float)h.p1; f.y2 = (float)h.p2; f.ay = (float)(h.p3 * kMixScale); f.c2 = (float)(3.75 - 2.0 * h.p2);
+            hot32[idx] = f;
+        }
     }
 }
 

@@ -185,6 +185,27 @@ int cs_fluxes_discretized(cs_ctx *ctx, int64_t nnu, const double *nu, int np, co
                           double *Mdn, double *Fup, double *Fdn);
 
 /*
+ * B3 on several GPUs of one node, from one process: radiate! (fluxes.jl:357-383) with `ngpu` devices behind it.  Every wavenumber is
+ * independent through the whole path; the only coupling is the trapezoid over nu (intF!, shared.jl:125-137).  The grid is cut into
+ * nctx contiguous ranges of equal estimated device time (cs_balanced_ranges); context i -- created by the caller on the device of
+ * its choice, holding the SAME gas tables in the same slots -- evaluates range i with slices of the global trapezoid weights (no
+ * halo), all contexts side by side (one host thread each); tau, M+, M- land in the caller's arrays range by range, and the band
+ * fluxes are added on the host in context order -- 2*np doubles per GPU, bitwise repeatable (SURVEY.md 8e's deterministic
+ * alternative to an all-reduce; the RCCL form for one process per GPU is bench.py's).  Arguments as cs_fluxes_discretized.
+ * Repeated calls on an unchanged grid re-use each context's resident shard.  nctx = 1 is cs_fluxes_discretized.
+ */
+int cs_fluxes_discretized_multi(cs_ctx *const *ctxs, int nctx, int64_t nnu, const double *nu, int np, const double *P, double g, int nlobatto,
+                                const double *T_nodes, const double *mu_nodes, const double *T_levels, int ngas, const int *gas_slots,
+                                const int *shapes, const double *dnu_cuts, const double *conc, double sigma_gray, const double *sigma_extra,
+                                const double *S_toa, const double *albedo, double theta_s, int nstream, double *tau, double *Mup,
+                                double *Mdn, double *Fup, double *Fdn);
+/* The partition of the above (host only, no GPU needed): nparts contiguous ranges [ranges[2r], ranges[2r+1]) of the grid with equal
+ * estimated device time -- a fixed cost per wavenumber plus, per gas, its local line density times a factor growing with nu
+ * (near-line pairs scale with the Doppler width); edges on multiples of 64 points where the grid is long enough; every range
+ * non-empty.  line_nu[g][0 .. nlines[g]) = the sorted line positions of gas g. */
+int cs_balanced_ranges(int64_t nnu, const double *nu, int ngas, const int64_t *nlines, const double *const *line_nu, int nparts, int64_t *ranges);
+
+/*
  * Device-resident form of B3 for callers that keep the column in HBM (benchmarks, torch/RCCL plumbing, RCM loops):
  *   cs_column_setup  uploads the inputs of cs_fluxes_discretized once and allocates all workspaces;
  *                    `wts` is NULL (trapezoid weights of `nu`, util.jl:26-33) or [nnu] weights of a nu-shard

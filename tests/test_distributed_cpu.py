@@ -56,3 +56,30 @@ def test_two_rank_shards_reduce_to_full_column():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert err < 1e-12
+
+
+def test_balanced_ranges_partition_properties():
+    """cs_balanced_ranges (the partition cs_fluxes_discretized_multi and bench.py cut the grid with; host only): contiguous, covering,
+    non-empty ranges -- also with a dense line cluster at the top of a grid whose length is not a multiple of the 64-point tile
+    (an interior edge used to round past the end) -- edges on tile boundaries where the grid is long enough, and about
+    equal estimated cost."""
+    import clearsky_jl_amd as cs
+    rng = np.random.default_rng(5)
+    nu = np.linspace(1.0, 100.0, 100037)
+    cluster = np.sort(np.concatenate([rng.uniform(99.5, 100.0, 50000), rng.uniform(0.0, 100.0, 100)]))
+    uniform = np.sort(rng.uniform(0.0, 125.0, 4000))
+    for tabs in ([cluster], [uniform], [cluster, uniform], []):
+        for n in (1, 2, 3, 8, 16):
+            r = cs.balanced_ranges(nu, tabs, n)
+            assert len(r) == n and r[0][0] == 0 and r[-1][1] == len(nu)
+            assert all(0 <= a < b <= len(nu) for a, b in r) and all(r[i][1] == r[i + 1][0] for i in range(n - 1))
+            assert all(a % 64 == 0 for a, _ in r)                     # 100037 >= 64 * 4 * 16: every interior edge on a tile boundary
+    # equal cost: a uniform table on a uniform grid gives equal ranges (to a tile)
+    r = cs.balanced_ranges(np.linspace(1.0, 2500.0, 64000), [np.sort(rng.uniform(0.0, 2525.0, 50000))], 8)
+    sizes = np.array([b - a for a, b in r])
+    assert sizes.max() - sizes.min() <= 0.2 * sizes.mean()             # (cost grows with nu -- Doppler widths: later ranges are a little shorter)
+    assert np.all(np.diff(sizes) <= 64)
+    # short grids: one point per range is the limit, more parts than points an error
+    assert cs.balanced_ranges(np.linspace(1.0, 2.0, 10), [], 10) == [(i, i + 1) for i in range(10)]
+    with pytest.raises(cs.ClearSkyHIPError):
+        cs.balanced_ranges(np.linspace(1.0, 2.0, 10), [], 11)

@@ -76,3 +76,51 @@ def test_bench_spawns_its_own_ranks():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu"], env=env2, capture_output=True,
                          text=True, timeout=120)
     assert bad.returncode == 2 and "WORLD_SIZE" in bad.stderr
+
+
+def test_multi_context_entry_point_vs_oracle(cs, O, lines):
+    """cs_fluxes_discretized_multi, the product's N-GPU form of B3 (radiate! with `ngpu` devices behind it): N contexts -- here two and
+    three on the box's one card -- each take a cost-balanced wavenumber range; tau, M+, M- land in the caller's arrays range by range,
+    band fluxes are added on the host in context order.  Against the oracle's whole column, against the one-context call bit for
+    bit where the arithmetic is per wavenumber (tau, M+, M-), and repeatable bit for bit."""
+    import workloads as W
+    nu = np.linspace(550.0, 800.0, 12000)
+    P = cs.pressuregrid(10.0, 1e5, 13)
+    T = W.earth_temperature(P)
+    gases = [cs.DirectGas(lines("H2O"), W.fC_h2o, nu), cs.DirectGas(lines("CO2"), 400e-6, nu), cs.GrayGas(3e-28, nu)]
+    one = cs.Context(0)
+    F1 = cs.radiate(P, 9.8, T, 0.029, 0.3, 0.2, *gases, core=cs.Discretized(5, 3), ctx=one)
+    col = cs.Column(P, 9.8, T, 0.029, 0.3, 0.2, *gases, core=cs.Discretized(5, 3), ctx=one, _setup=False)
+    ref = O.fluxes_discretized(nu, P, 9.8, 3, col.Tn, col.mun, col.Tlev, [g.sl for g in col.gases], ["voigt"] * 2, [25.0] * 2, col.conc,
+                               sigma_gray=col.sigma_gray, S_toa=col.S_toa, albedo=col.albedo)
+    for n in (2, 3):
+        mc = cs.MultiContext([0] * n)
+        F = cs.radiate(P, 9.8, T, 0.029, 0.3, 0.2, *gases, core=cs.Discretized(5, 3), ctx=mc)
+        assert np.max(np.abs(F.tau - ref["tau"]) / ref["tau"]) < 1e-11
+        sm = ref["Mup"].max()
+        assert np.max(np.abs(F.Mup - ref["Mup"])) < 1e-11 * sm and np.max(np.abs(F.Mdn - ref["Mdn"])) < 1e-11 * sm
+        assert np.max(np.abs(F.Fup - ref["Fup"])) < 1e-11 * ref["Fup"].max() and np.max(np.abs(F.Fdn - ref["Fdn"])) < 1e-11 * ref["Fup"].max()
+        # per-wavenumber results do not depend on how the grid was cut beyond the rounding of the far-wing interpolation
+        assert np.max(np.abs(F.tau - F1.tau) / F1.tau) < 5e-13
+        assert np.max(np.abs(F.Fup - F1.Fup)) < 1e-12 * F1.Fup.max()
+        # a second call re-uses the resident shards (same grid) with a new temperature profile; and is bitwise repeatable
+        G1 = cs.radiate(P, 9.8, T + 3.0, 0.029, 0.3, 0.2, *gases, core=cs.Discretized(5, 3), ctx=mc)
+        G2 = cs.radiate(P, 9.8, T + 3.0, 0.029, 0.3, 0.2, *gases, core=cs.Discretized(5, 3), ctx=mc)
+        assert np.array_equal(G1.Fup, G2.Fup) and np.array_equal(G1.Mup, G2.Mup) and not np.array_equal(G1.Fup, F.Fup)
+        Fb = cs.fluxes(P, 9.8, T + 3.0, 0.029, 0.3, 0.2, *gases, core=cs.Discretized(5, 3), ctx=mc)      # band fluxes only (NULL tau, M)
+        assert np.max(np.abs(Fb[0] - G1.Fup)) < 1e-13 * G1.Fup.max()
+        mc.close()
+    # contexts that do not hold the same tables are refused
+    import ctypes as C
+    from clearsky_jl_amd._lib import lib
+    a, b = cs.Context(0), cs.Context(0)
+    a.slot_of(lines("CO2"))
+    h = (C.c_void_p * 2)(a.handle.value, b.handle.value)
+    z = np.zeros(len(P))
+    dp = lambda x: x.ctypes.data_as(C.POINTER(C.c_double))
+    slots = (C.c_int * 1)(0)
+    Tn = np.asfortranarray(col.Tn).ravel(order="F").copy()
+    rc = lib().cs_fluxes_discretized_multi(h, 2, len(nu), dp(nu), len(P), dp(P), 9.8, 3, dp(Tn), dp(Tn), dp(col.Tlev), 1, slots, None, None,
+                                           dp(np.full(col.K, 4e-4)), 0.0, None, None, None, 0.841, 5, None, None, None, dp(z), dp(z.copy()))
+    assert rc == -1 and b"same table on every context" in lib().cs_last_error()
+    a.close(); b.close(); one.close()

@@ -75,26 +75,7 @@ def config(name: str, nnu=None, nl=None, lines_kind=None, nu_span=(1.0, 2500.0),
 
 
 def balanced_ranges(nu, absorbers, nparts: int):
-    """Contiguous nu ranges of equal estimated device time: the multi-GPU partition of SURVEY.md 8e.
-
-    Cost model per wavenumber, fitted to the per-class kernel times of the eight 1/8 shards of C3 (profiles/r02_notes.md):
-      * a fixed part (flux sweeps k_rt, interpolation apply, setup): 0.19
-      * per gas, proportional to its local line density rho [lines per cm^-1]: the per-point window, the node sums and the
-        near-line pairs, whose number grows with the Doppler width, i.e. with nu:  rho * (0.011 + 1.1e-6 * nu)
-    (with the far wings interpolated the +-25 cm^-1 window count no longer measures the work: what stays per point are the
-    lines within a few cm^-1 and the Doppler cores).  Range edges fall on multiples of 64 points (the kernels' tile)."""
-    nu = np.asarray(nu)
-    w = np.full(len(nu), 0.19)
-    for a in absorbers:
-        if isinstance(a, DirectGas):
-            nl = a.sl.nu
-            rho = (np.searchsorted(nl, nu + 2.0, "right") - np.searchsorted(nl, nu - 2.0, "left")) / 4.0
-            w += rho * (0.011 + 1.1e-6 * nu)
-    c = np.concatenate([[0.0], np.cumsum(w)])
-    edges = [int(np.searchsorted(c, c[-1] * r / nparts)) for r in range(nparts + 1)]
-    if len(nu) >= 64 * 4 * nparts:
-        edges = [int(round(e / 64.0)) * 64 for e in edges]
-    edges[0], edges[-1] = 0, len(nu)
-    for r in range(1, nparts + 1):
-        edges[r] = max(edges[r], edges[r - 1] + 1) if r < nparts else len(nu)
-    return [(edges[r], edges[r + 1]) for r in range(nparts)]
+    """Contiguous nu ranges of equal estimated device time: the multi-GPU partition of SURVEY.md 8e, as the product cuts it
+    (cs_balanced_ranges in the C ABI -- what cs_fluxes_discretized_multi uses; cost model and edge rules documented there)."""
+    from clearsky_jl_amd import balanced_ranges as _br
+    return _br(np.asarray(nu, float), [a.sl.nu for a in absorbers if isinstance(a, DirectGas)], nparts)
