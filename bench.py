@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--far-s", type=float, default=1e6, help="mixed precision: x^2 threshold of the fp32 region")
     ap.add_argument("--emulate-shard", default=None, help="R/N: time only shard R of an N-way split on this one GPU (rehearsal)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL, default) | gloo (rehearsal of N>1 on fewer GPUs)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and all-reduce the band fluxes even with one rank "
+                    "(rehearsal of the RCCL path on a one-GPU box)")
     ap.add_argument("--cpu-stride", type=int, default=0, help="cpu_baseline evaluates every n-th wavenumber (0 = size the sample for ~15 s)")
     args = ap.parse_args()
 
@@ -97,8 +99,13 @@ def main():
     dev = local_rank % ndev          # gloo rehearsals may put several ranks on one card
     torch.cuda.set_device(dev)
     dist = None
-    if N > 1:
+    use_dist = N > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
+        if "RANK" not in os.environ:     # --force-dist without a launcher: a one-rank group on a free local port
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
         else:
@@ -134,7 +141,7 @@ def main():
     def step():
         col.run(stream)
         col.flux_to(F.data_ptr(), stream)
-        if N > 1:
+        if use_dist:
             if args.dist_backend == "nccl":
                 dist.all_reduce(F)   # RCCL over xGMI: 2*np doubles, the only collective of the path
             else:
@@ -144,7 +151,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if N > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -156,7 +163,7 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    if N > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{dev}" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -353,10 +360,11 @@ def main():
                                         f"{len(nu)} wavenumbers x {nl} layers, {args.shape}, {cfg['lines_kind']} lines "
                                         f"({lines_total} total), Discretized(nstream=5,nlobatto=2)",
                                nnu=len(nu), layers=nl, lines=lines_total, parallelism=f"nu-shard x{N}"),
+                   collective=(f"{args.dist_backend} all_reduce of {2 * col.np} doubles per step" if use_dist else None),
                    olr_wm2=olr, setup_ms=setup_ms, launches_per_step=int(info["launches"]), launch_groups=int(info["groups"]), host_pointer_ms=host_ptr, kernel_source_sha16=source_stamp(),
                    roofline=roofline, cpu_baseline=cpu)
         print(json.dumps(out))
-    if N > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

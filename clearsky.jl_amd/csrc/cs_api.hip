@@ -534,6 +534,7 @@ struct Interp {
     EdgeZone *edge = nullptr; // NULL: all of the per-point sum on the vector unit
     bool sep_always = false;  // cs_set_matrix_cores(ctx, 2): also on grids too short to fill the chip with (interval, state group) blocks
     bool core = true;         // cs_set_matrix_cores(ctx, on | 4) switches the sub-tile treatment of the window core (k_voigt_sub) off
+    double margin = kChebMargin;   // cs_set_tuning key 3 (per cent): distance of an interval's interpolated set, in half-widths
     bool small_mx = false;    // cs_set_tuning key 1: the matrix-core kernels on short grids too (their four-waves-per-item variants)
     bool fuse_apply = false;  // the column's only interpolating group: k_voigt_edge_mx may carry the node sums to the grid itself
     double core4 = 0.0;       // the core takes the 4-term series where its radius is below core4 x the tile's span, else the 8-term one
@@ -757,6 +758,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
         za.nu = dnu; za.nul = G.nu.as<double>(); za.Tk = Tk; za.gbound = gbound; za.win = win; za.zones = zones; za.nnu = nnu;
         za.lorentz = lor ? 1 : 0;
         za.ntile = nt64; za.K = kn; za.mu_min = G.mu_min; za.mu_max = G.mu_max; za.cut = cut; za.far_s = far_s;
+        za.margin = itp.margin;
         const unsigned nb_zones = (unsigned)(((int64_t)nt64 * kn + 255) / 256);
         IzParams P;
         memset(&P, 0, sizeof P);
@@ -928,6 +930,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
         za.nu = dnu; za.nul = G.nu.as<double>(); za.Tk = Tk; za.gbound = gbound; za.win = win; za.zones = zones; za.nnu = nnu;
         za.lorentz = 0;
         za.ntile = nt64; za.K = kn; za.mu_min = G.mu_min; za.mu_max = G.mu_max; za.cut = cut; za.far_s = far_s;
+        za.margin = kChebMargin;
         const unsigned nb_zones = (unsigned)(((int64_t)nt64 * kn + 255) / 256);
         IzParams P;
         memset(&P, 0, sizeof P);
@@ -1095,20 +1098,22 @@ static int merged_table(cs_ctx *ctx, const std::vector<int> &slots, const GasTab
     G.niso = niso;
     G.members = key;
     struct Src { uint8_t m; int32_t j; };
-    std::vector<Src> order;
-    order.reserve(L);
+    std::vector<Src> order, next, mine;
     std::vector<int> iso_off(slots.size());
     int off = 0;
-    for (size_t m = 0; m < slots.size(); m++) {
+    auto nu_of = [&](const Src &q) { return ctx->gas[slots[q.m]].h_nu[q.j]; };
+    for (size_t m = 0; m < slots.size(); m++) {   // members are sorted: merge them one by one (stable: equal positions keep member order)
         const GasTable &g = ctx->gas[slots[m]];
         iso_off[m] = off;
         off += g.niso;
-        for (int64_t j = 0; j < g.L; j++) order.push_back(Src{(uint8_t)m, (int32_t)j});
+        mine.resize((size_t)g.L);
+        for (int64_t j = 0; j < g.L; j++) mine[j] = Src{(uint8_t)m, (int32_t)j};
+        next.resize(order.size() + mine.size());
+        std::merge(order.begin(), order.end(), mine.begin(), mine.end(), next.begin(), [&](const Src &a, const Src &b) { return nu_of(a) < nu_of(b); });
+        order.swap(next);
         G.h_ncheb.insert(G.h_ncheb.end(), g.h_ncheb.begin(), g.h_ncheb.end());
         G.h_cheb.insert(G.h_cheb.end(), g.h_cheb.begin(), g.h_cheb.end());
     }
-    // (each member is sorted: a stable sort of the concatenation is the stable merge)
-    std::stable_sort(order.begin(), order.end(), [&](const Src &a, const Src &b) { return ctx->gas[slots[a.m]].h_nu[a.j] < ctx->gas[slots[b.m]].h_nu[b.j]; });
     G.h_nu.resize(L); G.h_S.resize(L); G.h_ga.resize(L); G.h_gs.resize(L); G.h_Epp.resize(L); G.h_na.resize(L); G.h_mu.resize(L);
     G.h_iso.resize(L); G.h_gid.resize(L);
     for (int64_t i = 0; i < L; i++) {
@@ -1181,6 +1186,7 @@ int cs_set_tuning(cs_ctx *ctx, int key, int value)
 {
     if (!ctx) return fail(CS_EINVAL, "ctx is NULL");
     if (key < 0 || key >= CS_NTUNE) return fail(CS_EINVAL, "tuning key %d out of range", key);
+    if (key == 3 && value != 0 && (value < 15 || value > 100)) return fail(CS_EINVAL, "interpolation margin must be 15..100 per cent of the half-width");
     ctx->tune[key] = value;
     return CS_OK;
 }
@@ -1270,7 +1276,7 @@ static int shape_impl(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t 
         itp = interp_view(cheb, ginterp, kc);
         if (!ctx->matrix_nodes) itp.sep = nullptr, itp.edge = nullptr;
         itp.sep_always = ctx->matrix_nodes == 2;
-        itp.small_mx = ctx->tune[1] != 0;
+        itp.small_mx = ctx->tune[1] != 0; itp.margin = ctx->tune[3] > 0 ? 0.01 * ctx->tune[3] : kChebMargin;
         itp.core = ctx->matrix_core != 0;
     }
     for (int k0 = 0; k0 < K; k0 += kc) {
@@ -1358,7 +1364,7 @@ int cs_bake(cs_ctx *ctx, int gas_slot, int table_slot, int shape, double dnu_cut
         itp = interp_view(cheb, ginterp, kc);
         if (!ctx->matrix_nodes) itp.sep = nullptr, itp.edge = nullptr;
         itp.sep_always = ctx->matrix_nodes == 2;
-        itp.small_mx = ctx->tune[1] != 0;
+        itp.small_mx = ctx->tune[1] != 0; itp.margin = ctx->tune[3] > 0 ? 0.01 * ctx->tune[3] : kChebMargin;
         itp.core = ctx->matrix_core != 0;
     }
     for (int k0 = 0; k0 < M; k0 += kc) {
@@ -2047,7 +2053,7 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
             itp.sep = ctx->matrix_nodes ? dsep.as<SepZone>() : nullptr;
             itp.edge = ctx->matrix_nodes ? dedge.as<EdgeZone>() : nullptr;
             itp.sep_always = ctx->matrix_nodes == 2;
-            itp.small_mx = ctx->tune[1] != 0;
+            itp.small_mx = ctx->tune[1] != 0; itp.margin = ctx->tune[3] > 0 ? 0.01 * ctx->tune[3] : kChebMargin;
             itp.core = ctx->matrix_core != 0;
         }
         for (int64_t k0 = 0; k0 < BK; k0 += kc) {
@@ -2153,7 +2159,7 @@ static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e)
         itp.F = c.chebF.as<double>();
         if (!ctx->matrix_nodes) itp.sep = nullptr, itp.edge = nullptr;
         itp.sep_always = ctx->matrix_nodes == 2;
-        itp.small_mx = ctx->tune[1] != 0;
+        itp.small_mx = ctx->tune[1] != 0; itp.margin = ctx->tune[3] > 0 ? 0.01 * ctx->tune[3] : kChebMargin;
         itp.core = ctx->matrix_core != 0;
         itp.fuse_apply = ctx->tune[0] != 0 && n_itp == 1;
         launch_gas(s, cg.shape, G, cg.jlo, cg.jhi, K, c.Tk.as<double>(), c.Pk.as<double>(), cg.Pp.as<double>(), cg.conc.as<double>(), K,

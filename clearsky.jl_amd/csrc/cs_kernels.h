@@ -272,6 +272,7 @@ struct ZoneArgs {
     int64_t nnu;
     int ntile, K, lorentz;   // lorentz: pure Lorentz profile -- one body everywhere, no Doppler core, no near zone
     double mu_min, mu_max, cut, far_s;
+    double margin;           // an interval's interpolated set stays max(dA, margin x its half-width) away from it (kChebMargin)
 };
 __device__ __forceinline__ void zones_body(unsigned bid, const ZoneArgs &a)
 {
@@ -506,7 +507,7 @@ __device__ __forceinline__ int tile_block(const int32_t *__restrict__ xc, int ti
 // max(dA, 0.3 h) and the cut-off edges are left to the next smaller interval size, and finally to the per-point kernels.
 #define CS_NC 64
 #define CS_MAX_LEVEL 5
-constexpr double kChebMargin = 0.3;
+constexpr double kChebMargin = 0.3;   // default of ZoneArgs::margin
 // per (state, interval): own set = [E0,Z0) U [Z1,E1), cut into the 2-/3-/4-term zones of the far body; [P0,P1) and [P2,P3)
 // is the part of it the parent interval (next level up) has already summed.
 struct __attribute__((aligned(16))) IZone { int32_t E0, Q0, M0, Z0, Z1, M1, Q1, E1, P0, P1, P2, P3; };
@@ -566,7 +567,7 @@ struct IzParams {
 // point, dZ = how far the interpolated set stays from the interval; false if the set is empty
 __device__ __forceinline__ bool izone_frame(const IzParams &P, int l, int T, const double *__restrict__ nu, int64_t nnu, double vth,
                                             double mu_min, double cut, double &vlo, double &vhi, double &dA, double &dZ, int &E0, int &E1,
-                                            bool lorentz)
+                                            bool lorentz, double margin)
 {
     const int itv = P.itv[l];
     const int64_t i0 = (int64_t)T * itv, i1 = (i0 + itv - 1 < nnu ? i0 + itv - 1 : nnu - 1);
@@ -578,7 +579,7 @@ __device__ __forceinline__ bool izone_frame(const IzParams &P, int l, int T, con
     const double h = 0.5 * (vhi - vlo);
     const double amax = ((vhi + cut) / kC) * vth / sqrt(mu_min);
     dA = lorentz ? 0.0 : 100.0 * amax / kSqLn2 * (1.0 + 1e-6);   // (a Lorentz profile has no Doppler core to stay clear of)
-    dZ = fmax(dA, kChebMargin * h);
+    dZ = fmax(dA, margin * h);
     return true;
 }
 __device__ __forceinline__ void izones_body(unsigned bid, const IzParams &P, const ZoneArgs &a, IZone *__restrict__ iz)
@@ -599,7 +600,7 @@ __device__ __forceinline__ void izones_body(unsigned bid, const IzParams &P, con
     const double vth = sqrt(2.0 * kRgas * Tk[k]);
     double vlo, vhi, dA, dZ;
     IZone z;
-    if (!izone_frame(P, l, T, nu, nnu, vth, mu_min, cut, vlo, vhi, dA, dZ, z.E0, z.E1, a.lorentz)) {
+    if (!izone_frame(P, l, T, nu, nnu, vth, mu_min, cut, vlo, vhi, dA, dZ, z.E0, z.E1, a.lorentz, a.margin)) {
         z.Z0 = z.Z1 = z.Q0 = z.M0 = z.M1 = z.Q1 = z.P0 = z.P1 = z.P2 = z.P3 = z.E0;
         iz[idx] = z;
         return;
@@ -621,7 +622,7 @@ __device__ __forceinline__ void izones_body(unsigned bid, const IzParams &P, con
     if (l > P.l0) {
         int pshift = 0;
         for (int r = P.itv[l - 1] / P.itv[l]; r > 1; r >>= 1) pshift++;
-        par = izone_frame(P, l - 1, T >> pshift, nu, nnu, vth, mu_min, cut, pvlo, pvhi, pdA, pdZ, qE0, qE1, a.lorentz);
+        par = izone_frame(P, l - 1, T >> pshift, nu, nnu, vth, mu_min, cut, pvlo, pvhi, pdA, pdZ, qE0, qE1, a.lorentz, a.margin);
     }
     // own Z0, Z1 (set stays dZ away), M0, M1 (4-term zone), Q0, Q1 (3-term zone), parent's Z0, Z1: eight searches side by side
     const double sv[8] = {vlo - dZ, vlo - dAA, vlo - dQ, pvlo - pdZ, vhi + dZ, vhi + dAA, vhi + dQ, pvhi + pdZ};
@@ -835,6 +836,9 @@ __device__ __forceinline__ void sep_step(v4f64_sep (&acc)[4], const double (&vn)
         w = __builtin_fma(w, __builtin_fma(-s2, w, 1.0), w);   // second Newton step (powers of it are taken)
         if (MASK == 1) w = fabs(dv) > cut ? 0.0 : w;
         if (MASK == 2) w = (fabs(dv) > cut || fabs(dv) < rin) ? 0.0 : w;
+        // a sub-tile with every (point, line) of the step masked -- half of the columns at a window end, where the cut-off edge crosses
+        // the tile -- adds exact zeros: skip its matrix instructions (wave-uniform branch on one ballot)
+        if (MASK && !__builtin_amdgcn_ballot_w64(w != 0.0)) continue;
         double wn = w;
 #pragma unroll
         for (int n = 0; n < NT; n++) {

@@ -47,3 +47,12 @@ def lines(cs):
 def relerr(a, b, floor=0.0):
     a, b = np.asarray(a, float), np.asarray(b, float)
     return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor))) if a.size else 0.0
+
+
+def source_rounding_bound(cs, nu, Tlev, tau):
+    """How far the monochromatic fluxes of two evaluations may differ when their layer optical depths differ only in the last bit:
+    the source term (1 - t)(B1 - B2)/tau of layerplanck (discretized.jl:85-87) divides a difference of order tau by tau, so a
+    transmission t = exp(-tau m) that rounds the other way (2^-53) moves it by 2^-53 / tau x |B1 - B2| -- 1e-10 |dB| just above the
+    1e-6 floor -- per layer and stream (weights sum to pi).  Rounding of the reference's own formula, not of the line sums."""
+    B = cs.planck(np.asarray(nu)[None, :], np.asarray(Tlev)[:, None])
+    return float(np.max(np.sum(np.pi * np.abs(np.diff(B, axis=0)) * 2.0 ** -53 / np.asarray(tau), axis=0)))

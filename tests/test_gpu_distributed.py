@@ -124,3 +124,19 @@ def test_multi_context_entry_point_vs_oracle(cs, O, lines):
                                            dp(np.full(col.K, 4e-4)), 0.0, None, None, None, 0.841, 5, None, None, None, dp(z), dp(z.copy()))
     assert rc == -1 and b"same table on every context" in lib().cs_last_error()
     a.close(); b.close(); one.close()
+
+
+def test_bench_rccl_path_single_rank():
+    """The RCCL line of bench.py (init_process_group("nccl", device_id=...) + all_reduce of the band fluxes on the bench stream) with
+    the one rank a one-GPU box can hold: the collective the N > 1 job runs per step executes here too, and must leave the fluxes as
+    they are."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    res = {}
+    for flag in ([], ["--force-dist", "--dist-backend", "nccl"]):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", "C2", "--steps", "5", "--warmup", "2", "--no-cpu"] + flag,
+                             env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+        res[bool(flag)] = d
+    assert res[True]["collective"].startswith("nccl") and res[False]["collective"] is None
+    assert res[True]["olr_wm2"] == res[False]["olr_wm2"]

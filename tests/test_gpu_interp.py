@@ -11,7 +11,7 @@ import math
 import numpy as np
 import pytest
 
-from conftest import relerr
+from conftest import relerr, source_rounding_bound
 
 pytestmark = pytest.mark.gpu
 
@@ -116,9 +116,7 @@ def test_column_interp_on_off(cs, lines):
     # (2^-53), which moves (1 - t)/tau by 2^-53/tau -- 1e-10 just above the 1e-6 floor -- times |B1 - B2| per layer and stream.
     # Both are rounding of the reference's own formula, not of the line sums; (ii) was left out of this bound until the merged
     # line table changed which last bits differ (observed then: 7e-13 against 1.1e-13 before).
-    Blev = cs.planck(nu[None, :], np.array([T(p) for p in P])[:, None])
-    amp = np.max(np.sum(np.pi * np.abs(np.diff(Blev, axis=0)) * 2.0 ** -53 / Foff.tau, axis=0))
-    bound = 2 * col.nl / math.e * 5e-14 * sm + amp
+    bound = 2 * col.nl / math.e * 5e-14 * sm + source_rounding_bound(cs, nu, [T(p) for p in P], Foff.tau)
     assert np.max(np.abs(Fon.Mup - Foff.Mup)) < bound and np.max(np.abs(Fon.Mdn - Foff.Mdn)) < bound
     assert relerr(Fon.Fup, Foff.Fup) < 1e-13
     for a, b in zip(Bon, Boff):
