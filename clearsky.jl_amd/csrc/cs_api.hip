@@ -712,14 +712,16 @@ static bool mx_big(int nblocks, int kn, int min_blocks) { return (int64_t)nblock
 // waves of a block (k_cheb_nodes_mx with every level split, k_voigt_edge_mx<4>)
 static bool sep_in_use(bool have_sep, bool always, int nblocks_intervals, int kn, bool lor, bool mixed, bool small = false)
 {
-    return have_sep && !lor && !mixed && (always || small || mx_big(nblocks_intervals, kn, 2048));
+    (void)mixed;   // (the mixed-precision variant keeps the matrix-core pieces in fp64: only the vector bodies beyond far_s go to fp32)
+    return have_sep && !lor && (always || small || mx_big(nblocks_intervals, kn, 2048));
 }
 // the per-point pieces (k_voigt_edge_mx: one wave per (tile, state group), no reduction) pay on shorter grids -- 1/4 of C3 (1564
 // waves): far 0.42 -> 0.36 ms; 1/8: 0.261 -> 0.244 ms, which the extra zone launch eats -- but only on tables dense enough to give
 // a wave more than a few steps (C5's HITRAN fixtures: far 3.94 -> 4.01 ms with them; its synthetic O3 table: step 10.63 -> 10.51)
 static bool edge_in_use(bool have_edge, bool always, int ntiles, int kn, bool lor, bool mixed, int64_t lines_in_range, bool small = false)
 {
-    return have_edge && !lor && !mixed && (always || ((small || mx_big(ntiles, kn, 1024)) && lines_in_range >= (int64_t)ntiles * CS_EDGE_DENS));
+    (void)mixed;
+    return have_edge && !lor && (always || ((small || mx_big(ntiles, kn, 1024)) && lines_in_range >= (int64_t)ntiles * CS_EDGE_DENS));
 }
 
 // Short grids (a nu-shard): the kernels no longer fill the chip, a step is a chain of launch tails -- and the node sums (F) and the
@@ -883,6 +885,11 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
         const EdgeZone *edgez = use_edge ? itp.edge : nullptr;
         if (lor) {
             if (split == 1) CS_LOR_LAUNCH(1); else if (split == 2) CS_LOR_LAUNCH(2); else CS_LOR_LAUNCH(4);
+        } else if (hot32 && use_edge) {
+#define CS_EDGE32_LAUNCH(SP) CS_LAUNCH((k_voigt_far<true, SP, false, true>), grid_s, dim3(256), 0, s, dnu, nnu, G.L, hot, hot32, G.nu.as<double>(), \
+                                                  win, zones, nt64, nblk_s, cut, base, extra, sigma, accumulate, ranges, iz, itp.nItot, ishift, edgez)
+            if (split == 1) CS_EDGE32_LAUNCH(1); else if (split == 2) CS_EDGE32_LAUNCH(2); else CS_EDGE32_LAUNCH(4);
+#undef CS_EDGE32_LAUNCH
         } else if (hot32) {
             if (split == 1) CS_FAR_LAUNCH(true, 1); else if (split == 2) CS_FAR_LAUNCH(true, 2); else CS_FAR_LAUNCH(true, 4);
         } else if (use_edge) {

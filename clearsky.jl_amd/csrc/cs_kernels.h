@@ -756,7 +756,7 @@ __global__ __launch_bounds__(256) void k_cheb_nodes(const double *__restrict__ n
     const IZone z = iz[(size_t)k * nItot + T];
     const FarK c = load_fark();
     int sa[4] = {z.P0, z.Z0, z.Z1, z.P3}, sb[4] = {z.P0, z.Z0, z.Z1, z.P3};   // (no matrix-core pieces: empty ones at the window ends)
-    if (!MIXED && !LOR && sep) {
+    if (!LOR && sep) {   // (also in the mixed-precision variant: what the matrix cores take stays fp64 -- they beat the fp32 vector bodies)
         const SepZone sz = sep[(size_t)(k >> 4) * nItot + T];
 #pragma unroll
         for (int p = 0; p < 4; p++)
@@ -836,9 +836,8 @@ __device__ __forceinline__ void sep_step(v4f64_sep (&acc)[4], const double (&vn)
         w = __builtin_fma(w, __builtin_fma(-s2, w, 1.0), w);   // second Newton step (powers of it are taken)
         if (MASK == 1) w = fabs(dv) > cut ? 0.0 : w;
         if (MASK == 2) w = (fabs(dv) > cut || fabs(dv) < rin) ? 0.0 : w;
-        // a sub-tile with every (point, line) of the step masked -- half of the columns at a window end, where the cut-off edge crosses
-        // the tile -- adds exact zeros: skip its matrix instructions (wave-uniform branch on one ballot)
-        if (MASK && !__builtin_amdgcn_ballot_w64(w != 0.0)) continue;
+        // (tried: skip the matrix instructions of a sub-tile whose (point, line) pairs are all masked, one ballot per sub-tile -- half of
+        //  the columns at a cut-off edge add exact zeros -- 0.428 -> 0.429 ms: the branch costs what the instructions did)
         double wn = w;
 #pragma unroll
         for (int n = 0; n < NT; n++) {

@@ -70,9 +70,10 @@ int cs_gas_clear(cs_ctx *ctx, int slot);
 /*
  * Arithmetic of the Voigt far wings (BASELINE configs[4], "fp32 mixed-precision variant with tolerance sweep"):
  *   mode 0 (default): fp64 everywhere;
- *   mode 1: (nu, line) pairs with x^2 >= far_s (far_s >= 1e6) are evaluated in fp32 (nu - nul is still formed in fp64, partial
- *           sums of 4 terms, fp64 accumulation); everything nearer stays fp64.  far_s is the knob of the tolerance sweep
- *           (1e6: ~90 % of the pairs in fp32; larger: fewer).  Cross-sections then agree with mode 0 to ~1e-7.
+ *   mode 1: (nu, line) pairs with x^2 >= far_s (far_s >= 1e6) that the VECTOR unit evaluates go to fp32 (nu - nul is still formed in
+ *           fp64, partial sums of 4 terms, fp64 accumulation); everything nearer, and every piece the matrix cores sum
+ *           (cs_set_matrix_cores: v_mfma_f64 beats the fp32 vector bodies), stays fp64.  far_s is the knob of the tolerance sweep
+ *           (larger: fewer pairs in fp32).  Cross-sections then agree with mode 0 to ~1e-7.
  * Applies to every later cs_shape_batch / cs_bake / cs_column_run of the context.
  */
 int cs_set_precision(cs_ctx *ctx, int mode, double far_s);
