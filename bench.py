@@ -37,14 +37,10 @@ FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md: the fp64 matrix path has t
 
 
 def source_stamp():
-    """sha256 (16 hex digits) of the kernel sources the loaded library was built from: PMC traffic collected offline is only
-    quoted while it belongs to these exact kernels (profiles/pmc_traffic.json carries the stamp of the build it was measured on)."""
-    h = hashlib.sha256()
-    csrc = os.path.join(_ROOT, "clearsky.jl_amd", "csrc")
-    for f in sorted(os.listdir(csrc)):
-        if f.endswith((".hip", ".h")):
-            h.update(open(os.path.join(csrc, f), "rb").read())
-    return h.hexdigest()[:16]
+    """Build id of the LOADED library (cs_build_id: the sha256 of the sources it was compiled from, baked in at build time): PMC
+    traffic collected offline is only quoted while profiles/pmc_traffic.json carries the id of this very binary."""
+    import clearsky_jl_amd as cs
+    return cs.lib().cs_build_id().decode()
 
 
 def main():

@@ -10,7 +10,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.environ.get("CLEARSKY_HIP_LIB", os.path.join(CSRC, "libclearsky_hip.so"))   # override: kernel A/B builds
+LIB_PATH = os.path.join(CSRC, "libclearsky_hip.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "clearsky_hip.h")
 
 CS_MAX_GAS = 16
@@ -27,6 +27,7 @@ _vp = C.c_void_p
 # name -> (restype, argtypes); must list every symbol the header declares
 SIGNATURES = {
     "cs_version": (C.c_int, []),
+    "cs_build_id": (C.c_char_p, []),
     "cs_last_error": (C.c_char_p, []),
     "cs_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "cs_destroy": (None, [_vp]),
@@ -95,6 +96,18 @@ class ClearSkyHIPError(RuntimeError):
         self.code = code
 
 
+def source_id() -> str:
+    """sha256 (16 hex digits) of the sources the library is built from -- compiled into it as cs_build_id(), so that a measurement
+    can name the binary it was taken on (bench.py's kernel_source_sha16, profiles/pmc_traffic.json)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(open(HEADER, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def build_native(force: bool = False, verbose: bool = False) -> str:
     """Compile csrc/*.hip for gfx950 into csrc/libclearsky_hip.so with hipcc (cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, "cs_api.hip")]
@@ -102,7 +115,7 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH] + srcs
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", f'-DCS_BUILD_ID="{source_id()}"', "-o", LIB_PATH] + srcs
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=CSRC)

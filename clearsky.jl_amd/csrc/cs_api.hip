@@ -207,6 +207,12 @@ struct Column {
     std::vector<ColGas> gas;     // launch groups
     int merge = 1;               // the context's cs_set_merge at setup time
     int launches = 0;            // kernel launches of the last cs_column_run
+    // cs_set_tuning key 4: the step as ONE hipGraph launch (captured on the second run after a change, replayed from the third on):
+    // kernel arguments are device addresses that stay put between cs_column_update_state calls, so only what changes launch
+    // geometry or pointers (setup, tables, CIA pairs, accelerated absorber, spectra switched on or off) drops the graph
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    int runs_since_change = 0;
     std::vector<ColTab> tab;
     std::vector<ColCia> cia;
     ColAccel accel;
@@ -218,6 +224,15 @@ struct Column {
 };
 
 }  // namespace
+
+static void drop_graph(Column &c)
+{
+    if (c.graph_exec) (void)hipGraphExecDestroy(c.graph_exec);
+    if (c.graph) (void)hipGraphDestroy(c.graph);
+    c.graph_exec = nullptr;
+    c.graph = nullptr;
+    c.runs_since_change = 0;
+}
 
 // workspace of the PHCO2 fast path (k_phco2): per-(state, line) chi factors and per-tile region windows
 constexpr int CS_NTUNE = 8;
@@ -991,6 +1006,10 @@ int check_ascending(const double *nu, int64_t n)
 extern "C" {
 
 int cs_version(void) { return 100; }
+#ifndef CS_BUILD_ID
+#define CS_BUILD_ID "unknown"
+#endif
+const char *cs_build_id(void) { return CS_BUILD_ID; }
 const char *cs_last_error(void) { return g_err.c_str(); }
 
 int cs_create(int device, cs_ctx **out)
@@ -1017,6 +1036,7 @@ void cs_destroy(cs_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+    drop_graph(ctx->col);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
@@ -1146,6 +1166,7 @@ int cs_set_precision(cs_ctx *ctx, int mode, double far_s)
     if (!(far_s >= 1e6)) return fail(CS_EINVAL, "far_s must be >= 1e6");
     ctx->mixed = mode;
     ctx->far_s = far_s;
+    drop_graph(ctx->col);
     return CS_OK;
 }
 
@@ -1174,6 +1195,7 @@ int cs_set_matrix_cores(cs_ctx *ctx, int on)
     ctx->matrix_core = (on & 4) ? 0 : 1;   // (tuning / tests: | 4 keeps the tile-wide near-zone pass everywhere)
     on &= 3;
     ctx->matrix_nodes = on > 2 ? 2 : on;
+    drop_graph(ctx->col);
     return CS_OK;
 }
 
@@ -1195,6 +1217,7 @@ int cs_set_tuning(cs_ctx *ctx, int key, int value)
     if (key < 0 || key >= CS_NTUNE) return fail(CS_EINVAL, "tuning key %d out of range", key);
     if (key == 3 && value != 0 && (value < 15 || value > 100)) return fail(CS_EINVAL, "interpolation margin must be 15..100 per cent of the half-width");
     ctx->tune[key] = value;
+    drop_graph(ctx->col);
     return CS_OK;
 }
 
@@ -1493,6 +1516,7 @@ int cs_column_set_tables(cs_ctx *ctx, int ntab, const int *table_slots, const do
     if (ntab < 0 || ntab > CS_MAX_TABLE) return fail(CS_EINVAL, "ntab out of range");
     Column &c = ctx->col;
     HIPCHK(hipSetDevice(ctx->device));
+    drop_graph(c);
     c.tab.clear();
     c.tab.resize(ntab);
     for (int t = 0; t < ntab; t++) {
@@ -1605,6 +1629,7 @@ int cs_column_set_cia(cs_ctx *ctx, int ncia, const int *cia_slots, const int *fl
     if (ncia < 0 || ncia > CS_MAX_CIA) return fail(CS_EINVAL, "ncia out of range");
     Column &c = ctx->col;
     HIPCHK(hipSetDevice(ctx->device));
+    drop_graph(c);
     c.cia.clear();
     c.cia.resize(ncia);
     int rc;
@@ -1714,6 +1739,7 @@ int cs_column_set_accel(cs_ctx *ctx, int accel_slot)
 {
     if (!ctx || !ctx->col.ready) return fail(CS_ESTATE, "cs_column_setup has not been called");
     Column &c = ctx->col;
+    drop_graph(c);
     if (accel_slot < 0) { c.accel.slot = -1; return CS_OK; }
     if (accel_slot >= CS_MAX_ACCEL || !ctx->accel[accel_slot].present) return fail(CS_EINVAL, "accelerated-absorber slot %d is empty", accel_slot);
     // an AcceleratedAbsorber stands for ALL absorbers of a column (unifyabsorbers(::Tuple{AcceleratedAbsorber}), absorbers.jl:216)
@@ -1743,6 +1769,7 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
     if (!ctx) return fail(CS_EINVAL, "ctx is NULL");
     Column &c = ctx->col;
     c.ready = false;
+    drop_graph(c);
     if (np < 2) return fail(CS_EINVAL, "need at least two pressure levels");
     if (nlobatto < 2 || nlobatto > CS_MAX_LOBATTO) return fail(CS_EINVAL, "nlobatto must be in [2,%d]", CS_MAX_LOBATTO);
     if (nstream < 1 || nstream > CS_MAX_STREAM) return fail(CS_EINVAL, "nstream must be in [1,%d]", CS_MAX_STREAM);
@@ -2232,7 +2259,30 @@ int cs_column_run(cs_ctx *ctx, void *stream)
 {
     if (!ctx || !ctx->col.ready) return fail(CS_ESTATE, "cs_column_setup has not been called");
     HIPCHK(hipSetDevice(ctx->device));   // (a process may drive several contexts on several devices: cs_fluxes_discretized_multi)
-    return run_impl(ctx, stream ? (hipStream_t)stream : ctx->stream, nullptr);
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    Column &c = ctx->col;
+    if (!ctx->tune[4]) return run_impl(ctx, s, nullptr);
+    if (c.graph_exec) {
+        for (auto &ug : c.ugas)
+            if (!ctx->gas[ug.slot].present || ctx->gas[ug.slot].generation != ug.generation) { drop_graph(c); return run_impl(ctx, s, nullptr); }
+        HIPCHK(hipGraphLaunch(c.graph_exec, s));
+        return CS_OK;
+    }
+    if (c.runs_since_change++ == 0) return run_impl(ctx, s, nullptr);   // first run after a change: eager (workspaces may still grow)
+    HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+    const int rc = run_impl(ctx, s, nullptr);
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(s, &g);
+    if (rc || e != hipSuccess || !g) {
+        if (g) (void)hipGraphDestroy(g);
+        c.runs_since_change = 0;
+        if (rc) return rc;
+        return run_impl(ctx, s, nullptr);   // (capture refused: run eagerly)
+    }
+    c.graph = g;
+    if (hipGraphInstantiate(&c.graph_exec, g, nullptr, nullptr, 0) != hipSuccess) { c.graph_exec = nullptr; drop_graph(c); return run_impl(ctx, s, nullptr); }
+    HIPCHK(hipGraphLaunch(c.graph_exec, s));
+    return CS_OK;
 }
 
 int cs_column_profile(cs_ctx *ctx, void *stream, int reps, double *ms)
@@ -2630,9 +2680,11 @@ int cs_fluxes_discretized(cs_ctx *ctx, int64_t nnu, const double *nu, int np, co
         Column &c = ctx->col;
         HIPCHK(hipSetDevice(ctx->device));
         hipStream_t s = ctx->stream;
+        const bool was[3] = {c.has_extra, c.has_S, c.has_alb};
         c.has_extra = sigma_extra != nullptr;
         c.has_S = S_toa != nullptr && std::any_of(S_toa, S_toa + nnu, [](double x) { return x != 0.0; });
         c.has_alb = albedo != nullptr && std::any_of(albedo, albedo + nnu, [](double x) { return x != 0.0; });
+        if (was[0] != c.has_extra || was[1] != c.has_S || was[2] != c.has_alb) drop_graph(c);   // (other kernel arguments)
         if (c.has_extra && (rc = upload(c.extra, sigma_extra, (size_t)nnu * c.K, s))) return rc;
         if (c.has_S && (rc = upload(c.S_toa, S_toa, nnu, s))) return rc;
         if (c.has_alb && (rc = upload(c.albedo, albedo, nnu, s))) return rc;
@@ -2911,6 +2963,7 @@ int cs_fluxes_discretized_multi(cs_ctx *const *ctxs, int nctx, int64_t nnu, cons
             Column &c = ctx->col;
             hipStream_t s = ctx->stream;
             r = hipSetDevice(ctx->device) == hipSuccess ? CS_OK : fail(CS_EHIP, "hipSetDevice(%d) failed", ctx->device);
+            drop_graph(c);   // (spectra may have been switched on or off: other kernel arguments)
             c.has_extra = sigma_extra != nullptr;
             c.has_S = S_toa != nullptr && std::any_of(S_toa + a, S_toa + a + n, [](double x) { return x != 0.0; });
             c.has_alb = albedo != nullptr && std::any_of(albedo + a, albedo + a + n, [](double x) { return x != 0.0; });

@@ -48,6 +48,9 @@ enum { CS_SHAPE_VOIGT = 0, CS_SHAPE_LORENTZ = 1, CS_SHAPE_DOPPLER = 2, CS_SHAPE_
 #define CS_MAX_LOBATTO 16
 
 int cs_version(void);
+/* 16 hex digits naming the sources this binary was compiled from (sha256 over csrc/ and this header, set by the build recipe;
+ * "unknown" for a build that did not pass it): measurements quote it, so a profile can be matched to the library it was taken on */
+const char *cs_build_id(void);
 const char *cs_last_error(void);
 
 /* Create a context on HIP device `device` (one per host thread). */
@@ -112,7 +115,10 @@ int cs_set_merge(cs_ctx *ctx, int on);
  *   key 1: the matrix-core kernels also on grids too short to fill the chip with one (interval | tile, state group) per wave, through
  *          their four-waves-per-item variants (1, default; 0: such grids stay on the vector unit);
  *   key 2: the node sums of a launch group run on a side stream beside its per-point kernels -- 2 (default) always, 1 on short
- *          grids only (fewer than 16384 (tile, state) waves: a nu-shard), 0 never.
+ *          grids only (fewer than 16384 (tile, state) waves: a nu-shard), 0 never;
+ *   key 3: distance of an interval's interpolated set from the interval, per cent of its half-width (0 = the default 30; 15..100);
+ *   key 4: cs_column_run replays the step as one hipGraph (captured on the second run after anything changed launch geometry or
+ *          kernel arguments; cs_column_update_state does not) instead of enqueuing its kernels one by one -- 0 (default) off, 1 on.
  * Applies to every later cs_column_setup / cs_column_run of the context. */
 int cs_set_tuning(cs_ctx *ctx, int key, int value);
 

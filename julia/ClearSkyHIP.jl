@@ -22,6 +22,7 @@ using ClearSky: AbstractNumericalCore, AbstractGas, SpectralLines, GrayGas, MOLP
 
 const LIB = get(ENV, "CLEARSKY_HIP_LIB", joinpath(@__DIR__, "..", "clearsky.jl_amd", "csrc", "libclearsky_hip.so"))
 const CHEB_LD = 16
+const CS_MAX_GAS = 16        # gas slots per context (include/clearsky_hip.h)
 const SHAPES = Dict(:voigt=>0, :lorentz=>1, :doppler=>2, :PHCO2=>3)
 
 lasterror() = unsafe_string(ccall((:cs_last_error, LIB), Cstring, ()))
@@ -32,26 +33,43 @@ check(rc::Cint) = rc == 0 ? nothing : error("clearsky_hip ($rc): $(lasterror())"
 
 mutable struct Context
     handle::Ptr{Cvoid}
+    device::Int
     slots::IdDict{Any,Cint}            # SpectralLines objects (slot!) or the arguments of slotfrompar!
+    order::Vector{Any}                 # keys of `slots`, oldest first (eviction order once all CS_MAX_GAS slots are taken)
     function Context(device::Integer=0)
         h = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:cs_create, LIB), Cint, (Cint, Ref{Ptr{Cvoid}}), device, h))
-        c = new(h[], IdDict{Any,Cint}())
+        c = new(h[], device, IdDict{Any,Cint}(), Any[])
         finalizer(x -> ccall((:cs_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.handle), c)
         return c
     end
 end
 
-const CONTEXTS = Dict{Int,Context}()
+# a free gas slot, or the oldest table's (same policy as the Python mirror's Context._take_slot; the library refuses slots >= CS_MAX_GAS)
+function takeslot!(ctx::Context, key)::Cint
+    if length(ctx.order) >= CS_MAX_GAS
+        old = popfirst!(ctx.order)
+        slot = ctx.slots[old]
+        delete!(ctx.slots, old)
+    else
+        slot = Cint(length(ctx.order))
+    end
+    push!(ctx.order, key)
+    ctx.slots[key] = slot
+    return slot
+end
+
+# one context per (Julia thread, device): a context is not re-entrant, and `ngpu` devices take `ngpu` contexts
+const CONTEXTS = Dict{Tuple{Int,Int},Context}()
 const CTXLOCK = ReentrantLock()
-context() = lock(CTXLOCK) do
-    get!(() -> Context(parse(Int, get(ENV, "CLEARSKY_HIP_DEVICE", "0"))), CONTEXTS, Threads.threadid())
+context(device::Integer=parse(Int, get(ENV, "CLEARSKY_HIP_DEVICE", "0"))) = lock(CTXLOCK) do
+    get!(() -> Context(device), CONTEXTS, (Threads.threadid(), Int(device)))
 end
 
 # upload a SpectralLines table (hitran/par.jl:224-251) + the MOLPARAM rows of its molecule, once per context
 function slot!(ctx::Context, sl::SpectralLines)::Cint
     haskey(ctx.slots, sl) && return ctx.slots[sl]
-    slot = Cint(length(ctx.slots))
+    slot = takeslot!(ctx, sl)
     mp = MOLPARAM[sl.M]
     niso = length(mp.I)
     ncheb = Int32[mp.hascheb[i] ? mp.ncheb[i] : 0 for i in 1:niso]
@@ -63,7 +81,6 @@ function slot!(ctx::Context, sl::SpectralLines)::Cint
         (Ptr{Cvoid}, Cint, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
          Ptr{Float64}, Ptr{Int16}, Cint, Ptr{Int32}, Ptr{Float64}),
         ctx.handle, slot, sl.N, sl.ν, sl.S, sl.γa, sl.γs, sl.Epp, sl.na, sl.μ, sl.I, niso, ncheb, cheb))
-    ctx.slots[sl] = slot
     return slot
 end
 
@@ -78,13 +95,12 @@ function slotfrompar!(ctx::Context, filename::String, M::Integer; νmin::Real=0,
         cheb[k,i] = mp.cheb[i][k]
     end
     keep = Cint[x isa Char ? ClearSky.ISOINDEX[x] : x for x in I]
-    slot = Cint(length(ctx.slots))
+    slot = takeslot!(ctx, (filename, M, νmin, νmax, Scut, Tuple(keep), maxlines))
     L = Ref{Int64}(0)
     check(ccall((:cs_gas_upload_par, LIB), Cint,
         (Ptr{Cvoid}, Cint, Cstring, Cdouble, Cdouble, Cdouble, Ptr{Cint}, Cint, Int64, Cint, Ptr{Float64}, Cint, Ptr{Int32},
          Ptr{Float64}, Ref{Int64}),
         ctx.handle, slot, filename, νmin, min(νmax, 1e300), Scut, keep, length(keep), maxlines, M, mp.μ, niso, ncheb, cheb, L))
-    ctx.slots[(filename, M, νmin, νmax, Scut, Tuple(keep), maxlines)] = slot
     return slot, L[]
 end
 
@@ -160,8 +176,9 @@ end
 struct HIPDiscretized <: AbstractNumericalCore
     nstream::Int64
     nlobatto::Int64
+    ngpu::Int64     # devices 0 .. ngpu-1 of this node share the wavenumber grid (cs_fluxes_discretized_multi); 1: one device
 end
-HIPDiscretized(; nstream::Int=5, nlobatto::Int=2) = HIPDiscretized(nstream, nlobatto)
+HIPDiscretized(; nstream::Int=5, nlobatto::Int=2, ngpu::Int=1) = HIPDiscretized(nstream, nlobatto, ngpu)
 
 function ClearSky.monochromaticfluxes!(M⁺::AbstractMatrix, M⁻::AbstractMatrix, τ::AbstractMatrix, core::HIPDiscretized,
                                        P::AbstractVector{<:Real}, g::Real, T, μ, 𝒻S, 𝒻a, absorbers...; θₛ::Real=0.841)::Nothing
@@ -185,8 +202,13 @@ function ClearSky.monochromaticfluxes!(M⁺::AbstractMatrix, M⁻::AbstractMatri
     direct = filter(x -> x isa DirectGas, collect(𝒜.gas))
     gray   = filter(x -> x isa GrayGas, collect(𝒜.gas))
     length(direct) + length(gray) == length(𝒜.gas) || error("HIPDiscretized needs DirectGas / GrayGas members (baked Gas objects: see DESIGN.md, row f1)")
-    ctx = context()
+    # one context per device; every context holds the same tables in the same slots (same upload order on each)
+    ctxs = [context(d) for d in 0:core.ngpu-1]
+    ctx = ctxs[1]
     ngas = length(direct)
+    for c in ctxs[2:end], x in direct
+        slot!(c, x.sl)
+    end
     slots  = Cint[slot!(ctx, x.sl) for x in direct]
     shapes = Cint[SHAPES[x.shape] for x in direct]
     cuts   = Float64[x.Δνcut for x in direct]
@@ -199,13 +221,23 @@ function ClearSky.monochromaticfluxes!(M⁺::AbstractMatrix, M⁻::AbstractMatri
     F⁺ = Vector{Float64}(undef, np); F⁻ = similar(F⁺)
     dense(A) = (A isa Matrix{Float64}) ? A : Matrix{Float64}(undef, size(A))
     Mu, Md, Ta = dense(M⁺), dense(M⁻), dense(τ)
-    GC.@preserve ν P Tn μn Tlev slots shapes cuts conc extra Stoa alb Mu Md Ta F⁺ F⁻ begin
+    handles = Ptr{Cvoid}[c.handle for c in ctxs]
+    GC.@preserve ν P Tn μn Tlev slots shapes cuts conc extra Stoa alb Mu Md Ta F⁺ F⁻ handles begin
+        if core.ngpu > 1      # ν cut into ngpu cost-balanced ranges, one per device; band fluxes added on the host in device order
+            check(ccall((:cs_fluxes_discretized_multi, LIB), Cint,
+                (Ptr{Ptr{Cvoid}}, Cint, Int64, Ptr{Float64}, Cint, Ptr{Float64}, Float64, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+                 Cint, Ptr{Cint}, Ptr{Cint}, Ptr{Float64}, Ptr{Float64}, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+                 Float64, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                handles, core.ngpu, nν, ν, np, collect(Float64, P), Float64(g), nlobatto, Tn, μn, Tlev, ngas, slots, shapes, cuts, conc,
+                σgray, extra === nothing ? C_NULL : pointer(extra), Stoa, alb, Float64(θₛ), nstream, Ta, Mu, Md, F⁺, F⁻))
+        else
         check(ccall((:cs_fluxes_discretized, LIB), Cint,
             (Ptr{Cvoid}, Int64, Ptr{Float64}, Cint, Ptr{Float64}, Float64, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
              Cint, Ptr{Cint}, Ptr{Cint}, Ptr{Float64}, Ptr{Float64}, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
              Float64, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
             ctx.handle, nν, ν, np, collect(Float64, P), Float64(g), nlobatto, Tn, μn, Tlev, ngas, slots, shapes, cuts, conc,
             σgray, extra === nothing ? C_NULL : pointer(extra), Stoa, alb, Float64(θₛ), nstream, Ta, Mu, Md, F⁺, F⁻))
+        end
     end
     Mu === M⁺ || copyto!(M⁺, Mu); Md === M⁻ || copyto!(M⁻, Md); Ta === τ || copyto!(τ, Ta)
     nothing
@@ -226,14 +258,16 @@ end # module
 #       (BilinearInterpolator grid: ν = Φ.G.x, T = Φ.G.y, ln k = Φ.G.Z) and per ϕ (single-temperature range, nt = 1).
 #   monochromaticfluxes!(…, core::HIPDiscretized, …) with such members uses, instead of cs_fluxes_discretized:
 #       cs_column_setup(…) ; cs_column_set_tables(ctx, ntab, slots, conc_tab[ntab,K]) ;
-#       cs_column_set_cia(ctx, ncia, slots, flags, P1[ncia,K], P2[ncia,K]) ; cs_column_run ; cs_column_fetch(τ, M⁺, M⁻, F⁺, F⁻)
+#       cs_column_set_cia(ctx, ncia, slots, flags, P1[ncia,K], P2[ncia,K]) ; cs_column_run(ctx, C_NULL) ;
+#       cs_column_fetch(ctx, nν, np, τ, M⁺, M⁻, F⁺, F⁻)      # (nν, np: what the caller's arrays were allocated for; any of τ, M⁺, M⁻ may be C_NULL)
 #   with conc_tab[t,k] = fC_t(T_k,P_k) and P1/P2 = P_k*concentration(g₁/g₂, T_k, P_k) (cia…jl:378-382), all evaluated on
 #   the Julia side at the node states (T_k, P_k) built in the method above.
 #   AcceleratedAbsorber / update! / Σ(A, i, T, P) (absorbers.jl:114-207), what RCM holds (radiative_convective.jl:95):
 #       knots = a resident column over U's members with nlobatto = 2 on the knot pressures (node k = knot k = (T_k, P_k));
 #       cs_accel_store(ctx, slot) evaluates ln Σ(U, i, T_k, P_k) for every ν and knot and keeps it in HBM; call it again after
 #       cs_column_update_state(new T) = update!(A, T);  cs_accel_eval(ctx, slot, P, i-1, 1, out) = Σ(A, i, ·, P);
-#       a column over A: cs_column_setup(ngas = 0, …) ; cs_column_set_accel(ctx, slot) ; cs_column_run ; cs_column_fetch.
+#       a column over A: cs_column_setup(ngas = 0, …) ; cs_column_set_accel(ctx, slot) ; cs_column_run(ctx, C_NULL) ;
+#       cs_column_fetch(ctx, nν, np, τ, M⁺, M⁻, F⁺, F⁻)  (and cs_column_sigma_fetch(ctx, nν, K, σ) for the node cross-sections).
 #       jacobian! (radiative_convective.jl:154-171): cs_column_batch(ctx, np+1, T_nodes, μ_nodes, T_levels, conc, conc_tab,
 #       cia_P1, cia_P2, F⁺[np, B], F⁻[np, B]) evaluates all perturbed profiles side by side.
 #   Scalar Σ(U, i, T, P) (absorbers.jl:95): cs_shape_points = the scalar-ν line-shape methods (inclusive cut-off) for DirectGas
@@ -241,5 +275,7 @@ end # module
 #   This file has never been executed (no Julia toolchain on either box): tests/test_gpu_boundary.py drives the same symbol
 #   with the same memory layout through ctypes.
 #   cs_set_precision(ctx, 1, 1e6) selects the fp32 far-wing variant (BASELINE configs[4]).
+#   The gases of a column that share shape and cut-off run as ONE merged line table (cs_set_merge, on by default): nothing changes
+#   on the Julia side, conc stays [ngas, K] over the gases as named.
 #   cs_set_interp(ctx, 0) switches the far-wing interpolation off (every (nu, line) pair evaluated, as surf! does); it is on
 #   by default and exact to rounding (DESIGN.md section 3, K2c).

@@ -165,11 +165,11 @@ def test_merged_shards_add_up(cs, O, lines):
     ctx.close()
 
 
-@pytest.mark.parametrize("tune", [{0: 1}, {1: 0}, {2: 0}, {2: 1}, {0: 1, 2: 0}])
+@pytest.mark.parametrize("tune", [{0: 1}, {1: 0}, {2: 0}, {2: 1}, {0: 1, 2: 0}, {3: 20}, {4: 1}])
 def test_tuning_switches_same_results(cs, O, lines, tune):
     """cs_set_tuning: interpolated wings applied inside k_voigt_edge_mx (0), matrix-core kernels on short grids through their
-    four-waves-per-item variants (1), node sums on a side stream (2) -- none of them may change a result beyond rounding.  Every
-    case is compared with the library's defaults."""
+    four-waves-per-item variants (1), node sums on a side stream (2), interpolation margin (3), the step as one hipGraph (4) -- none
+    of them may change a result beyond rounding.  Every case is compared with the library's defaults."""
     nu = np.linspace(580.0, 780.0, 20000)
     P = cs.pressuregrid(10.0, 1e5, 21)
     T = W.earth_temperature(P)
@@ -183,6 +183,12 @@ def test_tuning_switches_same_results(cs, O, lines, tune):
             for k, v in t.items():
                 ctx.set_tuning(k, v)
             col = _column(cs, ctx, gases, P, T)
+            if 4 in t:       # graph replay: eager run, capturing run, two replays -- the last one after update! with a new profile and back
+                for _ in range(3):
+                    col.run()
+                col.update(T + 5.0)
+                col.run()
+                col.update(T)
             res.append(_results(col))
             res[-1]["work"] = col.work()
             res[-1]["launches"] = col.info()["launches"]

@@ -58,9 +58,13 @@ def test_product_imports_and_links_without_the_oracle():
     import clearsky_jl_amd as cs
     dyn = subprocess.run(["readelf", "-d", cs.LIB_PATH], capture_output=True, text=True).stdout
     assert "NEEDED" in dyn and "oracle" not in dyn.lower()
-    code2 = (f"import sys, os\nsys.path.insert(0, {ROOT!r})\nos.environ['CLEARSKY_HIP_LIB'] = '/nonexistent/libclearsky_hip.so'\n"
-             "import clearsky_jl_amd as cs\n"
-             "try:\n    cs.lib()\nexcept cs.ClearSkyHIPError as e:\n    print('raised', e.code)\n")
+    # a missing library raises (no fallback path); the loader takes no environment override -- the in-tree library is the one that runs
+    code2 = (f"import sys, os\nsys.path.insert(0, {ROOT!r})\nos.environ['CLEARSKY_HIP_LIB'] = '/tmp/some_other_build.so'\n"
+             "import clearsky_jl_amd as cs\nimport clearsky_jl_amd._lib as L\n"
+             "assert L.LIB_PATH.endswith('clearsky.jl_amd/csrc/libclearsky_hip.so')\n"
+             "assert cs.lib().cs_build_id().decode() == L.source_id(), 'library built from other sources: rebuild'\n"
+             "L._lib = None\nL.LIB_PATH = '/nonexistent/libclearsky_hip.so'\n"
+             "try:\n    L.lib()\nexcept cs.ClearSkyHIPError as e:\n    print('raised', e.code)\n")
     out2 = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=300)
     assert out2.stdout.startswith("raised -100"), out2.stdout + out2.stderr[-800:]
 
