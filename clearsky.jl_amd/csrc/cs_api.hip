@@ -188,7 +188,7 @@ struct ColGas {
 };
 
 // k_rt launch geometry (rt_geometry)
-struct RtGeom { bool ud; int tiles, nblk, threads; size_t shmem; };
+struct RtGeom { bool ud, streams; int tiles, nblk, threads; size_t shmem; };   // streams: k_rt_streams (one wave per stream and sweep)
 
 struct Column {
     bool ready = false;
@@ -257,7 +257,7 @@ struct cs_ctx {
     int merge = 1;          // cs_set_merge: gases of a column with the same shape and cut-off share one merged line table
     // cs_set_tuning: [0] interpolated wings applied inside k_voigt_edge_mx where one launch group has them, [1] matrix-core kernels on
     // short grids (four waves per item), [2] node sums on a side stream (1: short grids only, 2: always)
-    int tune[CS_NTUNE] = {0, 1, 2, 0, 0, 0, 0, 0};
+    int tune[CS_NTUNE] = {0, 1, 2, 0, 0, 1, 0, 0};   // ... [3] interpolation margin (per cent), [4] hipGraph replay, [5] k_rt_streams on short grids
     std::vector<std::unique_ptr<GasTable>> merged;   // merged tables (keyed by their members' (slot, generation)), a few kept
     double far_s = 1e6;
     DevBuf hot32;
@@ -363,15 +363,23 @@ void launch_linesum_shape(int shape, dim3 grid, hipStream_t s, const double *nu,
 
 // k_rt launch geometry: up/down split (two waves per 64-point tile) while the grid has fewer than ~4 waves per SIMD,
 // tiles per block so that the grid still covers the chip
-RtGeom rt_geometry(int64_t nnu, int np, int ncol)
+RtGeom rt_geometry(int64_t nnu, int np, int ncol, int ns = 0, bool allow_streams = false)
 {
     RtGeom g;
     const int64_t nwave = (nnu + 63) / 64 * ncol;
     g.ud = nwave < 4096;
+    g.streams = false;
     g.tiles = g.ud ? (nnu >= 65536 ? 2 : 1) : (nnu >= 65536 ? 4 : 1);
     g.nblk = (int)((nnu + (int64_t)g.tiles * 64 - 1) / ((int64_t)g.tiles * 64));
     g.threads = g.tiles * 64 * (g.ud ? 2 : 1);
     g.shmem = ((size_t)2 * np * g.tiles + (g.ud ? (size_t)g.tiles * 64 : 0)) * sizeof(double);
+    // short grids: the sweeps are latency chains -- one wave per (sweep, stream) of a tile instead of one per sweep (k_rt_streams)
+    const size_t sh2 = ((size_t)np * 64 + (size_t)4 * ns * 64 + (size_t)2 * np + 64) * sizeof(double);
+    if (allow_streams && g.ud && g.tiles == 1 && ns >= 2 && ns <= 8 && sh2 <= 65536) {
+        g.streams = true;
+        g.threads = 2 * ns * 64;
+        g.shmem = sh2;
+    }
     return g;
 }
 
@@ -380,7 +388,11 @@ void launch_rt_ns(const RtGeom &g, int B, hipStream_t s, const RtParams &p, cons
                   int64_t nnu, const double *sigma, const double *muk, const double *P, const double *Tlev,
                   const double *S, const double *alb, double *tau, double *Mup, double *Mdn, double *partial, size_t sig_bstride)
 {
-    if (g.ud)
+    if (g.streams) {
+        if constexpr (NS >= 2 && NS <= 8)
+            CS_LAUNCH((k_rt_streams<NS>), dim3(g.nblk, B), dim3(g.threads), g.shmem, s, p, nu, wts, nnu, sigma, muk, P, Tlev, S, alb, tau, Mup,
+                      Mdn, partial, sig_bstride);
+    } else if (g.ud)
         CS_LAUNCH((k_rt<NS, true>), dim3(g.nblk, B), dim3(g.threads), g.shmem, s, p, nu, wts, nnu, sigma, muk, P, Tlev, S, alb,
                            tau, Mup, Mdn, partial, sig_bstride);
     else
@@ -1208,7 +1220,7 @@ int cs_set_merge(cs_ctx *ctx, int on)
 
 static int interp_key(const cs_ctx *ctx)
 {
-    return ctx->interp * 4096 + (ctx->itp_first + 1) * 256 + (ctx->itp_min >> 7) * 16 + (ctx->itp_max >> 7);
+    return (ctx->tune[5] ? 65536 : 0) + ctx->interp * 4096 + (ctx->itp_first + 1) * 256 + (ctx->itp_min >> 7) * 16 + (ctx->itp_max >> 7);
 }
 
 int cs_set_tuning(cs_ctx *ctx, int key, int value)
@@ -1785,7 +1797,7 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
     hipStream_t s = ctx->stream;
     c.nnu = nnu; c.np = np; c.nl = np - 1; c.nlob = nlobatto; c.K = (np - 1) * (nlobatto - 1) + 1;
     c.nstream = nstream; c.ngas = ngas; c.ntile = (int)((nnu + 255) / 256);
-    c.rtg = rt_geometry(nnu, np, 1);
+    c.rtg = rt_geometry(nnu, np, 1, nstream, ctx->tune[5] != 0);
     c.want_tau = want_tau != 0; c.want_M = want_M != 0;
     c.g = g; c.sigma_gray = sigma_gray; c.theta_s = theta_s;
     const int K = c.K, nl = c.nl;
@@ -2024,7 +2036,7 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
     if ((rc = upload(dTk, Tk.data(), BK, s)) || (rc = upload(dPk, Pk.data(), BK, s)) || (rc = upload(dmuk, muk.data(), BK, s)) ||
         (rc = upload(dTlev, T_levels, (size_t)B * np, s)))
         return rc;
-    const RtGeom bg = rt_geometry(c.nnu, np, B);
+    const RtGeom bg = rt_geometry(c.nnu, np, B, c.nstream, ctx->tune[5] != 0);
     if (!shared_sigma) HIPCHK(dsig.reserve((size_t)BK * c.nnu * sizeof(double)));
     HIPCHK(dpart.reserve((size_t)B * bg.nblk * 2 * np * sizeof(double)));
     HIPCHK(dF.reserve((size_t)B * 2 * np * sizeof(double)));

@@ -2232,6 +2232,149 @@ __global__ __launch_bounds__(256) void k_rt(RtParams p, const double *__restrict
     }
 }
 
+// K3 for short grids (a nu-shard, a small column): there a sweep is one chain of ~200 dependent fp64 instructions per layer that no
+// second wave shortens -- but the NS stream intensities of a sweep are independent recurrences; only their weighted sum is needed
+// per level.  One block = ONE 64-point tile, 2 NS waves: wave (role, k) carries stream k of the downward / upward sweep and leaves
+// W_k I_k in LDS every layer; after the layer's barrier the role's wave 0 adds them in stream order (as k_rt does: same rounding,
+// bitwise the same results), adds the stellar beam, reduces over the wave and stores.  Planck at the levels is computed once per
+// tile by all waves together (level i by wave i mod 2 NS) instead of inside both chains.  Chain per layer: layer optical depth + one
+// exp + layerplanck, ~45 instructions, + one barrier.
+// With a non-zero albedo the upward sweep needs the surface downward flux: the two roles then run one after the other.
+template <int NS>
+__global__ __launch_bounds__(2 * NS * 64) void k_rt_streams(RtParams p, const double *__restrict__ nu, const double *__restrict__ wts,
+                                                            int64_t nnu, const double *__restrict__ sigma, const double *__restrict__ muk,
+                                                            const double *__restrict__ P, const double *__restrict__ Tlev,
+                                                            const double *__restrict__ S_toa, const double *__restrict__ albedo,
+                                                            double *__restrict__ tau, double *__restrict__ Mup, double *__restrict__ Mdn,
+                                                            double *__restrict__ partial, size_t sig_bstride)
+{
+    extern __shared__ double sh[];   // Blev[np][64] | xch[2 buffers][2 roles][NS][64] | red[2 np] | msurf[64]
+    const int np = p.np, nl = np - 1, nlob = p.nlobatto;
+    double *Blev = sh, *xch = sh + (size_t)np * 64, *red = xch + (size_t)2 * 2 * NS * 64, *msurf = red + 2 * np;
+    {   // blockIdx.y = column of a batch (cs_column_batch)
+        const size_t b = blockIdx.y;
+        sigma += b * sig_bstride;
+        muk += b * p.K;
+        Tlev += b * p.np;
+        if (tau) tau += b * (size_t)(p.np - 1) * nnu;
+        partial += b * (size_t)gridDim.x * 2 * p.np;
+    }
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool up = wave >= NS;
+    const int k = up ? wave - NS : wave;
+    const int64_t j = (int64_t)blockIdx.x * 64 + lane;
+    const bool live = j < nnu;
+    const int64_t jj = live ? j : nnu - 1;
+    const double v = nu[jj];
+    const double w = live ? wts[jj] : 0.0;
+    const double fS = S_toa ? S_toa[jj] : 0.0;
+    const double fa = albedo ? albedo[jj] : 0.0;
+    const double c = p.cos_ts;
+    for (int i = wave; i < np; i += 2 * NS) Blev[(size_t)i * 64 + lane] = planck(v, Tlev[i]);
+    __syncthreads();
+    const bool serial = albedo != nullptr;           // (block-uniform) the upward sweep waits for the surface downward flux
+    const double mk = p.m[k], imk = p.im[k], Wk = p.W[k];
+    auto slot = [&](int buf, int role, int kk) { return xch + (((size_t)buf * 2 + role) * NS + kk) * 64 + lane; };
+    // optical depth of layer i exactly as k_rt forms it (dDepth!, discretized.jl:136-177): beta at the layer's nodes, 1e-6 floor
+    auto layer_tau = [&](int i) {
+        const double dP = P[i + 1] - P[i];
+        const int kl = i * (nlob - 1);
+        double ti = (dP * p.ws[0]) * (p.C * (sigma[(size_t)kl * nnu + jj] / muk[kl]));
+        for (int n = 1; n < nlob - 1; n++) ti += (dP * p.ws[n]) * (p.C * (sigma[(size_t)(kl + n) * nnu + jj] / muk[kl + n]));
+        ti += (dP * p.ws[nlob - 1]) * (p.C * (sigma[(size_t)(kl + nlob - 1) * nnu + jj] / muk[kl + nlob - 1]));
+        return ti > 1e-6 ? ti : 1e-6;
+    };
+    double I = 0.0, Ms = c * fS;
+    // ---- downward sweep (the up-waves run their own sweep in the same loop when nothing ties them to this one)
+    if (!up && k == 0) {   // level 0: M-[1] = c fS(nu), discretized.jl:299
+        const double r = wave_sum(w * Ms);
+        if (lane == 0) red[np + 0] = r;
+        if (Mdn && live) Mdn[j] = Ms;
+    }
+    double Iu = 0.0;
+    if (up && !serial) {   // surface: Planck emission only (no reflected part without an albedo), discretized.jl:309-310
+        Iu = Blev[(size_t)(np - 1) * 64 + lane];
+        if (k == 0) {
+            const double Mu = Iu * kPi;
+            const double r = wave_sum(w * Mu);
+            if (lane == 0) red[np - 1] = r;
+            if (Mup && live) Mup[(size_t)(np - 1) * nnu + j] = Mu;
+        }
+    }
+    for (int s = 0; s < nl; s++) {
+        const int buf = s & 1;
+        if (!up) {
+            const double t = layer_tau(s);
+            if (k == 0 && tau && live) tau[(size_t)s * nnu + j] = t;
+            const double tr = exp_rt(-(t * mk));
+            const double Be = layerplanck_inv(Blev[(size_t)s * 64 + lane], Blev[(size_t)(s + 1) * 64 + lane], (1.0 / t) * imk, tr);
+            I = I * tr + Be;
+            *slot(buf, 0, k) = Wk * I;
+            if (k == 0 && S_toa) Ms *= exp(-t / c);
+        } else if (!serial) {
+            const int i = nl - 1 - s;
+            const double t = layer_tau(i);
+            const double tr = exp_rt(-(t * mk));
+            const double Be = layerplanck_inv(Blev[(size_t)(i + 1) * 64 + lane], Blev[(size_t)i * 64 + lane], (1.0 / t) * imk, tr);
+            Iu = Iu * tr + Be;
+            *slot(buf, 1, k) = Wk * Iu;
+        }
+        __syncthreads();
+        if (k == 0 && (!up || !serial)) {   // the role's sum over the streams, in stream order
+            const int role = up ? 1 : 0;
+            double M = 0.0;
+#pragma unroll
+            for (int kk = 0; kk < NS; kk++) M += *slot(buf, role, kk);
+            if (!up) {
+                M += Ms;
+                const double r = wave_sum(w * M);
+                if (lane == 0) red[np + s + 1] = r;
+                if (Mdn && live) Mdn[(size_t)(s + 1) * nnu + j] = M;
+                if (serial && s == nl - 1) msurf[lane] = M;
+            } else {
+                const int i = nl - 1 - s;
+                const double r = wave_sum(w * M);
+                if (lane == 0) red[i] = r;
+                if (Mup && live) Mup[(size_t)i * nnu + j] = M;
+            }
+        }
+    }
+    if (serial) {   // ---- upward sweep after the downward one: Lambertian reflection + Planck emission at the surface
+        __syncthreads();
+        if (up) {
+            Iu = msurf[lane] * fa / kPi + Blev[(size_t)(np - 1) * 64 + lane];
+            if (k == 0) {
+                const double Mu = Iu * kPi;
+                const double r = wave_sum(w * Mu);
+                if (lane == 0) red[np - 1] = r;
+                if (Mup && live) Mup[(size_t)(np - 1) * nnu + j] = Mu;
+            }
+        }
+        for (int s = 0; s < nl; s++) {
+            const int buf = s & 1, i = nl - 1 - s;
+            if (up) {
+                const double t = layer_tau(i);
+                const double tr = exp_rt(-(t * mk));
+                const double Be = layerplanck_inv(Blev[(size_t)(i + 1) * 64 + lane], Blev[(size_t)i * 64 + lane], (1.0 / t) * imk, tr);
+                Iu = Iu * tr + Be;
+                *slot(buf, 1, k) = Wk * Iu;
+            }
+            __syncthreads();
+            if (up && k == 0) {
+                double M = 0.0;
+#pragma unroll
+                for (int kk = 0; kk < NS; kk++) M += *slot(buf, 1, kk);
+                const double r = wave_sum(w * M);
+                if (lane == 0) red[i] = r;
+                if (Mup && live) Mup[(size_t)i * nnu + j] = M;
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * np; e += blockDim.x) partial[(size_t)blockIdx.x * 2 * np + e] = red[e];
+}
+
 // K4: F[e] = sum over blocks of partial[b][e], fixed order (bitwise reproducible run to run)
 __global__ __launch_bounds__(256) void k_freduce(const double *__restrict__ partial, int nblk, int n2, double *__restrict__ F)
 {

@@ -118,7 +118,9 @@ int cs_set_merge(cs_ctx *ctx, int on);
  *          grids only (fewer than 16384 (tile, state) waves: a nu-shard), 0 never;
  *   key 3: distance of an interval's interpolated set from the interval, per cent of its half-width (0 = the default 30; 15..100);
  *   key 4: cs_column_run replays the step as one hipGraph (captured on the second run after anything changed launch geometry or
- *          kernel arguments; cs_column_update_state does not) instead of enqueuing its kernels one by one -- 0 (default) off, 1 on.
+ *          kernel arguments; cs_column_update_state does not) instead of enqueuing its kernels one by one -- 0 (default) off, 1 on;
+ *   key 5: on short grids the flux sweeps run one wave per (sweep, stream) of a tile (k_rt_streams) instead of one per sweep -- 1
+ *          (default), 0 off.
  * Applies to every later cs_column_setup / cs_column_run of the context. */
 int cs_set_tuning(cs_ctx *ctx, int key, int value);
 
