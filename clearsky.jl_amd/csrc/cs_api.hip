@@ -5,8 +5,11 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -207,6 +210,7 @@ struct Column {
     std::vector<ColGas> gas;     // launch groups
     int merge = 1;               // the context's cs_set_merge at setup time
     int launches = 0;            // kernel launches of the last cs_column_run
+    hipStream_t last_stream = nullptr;   // the stream that run was enqueued on (cs_column_fetch waits for it, not for the whole device)
     // cs_set_tuning key 4: the step as ONE hipGraph launch (captured on the second run after a change, replayed from the third on):
     // kernel arguments are device addresses that stay put between cs_column_update_state calls, so only what changes launch
     // geometry or pointers (setup, tables, CIA pairs, accelerated absorber, spectra switched on or off) drops the graph
@@ -374,8 +378,8 @@ RtGeom rt_geometry(int64_t nnu, int np, int ncol, int ns = 0, bool allow_streams
     g.threads = g.tiles * 64 * (g.ud ? 2 : 1);
     g.shmem = ((size_t)2 * np * g.tiles + (g.ud ? (size_t)g.tiles * 64 : 0)) * sizeof(double);
     // short grids: the sweeps are latency chains -- one wave per (sweep, stream) of a tile instead of one per sweep (k_rt_streams)
-    const size_t sh2 = ((size_t)np * 64 + (size_t)4 * ns * 64 + (size_t)2 * np + 64) * sizeof(double);
-    if (allow_streams && g.ud && g.tiles == 1 && ns >= 2 && ns <= 8 && sh2 <= 65536) {
+    const size_t sh2 = ((size_t)(2 * np - 1) * 64 + (size_t)4 * ns * 64 + (size_t)2 * np + 64) * sizeof(double);   // Planck + optical depths + exchange
+    if (allow_streams && g.ud && g.tiles == 1 && ns >= 2 && ns <= 8 && sh2 <= 160 * 1024 - 4096) {
         g.streams = true;
         g.threads = 2 * ns * 64;
         g.shmem = sh2;
@@ -389,9 +393,11 @@ void launch_rt_ns(const RtGeom &g, int B, hipStream_t s, const RtParams &p, cons
                   const double *S, const double *alb, double *tau, double *Mup, double *Mdn, double *partial, size_t sig_bstride)
 {
     if (g.streams) {
-        if constexpr (NS >= 2 && NS <= 8)
+        if constexpr (NS >= 2 && NS <= 8) {
+            if (g.shmem > 65536) (void)hipFuncSetAttribute((const void *)k_rt_streams<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.shmem);
             CS_LAUNCH((k_rt_streams<NS>), dim3(g.nblk, B), dim3(g.threads), g.shmem, s, p, nu, wts, nnu, sigma, muk, P, Tlev, S, alb, tau, Mup,
                       Mdn, partial, sig_bstride);
+        }
     } else if (g.ud)
         CS_LAUNCH((k_rt<NS, true>), dim3(g.nblk, B), dim3(g.threads), g.shmem, s, p, nu, wts, nnu, sigma, muk, P, Tlev, S, alb,
                            tau, Mup, Mdn, partial, sig_bstride);
@@ -2243,6 +2249,7 @@ static int run_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev)
             return fail(CS_ESTATE, "gas slot %d was re-uploaded or cleared after cs_column_setup", ug.slot);
         }
     g_nlaunch = 0;
+    c.last_stream = s;
     if (ev) HIPCHK(hipEventRecord(ev[e++], s));
     if ((rc = sigma_impl(ctx, s, ev, e))) return rc;
     if (ev) HIPCHK(hipEventRecord(ev[e++], s));
@@ -2372,15 +2379,19 @@ int cs_column_fetch(cs_ctx *ctx, int64_t nnu, int np, double *tau, double *Mup, 
         return fail(CS_ESTATE, "resident column is %lld wavenumbers x %d levels, caller expects %lld x %d (another column was set up on this context)",
                     (long long)c.nnu, c.np, (long long)nnu, np);
     HIPCHK(hipSetDevice(ctx->device));
-    HIPCHK(hipDeviceSynchronize());
+    // wait for the column's own work only (its run's stream; the side stream has been joined into it): other contexts on the same
+    // device -- cs_fluxes_discretized_multi with several ranges per card -- keep computing while this one copies back
+    if (c.last_stream && c.last_stream != ctx->stream) HIPCHK(hipStreamSynchronize(c.last_stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     int rc;
     if (tau && !c.want_tau) return fail(CS_ESTATE, "column was set up without want_tau");
     if (tau && (rc = fetch_transposed(ctx, c.tau.as<double>(), c.nl, c.nnu, tau))) return rc;
     if ((Mup || Mdn) && !c.want_M) return fail(CS_ESTATE, "column was set up without want_M");
     if (Mup && (rc = fetch_transposed(ctx, c.Mup.as<double>(), c.np, c.nnu, Mup))) return rc;
     if (Mdn && (rc = fetch_transposed(ctx, c.Mdn.as<double>(), c.np, c.nnu, Mdn))) return rc;
-    if (Fup) HIPCHK(hipMemcpy(Fup, c.F.as<double>(), c.np * sizeof(double), hipMemcpyDeviceToHost));
-    if (Fdn) HIPCHK(hipMemcpy(Fdn, c.F.as<double>() + c.np, c.np * sizeof(double), hipMemcpyDeviceToHost));
+    if (Fup) HIPCHK(hipMemcpyAsync(Fup, c.F.as<double>(), c.np * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (Fdn) HIPCHK(hipMemcpyAsync(Fdn, c.F.as<double>() + c.np, c.np * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     return CS_OK;
 }
 
@@ -2883,6 +2894,64 @@ int cs_gas_fetch(cs_ctx *ctx, int slot, int64_t L, double *nu, double *S, double
 }
 
 // ---- multi-GPU --------------------------------------------------------------------------------------------
+namespace {
+// Host threads that drive the contexts of cs_fluxes_discretized_multi, kept for the life of the process: a thread's first HIP call
+// costs milliseconds (per-thread runtime state), which a thread spawned per call would pay on every radiate!.
+class WorkerPool {
+    struct Worker {
+        std::mutex m;
+        std::condition_variable cv;
+        std::function<void()> job;
+        bool ready = false, done = true;
+    };
+    std::vector<std::unique_ptr<Worker>> w_;
+    std::mutex run_m_;
+    static void loop(Worker *w)
+    {
+        for (;;) {
+            std::unique_lock<std::mutex> lk(w->m);
+            w->cv.wait(lk, [&] { return w->ready; });
+            w->ready = false;
+            std::function<void()> job = std::move(w->job);
+            lk.unlock();
+            job();
+            lk.lock();
+            w->done = true;
+            w->cv.notify_all();
+        }
+    }
+public:
+    // f(0) on the calling thread, f(1) .. f(n-1) on workers; returns when all are through
+    void run(int n, const std::function<void(int)> &f)
+    {
+        std::lock_guard<std::mutex> g(run_m_);
+        while ((int)w_.size() < n - 1) {
+            w_.emplace_back(new Worker());
+            std::thread(loop, w_.back().get()).detach();   // (parked on its condition variable until the process ends)
+        }
+        for (int i = 1; i < n; i++) {
+            Worker *w = w_[i - 1].get();
+            std::lock_guard<std::mutex> lk(w->m);
+            w->job = [&f, i] { f(i); };
+            w->done = false;
+            w->ready = true;
+            w->cv.notify_all();
+        }
+        f(0);
+        for (int i = 1; i < n; i++) {
+            Worker *w = w_[i - 1].get();
+            std::unique_lock<std::mutex> lk(w->m);
+            w->cv.wait(lk, [&] { return w->done; });
+        }
+    }
+};
+WorkerPool &worker_pool()
+{
+    static WorkerPool *p = new WorkerPool();   // (never destroyed: its threads outlive static destruction)
+    return *p;
+}
+}  // namespace
+
 int cs_balanced_ranges(int64_t nnu, const double *nu, int ngas, const int64_t *nlines, const double *const *line_nu, int nparts, int64_t *ranges)
 {
     if (!nu || nnu < 1 || nparts < 1 || !ranges || ngas < 0 || (ngas > 0 && (!nlines || !line_nu))) return fail(CS_EINVAL, "bad arguments");
@@ -2958,8 +3027,8 @@ int cs_fluxes_discretized_multi(cs_ctx *const *ctxs, int nctx, int64_t nnu, cons
     std::vector<int> rcs(nctx, CS_OK);
     std::vector<std::string> msgs(nctx);
     std::vector<double> Fpart((size_t)nctx * 2 * np, 0.0);
-    // one host thread per context: its uploads, kernels and copy-backs run beside the others' (a context is not re-entrant, but
-    // different contexts are independent; HIP calls carry their device through hipSetDevice per thread)
+    // one host thread per context (persistent workers): its uploads, kernels and copy-backs run beside the others' (a context is not
+    // re-entrant, but different contexts are independent; HIP calls carry their device through hipSetDevice per thread)
     auto work = [&](int i) {
         cs_ctx *ctx = ctxs[i];
         const int64_t a = ranges[2 * i], n = ranges[2 * i + 1] - a;
@@ -2995,10 +3064,7 @@ int cs_fluxes_discretized_multi(cs_ctx *const *ctxs, int nctx, int64_t nnu, cons
         rcs[i] = r;
         if (r) msgs[i] = g_err;   // (thread-local: carry it to the caller's thread)
     };
-    std::vector<std::thread> th;
-    for (int i = 1; i < nctx; i++) th.emplace_back(work, i);
-    work(0);
-    for (auto &t : th) t.join();
+    worker_pool().run(nctx, work);
     for (int i = 0; i < nctx; i++)
         if (rcs[i]) return fail(rcs[i], "context %d (device %d): %s", i, ctxs[i]->device, msgs[i].c_str());
     for (int l = 0; l < np; l++) {   // fixed-order host sum: bitwise repeatable (SURVEY 8e's deterministic alternative to an all-reduce)

@@ -2232,13 +2232,16 @@ __global__ __launch_bounds__(256) void k_rt(RtParams p, const double *__restrict
     }
 }
 
-// K3 for short grids (a nu-shard, a small column): there a sweep is one chain of ~200 dependent fp64 instructions per layer that no
-// second wave shortens -- but the NS stream intensities of a sweep are independent recurrences; only their weighted sum is needed
-// per level.  One block = ONE 64-point tile, 2 NS waves: wave (role, k) carries stream k of the downward / upward sweep and leaves
-// W_k I_k in LDS every layer; after the layer's barrier the role's wave 0 adds them in stream order (as k_rt does: same rounding,
-// bitwise the same results), adds the stellar beam, reduces over the wave and stores.  Planck at the levels is computed once per
-// tile by all waves together (level i by wave i mod 2 NS) instead of inside both chains.  Chain per layer: layer optical depth + one
-// exp + layerplanck, ~45 instructions, + one barrier.
+// K3 for short grids (a nu-shard, a small column): there a sweep is one chain per lane -- per layer a global load of the layer's
+// cross-sections (its latency is what k_rt spends most of a short grid's time on) and ~200 dependent fp64 instructions that no
+// second wave shortens.  But the layer optical depths and the Planck values do not depend on the sweep, and the NS stream
+// intensities of a sweep are independent recurrences of which only the weighted sum is needed per level.  One block = ONE 64-point
+// tile, 2 NS waves:
+//   phase 0  all waves together: Planck at the levels and the layer optical depths (dDepth!, 1e-6 floor) into LDS, level / layer i
+//            by wave i mod 2 NS -- every wave's loads are in flight at once;
+//   phase 1  wave (role, k) carries stream k of the downward / upward sweep and leaves W_k I_k in LDS every layer; after the layer's
+//            barrier the role's wave 0 adds them in stream order (as k_rt does: same rounding), adds the stellar beam, reduces over
+//            the wave and stores.  Chain per layer: one exp + layerplanck, ~40 instructions, + one barrier.
 // With a non-zero albedo the upward sweep needs the surface downward flux: the two roles then run one after the other.
 template <int NS>
 __global__ __launch_bounds__(2 * NS * 64) void k_rt_streams(RtParams p, const double *__restrict__ nu, const double *__restrict__ wts,
@@ -2248,9 +2251,9 @@ __global__ __launch_bounds__(2 * NS * 64) void k_rt_streams(RtParams p, const do
                                                             double *__restrict__ tau, double *__restrict__ Mup, double *__restrict__ Mdn,
                                                             double *__restrict__ partial, size_t sig_bstride)
 {
-    extern __shared__ double sh[];   // Blev[np][64] | xch[2 buffers][2 roles][NS][64] | red[2 np] | msurf[64]
+    extern __shared__ double sh[];   // Blev[np][64] | tl[nl][64] | xch[2 buffers][2 roles][NS][64] | red[2 np] | msurf[64]
     const int np = p.np, nl = np - 1, nlob = p.nlobatto;
-    double *Blev = sh, *xch = sh + (size_t)np * 64, *red = xch + (size_t)2 * 2 * NS * 64, *msurf = red + 2 * np;
+    double *Blev = sh, *tl = sh + (size_t)np * 64, *xch = tl + (size_t)nl * 64, *red = xch + (size_t)2 * 2 * NS * 64, *msurf = red + 2 * np;
     {   // blockIdx.y = column of a batch (cs_column_batch)
         const size_t b = blockIdx.y;
         sigma += b * sig_bstride;
@@ -2271,20 +2274,23 @@ __global__ __launch_bounds__(2 * NS * 64) void k_rt_streams(RtParams p, const do
     const double fS = S_toa ? S_toa[jj] : 0.0;
     const double fa = albedo ? albedo[jj] : 0.0;
     const double c = p.cos_ts;
-    for (int i = wave; i < np; i += 2 * NS) Blev[(size_t)i * 64 + lane] = planck(v, Tlev[i]);
+    for (int i = wave; i < np; i += 2 * NS) {
+        Blev[(size_t)i * 64 + lane] = planck(v, Tlev[i]);
+        if (i < nl) {   // optical depth of layer i exactly as k_rt forms it (dDepth!, discretized.jl:136-177): beta at the layer's nodes, 1e-6 floor
+            const double dP = P[i + 1] - P[i];
+            const int kl = i * (nlob - 1);
+            double ti = (dP * p.ws[0]) * (p.C * (sigma[(size_t)kl * nnu + jj] / muk[kl]));
+            for (int n = 1; n < nlob - 1; n++) ti += (dP * p.ws[n]) * (p.C * (sigma[(size_t)(kl + n) * nnu + jj] / muk[kl + n]));
+            ti += (dP * p.ws[nlob - 1]) * (p.C * (sigma[(size_t)(kl + nlob - 1) * nnu + jj] / muk[kl + nlob - 1]));
+            const double t = ti > 1e-6 ? ti : 1e-6;
+            tl[(size_t)i * 64 + lane] = t;
+            if (tau && live) tau[(size_t)i * nnu + j] = t;
+        }
+    }
     __syncthreads();
     const bool serial = albedo != nullptr;           // (block-uniform) the upward sweep waits for the surface downward flux
     const double mk = p.m[k], imk = p.im[k], Wk = p.W[k];
     auto slot = [&](int buf, int role, int kk) { return xch + (((size_t)buf * 2 + role) * NS + kk) * 64 + lane; };
-    // optical depth of layer i exactly as k_rt forms it (dDepth!, discretized.jl:136-177): beta at the layer's nodes, 1e-6 floor
-    auto layer_tau = [&](int i) {
-        const double dP = P[i + 1] - P[i];
-        const int kl = i * (nlob - 1);
-        double ti = (dP * p.ws[0]) * (p.C * (sigma[(size_t)kl * nnu + jj] / muk[kl]));
-        for (int n = 1; n < nlob - 1; n++) ti += (dP * p.ws[n]) * (p.C * (sigma[(size_t)(kl + n) * nnu + jj] / muk[kl + n]));
-        ti += (dP * p.ws[nlob - 1]) * (p.C * (sigma[(size_t)(kl + nlob - 1) * nnu + jj] / muk[kl + nlob - 1]));
-        return ti > 1e-6 ? ti : 1e-6;
-    };
     double I = 0.0, Ms = c * fS;
     // ---- downward sweep (the up-waves run their own sweep in the same loop when nothing ties them to this one)
     if (!up && k == 0) {   // level 0: M-[1] = c fS(nu), discretized.jl:299
@@ -2305,8 +2311,7 @@ __global__ __launch_bounds__(2 * NS * 64) void k_rt_streams(RtParams p, const do
     for (int s = 0; s < nl; s++) {
         const int buf = s & 1;
         if (!up) {
-            const double t = layer_tau(s);
-            if (k == 0 && tau && live) tau[(size_t)s * nnu + j] = t;
+            const double t = tl[(size_t)s * 64 + lane];
             const double tr = exp_rt(-(t * mk));
             const double Be = layerplanck_inv(Blev[(size_t)s * 64 + lane], Blev[(size_t)(s + 1) * 64 + lane], (1.0 / t) * imk, tr);
             I = I * tr + Be;
@@ -2314,7 +2319,7 @@ __global__ __launch_bounds__(2 * NS * 64) void k_rt_streams(RtParams p, const do
             if (k == 0 && S_toa) Ms *= exp(-t / c);
         } else if (!serial) {
             const int i = nl - 1 - s;
-            const double t = layer_tau(i);
+            const double t = tl[(size_t)i * 64 + lane];
             const double tr = exp_rt(-(t * mk));
             const double Be = layerplanck_inv(Blev[(size_t)(i + 1) * 64 + lane], Blev[(size_t)i * 64 + lane], (1.0 / t) * imk, tr);
             Iu = Iu * tr + Be;
@@ -2354,7 +2359,7 @@ __global__ __launch_bounds__(2 * NS * 64) void k_rt_streams(RtParams p, const do
         for (int s = 0; s < nl; s++) {
             const int buf = s & 1, i = nl - 1 - s;
             if (up) {
-                const double t = layer_tau(i);
+                const double t = tl[(size_t)i * 64 + lane];
                 const double tr = exp_rt(-(t * mk));
                 const double Be = layerplanck_inv(Blev[(size_t)(i + 1) * 64 + lane], Blev[(size_t)i * 64 + lane], (1.0 / t) * imk, tr);
                 Iu = Iu * tr + Be;
