@@ -242,8 +242,12 @@ static void drop_graph(Column &c)
 constexpr int CS_NTUNE = 8;
 struct PhScratch { DevBuf fac, win; double nu_lo = 0.0, nu_hi = 0.0, nu_c = 0.0; };   // nu_lo/nu_hi: ends of the grid, set by the caller
 
+// what cs_fluxes_discretized_multi keeps between calls (in its first context)
+struct MultiPlan { int nctx = 0; std::vector<double> nu, wt; std::vector<uint64_t> gens; std::vector<int64_t> ranges; };
+
 struct cs_ctx {
     PhScratch ph;
+    MultiPlan mplan;
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;            // side stream of short grids: node sums beside the per-point kernels (cs_set_tuning key 2)
@@ -377,9 +381,11 @@ RtGeom rt_geometry(int64_t nnu, int np, int ncol, int ns = 0, bool allow_streams
     g.nblk = (int)((nnu + (int64_t)g.tiles * 64 - 1) / ((int64_t)g.tiles * 64));
     g.threads = g.tiles * 64 * (g.ud ? 2 : 1);
     g.shmem = ((size_t)2 * np * g.tiles + (g.ud ? (size_t)g.tiles * 64 : 0)) * sizeof(double);
-    // short grids: the sweeps are latency chains -- one wave per (sweep, stream) of a tile instead of one per sweep (k_rt_streams)
+    // short grids: the sweeps are latency chains -- one wave per (sweep, stream) of a tile instead of one per sweep (k_rt_streams): 1/8
+    // of C3 (196 tiles) 0.061 -> 0.046 ms, C2 (157) 0.042 -> 0.033; from ~400 tiles on the two-wave form is as fast or faster (1/4 of
+    // C3 0.082 vs 0.085, 1/2 0.087 vs 0.126: ten waves per tile stop fitting beside each other)
     const size_t sh2 = ((size_t)(2 * np - 1) * 64 + (size_t)4 * ns * 64 + (size_t)2 * np + 64) * sizeof(double);   // Planck + optical depths + exchange
-    if (allow_streams && g.ud && g.tiles == 1 && ns >= 2 && ns <= 8 && sh2 <= 160 * 1024 - 4096) {
+    if (allow_streams && g.ud && g.tiles == 1 && nwave <= 400 && ns >= 2 && ns <= 8 && sh2 <= 160 * 1024 - 4096) {
         g.streams = true;
         g.threads = 2 * ns * 64;
         g.shmem = sh2;
@@ -2960,12 +2966,18 @@ int cs_balanced_ranges(int64_t nnu, const double *nu, int ngas, const int64_t *n
     // re-checked on the merged kernels, profiles/r03_notes.md): a fixed part (flux sweeps, interpolation apply, setup) + per gas its
     // local line density rho [lines per cm^-1 within +-2 cm^-1] x (0.011 + 1.1e-6 nu) -- near-line pairs grow with the Doppler width
     std::vector<double> cum((size_t)nnu + 1, 0.0);
-    for (int64_t i = 0; i < nnu; i++) {
+    std::vector<int64_t> lo(ngas, 0), hi(ngas, 0);   // nu ascends (asserted by the callers of the product path; any order still works,
+    for (int64_t i = 0; i < nnu; i++) {              // the two cursors just move both ways): lines in [nu - 2, nu + 2] by two cursors per gas
         double w = 0.19;
         for (int gq = 0; gq < ngas; gq++) {
-            const double *b = line_nu[gq], *e = b + nlines[gq];
-            const double rho = (double)(std::upper_bound(b, e, nu[i] + 2.0) - std::lower_bound(b, e, nu[i] - 2.0)) / 4.0;
-            w += rho * (0.011 + 1.1e-6 * nu[i]);
+            const double *t = line_nu[gq];
+            const int64_t L = nlines[gq];
+            int64_t &a = lo[gq], &b = hi[gq];
+            while (a < L && t[a] < nu[i] - 2.0) a++;
+            while (a > 0 && t[a - 1] >= nu[i] - 2.0) a--;
+            while (b < L && t[b] <= nu[i] + 2.0) b++;
+            while (b > 0 && t[b - 1] > nu[i] + 2.0) b--;
+            w += (double)(b - a) / 4.0 * (0.011 + 1.1e-6 * nu[i]);
         }
         cum[i + 1] = cum[i] + w;
     }
@@ -3020,9 +3032,21 @@ int cs_fluxes_discretized_multi(cs_ctx *const *ctxs, int nctx, int64_t nnu, cons
         nl_[gi] = ctxs[0]->gas[sl].L;
         ln_[gi] = ctxs[0]->gas[sl].h_nu.data();
     }
-    if ((rc = cs_balanced_ranges(nnu, nu, ngas, nl_.data(), ln_.data(), nctx, ranges.data()))) return rc;
-    std::vector<double> wt(nnu);   // trapezoid weights of the WHOLE grid (util.jl:26-33): shards use slices, so their band fluxes simply add
-    for (int64_t j = 0; j < nnu; j++) wt[j] = ((j > 0 ? nu[j] - nu[j - 1] : 0.0) + (j + 1 < nnu ? nu[j + 1] - nu[j] : 0.0)) / 2;
+    // (partition and weights of an unchanged grid and gas line-up are kept by the first context: radiate! calls this once per time step)
+    MultiPlan &mp = ctxs[0]->mplan;
+    std::vector<uint64_t> gens(ngas);
+    for (int gi = 0; gi < ngas; gi++) gens[gi] = ctxs[0]->gas[gas_slots[gi]].generation;
+    if (!(mp.nctx == nctx && (int64_t)mp.nu.size() == nnu && mp.gens == gens && memcmp(mp.nu.data(), nu, (size_t)nnu * sizeof(double)) == 0)) {
+        if ((rc = cs_balanced_ranges(nnu, nu, ngas, nl_.data(), ln_.data(), nctx, ranges.data()))) return rc;
+        mp.nctx = nctx;
+        mp.nu.assign(nu, nu + nnu);
+        mp.gens = gens;
+        mp.ranges = ranges;
+        mp.wt.resize(nnu);   // trapezoid weights of the WHOLE grid (util.jl:26-33): shards use slices, so their band fluxes simply add
+        for (int64_t j = 0; j < nnu; j++) mp.wt[j] = ((j > 0 ? nu[j] - nu[j - 1] : 0.0) + (j + 1 < nnu ? nu[j + 1] - nu[j] : 0.0)) / 2;
+    }
+    ranges = mp.ranges;
+    const std::vector<double> &wt = mp.wt;
     const int K = (np - 1) * (nlobatto - 1) + 1, nl = np - 1;
     std::vector<int> rcs(nctx, CS_OK);
     std::vector<std::string> msgs(nctx);
