@@ -574,6 +574,7 @@ struct Interp {
     bool sep_always = false;  // cs_set_matrix_cores(ctx, 2): also on grids too short to fill the chip with (interval, state group) blocks
     bool core = true;         // cs_set_matrix_cores(ctx, on | 4) switches the sub-tile treatment of the window core (k_voigt_sub) off
     double margin = kChebMargin;   // cs_set_tuning key 3 (per cent): distance of an interval's interpolated set, in half-widths
+    int nsplit_levels = 1;    // cs_set_tuning key 6: interval sizes (largest first) whose node sums four waves share in k_cheb_nodes_mx
     bool small_mx = false;    // cs_set_tuning key 1: the matrix-core kernels on short grids too (their four-waves-per-item variants)
     bool fuse_apply = false;  // the column's only interpolating group: k_voigt_edge_mx may carry the node sums to the grid itself
     double core4 = 0.0;       // the core takes the 4-term series where its radius is below core4 x the tile's span, else the 8-term one
@@ -863,9 +864,11 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
             if (evg) (void)hipEventRecord(evg[1], s);
             if (use_sep) {
                 const int nq = itp.nItot - q0;
-                // the largest interval size in use is shared by the four waves of a block (all sizes if it is the only one, or on a grid
-                // too short to fill the chip with one (interval, group) per wave)
-                const int nsplit = (itp.nlev - itp.l0 > 1 && mx_big(nq, kn, 2048)) ? itp.nI[itp.l0] : nq;
+                // the largest interval sizes in use are shared by the four waves of a block -- itp.nsplit_levels of them (all sizes on a
+                // grid too short to fill the chip with one (interval, group) per wave)
+                int nsplit = 0;
+                for (int l = itp.l0; l < std::min(itp.nlev, itp.l0 + itp.nsplit_levels); l++) nsplit += itp.nI[l];
+                if (!mx_big(nq, kn, 2048) || nsplit > nq) nsplit = nq;
                 const unsigned nblk_mx = (unsigned)(nsplit * ngrp) + (unsigned)(((int64_t)(nq - nsplit) * ngrp + 3) / 4);
                 CS_LAUNCH(k_cheb_nodes_mx, dim3(nblk_mx), dim3(256), 0, s, itp.nodes, G.L, hot, itp.sep, itp.nItot, q0, nsplit, kn,
                                    itp.Kpad, ngrp, itp.F);
@@ -1330,7 +1333,7 @@ static int shape_impl(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t 
         itp = interp_view(cheb, ginterp, kc);
         if (!ctx->matrix_nodes) itp.sep = nullptr, itp.edge = nullptr;
         itp.sep_always = ctx->matrix_nodes == 2;
-        itp.small_mx = ctx->tune[1] != 0; itp.margin = ctx->tune[3] > 0 ? 0.01 * ctx->tune[3] : kChebMargin;
+        itp.small_mx = ctx->tune[1] != 0; itp.margin = ctx->tune[3] > 0 ? 0.01 * ctx->tune[3] : kChebMargin; itp.nsplit_levels = ctx->tune[6] > 0 ? ctx->tune[6] : 1;
         itp.core = ctx->matrix_core != 0;
     }
     for (int k0 = 0; k0 < K; k0 += kc) {
@@ -1418,7 +1421,7 @@ int cs_bake(cs_ctx *ctx, int gas_slot, int table_slot, int shape, double dnu_cut
         itp = interp_view(cheb, ginterp, kc);
         if (!ctx->matrix_nodes) itp.sep = nullptr, itp.edge = nullptr;
         itp.sep_always = ctx->matrix_nodes == 2;
-        itp.small_mx = ctx->tune[1] != 0; itp.margin = ctx->tune[3] > 0 ? 0.01 * ctx->tune[3] : kChebMargin;
+        itp.small_mx = ctx->tune[1] != 0; itp.margin = ctx->tune[3] > 0 ? 0.01 * ctx->tune[3] : kChebMargin; itp.nsplit_levels = ctx->tune[6] > 0 ? ctx->tune[6] : 1;
         itp.core = ctx->matrix_core != 0;
     }
     for (int k0 = 0; k0 < M; k0 += kc) {
@@ -2111,7 +2114,7 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
             itp.sep = ctx->matrix_nodes ? dsep.as<SepZone>() : nullptr;
             itp.edge = ctx->matrix_nodes ? dedge.as<EdgeZone>() : nullptr;
             itp.sep_always = ctx->matrix_nodes == 2;
-            itp.small_mx = ctx->tune[1] != 0; itp.margin = ctx->tune[3] > 0 ? 0.01 * ctx->tune[3] : kChebMargin;
+            itp.small_mx = ctx->tune[1] != 0; itp.margin = ctx->tune[3] > 0 ? 0.01 * ctx->tune[3] : kChebMargin; itp.nsplit_levels = ctx->tune[6] > 0 ? ctx->tune[6] : 1;
             itp.core = ctx->matrix_core != 0;
         }
         for (int64_t k0 = 0; k0 < BK; k0 += kc) {
@@ -2217,7 +2220,7 @@ static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e)
         itp.F = c.chebF.as<double>();
         if (!ctx->matrix_nodes) itp.sep = nullptr, itp.edge = nullptr;
         itp.sep_always = ctx->matrix_nodes == 2;
-        itp.small_mx = ctx->tune[1] != 0; itp.margin = ctx->tune[3] > 0 ? 0.01 * ctx->tune[3] : kChebMargin;
+        itp.small_mx = ctx->tune[1] != 0; itp.margin = ctx->tune[3] > 0 ? 0.01 * ctx->tune[3] : kChebMargin; itp.nsplit_levels = ctx->tune[6] > 0 ? ctx->tune[6] : 1;
         itp.core = ctx->matrix_core != 0;
         itp.fuse_apply = ctx->tune[0] != 0 && n_itp == 1;
         launch_gas(s, cg.shape, G, cg.jlo, cg.jhi, K, c.Tk.as<double>(), c.Pk.as<double>(), cg.Pp.as<double>(), cg.conc.as<double>(), K,
@@ -3050,6 +3053,16 @@ int cs_fluxes_discretized_multi(cs_ctx *const *ctxs, int nctx, int64_t nnu, cons
     const int K = (np - 1) * (nlobatto - 1) + 1, nl = np - 1;
     std::vector<int> rcs(nctx, CS_OK);
     std::vector<std::string> msgs(nctx);
+    // Contexts that share a device (several ranges per card) take turns at the kernels, in context order: range i + 1 starts when the
+    // kernels of range i are through, so that the copy-back of one range -- tau, M+, M- are 24 bytes per spectral point over PCIe --
+    // runs beside the kernels of the next instead of all ranges finishing, then copying, together.  Different devices run side by side.
+    std::vector<int> prev(nctx, -1);
+    for (int i = 0; i < nctx; i++)
+        for (int q = 0; q < i; q++)
+            if (ctxs[q]->device == ctxs[i]->device) prev[i] = q;
+    std::mutex turn_m;
+    std::condition_variable turn_cv;
+    std::vector<char> kernels_done(nctx, 0);
     std::vector<double> Fpart((size_t)nctx * 2 * np, 0.0);
     // one host thread per context (persistent workers): its uploads, kernels and copy-backs run beside the others' (a context is not
     // re-entrant, but different contexts are independent; HIP calls carry their device through hipSetDevice per thread)
@@ -3082,7 +3095,17 @@ int cs_fluxes_discretized_multi(cs_ctx *const *ctxs, int nctx, int64_t nnu, cons
                                 theta_s, nstream, tau != nullptr, (Mup || Mdn) ? 1 : 0);
             if (!r) { ctx->col.g_nnu = nnu; ctx->col.g_start = a; ctx->col.g_left = gl; ctx->col.g_right = gr; }
         }
+        if (prev[i] >= 0) {
+            std::unique_lock<std::mutex> lk(turn_m);
+            turn_cv.wait(lk, [&] { return kernels_done[prev[i]] != 0; });
+        }
         if (!r) r = cs_column_run(ctx, nullptr);
+        if (!r && hipStreamSynchronize(ctx->stream) != hipSuccess) r = fail(CS_EHIP, "hipStreamSynchronize failed");
+        {
+            std::lock_guard<std::mutex> lk(turn_m);
+            kernels_done[i] = 1;   // (also on failure: nobody is left waiting)
+        }
+        turn_cv.notify_all();
         if (!r) r = cs_column_fetch(ctx, n, np, tau ? tau + (size_t)a * nl : nullptr, Mup ? Mup + (size_t)a * np : nullptr,
                                     Mdn ? Mdn + (size_t)a * np : nullptr, Fpart.data() + (size_t)i * 2 * np, Fpart.data() + (size_t)i * 2 * np + np);
         rcs[i] = r;

@@ -119,8 +119,10 @@ int cs_set_merge(cs_ctx *ctx, int on);
  *   key 3: distance of an interval's interpolated set from the interval, per cent of its half-width (0 = the default 30; 15..100);
  *   key 4: cs_column_run replays the step as one hipGraph (captured on the second run after anything changed launch geometry or
  *          kernel arguments; cs_column_update_state does not) instead of enqueuing its kernels one by one -- 0 (default) off, 1 on;
- *   key 5: on short grids the flux sweeps run one wave per (sweep, stream) of a tile (k_rt_streams) instead of one per sweep -- 1
- *          (default), 0 off.
+ *   key 5: on short grids (up to 400 tiles) the flux sweeps run one wave per (sweep, stream) of a tile (k_rt_streams) instead of one
+ *          per sweep -- 1 (default), 0 off;
+ *   key 6: how many interval sizes, largest first, have their matrix-core node sums shared by the four waves of a block (0 = the
+ *          default, see profiles/r03_notes.md).
  * Applies to every later cs_column_setup / cs_column_run of the context. */
 int cs_set_tuning(cs_ctx *ctx, int key, int value);
 

@@ -1,20 +1,16 @@
 #!/bin/bash
-# copy the summaries of a tools/run_final.sh run into profiles/ under the round's names:  tools/copy_profiles.sh <run tag> <round tag>
+# copy the summaries of a tools/r3_final.sh run into profiles/
 set -e
-t=$1; r=$2; o=gpurun_out
-test -f $o/${t}_bench_c3.json
-for n in c3 c2 c5 c5_mixed lorentz doppler PHCO2 c3_nomatrix shard0 shard3 shard7; do cp $o/${t}_bench_$n.json profiles/${r}_bench_$n.json; done
-cp $o/${t}_mode_t.json profiles/${r}_mode_t.json
-cp $o/prof_$t/stats/runc/*kernel_stats.csv profiles/${r}_kernel_stats.csv
-cp $o/prof_$t/pmc_fetch_summary.csv profiles/${r}_pmc_fetch_summary.csv
-cp $o/prof_$t/pmc_write_summary.csv profiles/${r}_pmc_write_summary.csv
-cp $o/prof_$t/pmc_traffic.json profiles/pmc_traffic.json
-cp $o/prof_$t/pmc_traffic.json profiles/${r}_pmc_traffic.json
-python3 - <<PY
-import json, bench
-d = json.load(open("profiles/pmc_traffic.json"))
-print("stamp of the profile:", d["source_sha16"], " loaded sources:", bench.source_stamp())
-for n in ["c3", "c3_nomatrix", "c2", "c5", "c5_mixed", "lorentz", "doppler", "PHCO2", "shard0", "shard3", "shard7"]:
-    b = json.loads(open(f"profiles/${r}_bench_{n}.json").readline())
-    print(n, "ms/step %.3f" % b["ms_per_step"], {k: round(v, 3) for k, v in b["roofline"]["kernel_ms"].items()})
-PY
+o=gpurun_out
+test -f $o/r03_bench_c3.json
+for f in $o/r03_bench_*.json; do cp $f profiles/; done
+cp $o/r03_mode_t.json profiles/ 2>/dev/null || true
+cp $o/r03_multi_overlap.json profiles/ 2>/dev/null || true
+cp $o/r03_ubench*.txt $o/r03_ubench.json profiles/
+cp $o/gray_kat.json profiles/r03_gray_kat.json
+find $o/prof_r03/stats -name "*kernel_stats.csv" -exec cp {} profiles/r03_kernel_stats.csv \;
+cp $o/prof_r03/pmc_fetch_summary.csv profiles/r03_pmc_fetch_summary.csv
+cp $o/prof_r03/pmc_write_summary.csv profiles/r03_pmc_write_summary.csv
+cp $o/prof_r03/pmc_traffic.json profiles/pmc_traffic.json
+cp $o/prof_r03/pmc_traffic.json profiles/r03_pmc_traffic.json
+tail -3 $o/r03_gputests.log > profiles/r03_gputests_tail.txt
