@@ -225,7 +225,6 @@ def main():
                                            note="k_voigt_near<0> (100 <= x^2+y^2 < 1e3: continued fraction) + <1> (< 100: trapezoid + pole); (nu, line, "
                                                 "state) pairs counted on the host from the device's per-(state, line) records; both tiers in one time"))
     # HBM-bound kernels: algorithmic bytes = what must cross HBM once
-    L_range = work.get("lines_in_windows", lines_total)
     setup_bytes = (58.0 * lines_total + 48.0 * K * lines_total + 32.0 * K * nt64 + 48.0 * K * work["intervals"]) / ngrp
     t = sec("prep")
     kern["k_gas_setup"] = dict(bound="hbm", ms_per_launch=t * 1e3, launches_per_step=ngrp, algorithmic_bytes_per_launch=setup_bytes,

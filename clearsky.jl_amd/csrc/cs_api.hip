@@ -222,7 +222,7 @@ struct Column {
     ColAccel accel;
     std::vector<double> h_Tk;
     DevBuf nu, wts, P, Pk, Tk, muk, Tlev, extra, S_toa, albedo;
-    DevBuf hot, cold, sigma, tau, Mup, Mdn, partial, F, stage, ranges;
+    DevBuf hot, cold, sigma, sigma2, tau, Mup, Mdn, partial, F, stage, ranges;   // sigma2: the near-line plane (k_voigt_near on a side stream)
     ChebGrid cheb;             // interpolation levels of the nu grid (nlev = 0: off)
     DevBuf chebF;              // node sums F [nItot][64][Kpad], summed over the column's gases (k_cheb_nodes accumulates)
 };
@@ -250,8 +250,9 @@ struct cs_ctx {
     MultiPlan mplan;
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;            // side stream of short grids: node sums beside the per-point kernels (cs_set_tuning key 2)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t stream2 = nullptr;            // side stream: node sums beside the per-point kernels (cs_set_tuning key 2)
+    hipStream_t stream3 = nullptr;            // side stream: near-line kernels beside the matrix-core per-point kernel (key 7)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork3 = nullptr, ev_join3 = nullptr;
     GasTable gas[CS_MAX_GAS];
     TableDev tab[CS_MAX_TABLE];
     CiaDev cia[CS_MAX_CIA];
@@ -265,7 +266,7 @@ struct cs_ctx {
     int merge = 1;          // cs_set_merge: gases of a column with the same shape and cut-off share one merged line table
     // cs_set_tuning: [0] interpolated wings applied inside k_voigt_edge_mx where one launch group has them, [1] matrix-core kernels on
     // short grids (four waves per item), [2] node sums on a side stream (1: short grids only, 2: always)
-    int tune[CS_NTUNE] = {0, 1, 2, 0, 0, 1, 0, 0};   // ... [3] interpolation margin (per cent), [4] hipGraph replay, [5] k_rt_streams on short grids
+    int tune[CS_NTUNE] = {0, 1, 2, 0, 0, 1, 0, 1};   // [6] split levels of k_cheb_nodes_mx, [7] near-line kernels on a second side stream   // ... [3] interpolation margin (per cent), [4] hipGraph replay, [5] k_rt_streams on short grids
     std::vector<std::unique_ptr<GasTable>> merged;   // merged tables (keyed by their members' (slot, generation)), a few kept
     double far_s = 1e6;
     DevBuf hot32;
@@ -396,27 +397,29 @@ RtGeom rt_geometry(int64_t nnu, int np, int ncol, int ns = 0, bool allow_streams
 template <int NS>
 void launch_rt_ns(const RtGeom &g, int B, hipStream_t s, const RtParams &p, const double *nu, const double *wts,
                   int64_t nnu, const double *sigma, const double *muk, const double *P, const double *Tlev,
-                  const double *S, const double *alb, double *tau, double *Mup, double *Mdn, double *partial, size_t sig_bstride)
+                  const double *S, const double *alb, double *tau, double *Mup, double *Mdn, double *partial, size_t sig_bstride,
+                  const double *sigma2)
 {
     if (g.streams) {
         if constexpr (NS >= 2 && NS <= 8) {
             if (g.shmem > 65536) (void)hipFuncSetAttribute((const void *)k_rt_streams<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.shmem);
             CS_LAUNCH((k_rt_streams<NS>), dim3(g.nblk, B), dim3(g.threads), g.shmem, s, p, nu, wts, nnu, sigma, muk, P, Tlev, S, alb, tau, Mup,
-                      Mdn, partial, sig_bstride);
+                      Mdn, partial, sig_bstride, sigma2);
         }
     } else if (g.ud)
         CS_LAUNCH((k_rt<NS, true>), dim3(g.nblk, B), dim3(g.threads), g.shmem, s, p, nu, wts, nnu, sigma, muk, P, Tlev, S, alb,
-                           tau, Mup, Mdn, partial, sig_bstride);
+                           tau, Mup, Mdn, partial, sig_bstride, sigma2);
     else
         CS_LAUNCH((k_rt<NS, false>), dim3(g.nblk, B), dim3(g.threads), g.shmem, s, p, nu, wts, nnu, sigma, muk, P, Tlev, S, alb,
-                           tau, Mup, Mdn, partial, sig_bstride);
+                           tau, Mup, Mdn, partial, sig_bstride, sigma2);
 }
 
 void launch_rt(int ns, const RtGeom &g, int B, hipStream_t s, const RtParams &p, const double *nu, const double *wts,
                int64_t nnu, const double *sigma, const double *muk, const double *P, const double *Tlev,
-               const double *S, const double *alb, double *tau, double *Mup, double *Mdn, double *partial, size_t sig_bstride = 0)
+               const double *S, const double *alb, double *tau, double *Mup, double *Mdn, double *partial, size_t sig_bstride = 0,
+               const double *sigma2 = nullptr)
 {
-#define CS_RT_CASE(N) case N: launch_rt_ns<N>(g, B, s, p, nu, wts, nnu, sigma, muk, P, Tlev, S, alb, tau, Mup, Mdn, partial, sig_bstride); break;
+#define CS_RT_CASE(N) case N: launch_rt_ns<N>(g, B, s, p, nu, wts, nnu, sigma, muk, P, Tlev, S, alb, tau, Mup, Mdn, partial, sig_bstride, sigma2); break;
     switch (ns) {
         CS_RT_CASE(1) CS_RT_CASE(2) CS_RT_CASE(3) CS_RT_CASE(4) CS_RT_CASE(5) CS_RT_CASE(6) CS_RT_CASE(7) CS_RT_CASE(8)
         CS_RT_CASE(9) CS_RT_CASE(10) CS_RT_CASE(11) CS_RT_CASE(12) CS_RT_CASE(13) CS_RT_CASE(14) CS_RT_CASE(15) CS_RT_CASE(16)
@@ -768,10 +771,19 @@ static bool edge_in_use(bool have_edge, bool always, int ntiles, int kn, bool lo
 // per-point kernels (sigma) of a group are independent until the interpolation carries F to the grid.  With a Fork the node kernels
 // go to a side stream behind an event recorded after k_gas_setup / k_mxzones; `pending` says the main stream has not yet waited
 // for them (it must before anything reads F or overwrites the records).
-struct Fork { hipStream_t s2; hipEvent_t ev_fork, ev_join; bool pending; };
-static void fork_join(Fork *f, hipStream_t s)
+struct Fork {
+    bool use_nodes, use_near;   // which of the two side streams this step uses
+    hipStream_t s2; hipEvent_t ev_fork, ev_join; bool pending;
+    // the same for the near-line kernels: they need the hand-off words of k_voigt_far / k_voigt_sub and nothing of k_voigt_edge_mx --
+    // a gather-bound kernel beside a matrix-core one -- but both add to sigma, so the near-line pairs go to a plane of their own
+    // (sigma2: cleared by the step's first k_voigt_far, read together with sigma by k_rt, folded in by k_fold where sigma is the result)
+    hipStream_t s3; hipEvent_t ev_fork3, ev_join3; bool pending3;
+    double *sigma2; bool zeroed, live;
+};
+static void fork_join(Fork *f, hipStream_t s, bool nodes = true, bool near = true)
 {
-    if (f && f->pending) { (void)hipStreamWaitEvent(s, f->ev_join, 0); f->pending = false; }
+    if (f && nodes && f->pending) { (void)hipStreamWaitEvent(s, f->ev_join, 0); f->pending = false; }
+    if (f && near && f->pending3) { (void)hipStreamWaitEvent(s, f->ev_join3, 0); f->pending3 = false; }
 }
 
 // K1 + K2 for one gas on `s`: parameters for `kn` states, then the line sum into sigma ([kn][nnu])
@@ -847,7 +859,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
             if (evg) (void)hipEventRecord(evg[0], s);
             const SepZone *sepz = use_sep ? itp.sep : nullptr;
             hipStream_t sm = s;   // main stream
-            if (fork && defer && !evg) {
+            if (fork && fork->use_nodes && defer && !evg) {
                 (void)hipEventRecord(fork->ev_fork, s);
                 (void)hipStreamWaitEvent(fork->s2, fork->ev_fork, 0);
                 s = fork->s2;     // the two node kernels below run beside what follows them on the main stream
@@ -921,22 +933,26 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
         // 8 x (blocks of the longest XCD stretch): XCD-aware tile mapping (tile_block); xtiles is a multiple of 4 tiles
         const dim3 grid_s((unsigned)(8 * (xtiles * split / 4)), kn);
 #define CS_FAR_LAUNCH(MIX, SP) CS_LAUNCH((k_voigt_far<MIX, SP, false>), grid_s, dim3(256), 0, s, dnu, nnu, G.L, hot, hot32, G.nu.as<double>(), \
-                                                  win, zones, nt64, nblk_s, cut, base, extra, sigma, accumulate, ranges, iz, itp.nItot, ishift, edgez)
+                                                  win, zones, nt64, nblk_s, cut, base, extra, sigma, accumulate, ranges, iz, itp.nItot, ishift, edgez, zero2)
 #define CS_LOR_LAUNCH(SP) CS_LAUNCH((k_voigt_far<false, SP, true>), grid_s, dim3(256), 0, s, dnu, nnu, G.L, hot, hot32, G.nu.as<double>(), \
                                                   win, zones, nt64, nblk_s, cut, base, extra, sigma, accumulate, ranges, iz, itp.nItot, ishift, edgez)
         const EdgeZone *edgez = use_edge ? itp.edge : nullptr;
+        // near-line kernels on a side stream, into their own plane (Voigt only; not while profiling): its first k_voigt_far of the step clears it
+        const bool near_fork = !lor && fork && fork->use_near && fork->sigma2 && defer && !evg;
+        double *zero2 = nullptr;
+        if (near_fork && !fork->zeroed) { zero2 = fork->sigma2; fork->zeroed = true; }
         if (lor) {
             if (split == 1) CS_LOR_LAUNCH(1); else if (split == 2) CS_LOR_LAUNCH(2); else CS_LOR_LAUNCH(4);
         } else if (hot32 && use_edge) {
 #define CS_EDGE32_LAUNCH(SP) CS_LAUNCH((k_voigt_far<true, SP, false, true>), grid_s, dim3(256), 0, s, dnu, nnu, G.L, hot, hot32, G.nu.as<double>(), \
-                                                  win, zones, nt64, nblk_s, cut, base, extra, sigma, accumulate, ranges, iz, itp.nItot, ishift, edgez)
+                                                  win, zones, nt64, nblk_s, cut, base, extra, sigma, accumulate, ranges, iz, itp.nItot, ishift, edgez, zero2)
             if (split == 1) CS_EDGE32_LAUNCH(1); else if (split == 2) CS_EDGE32_LAUNCH(2); else CS_EDGE32_LAUNCH(4);
 #undef CS_EDGE32_LAUNCH
         } else if (hot32) {
             if (split == 1) CS_FAR_LAUNCH(true, 1); else if (split == 2) CS_FAR_LAUNCH(true, 2); else CS_FAR_LAUNCH(true, 4);
         } else if (use_edge) {
 #define CS_EDGE_LAUNCH(SP) CS_LAUNCH((k_voigt_far<false, SP, false, true>), grid_s, dim3(256), 0, s, dnu, nnu, G.L, hot, hot32, G.nu.as<double>(), \
-                                                  win, zones, nt64, nblk_s, cut, base, extra, sigma, accumulate, ranges, iz, itp.nItot, ishift, edgez)
+                                                  win, zones, nt64, nblk_s, cut, base, extra, sigma, accumulate, ranges, iz, itp.nItot, ishift, edgez, zero2)
             if (split == 1) CS_EDGE_LAUNCH(1); else if (split == 2) CS_EDGE_LAUNCH(2); else CS_EDGE_LAUNCH(4);
 #undef CS_EDGE_LAUNCH
         } else {
@@ -948,6 +964,23 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
         if (use_edge && itp.core)   // the window cores of the groups whose series radius is short: pairs inside it (the rest: k_voigt_edge_mx)
             CS_LAUNCH(k_voigt_sub<CS_SUBW>, dim3((unsigned)nt64, (unsigned)((kn + 64 / CS_SUBW - 1) / (64 / CS_SUBW))), dim3(4096 / CS_SUBW), 0, s, dnu, nnu, G.L, hot, G.nu.as<double>(), zones,
                                itp.edge, nt64, kn, cut, sigma, reinterpret_cast<unsigned *>(ranges));
+        auto launch_near = [&](hipStream_t sn, double *out) {
+            const int ngrpn = (nt64 + CS_NEAR_R - 1) / CS_NEAR_R;   // near kernels: one wave = CS_NEAR_R consecutive tiles ...
+            // ... times nrep, one after the other, where the table is sparse against the grid (few tiles have candidates at all) and
+            // the grid long enough to keep the chip full with an eighth of the waves
+            const int nrep = (jhi - jlo < (int64_t)nt64 * 2 && (int64_t)ngrpn * kn >= 262144) ? 8 : 1;
+            const dim3 gridq((unsigned)(((ngrpn + nrep - 1) / nrep + 3) / 4), kn);
+            CS_LAUNCH(k_voigt_near<0>, gridq, dim3(256), 0, sn, dnu, nnu, G.L, hot, cold, zones, nt64, ngrpn, nrep, cut, out, ranges);
+            CS_LAUNCH(k_voigt_near<1>, gridq, dim3(256), 0, sn, dnu, nnu, G.L, hot, cold, zones, nt64, ngrpn, nrep, cut, out, ranges);
+        };
+        if (near_fork) {   // (everything the near kernels read is written by now: records, zones, hand-off words)
+            (void)hipEventRecord(fork->ev_fork3, s);
+            (void)hipStreamWaitEvent(fork->s3, fork->ev_fork3, 0);
+            launch_near(fork->s3, fork->sigma2);
+            (void)hipEventRecord(fork->ev_join3, fork->s3);
+            fork->pending3 = true;
+            fork->live = true;
+        }
         if (evg) (void)hipEventRecord(evg[4], s);
         if (use_edge)
         {
@@ -960,15 +993,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
                           itp.edge, nt64, kn, cut, sigma, fuse ? 1 : 0, Afuse, itp.Kpad);
         }
         if (evg) (void)hipEventRecord(evg[5], s);
-        if (!lor) {
-            const int ngrp = (nt64 + CS_NEAR_R - 1) / CS_NEAR_R;   // near kernels: one wave = CS_NEAR_R consecutive tiles ...
-            // ... times nrep, one after the other, where the table is sparse against the grid (few tiles have candidates at all) and
-            // the grid long enough to keep the chip full with an eighth of the waves
-            const int nrep = (jhi - jlo < (int64_t)nt64 * 2 && (int64_t)ngrp * kn >= 262144) ? 8 : 1;
-            const dim3 gridq((unsigned)(((ngrp + nrep - 1) / nrep + 3) / 4), kn);
-            CS_LAUNCH(k_voigt_near<0>, gridq, dim3(256), 0, s, dnu, nnu, G.L, hot, cold, zones, nt64, ngrp, nrep, cut, sigma, ranges);
-            CS_LAUNCH(k_voigt_near<1>, gridq, dim3(256), 0, s, dnu, nnu, G.L, hot, cold, zones, nt64, ngrp, nrep, cut, sigma, ranges);
-        }
+        if (!lor && !near_fork) launch_near(s, sigma);
     } else if (shape == SH_PHCO2 && ph && phco2_fast_ok(G, nnu, cut, kn, ph)) {
         // PHCO2 fast path (k_phco2): region-uniform far lines with factorised chi; needs the cut-off edges inside region 3 and the
         // near zone inside the chi = 1 core (phco2_fast_ok), else the generic kernel below
@@ -1050,8 +1075,11 @@ int cs_create(int device, cs_ctx **out)
     c->device = device;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork3, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming);
     if (e != hipSuccess) { cs_destroy(c); return fail(CS_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     *out = c;
     return CS_OK;
@@ -1063,9 +1091,13 @@ void cs_destroy(cs_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+    if (ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
     drop_graph(ctx->col);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->ev_fork3) (void)hipEventDestroy(ctx->ev_fork3);
+    if (ctx->ev_join3) (void)hipEventDestroy(ctx->ev_join3);
+    if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1683,7 +1715,8 @@ int cs_column_set_cia(cs_ctx *ctx, int ncia, const int *cia_slots, const int *fl
     return CS_OK;
 }
 
-static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e);
+static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e, bool *near_plane_live = nullptr);
+static int column_current(cs_ctx *ctx);
 
 // ---- AcceleratedAbsorber (absorbers.jl:114-203) -------------------------------------------------------------------------
 int cs_accel_store(cs_ctx *ctx, int accel_slot)
@@ -1945,6 +1978,9 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
     HIPCHK(c.hot.reserve(((size_t)K * maxL + 4) * sizeof(LineHot)));
     HIPCHK(c.cold.reserve((size_t)K * maxL * sizeof(LineCold)));
     HIPCHK(c.sigma.reserve((size_t)K * nnu * sizeof(double)));
+    bool any_voigt = false;
+    for (auto &cg : c.gas) any_voigt = any_voigt || cg.shape == SH_VOIGT;
+    if (any_voigt) HIPCHK(c.sigma2.reserve((size_t)K * nnu * sizeof(double)));
     if (ngas > 0) HIPCHK(c.ranges.reserve((size_t)K * nnu * sizeof(int2) + (size_t)2 * K * ((nnu + 63) / 64) * sizeof(int)));   // + per-(tile, state) flags
     if (c.want_tau) HIPCHK(c.tau.reserve((size_t)nl * nnu * sizeof(double)));   // (band fluxes only: no optical depth is stored)
     if (c.want_M) {
@@ -2021,6 +2057,10 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
     if (!ctx || !ctx->col.ready) return fail(CS_ESTATE, "cs_column_setup has not been called");
     Column &c = ctx->col;
     if (B < 1 || B > 65535) return fail(CS_EINVAL, "batch size must be in [1, 65535]");
+    {
+        const int rc0 = column_current(ctx);
+        if (rc0) return rc0;
+    }
     if (!c.tab.empty() && !conc_tab) return fail(CS_EINVAL, "the resident column has opacity tables: conc_tab is required");
     if (!c.cia.empty() && (!cia_P1 || !cia_P2)) return fail(CS_EINVAL, "the resident column has CIA pairs: cia_P1 and cia_P2 are required");
     HIPCHK(hipSetDevice(ctx->device));
@@ -2186,10 +2226,16 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
 
 // the cross-section stage of one evaluation: sigma[K][nnu] of all absorbers of the resident column at its node states
 // (Sigma(A, i, T, P) of absorbers.jl:95 for every i and node).  ev: see run_impl; e counts the events recorded.
-static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e)
+// near_plane_live: NULL = the cross-sections themselves are the result (the near-line plane is folded into sigma before returning);
+// else the caller (run_impl) hands both planes to k_rt and is told here whether the second one is in use this step
+static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e, bool *near_plane_live)
 {
     Column &c = ctx->col;
     const int K = c.K;
+    {
+        const int rc0 = column_current(ctx);
+        if (rc0) return rc0;
+    }
     double *sig = c.sigma.as<double>();
     const double *extra = c.has_extra ? c.extra.as<double>() : nullptr;
     if (c.accel.slot >= 0) {   // AcceleratedAbsorber: exp of the ln P-interpolated ln sigma (absorbers.jl:203)
@@ -2211,8 +2257,15 @@ static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e)
     int n_itp = 0;
     for (auto &cg : c.gas) n_itp += cg.itp.nlev > 0 ? 1 : 0;
     // cs_set_tuning key 2: node sums on a side stream -- 1: where the grid is short (fewer than 16384 (tile, state) waves), 2: always
-    Fork fk = {ctx->stream2, ctx->ev_fork, ctx->ev_join, false};
-    const bool use_fork = !ev && (ctx->tune[2] == 2 || (ctx->tune[2] == 1 && (c.nnu + 63) / 64 * (int64_t)K < 16384));
+    // key 7: the near-line kernels on a second side stream, into a plane of their own (1, default; 0: after k_voigt_edge_mx, into sigma)
+    Fork fk;
+    memset(&fk, 0, sizeof fk);
+    fk.s2 = ctx->stream2; fk.ev_fork = ctx->ev_fork; fk.ev_join = ctx->ev_join;
+    fk.s3 = ctx->stream3; fk.ev_fork3 = ctx->ev_fork3; fk.ev_join3 = ctx->ev_join3;
+    fk.use_nodes = !ev && (ctx->tune[2] == 2 || (ctx->tune[2] == 1 && (c.nnu + 63) / 64 * (int64_t)K < 16384));
+    fk.use_near = !ev && ctx->tune[7] != 0 && c.sigma2.p != nullptr;
+    fk.sigma2 = fk.use_near ? c.sigma2.as<double>() : nullptr;
+    const bool use_fork = fk.use_nodes || fk.use_near;
     for (int gi = 0; gi < (int)c.gas.size(); gi++) {
         ColGas &cg = c.gas[gi];
         const GasTable &G = *cg.tab;
@@ -2231,7 +2284,7 @@ static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e)
                    use_fork ? &fk : nullptr);
         if (ev) { e += 6; HIPCHK(hipEventRecord(ev[e++], s)); }
     }
-    fork_join(&fk, s);
+    fork_join(&fk, s, true, false);   // the node sums; the near-line kernels may run on beside what follows (none of it touches their plane)
     // interpolated far wings of all gases: sigma += sum_level C (sum_gas F)  (one pass over C and sigma)
     if (apply.ngas > 0) launch_apply(s, apply, cheb_kpad(K), c.nnu, K, 0.0, nullptr, sig, 1);
     for (auto &t : c.tab) {  // baked gases: sigma += fC * exp(Phi(T, ln P))
@@ -2242,7 +2295,25 @@ static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e)
     for (auto &cc : c.cia)  // CIA pairs
         CS_LAUNCH(k_cia, dim3((unsigned)c.ntile), dim3(256), 0, s, cc.nband, cc.bands.as<CiaBand>(), cc.st.as<CiaState>(),
                            c.nu.as<double>(), c.nnu, K, cc.rho1.as<double>(), cc.rho2.as<double>(), cc.rhoa.as<double>(), sig);
+    fork_join(&fk, s);
+    if (near_plane_live) *near_plane_live = fk.live;
+    else if (fk.live) {
+        const int64_t tot = (int64_t)K * c.nnu;
+        CS_LAUNCH(k_fold, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, tot, sig, c.sigma2.as<double>());
+    }
     HIPCHK(hipGetLastError());
+    return CS_OK;
+}
+
+// a table re-uploaded into (or cleared from) a slot of the resident column leaves its windows stale: refuse to run on them
+static int column_current(cs_ctx *ctx)
+{
+    Column &c = ctx->col;
+    for (auto &ug : c.ugas)
+        if (!ctx->gas[ug.slot].present || ctx->gas[ug.slot].generation != ug.generation) {
+            c.ready = false;
+            return fail(CS_ESTATE, "gas slot %d was re-uploaded or cleared after cs_column_setup", ug.slot);
+        }
     return CS_OK;
 }
 
@@ -2252,20 +2323,17 @@ static int run_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev)
     Column &c = ctx->col;
     double *sig = c.sigma.as<double>();
     int e = 0, rc;
-    for (auto &ug : c.ugas)   // (a table re-uploaded into a slot of the resident column: its windows are stale)
-        if (!ctx->gas[ug.slot].present || ctx->gas[ug.slot].generation != ug.generation) {
-            c.ready = false;
-            return fail(CS_ESTATE, "gas slot %d was re-uploaded or cleared after cs_column_setup", ug.slot);
-        }
     g_nlaunch = 0;
     c.last_stream = s;
     if (ev) HIPCHK(hipEventRecord(ev[e++], s));
-    if ((rc = sigma_impl(ctx, s, ev, e))) return rc;
+    bool near_live = false;
+    if ((rc = sigma_impl(ctx, s, ev, e, &near_live))) return rc;
     if (ev) HIPCHK(hipEventRecord(ev[e++], s));
     launch_rt(c.nstream, c.rtg, 1, s, c.rt, c.nu.as<double>(), c.wts.as<double>(),
               c.nnu, sig, c.muk.as<double>(), c.P.as<double>(), c.Tlev.as<double>(),
               c.has_S ? c.S_toa.as<double>() : nullptr, c.has_alb ? c.albedo.as<double>() : nullptr, c.want_tau ? c.tau.as<double>() : nullptr,
-              c.want_M ? c.Mup.as<double>() : nullptr, c.want_M ? c.Mdn.as<double>() : nullptr, c.partial.as<double>());
+              c.want_M ? c.Mup.as<double>() : nullptr, c.want_M ? c.Mdn.as<double>() : nullptr, c.partial.as<double>(), 0,
+              near_live ? c.sigma2.as<double>() : nullptr);
     if (ev) HIPCHK(hipEventRecord(ev[e++], s));
     CS_LAUNCH(k_freduce, dim3(2 * c.np), dim3(256), 0, s, c.partial.as<double>(), c.rtg.nblk, 2 * c.np,
                        c.F.as<double>());

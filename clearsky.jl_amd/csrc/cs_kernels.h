@@ -1193,8 +1193,10 @@ __global__ __launch_bounds__(256) CS_FAR_ATTR void k_voigt_far(const double *__r
                                                     const Zone *__restrict__ zones, int ntile, int nblk, double cut,
                                                     double base, const double *__restrict__ extra,
                                                     double *__restrict__ sigma, int accumulate, int2 *__restrict__ ranges,
-                                                    const IZone *__restrict__ iz, int nI, int ishift, const EdgeZone *__restrict__ edge)
+                                                    const IZone *__restrict__ iz, int nI, int ishift, const EdgeZone *__restrict__ edge,
+                                                    double *__restrict__ zero2 = nullptr)
 {
+    // zero2 != NULL: the plane k_voigt_near will add this step's near-line pairs into (its first writer of the step clears it)
     // edge != NULL: the window ends [W0, eL) and [eR, W1) of the tile -- the cut-off edges and the far lines no interval could
     // take -- and the pieces [mL0, mL1), [mR0, mR1) between the interpolated sets and the near zone where the series in 1/dnu^2 holds
     // are summed for 16 states at a time on the matrix cores (k_voigt_edge_mx): skip them here.
@@ -1356,6 +1358,7 @@ __global__ __launch_bounds__(256) CS_FAR_ATTR void k_voigt_far(const double *__r
         const size_t o = (size_t)k * nnu + i;
         if (!accumulate) sigma[o] = (base + (extra ? extra[o] : 0.0)) + acc;
         else if (acc != 0.0) sigma[o] += acc;   // (nothing to add -- most tiles of a sparse table: no trip to sigma at all; x + 0.0 = x bit for bit)
+        if (zero2) zero2[o] = 0.0;
     }
     // hand-off to k_voigt_near<0>, <1>: per (nu, node) and tier one word, (first line - N0) << 12 | count -- 8 bytes per
     // spectral point and node in all (cs_api.hip refuses tables dense enough to overflow 20 + 12 bits: check_near_density) --
@@ -2085,8 +2088,10 @@ __global__ __launch_bounds__(256) void k_rt(RtParams p, const double *__restrict
                                              const double *__restrict__ Tlev, const double *__restrict__ S_toa,
                                              const double *__restrict__ albedo, double *__restrict__ tau,
                                              double *__restrict__ Mup, double *__restrict__ Mdn,
-                                             double *__restrict__ partial, size_t sig_bstride)
+                                             double *__restrict__ partial, size_t sig_bstride, const double *__restrict__ sigma2)
 {
+    // sigma2 != NULL: the near-line pairs of the step were summed into a plane of their own (k_voigt_near on a side stream beside the
+    // matrix-core kernels): the cross-section is sigma + sigma2
     extern __shared__ double red[];  // [2*np][nw] (+ UD: [nw][64] surface downward flux)
     const int nwv = blockDim.x >> 6;
     const int nw = UD ? nwv >> 1 : nwv;   // 64-point tiles per block: 4 (2 with UD) for big grids, 1 for small ones (more blocks than CUs)
@@ -2112,13 +2117,14 @@ __global__ __launch_bounds__(256) void k_rt(RtParams p, const double *__restrict
     const double fS = S_toa ? S_toa[jj] : 0.0;
     const double fa = albedo ? albedo[jj] : 0.0;
     const double c = p.cos_ts;
+    auto sg = [&](size_t idx) { return sigma2 ? sigma[idx] + sigma2[idx] : sigma[idx]; };
 
     double I[NS];
     double Md = 0.0, Bprev = 0.0;
     if (down_role) {
 #pragma unroll
         for (int k = 0; k < NS; k++) I[k] = 0.0;
-        double b1 = p.C * (sigma[jj] / muk[0]);  // beta at node 0, discretized.jl:150
+        double b1 = p.C * (sg((size_t)jj) / muk[0]);  // beta at node 0, discretized.jl:150
         double Ms = c * fS;                      // M-[1] = c*fS(nu), discretized.jl:299
         Md = Ms;
         Bprev = planck(v, Tlev[0]);
@@ -2127,18 +2133,18 @@ __global__ __launch_bounds__(256) void k_rt(RtParams p, const double *__restrict
             if (lane == 0) red[(np + 0) * nw + wv] = r;
             if (Mdn && live) Mdn[j] = Md;
         }
-        double sg_next = sigma[(size_t)(nlob - 1) * nnu + jj];   // end node of layer 0; later layers are fetched one layer ahead
+        double sg_next = sg((size_t)(nlob - 1) * nnu + jj);   // end node of layer 0; later layers are fetched one layer ahead
         for (int i = 0; i < nl; i++) {
             const double dP = P[i + 1] - P[i];
             double ti = (dP * p.ws[0]) * b1;
             for (int n = 1; n < nlob - 1; n++) {
                 const int k = i * (nlob - 1) + n;
-                ti += (dP * p.ws[n]) * (p.C * (sigma[(size_t)k * nnu + jj] / muk[k]));
+                ti += (dP * p.ws[n]) * (p.C * (sg((size_t)k * nnu + jj) / muk[k]));
             }
             const int ke = (i + 1) * (nlob - 1);
-            const double sg = sg_next;
-            if (i + 1 < nl) sg_next = sigma[(size_t)(ke + nlob - 1) * nnu + jj];   // in flight during this layer's exp/divide chain
-            const double bn = p.C * (sg / muk[ke]);
+            const double sgv = sg_next;
+            if (i + 1 < nl) sg_next = sg((size_t)(ke + nlob - 1) * nnu + jj);   // in flight during this layer's exp/divide chain
+            const double bn = p.C * (sgv / muk[ke]);
             ti += (dP * p.ws[nlob - 1]) * bn;
             b1 = bn;
             const double t = ti > 1e-6 ? ti : 1e-6;  // floor, discretized.jl:147,174
@@ -2185,8 +2191,8 @@ __global__ __launch_bounds__(256) void k_rt(RtParams p, const double *__restrict
         const bool recompute = UD || !tau;   // no tau output requested ("OLR-only"): optical depths never touch HBM
         double t_next = 1.0, b_hi = 0.0, sg_lo = 0.0;
         if (recompute) {
-            b_hi = p.C * (sigma[(size_t)(p.K - 1) * nnu + jj] / muk[p.K - 1]);
-            sg_lo = sigma[(size_t)(nl - 1) * (nlob - 1) * nnu + jj];
+            b_hi = p.C * (sg((size_t)(p.K - 1) * nnu + jj) / muk[p.K - 1]);
+            sg_lo = sg((size_t)(nl - 1) * (nlob - 1) * nnu + jj);
         } else {
             t_next = live ? tau[(size_t)(nl - 1) * nnu + j] : 1.0;
         }
@@ -2196,9 +2202,9 @@ __global__ __launch_bounds__(256) void k_rt(RtParams p, const double *__restrict
                 const double dP = P[i + 1] - P[i];
                 const int kl = i * (nlob - 1);
                 const double b_lo = p.C * (sg_lo / muk[kl]);
-                if (i > 0) sg_lo = sigma[(size_t)(kl - (nlob - 1)) * nnu + jj];   // one layer ahead
+                if (i > 0) sg_lo = sg((size_t)(kl - (nlob - 1)) * nnu + jj);   // one layer ahead
                 double ti = (dP * p.ws[0]) * b_lo;
-                for (int n = 1; n < nlob - 1; n++) ti += (dP * p.ws[n]) * (p.C * (sigma[(size_t)(kl + n) * nnu + jj] / muk[kl + n]));
+                for (int n = 1; n < nlob - 1; n++) ti += (dP * p.ws[n]) * (p.C * (sg((size_t)(kl + n) * nnu + jj) / muk[kl + n]));
                 ti += (dP * p.ws[nlob - 1]) * b_hi;
                 b_hi = b_lo;
                 t = ti > 1e-6 ? ti : 1e-6;
@@ -2249,7 +2255,7 @@ __global__ __launch_bounds__(2 * NS * 64) void k_rt_streams(RtParams p, const do
                                                             const double *__restrict__ P, const double *__restrict__ Tlev,
                                                             const double *__restrict__ S_toa, const double *__restrict__ albedo,
                                                             double *__restrict__ tau, double *__restrict__ Mup, double *__restrict__ Mdn,
-                                                            double *__restrict__ partial, size_t sig_bstride)
+                                                            double *__restrict__ partial, size_t sig_bstride, const double *__restrict__ sigma2)
 {
     extern __shared__ double sh[];   // Blev[np][64] | tl[nl][64] | xch[2 buffers][2 roles][NS][64] | red[2 np] | msurf[64]
     const int np = p.np, nl = np - 1, nlob = p.nlobatto;
@@ -2279,9 +2285,10 @@ __global__ __launch_bounds__(2 * NS * 64) void k_rt_streams(RtParams p, const do
         if (i < nl) {   // optical depth of layer i exactly as k_rt forms it (dDepth!, discretized.jl:136-177): beta at the layer's nodes, 1e-6 floor
             const double dP = P[i + 1] - P[i];
             const int kl = i * (nlob - 1);
-            double ti = (dP * p.ws[0]) * (p.C * (sigma[(size_t)kl * nnu + jj] / muk[kl]));
-            for (int n = 1; n < nlob - 1; n++) ti += (dP * p.ws[n]) * (p.C * (sigma[(size_t)(kl + n) * nnu + jj] / muk[kl + n]));
-            ti += (dP * p.ws[nlob - 1]) * (p.C * (sigma[(size_t)(kl + nlob - 1) * nnu + jj] / muk[kl + nlob - 1]));
+            auto sg = [&](size_t idx) { return sigma2 ? sigma[idx] + sigma2[idx] : sigma[idx]; };   // (near-line plane, see k_rt)
+            double ti = (dP * p.ws[0]) * (p.C * (sg((size_t)kl * nnu + jj) / muk[kl]));
+            for (int n = 1; n < nlob - 1; n++) ti += (dP * p.ws[n]) * (p.C * (sg((size_t)(kl + n) * nnu + jj) / muk[kl + n]));
+            ti += (dP * p.ws[nlob - 1]) * (p.C * (sg((size_t)(kl + nlob - 1) * nnu + jj) / muk[kl + nlob - 1]));
             const double t = ti > 1e-6 ? ti : 1e-6;
             tl[(size_t)i * 64 + lane] = t;
             if (tau && live) tau[(size_t)i * nnu + j] = t;
@@ -2416,6 +2423,13 @@ __global__ __launch_bounds__(256) void k_transpose(const double *__restrict__ in
         int r = r0 + tx;
         if (r < R && cc < Cn) out[(size_t)cc * R + r] = t[tx][yy];
     }
+}
+
+// sigma += sigma2 (the near-line plane folded in where the cross-sections themselves are the result: cs_column_sigma_run)
+__global__ __launch_bounds__(256) void k_fold(int64_t n, double *__restrict__ sigma, const double *__restrict__ sigma2)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) sigma[i] += sigma2[i];
 }
 
 __global__ __launch_bounds__(256) void k_fill(int64_t n, double base, const double *__restrict__ extra, double *__restrict__ sigma)

@@ -122,7 +122,9 @@ int cs_set_merge(cs_ctx *ctx, int on);
  *   key 5: on short grids (up to 400 tiles) the flux sweeps run one wave per (sweep, stream) of a tile (k_rt_streams) instead of one
  *          per sweep -- 1 (default), 0 off;
  *   key 6: how many interval sizes, largest first, have their matrix-core node sums shared by the four waves of a block (0 = the
- *          default, see profiles/r03_notes.md).
+ *          default, see profiles/r03_notes.md);
+ *   key 7: the near-line kernels run on a second side stream beside k_voigt_edge_mx and what follows it, adding into a plane of
+ *          their own that k_rt reads together with sigma (1, default), or after k_voigt_edge_mx into sigma (0).
  * Applies to every later cs_column_setup / cs_column_run of the context. */
 int cs_set_tuning(cs_ctx *ctx, int key, int value);
 
