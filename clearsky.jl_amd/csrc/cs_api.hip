@@ -210,6 +210,7 @@ struct Column {
     std::vector<ColGas> gas;     // launch groups
     int merge = 1;               // the context's cs_set_merge at setup time
     int launches = 0;            // kernel launches of the last cs_column_run
+    bool near_live = false;      // the last cs_column_run left its near-line pairs in sigma2 (k_rt read both planes): cs_column_sigma_fetch folds them in
     hipStream_t last_stream = nullptr;   // the stream that run was enqueued on (cs_column_fetch waits for it, not for the whole device)
     // cs_set_tuning key 4: the step as ONE hipGraph launch (captured on the second run after a change, replayed from the third on):
     // kernel arguments are device addresses that stay put between cs_column_update_state calls, so only what changes launch
@@ -2263,7 +2264,10 @@ static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e, bool *
     fk.s2 = ctx->stream2; fk.ev_fork = ctx->ev_fork; fk.ev_join = ctx->ev_join;
     fk.s3 = ctx->stream3; fk.ev_fork3 = ctx->ev_fork3; fk.ev_join3 = ctx->ev_join3;
     fk.use_nodes = !ev && (ctx->tune[2] == 2 || (ctx->tune[2] == 1 && (c.nnu + 63) / 64 * (int64_t)K < 16384));
-    fk.use_near = !ev && ctx->tune[7] != 0 && c.sigma2.p != nullptr;
+    // (1 = where it was measured to pay: 1/8 shards of C3 -3..-6 %, C3 -1 %; not on tiny columns -- C2 +19 %: the join costs more than
+    //  the kernels -- nor on very long sparse ones -- C5 +2 %; 2 = always)
+    const int64_t tswaves = (c.nnu + 63) / 64 * (int64_t)K;
+    fk.use_near = !ev && c.sigma2.p != nullptr && (ctx->tune[7] == 2 || (ctx->tune[7] == 1 && tswaves >= 8192 && tswaves <= 300000));
     fk.sigma2 = fk.use_near ? c.sigma2.as<double>() : nullptr;
     const bool use_fork = fk.use_nodes || fk.use_near;
     for (int gi = 0; gi < (int)c.gas.size(); gi++) {
@@ -2296,6 +2300,7 @@ static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e, bool *
         CS_LAUNCH(k_cia, dim3((unsigned)c.ntile), dim3(256), 0, s, cc.nband, cc.bands.as<CiaBand>(), cc.st.as<CiaState>(),
                            c.nu.as<double>(), c.nnu, K, cc.rho1.as<double>(), cc.rho2.as<double>(), cc.rhoa.as<double>(), sig);
     fork_join(&fk, s);
+    c.near_live = false;
     if (near_plane_live) *near_plane_live = fk.live;
     else if (fk.live) {
         const int64_t tot = (int64_t)K * c.nnu;
@@ -2328,6 +2333,7 @@ static int run_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev)
     if (ev) HIPCHK(hipEventRecord(ev[e++], s));
     bool near_live = false;
     if ((rc = sigma_impl(ctx, s, ev, e, &near_live))) return rc;
+    c.near_live = near_live;
     if (ev) HIPCHK(hipEventRecord(ev[e++], s));
     launch_rt(c.nstream, c.rtg, 1, s, c.rt, c.nu.as<double>(), c.wts.as<double>(),
               c.nnu, sig, c.muk.as<double>(), c.P.as<double>(), c.Tlev.as<double>(),
@@ -2481,6 +2487,13 @@ int cs_column_sigma_fetch(cs_ctx *ctx, int64_t nnu, int K, double *sigma)
                     (long long)nnu, K);
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipDeviceSynchronize());
+    if (c.near_live) {   // the run handed k_rt two planes: the total is their sum (folded in once)
+        const int64_t tot = (int64_t)c.K * c.nnu;
+        CS_LAUNCH(k_fold, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, tot, c.sigma.as<double>(), c.sigma2.as<double>());
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        c.near_live = false;
+    }
     HIPCHK(hipMemcpy(sigma, c.sigma.p, (size_t)c.K * c.nnu * sizeof(double), hipMemcpyDeviceToHost));
     return CS_OK;
 }
