@@ -253,7 +253,7 @@ struct cs_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;            // side stream: node sums beside the per-point kernels (cs_set_tuning key 2)
     hipStream_t stream3 = nullptr;            // side stream: near-line kernels beside the matrix-core per-point kernel (key 7)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork3 = nullptr, ev_join3 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork3 = nullptr, ev_join3 = nullptr, ev_far3 = nullptr;
     GasTable gas[CS_MAX_GAS];
     TableDev tab[CS_MAX_TABLE];
     CiaDev cia[CS_MAX_CIA];
@@ -777,8 +777,9 @@ struct Fork {
     hipStream_t s2; hipEvent_t ev_fork, ev_join; bool pending;
     // the same for the near-line kernels: they need the hand-off words of k_voigt_far / k_voigt_sub and nothing of k_voigt_edge_mx --
     // a gather-bound kernel beside a matrix-core one -- but both add to sigma, so the near-line pairs go to a plane of their own
-    // (sigma2: cleared by the step's first k_voigt_far, read together with sigma by k_rt, folded in by k_fold where sigma is the result)
-    hipStream_t s3; hipEvent_t ev_fork3, ev_join3; bool pending3;
+    // (sigma2: cleared at the start of the step's first Voigt group, read together with sigma by k_rt, folded in by k_fold where sigma is
+    // the result).  k_voigt_sub goes there too: it needs the zones only, not k_voigt_far, so it runs beside it.
+    hipStream_t s3; hipEvent_t ev_fork3, ev_join3, ev_far3; bool pending3;
     double *sigma2; bool zeroed, live;
 };
 static void fork_join(Fork *f, hipStream_t s, bool nodes = true, bool near = true)
@@ -938,10 +939,20 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
 #define CS_LOR_LAUNCH(SP) CS_LAUNCH((k_voigt_far<false, SP, true>), grid_s, dim3(256), 0, s, dnu, nnu, G.L, hot, hot32, G.nu.as<double>(), \
                                                   win, zones, nt64, nblk_s, cut, base, extra, sigma, accumulate, ranges, iz, itp.nItot, ishift, edgez)
         const EdgeZone *edgez = use_edge ? itp.edge : nullptr;
-        // near-line kernels on a side stream, into their own plane (Voigt only; not while profiling): its first k_voigt_far of the step clears it
+        // near-line kernels and the sub-tile cores on a side stream, into their own plane (Voigt only; not while profiling)
         const bool near_fork = !lor && fork && fork->use_near && fork->sigma2 && defer && !evg;
-        double *zero2 = nullptr;
-        if (near_fork && !fork->zeroed) { zero2 = fork->sigma2; fork->zeroed = true; }
+        double *zero2 = nullptr;   // (the far kernel can clear the plane itself: unused since k_voigt_sub adds to it beside k_voigt_far)
+        if (near_fork) {   // zones, records and piece tables are written: the side stream may start
+            (void)hipEventRecord(fork->ev_fork3, s);
+            (void)hipStreamWaitEvent(fork->s3, fork->ev_fork3, 0);
+            if (!fork->zeroed) {
+                (void)hipMemsetAsync(fork->sigma2, 0, (size_t)kn * nnu * sizeof(double), fork->s3);
+                fork->zeroed = true;
+            }
+            if (use_edge && itp.core)
+                CS_LAUNCH(k_voigt_sub<CS_SUBW>, dim3((unsigned)nt64, (unsigned)((kn + 64 / CS_SUBW - 1) / (64 / CS_SUBW))), dim3(4096 / CS_SUBW), 0, fork->s3, dnu, nnu, G.L, hot,
+                          G.nu.as<double>(), zones, itp.edge, nt64, kn, cut, fork->sigma2, reinterpret_cast<unsigned *>(ranges));
+        }
         if (lor) {
             if (split == 1) CS_LOR_LAUNCH(1); else if (split == 2) CS_LOR_LAUNCH(2); else CS_LOR_LAUNCH(4);
         } else if (hot32 && use_edge) {
@@ -962,7 +973,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
 #undef CS_FAR_LAUNCH
 #undef CS_LOR_LAUNCH
         if (evg) (void)hipEventRecord(evg[3], s);
-        if (use_edge && itp.core)   // the window cores of the groups whose series radius is short: pairs inside it (the rest: k_voigt_edge_mx)
+        if (use_edge && itp.core && !near_fork)   // the window cores of the groups whose series radius is short: pairs inside it (the rest: k_voigt_edge_mx)
             CS_LAUNCH(k_voigt_sub<CS_SUBW>, dim3((unsigned)nt64, (unsigned)((kn + 64 / CS_SUBW - 1) / (64 / CS_SUBW))), dim3(4096 / CS_SUBW), 0, s, dnu, nnu, G.L, hot, G.nu.as<double>(), zones,
                                itp.edge, nt64, kn, cut, sigma, reinterpret_cast<unsigned *>(ranges));
         auto launch_near = [&](hipStream_t sn, double *out) {
@@ -974,9 +985,9 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
             CS_LAUNCH(k_voigt_near<0>, gridq, dim3(256), 0, sn, dnu, nnu, G.L, hot, cold, zones, nt64, ngrpn, nrep, cut, out, ranges);
             CS_LAUNCH(k_voigt_near<1>, gridq, dim3(256), 0, sn, dnu, nnu, G.L, hot, cold, zones, nt64, ngrpn, nrep, cut, out, ranges);
         };
-        if (near_fork) {   // (everything the near kernels read is written by now: records, zones, hand-off words)
-            (void)hipEventRecord(fork->ev_fork3, s);
-            (void)hipStreamWaitEvent(fork->s3, fork->ev_fork3, 0);
+        if (near_fork) {   // the near kernels need the hand-off words of both k_voigt_far (main stream) and k_voigt_sub (theirs)
+            (void)hipEventRecord(fork->ev_far3, s);
+            (void)hipStreamWaitEvent(fork->s3, fork->ev_far3, 0);
             launch_near(fork->s3, fork->sigma2);
             (void)hipEventRecord(fork->ev_join3, fork->s3);
             fork->pending3 = true;
@@ -1081,6 +1092,7 @@ int cs_create(int device, cs_ctx **out)
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork3, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_far3, hipEventDisableTiming);
     if (e != hipSuccess) { cs_destroy(c); return fail(CS_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     *out = c;
     return CS_OK;
@@ -1098,6 +1110,7 @@ void cs_destroy(cs_ctx *ctx)
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->ev_fork3) (void)hipEventDestroy(ctx->ev_fork3);
     if (ctx->ev_join3) (void)hipEventDestroy(ctx->ev_join3);
+    if (ctx->ev_far3) (void)hipEventDestroy(ctx->ev_far3);
     if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -2262,7 +2275,7 @@ static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e, bool *
     Fork fk;
     memset(&fk, 0, sizeof fk);
     fk.s2 = ctx->stream2; fk.ev_fork = ctx->ev_fork; fk.ev_join = ctx->ev_join;
-    fk.s3 = ctx->stream3; fk.ev_fork3 = ctx->ev_fork3; fk.ev_join3 = ctx->ev_join3;
+    fk.s3 = ctx->stream3; fk.ev_fork3 = ctx->ev_fork3; fk.ev_join3 = ctx->ev_join3; fk.ev_far3 = ctx->ev_far3;
     fk.use_nodes = !ev && (ctx->tune[2] == 2 || (ctx->tune[2] == 1 && (c.nnu + 63) / 64 * (int64_t)K < 16384));
     // (1 = where it was measured to pay: 1/8 shards of C3 -3..-6 %, C3 -1 %; not on tiny columns -- C2 +19 %: the join costs more than
     //  the kernels -- nor on very long sparse ones -- C5 +2 %; 2 = always)

@@ -123,9 +123,10 @@ int cs_set_merge(cs_ctx *ctx, int on);
  *          per sweep -- 1 (default), 0 off;
  *   key 6: how many interval sizes, largest first, have their matrix-core node sums shared by the four waves of a block (0 = the
  *          default, see profiles/r03_notes.md);
- *   key 7: the near-line kernels run on a second side stream beside k_voigt_edge_mx and what follows it, adding into a plane of
- *          their own that k_rt reads together with sigma -- 1 (default) on grids of 8192 .. 300000 (tile, state) waves, where it was
- *          measured to pay; 2 always; 0: after k_voigt_edge_mx into sigma.
+ *   key 7: the sub-tile cores (k_voigt_sub) and the near-line kernels run on a second side stream -- the former beside k_voigt_far,
+ *          the latter beside k_voigt_edge_mx and what follows it -- adding into a plane of their own that k_rt reads together with
+ *          sigma: 1 (default) on grids of 8192 .. 300000 (tile, state) waves, where it was measured to pay; 2 always; 0: on the
+ *          main stream, into sigma.
  * Applies to every later cs_column_setup / cs_column_run of the context. */
 int cs_set_tuning(cs_ctx *ctx, int key, int value);
 
