@@ -248,7 +248,7 @@ def main():
     try:
         pm = json.load(open(os.path.join(_ROOT, "profiles", "pmc_traffic.json")))
         default_wl = (args.nnu is None and args.lines is None and args.shape == "voigt" and N == 1 and interp_on and args.precision == "fp64"
-                      and not args.emulate_shard and args.tune in ("", "2=0") and not args.no_merge)
+                      and not args.emulate_shard and args.tune in ("", "2=0", "2=0,7=0") and not args.no_merge)
         if pm.get("source_sha16") != source_stamp():
             traffic_note = f"profiles/pmc_traffic.json belongs to build {pm.get('source_sha16')}, the loaded library is {source_stamp()}"
         elif pm.get("config") != args.config or not default_wl:
