@@ -296,8 +296,13 @@ def main():
         d = cs.Column(cfg["P"], cfg["g"], cfg["T"], cfg["mu"], cfg["fS"], cfg["fa"], *cfg["absorbers"], core=cfg["core"],
                       theta_s=cfg["theta_s"], ctx=ctx, _setup=False)
         ctx2 = cs.Context(dev)      # a context of its own: first call = full setup, later calls re-use the resident column
-        ctx2.set_precision(args.precision, args.far_s)
+        ctx2.set_precision(args.precision, args.far_s)      # ... with every setting of the run beside it
         ctx2.set_interp(not args.no_interp)
+        ctx2.set_interp_plan(first_level=args.interp_first_level)
+        ctx2.set_matrix_cores(0 if args.no_matrix_nodes else args.matrix_cores)
+        ctx2.set_merge(not args.no_merge)
+        for kv in filter(None, args.tune.split(",")):
+            ctx2.set_tuning(*map(int, kv.split("=")))
         d.ctx = ctx2
         d.slots = np.array([ctx2.slot_of(g_.sl) for g_ in d.gases], dtype=np.int32)
         def timed(*bufs, reps=1):

@@ -7,6 +7,7 @@ set -e
 tag=$1; shift
 root=${GRAFT_REPO_ROOT:-$PWD}
 out=$root/gpurun_out/prof_$tag
+rm -rf $out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 # (--tune 2=0,7=0: kernels one after the other on one stream, as in the HIP-event profile bench.py's roofline is built from; with the side
