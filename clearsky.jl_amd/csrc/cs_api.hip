@@ -240,7 +240,7 @@ static void drop_graph(Column &c)
 }
 
 // workspace of the PHCO2 fast path (k_phco2): per-(state, line) chi factors and per-tile region windows
-constexpr int CS_NTUNE = 8;
+constexpr int CS_NTUNE = 12;
 struct PhScratch { DevBuf fac, win; double nu_lo = 0.0, nu_hi = 0.0, nu_c = 0.0; };   // nu_lo/nu_hi: ends of the grid, set by the caller
 
 // what cs_fluxes_discretized_multi keeps between calls (in its first context)
@@ -267,7 +267,7 @@ struct cs_ctx {
     int merge = 1;          // cs_set_merge: gases of a column with the same shape and cut-off share one merged line table
     // cs_set_tuning: [0] interpolated wings applied inside k_voigt_edge_mx where one launch group has them, [1] matrix-core kernels on
     // short grids (four waves per item), [2] node sums on a side stream (1: short grids only, 2: always)
-    int tune[CS_NTUNE] = {0, 1, 2, 0, 0, 1, 0, 1};   // [6] split levels of k_cheb_nodes_mx, [7] near-line kernels on a second side stream   // ... [3] interpolation margin (per cent), [4] hipGraph replay, [5] k_rt_streams on short grids
+    int tune[CS_NTUNE] = {0, 1, 2, 0, 0, 1, 0, 1, 7, 0, 0, 0};   // ... [8] states of a group that must be able to use a line for it to join the group's matrix-core node piece   // [6] split levels of k_cheb_nodes_mx, [7] near-line kernels on a second side stream   // ... [3] interpolation margin (per cent), [4] hipGraph replay, [5] k_rt_streams on short grids
     std::vector<std::unique_ptr<GasTable>> merged;   // merged tables (keyed by their members' (slot, generation)), a few kept
     double far_s = 1e6;
     DevBuf hot32;
@@ -578,6 +578,7 @@ struct Interp {
     bool sep_always = false;  // cs_set_matrix_cores(ctx, 2): also on grids too short to fill the chip with (interval, state group) blocks
     bool core = true;         // cs_set_matrix_cores(ctx, on | 4) switches the sub-tile treatment of the window core (k_voigt_sub) off
     double margin = kChebMargin;   // cs_set_tuning key 3 (per cent): distance of an interval's interpolated set, in half-widths
+    int mx_min_states = 7;    // cs_set_tuning key 8
     int nsplit_levels = 1;    // cs_set_tuning key 6: interval sizes (largest first) whose node sums four waves share in k_cheb_nodes_mx
     bool small_mx = false;    // cs_set_tuning key 1: the matrix-core kernels on short grids too (their four-waves-per-item variants)
     bool fuse_apply = false;  // the column's only interpolating group: k_voigt_edge_mx may carry the node sums to the grid itself
@@ -845,7 +846,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
             if (use_sep || use_edge) {   // what the matrix cores take of the interpolated sets and of the window ends (needs the zones of k_gas_setup)
                 SepArgs sa;
                 sa.nodes = itp.nodes; sa.nul = G.nu.as<double>(); sa.gbound = gbound; sa.Tk = Tk; sa.iz = itp.iz; sa.out = itp.sep;
-                sa.nItot = itp.nItot; sa.q0 = q0; sa.K = kn; sa.ngrp = ngrp; sa.mu_min = G.mu_min; sa.cut = cut;
+                sa.nItot = itp.nItot; sa.q0 = q0; sa.K = kn; sa.ngrp = ngrp; sa.mu_min = G.mu_min; sa.cut = cut; sa.min_states = itp.mx_min_states;
                 EdgeArgs ea;
                 ea.nu = dnu; ea.nul = G.nu.as<double>(); ea.gbound = gbound; ea.Tk = Tk; ea.win = win; ea.zones = zones;
                 ea.iz = itp.iz + itp.ioff[itp.nlev - 1]; ea.out = itp.edge; ea.nnu = nnu; ea.ntile = nt64; ea.K = kn; ea.ngrp = ngrp;
@@ -885,7 +886,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
                 if (!mx_big(nq, kn, 2048) || nsplit > nq) nsplit = nq;
                 const unsigned nblk_mx = (unsigned)(nsplit * ngrp) + (unsigned)(((int64_t)(nq - nsplit) * ngrp + 3) / 4);
                 CS_LAUNCH(k_cheb_nodes_mx, dim3(nblk_mx), dim3(256), 0, s, itp.nodes, G.L, hot, itp.sep, itp.nItot, q0, nsplit, kn,
-                                   itp.Kpad, ngrp, itp.F);
+                                   itp.Kpad, ngrp, itp.F, itp.iz);
             }
             if (s != sm) {
                 (void)hipEventRecord(fork->ev_join, s);
@@ -1379,7 +1380,7 @@ static int shape_impl(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t 
         itp = interp_view(cheb, ginterp, kc);
         if (!ctx->matrix_nodes) itp.sep = nullptr, itp.edge = nullptr;
         itp.sep_always = ctx->matrix_nodes == 2;
-        itp.small_mx = ctx->tune[1] != 0; itp.margin = ctx->tune[3] > 0 ? 0.01 * ctx->tune[3] : kChebMargin; itp.nsplit_levels = ctx->tune[6] > 0 ? ctx->tune[6] : 1;
+        itp.small_mx = ctx->tune[1] != 0; itp.margin = ctx->tune[3] > 0 ? 0.01 * ctx->tune[3] : kChebMargin; itp.nsplit_levels = ctx->tune[6] > 0 ? ctx->tune[6] : 1; itp.mx_min_states = ctx->tune[8] > 0 ? ctx->tune[8] : 7;
         itp.core = ctx->matrix_core != 0;
     }
     for (int k0 = 0; k0 < K; k0 += kc) {
@@ -1467,7 +1468,7 @@ int cs_bake(cs_ctx *ctx, int gas_slot, int table_slot, int shape, double dnu_cut
         itp = interp_view(cheb, ginterp, kc);
         if (!ctx->matrix_nodes) itp.sep = nullptr, itp.edge = nullptr;
         itp.sep_always = ctx->matrix_nodes == 2;
-        itp.small_mx = ctx->tune[1] != 0; itp.margin = ctx->tune[3] > 0 ? 0.01 * ctx->tune[3] : kChebMargin; itp.nsplit_levels = ctx->tune[6] > 0 ? ctx->tune[6] : 1;
+        itp.small_mx = ctx->tune[1] != 0; itp.margin = ctx->tune[3] > 0 ? 0.01 * ctx->tune[3] : kChebMargin; itp.nsplit_levels = ctx->tune[6] > 0 ? ctx->tune[6] : 1; itp.mx_min_states = ctx->tune[8] > 0 ? ctx->tune[8] : 7;
         itp.core = ctx->matrix_core != 0;
     }
     for (int k0 = 0; k0 < M; k0 += kc) {
@@ -2168,7 +2169,7 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
             itp.sep = ctx->matrix_nodes ? dsep.as<SepZone>() : nullptr;
             itp.edge = ctx->matrix_nodes ? dedge.as<EdgeZone>() : nullptr;
             itp.sep_always = ctx->matrix_nodes == 2;
-            itp.small_mx = ctx->tune[1] != 0; itp.margin = ctx->tune[3] > 0 ? 0.01 * ctx->tune[3] : kChebMargin; itp.nsplit_levels = ctx->tune[6] > 0 ? ctx->tune[6] : 1;
+            itp.small_mx = ctx->tune[1] != 0; itp.margin = ctx->tune[3] > 0 ? 0.01 * ctx->tune[3] : kChebMargin; itp.nsplit_levels = ctx->tune[6] > 0 ? ctx->tune[6] : 1; itp.mx_min_states = ctx->tune[8] > 0 ? ctx->tune[8] : 7;
             itp.core = ctx->matrix_core != 0;
         }
         for (int64_t k0 = 0; k0 < BK; k0 += kc) {
@@ -2290,7 +2291,7 @@ static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e, bool *
         itp.F = c.chebF.as<double>();
         if (!ctx->matrix_nodes) itp.sep = nullptr, itp.edge = nullptr;
         itp.sep_always = ctx->matrix_nodes == 2;
-        itp.small_mx = ctx->tune[1] != 0; itp.margin = ctx->tune[3] > 0 ? 0.01 * ctx->tune[3] : kChebMargin; itp.nsplit_levels = ctx->tune[6] > 0 ? ctx->tune[6] : 1;
+        itp.small_mx = ctx->tune[1] != 0; itp.margin = ctx->tune[3] > 0 ? 0.01 * ctx->tune[3] : kChebMargin; itp.nsplit_levels = ctx->tune[6] > 0 ? ctx->tune[6] : 1; itp.mx_min_states = ctx->tune[8] > 0 ? ctx->tune[8] : 7;
         itp.core = ctx->matrix_core != 0;
         itp.fuse_apply = ctx->tune[0] != 0 && n_itp == 1;
         launch_gas(s, cg.shape, G, cg.jlo, cg.jhi, K, c.Tk.as<double>(), c.Pk.as<double>(), cg.Pp.as<double>(), cg.conc.as<double>(), K,
@@ -2588,12 +2589,16 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
                     int sa[4] = {z.P0, z.Z0, z.Z1, z.P3}, sb[4] = {z.P0, z.Z0, z.Z1, z.P3};
                     if (use_sep) {
                         const SepZone &s4 = sz[(size_t)(k >> 4) * nItot + q];
-                        for (int p = 0; p < 4; p++)
-                            if (s4.b[p] > s4.a[p]) {
-                                sa[p] = s4.a[p]; sb[p] = s4.b[p]; sepn += (int64_t)CS_NC * (s4.b[p] - s4.a[p]);
-                                mx3 += (int64_t)CS_NC * (p < 2 ? s4.m[p] - s4.a[p] : s4.b[p] - s4.m[p]);
-                                mx3n += (int64_t)CS_NC * (p < 2 ? s4.m[p] - s4.a[p] : s4.b[p] - s4.m[p]);
+                        for (int p = 0; p < 4; p++) {   // of the group's piece, this state's part: the lines beyond its own series radius (k_cheb_nodes_mx's mask)
+                            const int pa = p < 2 ? s4.a[p] : std::max(s4.a[p], z.S1), pb = p < 2 ? std::min(s4.b[p], z.S0) : s4.b[p];
+                            if (pb > pa) {
+                                sa[p] = pa; sb[p] = pb; sepn += (int64_t)CS_NC * (pb - pa);
+                                const int n3 = p < 2 ? std::max(0, std::min(s4.m[p], pb) - pa) : std::max(0, pb - std::max(s4.m[p], pa));
+                                mx3 += (int64_t)CS_NC * n3;
+                                mx3n += (int64_t)CS_NC * n3;
+                                fl_nodes_useful += 2.0 * CS_NC * (3.0 * n3 + 4.0 * ((pb - pa) - n3));
                             }
+                        }
                     }
                     const int lo8[8] = {z.E0, sb[0], z.P1, sb[1], sb[3], z.P3, sb[2], z.Z1}, hi8[8] = {sa[0], z.P0, sa[1], z.Z0, z.E1, sa[3], z.P2, sa[2]};
                     for (int w8 = 0; w8 < 8; w8++) {
@@ -2618,7 +2623,7 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
                         for (int p = 0; p < 4; p++) {
                             if (z.b[p] <= z.a[p]) continue;
                             const int n3 = p < 2 ? z.m[p] - z.a[p] : z.b[p] - z.m[p], n4 = (z.b[p] - z.a[p]) - n3;
-                            fl_nodes_useful += 2.0 * CS_NC * ns * (3.0 * n3 + 4.0 * n4);
+                            (void)ns;   // (useful flops: per state, above -- a state takes part only beyond its own series radius)
                             fl_nodes_issued += 2.0 * CS_NC * 16 * (3.0 * ((n3 + 3) / 4 * 4) + 4.0 * ((n4 + 3) / 4 * 4));
                         }
                     }

@@ -510,7 +510,11 @@ __device__ __forceinline__ int tile_block(const int32_t *__restrict__ xc, int ti
 constexpr double kChebMargin = 0.3;   // default of ZoneArgs::margin
 // per (state, interval): own set = [E0,Z0) U [Z1,E1), cut into the 2-/3-/4-term zones of the far body; [P0,P1) and [P2,P3)
 // is the part of it the parent interval (next level up) has already summed.
-struct __attribute__((aligned(16))) IZone { int32_t E0, Q0, M0, Z0, Z1, M1, Q1, E1, P0, P1, P2, P3; };
+// S0, S1: the lines below S0 and from S1 on are at least R4(state) = 133.6 sqrt(gamma_max^2 + 4.33 alpha_max^2) from the interval -- where
+// the 4-term series in 1/dnu^2 holds for THIS state (k_cheb_nodes_mx sums them for the states of a group it holds for, k_cheb_nodes
+// the rest: a group of 16 states spans a factor 3-7 in pressure, and one radius for all of it -- its widest line's -- left the
+// lower-pressure states' lines to the vector unit)
+struct __attribute__((aligned(16))) IZone { int32_t E0, Q0, M0, Z0, Z1, M1, Q1, E1, P0, P1, P2, P3, S0, S1, pad0, pad1; };
 
 // nodes[T][m] = centre + h cos(pi m/63) and C[T][m][i] = l_m(nu_i): Lagrange basis of the extrema, barycentric form
 __global__ __launch_bounds__(256) void k_cheb_setup(const double *__restrict__ nu, int64_t nnu, int itv, int nI,
@@ -601,7 +605,8 @@ __device__ __forceinline__ void izones_body(unsigned bid, const IzParams &P, con
     double vlo, vhi, dA, dZ;
     IZone z;
     if (!izone_frame(P, l, T, nu, nnu, vth, mu_min, cut, vlo, vhi, dA, dZ, z.E0, z.E1, a.lorentz, a.margin)) {
-        z.Z0 = z.Z1 = z.Q0 = z.M0 = z.M1 = z.Q1 = z.P0 = z.P1 = z.P2 = z.P3 = z.E0;
+        z.Z0 = z.Z1 = z.Q0 = z.M0 = z.M1 = z.Q1 = z.P0 = z.P1 = z.P2 = z.P3 = z.S0 = z.S1 = z.E0;
+        z.pad0 = z.pad1 = 0;
         iz[idx] = z;
         return;
     }
@@ -624,20 +629,28 @@ __device__ __forceinline__ void izones_body(unsigned bid, const IzParams &P, con
         for (int r = P.itv[l - 1] / P.itv[l]; r > 1; r >>= 1) pshift++;
         par = izone_frame(P, l - 1, T >> pshift, nu, nnu, vth, mu_min, cut, pvlo, pvhi, pdA, pdZ, qE0, qE1, a.lorentz, a.margin);
     }
-    // own Z0, Z1 (set stays dZ away), M0, M1 (4-term zone), Q0, Q1 (3-term zone), parent's Z0, Z1: eight searches side by side
-    const double sv[8] = {vlo - dZ, vlo - dAA, vlo - dQ, pvlo - pdZ, vhi + dZ, vhi + dAA, vhi + dQ, pvhi + pdZ};
-    int slo[8] = {z.E0, z.E0, z.E0, qE0, z.E0, z.E0, z.E0, qE0};
-    int shi[8] = {z.E1, z.E1, wantq ? z.E1 : z.E0, par ? qE1 : qE0, z.E1, z.E1, wantq ? z.E1 : z.E0, par ? qE1 : qE0};
-    search_many<8>(nul, sv, 0xf0u, slo, shi);
+    // this state's radius of the 4-term series in 1/dnu^2 (sepzones_body takes the group's pieces from these)
+    const double R4 = [&] {
+        const double amax = ((vhi + cut) / kC) * vth / sqrt(mu_min), gb = gbound[k];
+        return 133.6 * sqrt(gb * gb + 4.33 * amax * amax) * (1.0 + 1e-6);
+    }();
+    // own Z0, Z1 (set stays dZ away), M0, M1 (4-term zone), Q0, Q1 (3-term zone), parent's Z0, Z1, series radius: ten searches side by side
+    const double sv[10] = {vlo - dZ, vlo - dAA, vlo - dQ, pvlo - pdZ, vlo - R4, vhi + dZ, vhi + dAA, vhi + dQ, pvhi + pdZ, vhi + R4};
+    int slo[10] = {z.E0, z.E0, z.E0, qE0, z.E0, z.E0, z.E0, z.E0, qE0, z.E0};
+    int shi[10] = {z.E1, z.E1, wantq ? z.E1 : z.E0, par ? qE1 : qE0, z.E1, z.E1, z.E1, wantq ? z.E1 : z.E0, par ? qE1 : qE0, z.E1};
+    search_many<10>(nul, sv, 0x3e0u, slo, shi);
+    z.S0 = slo[4];                 // first line with nul >= vlo - R4: the lines below it are far enough on the left
+    z.S1 = max(slo[9], z.S0);      // first line with nul >  vhi + R4: from here on far enough on the right
+    z.pad0 = z.pad1 = 0;
     z.Z0 = slo[0];
-    z.Z1 = max(slo[4], z.Z0);
+    z.Z1 = max(slo[5], z.Z0);
     z.M0 = min(slo[1], z.Z0);
-    z.M1 = max(slo[5], z.Z1);
+    z.M1 = max(slo[6], z.Z1);
     if (y2b <= 60.0) {
         z.Q0 = z.M0; z.Q1 = z.M1;
     } else if (wantq) {
         z.Q0 = min(slo[2], z.M0);
-        z.Q1 = max(slo[6], z.M1);
+        z.Q1 = max(slo[7], z.M1);
     } else {
         z.Q0 = z.E0; z.Q1 = z.E1;
     }
@@ -646,7 +659,7 @@ __device__ __forceinline__ void izones_body(unsigned bid, const IzParams &P, con
     z.P0 = z.P1 = z.E0;
     z.P2 = z.P3 = z.E1;
     if (par) {
-        const int qZ0 = slo[3], qZ1 = max(slo[7], qZ0);
+        const int qZ0 = slo[3], qZ1 = max(slo[8], qZ0);
         if (qZ0 > qE0) { z.P0 = min(max(qE0, z.E0), z.Z0); z.P1 = min(max(qZ0, z.P0), z.Z0); }
         if (qE1 > qZ1) { z.P2 = min(max(qZ1, z.Z1), z.E1); z.P3 = min(max(qE1, z.P2), z.E1); }
     }
@@ -758,9 +771,13 @@ __global__ __launch_bounds__(256) void k_cheb_nodes(const double *__restrict__ n
     int sa[4] = {z.P0, z.Z0, z.Z1, z.P3}, sb[4] = {z.P0, z.Z0, z.Z1, z.P3};   // (no matrix-core pieces: empty ones at the window ends)
     if (!LOR && sep) {   // (also in the mixed-precision variant: what the matrix cores take stays fp64 -- they beat the fp32 vector bodies)
         const SepZone sz = sep[(size_t)(k >> 4) * nItot + T];
+        // of the group's piece the matrix cores sum, for THIS state, only the lines beyond its own series radius (IZone::S0, S1): the
+        // rest of the piece stays here
 #pragma unroll
-        for (int p = 0; p < 4; p++)
-            if (sz.b[p] > sz.a[p]) { sa[p] = sz.a[p]; sb[p] = sz.b[p]; }
+        for (int p = 0; p < 4; p++) {
+            const int pa = p < 2 ? sz.a[p] : max(sz.a[p], z.S1), pb = p < 2 ? min(sz.b[p], z.S0) : sz.b[p];
+            if (pb > pa) { sa[p] = pa; sb[p] = pb; }
+        }
     }
     const double acc = node_sum_valu<MIXED, LOR>(v, hk, hf, gnul, z, sa, sb, cut, c);
     double *__restrict__ Fo = F + ((size_t)T * CS_NC + lane) * Kpad + k;
@@ -849,15 +866,17 @@ __device__ __forceinline__ void sep_step(v4f64_sep (&acc)[4], const double (&vn)
 }
 // the lines [ja, jb) of one (state-row pointer hk) in steps of 4, ascending or descending; the load of step t + 1 is issued before the
 // matrix instructions of step t and waited for after them
+// [jlo_ok, jhi_ok): the lines of the run this LANE's state takes part in (its coefficients are zero for the others: a state whose own
+// series radius excludes a line of the group's piece leaves it to the vector-unit kernel)
 template <int NT, int MASK>
 __device__ __forceinline__ void sep_run(v4f64_sep (&acc)[4], const double (&vn)[4], const LineHot *__restrict__ hk, int ja, int jb, bool asc,
-                                        int lq, double cut, double rin = 0.0)
+                                        int lq, double cut, double rin = 0.0, int jlo_ok = -0x7fffffff, int jhi_ok = 0x7fffffff)
 {
     if (ja >= jb) return;
     const int nst = (jb - ja + 3) >> 2;
     const int b0 = asc ? ja + lq : jb - 4 + lq, db = asc ? 4 : -4;   // line of this lane group at step t: b0 + t db
     auto rec = [&](int t) { return hk[min(max(b0 + t * db, ja), jb - 1)]; };
-    auto ok = [&](int t) { const int j = b0 + t * db; return j >= ja && j < jb; };
+    auto ok = [&](int t) { const int j = b0 + t * db; return j >= max(ja, jlo_ok) && j < min(jb, jhi_ok); };
     LineHot cur = rec(0);
     for (int t = 0; t < nst; t++) {
         const LineHot nxt = rec(t + 1);      // (past the end: a harmless re-read of an end record, never used)
@@ -873,6 +892,7 @@ struct SepArgs {
     const IZone *iz;
     SepZone *out;
     int nItot, q0, K, ngrp;
+    int min_states;   // a line joins a group's matrix-core piece when at least this many of its states are beyond their series radius
     double mu_min, cut;
 };
 // per (state group, interval): the four pieces common to the group's states, clipped to the distance at which the 4-term series
@@ -885,27 +905,52 @@ __device__ __forceinline__ void sepzones_body(unsigned bid, const SepArgs &a)
     const int g = idx / nq, T = a.q0 + (idx - g * nq);
     const double vhi = a.nodes[(size_t)T * CS_NC], vlo = a.nodes[(size_t)T * CS_NC + CS_NC - 1];   // nodes run from the upper end down
     int lo[4] = {0, 0, 0, 0}, hi[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
-    double R = 0.0, R3 = 0.0;
+    double R3 = 0.0;
     int E0 = 0, E1 = 0;
-    for (int k = g * 16; k < min(g * 16 + 16, a.K); k++) {
+    int s0v[16], s1v[16], ns = 0;
+#pragma unroll
+    for (int kk = 0; kk < 16; kk++) { s0v[kk] = -0x7fffffff; s1v[kk] = 0x7fffffff; }   // (a group's missing tail states never count)
+#pragma unroll
+    for (int kk = 0; kk < 16; kk++) {
+        const int k = g * 16 + kk;
+        if (k >= a.K) continue;
         const IZone z = a.iz[(size_t)k * a.nItot + T];
         lo[0] = max(lo[0], z.E0); hi[0] = min(hi[0], z.P0);
         lo[1] = max(lo[1], z.P1); hi[1] = min(hi[1], z.Z0);
         lo[2] = max(lo[2], z.Z1); hi[2] = min(hi[2], z.P2);
         lo[3] = max(lo[3], z.P3); hi[3] = min(hi[3], z.E1);
         E0 = z.E0; E1 = z.E1;
+        s0v[kk] = z.S0; s1v[kk] = z.S1; ns = kk + 1;
         const double amax = ((vhi + a.cut) / kC) * sqrt(2.0 * kRgas * a.Tk[k]) / sqrt(a.mu_min);
         const double gb = a.gbound[k];
-        R = fmax(R, kSep4 * sqrt(gb * gb + 4.33 * amax * amax) * (1.0 + 1e-6));
         R3 = fmax(R3, kSep3 * sqrt(gb * gb + 5.05 * amax * amax) * (1.0 + 1e-6));
     }
+    // A matrix step costs the same whether one or sixteen states of the group can use a line (the others' coefficients are zero:
+    // IZone::S0, S1), the vector unit per (state, line): a line joins the piece when at least min_states states are beyond their own
+    // series radius -- ~500 cycles per line and 64 nodes for the group against ~80 per state on the vector unit.  The states' bounds are
+    // ordered (sort them: 16 values): left pieces end at the min_states-th largest S0, right pieces start at the min_states-th smallest S1
+    const int rk = min(max(a.min_states, 1), ns) - 1;
+    int S0 = 0, S1 = 0;
+    // rank selection with every index static (the arrays stay in registers; a sort with run-time indices puts them in scratch memory,
+    // 0.027 -> 0.045 ms for this kernel): element i is the rk-th largest S0 when rk others precede it in descending order
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        int c0 = 0, c1 = 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            c0 += (s0v[j] > s0v[i] || (s0v[j] == s0v[i] && j < i)) ? 1 : 0;
+            c1 += (s1v[j] < s1v[i] || (s1v[j] == s1v[i] && j < i)) ? 1 : 0;
+        }
+        if (c0 == rk) S0 = s0v[i];
+        if (c1 == rk) S1 = s1v[i];
+    }
+    S1 = max(S1, S0);
     int sr[4];
     {
-        const double sv[4] = {vlo - R, vlo - R3, vhi + R, vhi + R3};
+        const double sv[4] = {vlo - R3, vlo - R3, vhi + R3, vhi + R3};
         search4(a.nul, sv, E0, E1, sr);
     }
-    const int S0 = sr[0], S1 = max(sr[2], S0);
-    const int T0 = min(sr[1], S0), T1 = max(sr[3], S1);   // three terms do in [E0, T0) and [T1, E1)
+    const int T0 = min(sr[1], S0), T1 = max(sr[3], S1);   // three terms do in [E0, T0) and [T1, E1): beyond the 3-term radius of the group's WIDEST state
     SepZone z;
     for (int p = 0; p < 4; p++) {
         int pa = lo[p], pb = hi[p];
@@ -929,7 +974,7 @@ __device__ __forceinline__ void sepzones_body(unsigned bid, const SepArgs &a)
 // this kernel's registers and LDS allow four: 0.94 ms for a quarter of the vector work, profiles/r02_notes.md.)
 __global__ __launch_bounds__(256) void k_cheb_nodes_mx(const double *__restrict__ nodes, int64_t L, const LineHot *__restrict__ hot,
                                                        const SepZone *__restrict__ sep, int nItot, int q0, int nsplit, int K, int Kpad,
-                                                       int ngrp, double *__restrict__ F)
+                                                       int ngrp, double *__restrict__ F, const IZone *__restrict__ iz)
 {
     // the first nsplit intervals (the largest interval size in use: several hundred lines per piece) are shared by the four waves
     // of a block as described; the rest (a few dozen lines, ~10 steps) go one (interval, group) per wave -- no LDS, no barrier
@@ -953,6 +998,8 @@ __global__ __launch_bounds__(256) void k_cheb_nodes_mx(const double *__restrict_
         const int lr = lane & 15, lq = lane >> 4;
         const int kk = min(g * 16 + lr, K - 1);                       // (a group's tail states re-read the last one: never stored)
         const LineHot *__restrict__ hk = hot + (size_t)kk * L;
+        // this lane's state: the lines below S0k (left pieces) and from S1k on (right pieces) are beyond ITS 4-term radius
+        const int S0k = iz[(size_t)kk * nItot + T].S0, S1k = iz[(size_t)kk * nItot + T].S1;
         double vn[4];
 #pragma unroll
         for (int st = 0; st < 4; st++) vn[st] = nodes[(size_t)T * CS_NC + st * 16 + lr];
@@ -973,11 +1020,11 @@ __global__ __launch_bounds__(256) void k_cheb_nodes_mx(const double *__restrict_
             if (z.b[p] <= z.a[p]) continue;
             int ja, jb;
             if (asc) {
-                if (z.m[p] > z.a[p]) { quarter(z.a[p], z.m[p], true, ja, jb); sep_run<3, 0>(acc, vn, hk, ja, jb, true, lq, 0.0); }
-                if (z.b[p] > z.m[p]) { quarter(z.m[p], z.b[p], true, ja, jb); sep_run<4, 0>(acc, vn, hk, ja, jb, true, lq, 0.0); }
+                if (z.m[p] > z.a[p]) { quarter(z.a[p], z.m[p], true, ja, jb); sep_run<3, 0>(acc, vn, hk, ja, jb, true, lq, 0.0, 0.0, -0x7fffffff, S0k); }
+                if (z.b[p] > z.m[p]) { quarter(z.m[p], z.b[p], true, ja, jb); sep_run<4, 0>(acc, vn, hk, ja, jb, true, lq, 0.0, 0.0, -0x7fffffff, S0k); }
             } else {
-                if (z.b[p] > z.m[p]) { quarter(z.m[p], z.b[p], false, ja, jb); sep_run<3, 0>(acc, vn, hk, ja, jb, false, lq, 0.0); }
-                if (z.m[p] > z.a[p]) { quarter(z.a[p], z.m[p], false, ja, jb); sep_run<4, 0>(acc, vn, hk, ja, jb, false, lq, 0.0); }
+                if (z.b[p] > z.m[p]) { quarter(z.m[p], z.b[p], false, ja, jb); sep_run<3, 0>(acc, vn, hk, ja, jb, false, lq, 0.0, 0.0, S1k); }
+                if (z.m[p] > z.a[p]) { quarter(z.a[p], z.m[p], false, ja, jb); sep_run<4, 0>(acc, vn, hk, ja, jb, false, lq, 0.0, 0.0, S1k); }
             }
         }
         if (!split) {   // D[state 4r + lq][node 16 st + lr] straight into F

@@ -126,7 +126,10 @@ int cs_set_merge(cs_ctx *ctx, int on);
  *   key 7: the sub-tile cores (k_voigt_sub) and the near-line kernels run on a second side stream -- the former beside k_voigt_far,
  *          the latter beside k_voigt_edge_mx and what follows it -- adding into a plane of their own that k_rt reads together with
  *          sigma: 1 (default) on grids of 8192 .. 300000 (tile, state) waves, where it was measured to pay; 2 always; 0: on the
- *          main stream, into sigma.
+ *          main stream, into sigma;
+ *   key 8: a far line joins a state group's matrix-core node piece when at least this many of the group's 16 states are beyond their
+ *          own series radius (the others' coefficients are masked, the vector unit sums them) -- default 7; 16 = the group's widest
+ *          line decides (round 2), 1 = its narrowest.
  * Applies to every later cs_column_setup / cs_column_run of the context. */
 int cs_set_tuning(cs_ctx *ctx, int key, int value);
 
