@@ -2,6 +2,7 @@
 // Reference interfaces replaced are cited in the header; orchestration follows fluxes.jl:238-279 / :357-383.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -209,6 +210,7 @@ struct Column {
     std::vector<UserGas> ugas;   // the caller's gases (ngas of them)
     std::vector<ColGas> gas;     // launch groups
     int merge = 1;               // the context's cs_set_merge at setup time
+    uint64_t grid_id = 0;        // names this setup's nu grid (what the PHCO2 path keeps per grid: PhScratch)
     int launches = 0;            // kernel launches of the last cs_column_run
     bool near_live = false;      // the last cs_column_run left its near-line pairs in sigma2 (k_rt read both planes): cs_column_sigma_fetch folds them in
     hipStream_t last_stream = nullptr;   // the stream that run was enqueued on (cs_column_fetch waits for it, not for the whole device)
@@ -241,7 +243,18 @@ static void drop_graph(Column &c)
 
 // workspace of the PHCO2 fast path (k_phco2): per-(state, line) chi factors and per-tile region windows
 constexpr int CS_NTUNE = 12;
-struct PhScratch { DevBuf fac, win; double nu_lo = 0.0, nu_hi = 0.0, nu_c = 0.0; };   // nu_lo/nu_hi: ends of the grid, set by the caller
+// nu_lo .. grid_id: the grid of the call, set by the caller (ph_set_grid); cheb, piw, F: the interpolation levels of that grid for the
+// PHCO2 cut-off (k_phco2_nodes), rebuilt when the key (grid_id, nnu, cut) changes
+struct PhScratch {
+    DevBuf fac, win, piw, F, win3, zones3;   // win3, zones3: windows and zones of the Voigt pass over the pairs within 3 cm^-1
+    struct Dens { const void *tab; uint64_t gen, grid; bool ok; };
+    std::vector<Dens> dens;                  // check_near_density() per (table, grid), a few kept
+    double nu_lo = 0.0, nu_hi = 0.0, nu_c = 0.0, max_span = 0.0, margin = kChebMargin;
+    int itp_on = 0, itp_min = 128, itp_max = 2048, dbg = 0;
+    uint64_t grid_id = 0;
+    ChebGrid cheb;
+    uint64_t built_id = 0; int64_t built_nnu = 0; double built_cut = 0.0; int built_min = 0, built_max = 0;
+};
 
 // what cs_fluxes_discretized_multi keeps between calls (in its first context)
 struct MultiPlan { int nctx = 0; std::vector<double> nu, wt; std::vector<uint64_t> gens; std::vector<int64_t> ranges; };
@@ -273,6 +286,16 @@ struct cs_ctx {
     DevBuf hot32;
     DevBuf tmpA, tmpB, tmpC;
 };
+void ph_set_grid(const cs_ctx *ctx, PhScratch &ph, const double *nu, int64_t nnu, uint64_t grid_id)
+{
+    ph.nu_lo = nu[0]; ph.nu_hi = nu[nnu - 1];
+    ph.max_span = 0.0;
+    for (int64_t i0 = 0; i0 < nnu; i0 += 64) ph.max_span = std::max(ph.max_span, nu[std::min(i0 + 63, nnu - 1)] - nu[i0]);
+    ph.grid_id = grid_id;
+    ph.itp_on = ctx->interp; ph.itp_min = ctx->itp_min; ph.itp_max = ctx->itp_max;
+    ph.margin = ctx->tune[3] > 0 ? 0.01 * ctx->tune[3] : kChebMargin;
+    ph.dbg = ctx->tune[9];
+}
 
 namespace {
 
@@ -464,12 +487,17 @@ void tile_windows(const std::vector<double> &nul, int64_t g0, int64_t g1, const 
 // The far kernel hands k_voigt_near the near-line ranges of every (nu, node) as 20-bit offsets into the tile's near zone and
 // 12-bit counts.  Bound both for any state (widest Doppler width: upper end of the grid, TMAX, lightest isotopologue) and
 // refuse tables too dense for the fields -- 4096 lines within a few Doppler widths is ~1e5 lines per cm^-1, far beyond HITEMP.
+int check_near_density(const GasTable &G, double nu_hi, double span, double cut);
 int check_near_density(const GasTable &G, const double *nu, int64_t nnu, double cut)
 {
-    const double amax = ((nu[nnu - 1] + cut) / kC) * std::sqrt(2.0 * kRgas * kTmax / G.mu_min);
-    const double dA = 100.0 * amax / kSqLn2 * (1.0 + 1e-6), r0 = std::sqrt(kSerS) * amax / kSqLn2 * 1.01;
     double span = 0.0;
     for (int64_t i0 = 0; i0 < nnu; i0 += 64) span = std::max(span, nu[std::min<int64_t>(i0 + 63, nnu - 1)] - nu[i0]);
+    return check_near_density(G, nu[nnu - 1], span, cut);
+}
+int check_near_density(const GasTable &G, double nu_hi, double span, double cut)   // span: widest 64-point tile of the grid
+{
+    const double amax = ((nu_hi + cut) / kC) * std::sqrt(2.0 * kRgas * kTmax / G.mu_min);
+    const double dA = 100.0 * amax / kSqLn2 * (1.0 + 1e-6), r0 = std::sqrt(kSerS) * amax / kSqLn2 * 1.01;
     const std::vector<double> &v = G.h_nu;
     auto max_in = [&](double width) {
         int64_t best = 0;
@@ -587,22 +615,31 @@ struct Interp {
 };
 
 // interval sizes worth using on this grid: an interval of width W leaves lines over (2 cut - 2.3 W) to interpolate
-int choose_levels(const double *nu, int64_t nnu, double cut, int *itv, int szmin = 128, int szmax = 2048)
+int choose_levels(double nu_lo, double nu_hi, int64_t nnu, double cut, int *itv, int szmin = 128, int szmax = 2048)
 {
     int n = 0;
     if (nnu < 128) return 0;
-    const double dnu = (nu[nnu - 1] - nu[0]) / (double)(nnu - 1);
-    for (int sz = 2048; sz >= 128 && n < CS_MAX_LEVEL; sz >>= 1)
+    const double dnu = (nu_hi - nu_lo) / (double)(nnu - 1);
+    for (int sz = 8192; sz >= 128 && n < CS_MAX_LEVEL; sz >>= 1)
         if (sz <= szmax && sz >= szmin && 2.3 * sz * dnu <= 1.5 * cut && sz / 2 <= nnu &&
-            sz * dnu > 1e-8 * std::fabs(nu[nnu - 1]))   // (nodes 1e-3 of an interval apart must stay distinct doubles)
+            sz * dnu > 1e-8 * std::fabs(nu_hi))   // (nodes 1e-3 of an interval apart must stay distinct doubles)
             itv[n++] = sz;
     return n;
 }
+int choose_levels(const double *nu, int64_t nnu, double cut, int *itv, int szmin = 128, int szmax = 2048)
+{
+    return nnu < 1 ? 0 : choose_levels(nu[0], nu[nnu - 1], nnu, cut, itv, szmin, szmax);
+}
 
 // the grid part: nodes [nItot][64] and interpolation matrices [nI][64][itv] per level
+int cheb_build_range(ChebGrid &g, double nu_lo, double nu_hi, const double *dnu, int64_t nnu, double cut, int szmin, int szmax, hipStream_t s);
 int cheb_build(const cs_ctx *ctx, ChebGrid &g, const double *h_nu, const double *dnu, int64_t nnu, double cut, hipStream_t s)
 {
-    g.nlev = choose_levels(h_nu, nnu, cut, g.itv, ctx->itp_min, ctx->itp_max);
+    return cheb_build_range(g, h_nu[0], h_nu[nnu - 1], dnu, nnu, cut, ctx->itp_min, ctx->itp_max, s);
+}
+int cheb_build_range(ChebGrid &g, double nu_lo, double nu_hi, const double *dnu, int64_t nnu, double cut, int szmin, int szmax, hipStream_t s)
+{
+    g.nlev = choose_levels(nu_lo, nu_hi, nnu, cut, g.itv, szmin, szmax);
     g.nItot = 0;
     for (int l = 0; l < g.nlev; l++) {
         g.nI[l] = (int)((nnu + g.itv[l] - 1) / g.itv[l]);
@@ -735,10 +772,35 @@ bool phco2_fast_ok(const GasTable &G, int64_t nnu, double cut, int kn, PhScratch
     const double amax = ((ph->nu_hi + cut) / kC) * std::sqrt(2.0 * kRgas * kTmax / G.mu_min);
     if (100.0 * amax / kSqLn2 * (1.0 + 1e-6) > 2.9) return false;
     const int nt64 = (int)((nnu + 63) / 64);
-    if ((ph->nu_hi - ph->nu_lo) / (double)(nnu - 1) * 64.0 > 5.0) return false;   // (mean tile span; wider tiles are handled, just not faster)
+    if ((ph->nu_hi - ph->nu_lo) / (double)(nnu - 1) * 64.0 > 5.0) return false;   // (mean tile span: wider tiles would not be faster)
+    if (!(ph->max_span <= 27.0)) return false;   // k_phco2's boundary sets hold one region boundary each: no tile wider than 30 - 3 cm^-1
+    // the tabulated line factors exp(+-b_r (nul - nu_c)) must stay in range: b_r <= 0.0888
+    if (0.0888 * (0.5 * (ph->nu_hi - ph->nu_lo) + cut) > 600.0) return false;
     if (ph->fac.reserve((size_t)6 * kn * G.L * sizeof(double)) != hipSuccess) return false;
     if (ph->win.reserve((size_t)nt64 * sizeof(PhWin)) != hipSuccess) return false;
     ph->nu_c = 0.5 * (ph->nu_lo + ph->nu_hi);
+    return true;
+}
+// the grid of the coming launch_gas calls (host copy `nu`), and the context's interpolation settings
+static std::atomic<uint64_t> g_grid_counter{0};
+// interpolation levels of the PHCO2 far wings on that grid; false: none (k_phco2 sums every pair per point)
+bool ph_interp_ready(PhScratch *ph, const double *dnu, int64_t nnu, double cut, int kn, hipStream_t s)
+{
+    if (!ph->itp_on) return false;
+    if (!(ph->built_id == ph->grid_id && ph->built_nnu == nnu && ph->built_cut == cut && ph->built_min == ph->itp_min &&
+          ph->built_max == ph->itp_max)) {
+        ph->built_id = 0;
+        // (cs_set_interp_plan's upper limit of 2048 points is the Voigt path's largest size; left there, the wide PHCO2 window also takes 4096 and 8192)
+        if (cheb_build_range(ph->cheb, ph->nu_lo, ph->nu_hi, dnu, nnu, cut, ph->itp_min, ph->itp_max >= 2048 ? 8192 : ph->itp_max, s) != CS_OK) { ph->cheb.nlev = 0; return false; }
+        ph->built_id = ph->grid_id; ph->built_nnu = nnu; ph->built_cut = cut; ph->built_min = ph->itp_min; ph->built_max = ph->itp_max;
+    }
+    if (ph->cheb.nlev == 0) return false;
+    if (ph->piw.reserve((size_t)ph->cheb.nItot * sizeof(PhIWin)) != hipSuccess) return false;
+    const size_t fb = (size_t)ph->cheb.nItot * CS_NC * cheb_kpad(kn) * sizeof(double);
+    if (ph->F.bytes < fb) {
+        if (ph->F.reserve(fb) != hipSuccess) return false;
+        if (hipMemsetAsync(ph->F.p, 0, ph->F.bytes, s) != hipSuccess) return false;   // padding states stay finite
+    }
     return true;
 }
 
@@ -796,7 +858,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
                 const int32_t *J0, const int32_t *J1, const WaveWin *win, int xtiles, Zone *zones, int2 *ranges, const double *gbound, double cut, double base,
                 const double *extra, double *sigma, int accumulate, hipEvent_t *evg,   // NULL or 6 events: after K1 (+ zones), nodes (vector unit), nodes (matrix cores), far (vector unit), sub-tile cores, far (matrix cores)
                 LineF32 *hot32 = nullptr, double far_s = 1e6, Interp itp = Interp(), ChebApply *defer = nullptr, PhScratch *ph = nullptr,
-                Fork *fork = nullptr)
+                Fork *fork = nullptr, bool records_ready = false /* hot / cold already hold this gas at these states: zones and sums only */)
 {
     fork_join(fork, s);   // (an earlier group's node kernels may still read the records this launch overwrites)
     // only the lines some window can reach (windows are sorted: first tile's start .. last tile's end)
@@ -806,7 +868,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
     pa.Tk = Tk; pa.Pk = Pk; pa.Ppk = Ppk; pa.scale = scale; pa.mstride = mstride; pa.lrt = lrt; pa.qrefq = qrefq; pa.niso = G.niso; pa.hot = hot; pa.cold = cold; pa.hot32 = shape == SH_VOIGT ? hot32 : nullptr;
     pa.phfac = nullptr;
     pa.nu_c = 0.0;
-    const unsigned nb_prep = (unsigned)((jhi - jlo + 255) / 256) * (unsigned)((kn + CS_PREP_KC - 1) / CS_PREP_KC);   // (line block, chunk of states)
+    const unsigned nb_prep = records_ready ? 0u : (unsigned)((jhi - jlo + 255) / 256) * (unsigned)((kn + CS_PREP_KC - 1) / CS_PREP_KC);   // (line block, chunk of states)
     const bool lor = shape == SH_LORENTZ;   // lorentz! runs on the same far-wing machinery with its own (exact) body
     if (shape == SH_VOIGT || lor) {
         if (lor) hot32 = nullptr;           // (no fp32 variant of the Lorentz body)
@@ -1022,14 +1084,75 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
         IzParams P;
         memset(&P, 0, sizeof P);
         CS_LAUNCH(k_gas_setup, dim3(nb_prep + nb_zones), dim3(256), 0, s, nb_prep, nb_zones, pa, za, P, (IZone *)nullptr);
+        const bool use_itp = ph_interp_ready(ph, dnu, nnu, cut, kn, s);
+        const ChebGrid &cg = ph->cheb;
         PhArgs pw;
         pw.nu = dnu; pw.nul = G.nu.as<double>(); pw.nnu = nnu; pw.ntile = nt64; pw.J0 = (int32_t)jlo; pw.J1 = (int32_t)jhi; pw.cut = cut;
+        pw.tol = 1e-9 * (std::max(std::fabs(ph->nu_lo), std::fabs(ph->nu_hi)) + cut + 1.0);
         pw.out = ph->win.as<PhWin>();
-        CS_LAUNCH(k_phwin, dim3((unsigned)((nt64 + 255) / 256)), dim3(256), 0, s, pw);
-        if (evg) { (void)hipEventRecord(evg[0], s); (void)hipEventRecord(evg[1], s); (void)hipEventRecord(evg[2], s); }
+        PhIArgs ia;
+        memset(&ia, 0, sizeof ia);
+        if (use_itp) {
+            ia.nu = dnu; ia.nul = pw.nul; ia.nnu = nnu; ia.J0 = pw.J0; ia.J1 = pw.J1; ia.cut = cut; ia.tol = pw.tol; ia.margin = ph->margin;
+            ia.lv.nlev = cg.nlev; ia.lv.nItot = cg.nItot;
+            for (int l = 0; l < cg.nlev; l++) { ia.lv.itv[l] = cg.itv[l]; ia.lv.nI[l] = cg.nI[l]; ia.lv.ioff[l] = cg.ioff[l]; }
+            ia.out = ph->piw.as<PhIWin>();
+        }
+        // the pairs within 3 cm^-1 (chi = 1: plain Voigt, every near-line pair among them) through the Voigt kernels, where their
+        // near-line hand-off takes this table (check_near_density; else k_phco2's own core loop)
+        bool inner = false;
+        if (ranges && !(ph->dbg & 16)) {
+            const PhScratch::Dens *hit = nullptr;
+            for (auto &d : ph->dens) if (d.tab == (const void *)&G && d.gen == G.generation && d.grid == ph->grid_id) hit = &d;
+            if (!hit) {
+                if (ph->dens.size() >= 8) ph->dens.erase(ph->dens.begin());
+                ph->dens.push_back({(const void *)&G, G.generation, ph->grid_id, check_near_density(G, ph->nu_hi, ph->max_span, 3.0) == CS_OK});
+                hit = &ph->dens.back();
+            }
+            inner = hit->ok && ph->win3.reserve((size_t)(nt64 + 3) * sizeof(WaveWin)) == hipSuccess &&
+                    ph->zones3.reserve((size_t)kn * nt64 * sizeof(Zone)) == hipSuccess;
+        }
+        WwArgs wa;
+        memset(&wa, 0, sizeof wa);
+        if (inner) {
+            wa.nu = dnu; wa.nul = pw.nul; wa.nnu = nnu; wa.ntile = nt64; wa.J0 = pw.J0; wa.J1 = pw.J1; wa.cut = 3.0;
+            wa.sparse = (jhi - jlo) * 8 < nnu ? 1 : 0;
+            wa.out = ph->win3.as<WaveWin>();
+        }
+        const unsigned nb_tiles = (unsigned)((nt64 + 255) / 256), nb_itv = (unsigned)((ia.lv.nItot + 255) / 256);
+        CS_LAUNCH(k_phwin, dim3(nb_tiles + nb_itv + (inner ? nb_tiles : 0u)), dim3(256), 0, s, nb_tiles, nb_itv, pw, ia, wa);
+        if (evg) (void)hipEventRecord(evg[0], s);
+        const PhIWin *fine = nullptr;
+        int ishift = 0;
+        if (use_itp) {   // far wings of the region-uniform lines: node sums, carried to the grid (sigma = base + extra + them)
+            const int Kpad = cheb_kpad(kn);
+            CS_LAUNCH(k_phco2_nodes, dim3((unsigned)cg.nItot * (unsigned)((kn + 3) / 4)), dim3(256), 0, s, cg.nodes.as<double>(), G.L, hot,
+                      ph->fac.as<double>(), ph->nu_c, ph->piw.as<PhIWin>(), ia.lv, kn, Kpad, Tk, cut, gbound, G.mu_min, G.mu_max, far_s, ph->F.as<double>());
+            if (evg) (void)hipEventRecord(evg[1], s);
+            ChebApply A;
+            memset(&A, 0, sizeof A);
+            A.nlev = cg.nlev; A.ngas = 1; A.F[0] = ph->F.as<double>(); A.l0[0] = 0;
+            for (int l = 0; l < cg.nlev; l++) {
+                for (int r = cg.itv[l] / 64; r > 1; r >>= 1) A.shift[l]++;
+                A.ioff[l] = cg.ioff[l];
+                A.Cm[l] = cg.Cm[l].as<double>();
+            }
+            launch_apply(s, A, Kpad, nnu, kn, base, extra, sigma, accumulate);
+            accumulate = 1;
+            if (evg) (void)hipEventRecord(evg[2], s);
+            fine = ph->piw.as<PhIWin>() + cg.ioff[cg.nlev - 1];
+            ishift = A.shift[cg.nlev - 1];
+        } else if (evg) { (void)hipEventRecord(evg[1], s); (void)hipEventRecord(evg[2], s); }
         CS_LAUNCH(k_phco2, dim3((unsigned)((nt64 + 3) / 4), kn), dim3(256), 0, s, dnu, nnu, G.L, hot, cold, ph->fac.as<double>(), ph->nu_c,
-                           ph->win.as<PhWin>(), zones, nt64, cut, Tk, kn, base, extra, sigma, accumulate);
-        if (evg) { (void)hipEventRecord(evg[3], s); (void)hipEventRecord(evg[4], s); (void)hipEventRecord(evg[5], s); }
+                           ph->win.as<PhWin>(), zones, nt64, cut, Tk, kn, base, extra, sigma, accumulate, fine, ishift, inner ? 1 : 0, ph->dbg);
+        if (evg) (void)hipEventRecord(evg[3], s);
+        if (inner) {
+            const int nt4 = (nt64 + 3) / 4 * 4, per = ((nt4 / 4 + 7) / 8) * 4;   // (wave_windows' stretch length)
+            launch_gas(s, SH_VOIGT, G, jrange0, jrange1, kn, Tk, Pk, Ppk, scale, mstride, lrt, qrefq, hot, cold, dnu, nnu, ntile256, J0, J1,
+                       ph->win3.as<WaveWin>(), per, ph->zones3.as<Zone>(), ranges, gbound, 3.0, 0.0, nullptr, sigma, 1, nullptr, nullptr, far_s,
+                       Interp(), nullptr, nullptr, nullptr, true);
+        }
+        if (evg) { (void)hipEventRecord(evg[4], s); (void)hipEventRecord(evg[5], s); }
     } else {
         if (nb_prep > 0) {
             ZoneArgs za;
@@ -1331,7 +1454,7 @@ static int shape_impl(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t 
     GasTable &G = ctx->gas[slot];
     if ((rc = check_gas_states(G, K, T))) return rc;
     if (shape == SH_VOIGT && (rc = check_near_density(G, nu, nnu, dnu_cut))) return rc;
-    ctx->ph.nu_lo = nu[0]; ctx->ph.nu_hi = nu[nnu - 1];
+    ph_set_grid(ctx, ctx->ph, nu, nnu, ++g_grid_counter);
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     int64_t g0, g1, pairs, inr;
@@ -1422,7 +1545,7 @@ int cs_bake(cs_ctx *ctx, int gas_slot, int table_slot, int shape, double dnu_cut
     GasTable &G = ctx->gas[gas_slot];
     if ((rc = check_gas_states(G, M, Ts.data()))) return rc;
     if (shape == SH_VOIGT && (rc = check_near_density(G, nu, nnu, dnu_cut))) return rc;
-    ctx->ph.nu_lo = nu[0]; ctx->ph.nu_hi = nu[nnu - 1];
+    ph_set_grid(ctx, ctx->ph, nu, nnu, ++g_grid_counter);
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     TableDev &tb = ctx->tab[table_slot];
@@ -1912,6 +2035,7 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
     c.ugas.clear();
     c.ugas.resize(ngas);
     c.merge = ctx->merge;
+    c.grid_id = ++g_grid_counter;
     c.cheb.nlev = 0;
     if (ctx->interp) {   // interval sizes from the narrowest Voigt cut-off of the column
         double cmin = 0.0;
@@ -2128,7 +2252,7 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
         HIPCHK(dranges.reserve((size_t)kc * c.nnu * sizeof(int2) + (size_t)2 * kc * ((c.nnu + 63) / 64) * sizeof(int)));
         if (ctx->mixed) HIPCHK(ctx->hot32.reserve(((size_t)kc * maxL + 4) * sizeof(LineF32)));
     }
-    ctx->ph.nu_lo = c.h_nu.front(); ctx->ph.nu_hi = c.h_nu.back();
+    ph_set_grid(ctx, ctx->ph, c.h_nu.data(), c.nnu, c.grid_id);
     for (size_t qi = 0; qi < c.gas.size(); qi++) {
         ColGas &cg = c.gas[qi];
         const GasTable &G = *cg.tab;
@@ -2268,7 +2392,7 @@ static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e, bool *
     }
     ChebApply apply;
     apply.ngas = 0;
-    ctx->ph.nu_lo = c.h_nu.front(); ctx->ph.nu_hi = c.h_nu.back();
+    ph_set_grid(ctx, ctx->ph, c.h_nu.data(), c.nnu, c.grid_id);
     int n_itp = 0;
     for (auto &cg : c.gas) n_itp += cg.itp.nlev > 0 ? 1 : 0;
     // cs_set_tuning key 2: node sums on a side stream -- 1: where the grid is short (fewer than 16384 (tile, state) waves), 2: always

@@ -506,7 +506,7 @@ __device__ __forceinline__ int tile_block(const int32_t *__restrict__ xc, int ti
 // EVERY point of the interval qualify (the cut-off makes the others discontinuous in nu); lines nearer than
 // max(dA, 0.3 h) and the cut-off edges are left to the next smaller interval size, and finally to the per-point kernels.
 #define CS_NC 64
-#define CS_MAX_LEVEL 5
+#define CS_MAX_LEVEL 7   // (Voigt: 2048 .. 128 points, five sizes; PHCO2 with its 500 cm^-1 cut-off: from 8192)
 constexpr double kChebMargin = 0.3;   // default of ZoneArgs::margin
 // per (state, interval): own set = [E0,Z0) U [Z1,E1), cut into the 2-/3-/4-term zones of the far body; [P0,P1) and [P2,P3)
 // is the part of it the parent interval (next level up) has already summed.
@@ -1757,7 +1757,7 @@ struct PhWin {
     // generic sets: [L3,L2a), [L2,L1a), [L1,R1) (contains the chi = 1 core [C0,C1)), [R1b,R2), [R2b,R3)
     int32_t E0, E1;   // lines inside the cut-off of every lane (as WaveWin)
 };
-struct PhArgs { const double *nu, *nul; int64_t nnu; int ntile; int32_t J0, J1; double cut; PhWin *out; };
+struct PhArgs { const double *nu, *nul; int64_t nnu; int ntile; int32_t J0, J1; double cut, tol; PhWin *out; };   // tol: one value per grid (phi_tol)
 __device__ __forceinline__ void phwin_body(unsigned bid, const PhArgs &a)
 {
     const int t = bid * blockDim.x + threadIdx.x;
@@ -1765,7 +1765,8 @@ __device__ __forceinline__ void phwin_body(unsigned bid, const PhArgs &a)
     const int64_t i0 = (int64_t)t * 64, i1 = (i0 + 63 < a.nnu ? i0 + 63 : a.nnu - 1);
     const double vlo = a.nu[i0], vhi = a.nu[i1];
     const double *__restrict__ nul = a.nul;
-    const double tol = 1e-9 * (fabs(vhi) + a.cut + 1.0);   // boundary lines go to the generic sets (chi is continuous across them)
+    const double tol = a.tol;   // boundary lines go to the generic sets (chi is continuous across them); ONE value for the whole grid, so that
+                                // the sets of a tile, of its interval and of that one's parents are nested exactly (phiwin_body)
     auto lower = [&](double val) { int lo = a.J0, hi = a.J1; while (lo < hi) { const int m = (lo + hi) >> 1; if (nul[m] < val) lo = m + 1; else hi = m; } return lo; };
     PhWin w;
     w.W0 = lower(vlo - a.cut - tol);
@@ -1792,7 +1793,78 @@ __device__ __forceinline__ void phwin_body(unsigned bid, const PhArgs &a)
     a.out[t] = w;
 }
 
-__global__ __launch_bounds__(256) void k_phwin(PhArgs a) { phwin_body(blockIdx.x, a); }
+// ---- PHCO2 far wings by interpolation ------------------------------------------------------------------------------------------
+// Inside one chi-region and on one side, a far line's term A K(x, chi y) with chi = exp(a_r -+ b_r (nu - nul)) is analytic in nu, so
+// the sums over the lines that are region-uniform for a whole INTERVAL of the grid go through the Chebyshev machinery of the Voigt
+// path (k_cheb_setup's nodes and matrices, k_cheb_apply_mfma): 64 node evaluations instead of 128 .. 2048 point evaluations per
+// line.  What keeps a line out of an interval's set is state-independent here: a region boundary (3, 30, 120 cm^-1 or the
+// cut-off) crossing the interval, or the line being nearer than max(3 cm^-1, margin x half-width).  Per interval and (region,
+// side) -- s = 0..5 in line order: r3 left, r2 left, r1 left, r1 right, r2 right, r3 right -- the uniform range [a[s], b[s]).
+// The ranges of an interval contain those of its parent (next size up) and are contained in those of its tiles (PhWin): a level
+// sums its ranges minus its parent's, and k_phco2 the tile's minus the smallest interval's.
+struct PhIWin { int32_t a[6], b[6]; };
+struct PhLevels { int nlev, nItot; int itv[CS_MAX_LEVEL], nI[CS_MAX_LEVEL], ioff[CS_MAX_LEVEL]; };
+struct PhIArgs { const double *nu, *nul; int64_t nnu; int32_t J0, J1; double cut, tol, margin; PhLevels lv; PhIWin *out; };
+__device__ __forceinline__ void phiwin_body(unsigned bid, const PhIArgs &A)
+{
+    const int q = bid * blockDim.x + threadIdx.x;
+    if (q >= A.lv.nItot) return;
+    int l = 0;
+    while (l + 1 < A.lv.nlev && q >= A.lv.ioff[l + 1]) l++;
+    const int T = q - A.lv.ioff[l], itv = A.lv.itv[l];
+    const int64_t i0 = (int64_t)T * itv, i1 = (i0 + itv - 1 < A.nnu ? i0 + itv - 1 : A.nnu - 1);
+    const double vlo = A.nu[i0], vhi = A.nu[i1];
+    const double dZ = A.margin * 0.5 * (vhi - vlo), tol = A.tol, cut = A.cut;
+    const double d1 = fmax(3.0, dZ), d2 = fmax(30.0, dZ), d3 = fmax(120.0, dZ);
+    // lower bounds (first line with nul >= value), twelve searches side by side; every value is monotone in vlo, vhi and dZ with the
+    // same tol as the tiles' (phwin_body), which is what nests the ranges
+    const double sv[12] = {vhi - cut + tol, vlo - d3 - tol, vhi - 120.0 + tol, vlo - d2 - tol, vhi - 30.0 + tol, vlo - d1 - tol,
+                           vhi + d1 + tol, vlo + 30.0 - tol, vhi + d2 + tol, vlo + 120.0 - tol, vhi + d3 + tol, vlo + cut - tol};
+    int lo[12], hi[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) { lo[i] = A.J0; hi[i] = A.J1; }
+    search_many<12>(A.nul, sv, 0u, lo, hi);
+    PhIWin w;
+#pragma unroll
+    for (int s = 0; s < 6; s++) { w.a[s] = lo[2 * s]; w.b[s] = max(lo[2 * s + 1], lo[2 * s]); }
+    // r3 left starts inside the cut-off of every point, r3 right ends there; sets in line order never overlap
+#pragma unroll
+    for (int s = 1; s < 6; s++) { w.a[s] = max(w.a[s], w.b[s - 1]); w.b[s] = max(w.b[s], w.a[s]); }
+    A.out[q] = w;
+}
+// Within 3 cm^-1 of a line chi = 1: PHCO2 is the Voigt profile there, and those pairs -- every near-line pair among them -- go
+// through the Voigt kernels with a 3 cm^-1 cut-off (k_voigt_far, k_voigt_near) after k_phco2 has summed the pairs beyond.  Their
+// per-tile windows (WaveWin as wave_windows() builds them on the host) for that cut-off, XCD stretch table behind them:
+struct WwArgs { const double *nu, *nul; int64_t nnu; int ntile; int32_t J0, J1; double cut; int sparse; WaveWin *out; };
+__device__ __forceinline__ void wavewin_body(unsigned bid, const WwArgs &a)
+{
+    const int t = bid * blockDim.x + threadIdx.x;
+    if (t >= a.ntile) return;
+    const int64_t i0 = (int64_t)t * 64, i1 = (i0 + 63 < a.nnu ? i0 + 63 : a.nnu - 1);
+    const double vlo = a.nu[i0], vhi = a.nu[i1], cut = a.cut;
+    const double tol = 1e-9 * (fabs(vhi) + cut + 1.0);
+    const double sv[4] = {vlo - cut - tol, vhi - cut + tol, vhi + cut + tol, vlo + cut - tol};
+    int lo[4] = {a.J0, a.J0, a.J0, a.J0}, hi[4] = {a.J1, a.J1, a.J1, a.J1};
+    search_many<4>(a.nul, sv, 0xcu, lo, hi);
+    WaveWin w;
+    w.W0 = lo[0]; w.W1 = max(lo[2], lo[0]);
+    w.E0 = min(max(lo[1], w.W0), w.W1);
+    w.E1 = min(max(lo[3], w.E0), w.W1);
+    a.out[t] = w;
+    if (t == 0) {   // tile_block()'s table: eight stretches of `per` tiles, or plain order for a table sparse against the grid
+        int32_t *xc = reinterpret_cast<int32_t *>(a.out + a.ntile);
+        const int nt4 = (a.ntile + 3) / 4 * 4, per = ((nt4 / 4 + 7) / 8) * 4;
+        for (int x = 0; x <= 8; x++) xc[x] = min(x * per, nt4);
+        for (int x = 9; x < 12; x++) xc[x] = 0;
+        if (a.sparse) xc[0] = -1;
+    }
+}
+__global__ __launch_bounds__(256) void k_phwin(unsigned nb_tiles, unsigned nb_itv, PhArgs a, PhIArgs ia, WwArgs wa)
+{
+    if (blockIdx.x < nb_tiles) phwin_body(blockIdx.x, a);
+    else if (blockIdx.x < nb_tiles + nb_itv) phiwin_body(blockIdx.x - nb_tiles, ia);
+    else wavewin_body(blockIdx.x - nb_tiles - nb_itv, wa);
+}
 
 // far-wing term with a per-lane Lorentz-width factor chi: y -> chi y.  FOUR: 4-term series (s >= 1e4), else 2-term + y-dependent u^2
 // terms (exact wherever k_zones' Q bounds put a line, which it derived for the unscaled, i.e. larger, y)
@@ -1829,12 +1901,116 @@ __device__ __forceinline__ double ph_segment(double acc, double v, double glane,
     return acc;
 }
 
+template <bool PRED, bool FOUR>
+__device__ __forceinline__ double ph_segment_rev(double acc, double v, double glane, const LineHot *__restrict__ hk, const double *__restrict__ fk,
+                                                 int j0, int j1, double cut, const FarK &c)
+{
+#pragma unroll 4
+    for (int j = j1 - 1; j >= j0; j--) acc += ph_term<PRED, FOUR>(hk[j], glane * fk[j], v, cut, c);
+    return acc;
+}
+// chi = exp(a_r - b_r |dnu|) on [3,30), [30,120), [120, cut] (line_shapes.jl:467-481): a_r, b_r for r = 1..3
+struct PhCoef { double a[3], b[3]; };
+__device__ __forceinline__ PhCoef ph_coef(double T)
+{
+    PhCoef p;
+    const double B1 = 0.0888 - 0.16 * exp(-0.0041 * T), B2 = 0.0526 * exp(-0.00152 * T), B3 = 0.0232;
+    p.b[0] = B1; p.b[1] = B2; p.b[2] = B3;
+    p.a[0] = 3.0 * B1; p.a[1] = -27.0 * B1 + 30.0 * B2; p.a[2] = -27.0 * B1 - 90.0 * B2 + 120.0 * B3;
+    return p;
+}
+
+// one wave = the 64 nodes of one interval x one state: F[interval][node][state] = sum over the interval's own ranges (its
+// region-uniform ranges minus its parent's), every line with the 4-term far body (all of them are >= 3 cm^-1 >= 100 Doppler
+// widths away: phco2_fast_ok) and chi = (node factor) x (tabulated line factor).  Both sides are summed towards the interval.
+__global__ __launch_bounds__(256) void k_phco2_nodes(const double *__restrict__ nodes, int64_t L, const LineHot *__restrict__ hot,
+                                                      const double *__restrict__ phfac, double nu_c, const PhIWin *__restrict__ piw,
+                                                      PhLevels lv, int K, int Kpad, const double *__restrict__ Tk, double cut,
+                                                      const double *__restrict__ gbound, double mu_min, double mu_max, double far_s,
+                                                      double *__restrict__ F)
+{
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int nsb = (K + 3) >> 2;
+    const int T = (int)(blockIdx.x / nsb);
+    const int k = (int)((blockIdx.x % nsb + T) % nsb) * 4 + wv;   // (rotated: see k_cheb_nodes)
+    if (k >= K) return;
+    int l = 0;
+    while (l + 1 < lv.nlev && T >= lv.ioff[l + 1]) l++;
+    const PhIWin w = piw[T];
+    PhIWin p = w;
+    const bool par = l > 0;
+    if (par) {
+        int pshift = 0;
+        for (int r = lv.itv[l - 1] / lv.itv[l]; r > 1; r >>= 1) pshift++;
+        p = piw[lv.ioff[l - 1] + ((T - lv.ioff[l]) >> pshift)];
+    }
+    const LineHot *__restrict__ hk = hot + (size_t)k * L;
+    const size_t KL = (size_t)K * L;
+    const double v = nodes[(size_t)T * CS_NC + lane];
+    const FarK c = load_fark();
+    const PhCoef pc = ph_coef(Tk[k]);
+    const double dc = v - nu_c;
+    // the two-term body does for a region whose every line has s >= max(cbrt(1.5e16 y^2), far_s) -- the bound behind Zone::Q0, Q1
+    // (zones_body), with the widest Doppler width of the window for x and the narrowest for y (chi <= 1 only shrinks y)
+    bool two[3];
+    {
+        const double vhi = nodes[(size_t)T * CS_NC], vlo = nodes[(size_t)T * CS_NC + CS_NC - 1];   // nodes run from the upper end down
+        const double vth = sqrt(2.0 * kRgas * Tk[k]);
+        const double amax = ((vhi + cut) / kC) * vth / sqrt(mu_min);
+        const double vmin = w.b[5] > w.a[0] ? fmax(vlo - cut, hk[w.a[0]].nul) : vlo - cut;   // (the lowest line any range holds)
+        double need = 1e300;
+        if (vmin > 0.0) {
+            const double amin = (vmin / kC) * vth / sqrt(mu_max), yb = gbound[k] * kSqLn2 / amin;
+            need = fmax(cbrt(1.5e16 * yb * yb), far_s) * (1.0 + 1e-6);
+        }
+        const double D[3] = {3.0, 30.0, 120.0};
+#pragma unroll
+        for (int r = 0; r < 3; r++) { const double x = D[r] * kSqLn2 / amax; two[r] = x * x >= need; }
+    }
+    double accL = 0.0, accR = 0.0;
+#pragma unroll
+    for (int s = 0; s < 3; s++) {   // left of the interval: r = 3, 2, 1, ascending lines
+        const int r = 2 - s;
+        const double *__restrict__ f = phfac + (size_t)r * KL + (size_t)k * L;   // exp(+b_r (nul - nu_c))
+        const double g = exp(pc.a[r] - pc.b[r] * dc);
+        const int lo = w.a[s], hi = w.b[s];
+        const int pa = par ? min(max(p.a[s], lo), hi) : hi, pb = par ? min(max(p.b[s], pa), hi) : hi;
+        if (two[r]) {
+            accL = ph_segment<false, false>(accL, v, g, hk, f, lo, pa, cut, c);
+            accL = ph_segment<false, false>(accL, v, g, hk, f, pb, hi, cut, c);
+        } else {
+            accL = ph_segment<false, true>(accL, v, g, hk, f, lo, pa, cut, c);
+            accL = ph_segment<false, true>(accL, v, g, hk, f, pb, hi, cut, c);
+        }
+    }
+#pragma unroll
+    for (int s = 5; s >= 3; s--) {  // right of it: r = 3, 2, 1, descending lines
+        const int r = s - 3;
+        const double *__restrict__ f = phfac + (size_t)(3 + r) * KL + (size_t)k * L;   // exp(-b_r (nul - nu_c))
+        const double g = exp(pc.a[r] + pc.b[r] * dc);
+        const int lo = w.a[s], hi = w.b[s];
+        const int pa = par ? min(max(p.a[s], lo), hi) : hi, pb = par ? min(max(p.b[s], pa), hi) : hi;
+        if (two[r]) {
+            accR = ph_segment_rev<false, false>(accR, v, g, hk, f, pb, hi, cut, c);
+            accR = ph_segment_rev<false, false>(accR, v, g, hk, f, lo, pa, cut, c);
+        } else {
+            accR = ph_segment_rev<false, true>(accR, v, g, hk, f, pb, hi, cut, c);
+            accR = ph_segment_rev<false, true>(accR, v, g, hk, f, lo, pa, cut, c);
+        }
+    }
+    F[((size_t)T * CS_NC + lane) * Kpad + k] = accL + accR;
+}
+
 __global__ __launch_bounds__(256) void k_phco2(const double *__restrict__ nu, int64_t nnu, int64_t L, const LineHot *__restrict__ hot,
                                                const LineCold *__restrict__ cold, const double *__restrict__ phfac, double nu_c,
                                                const PhWin *__restrict__ pw, const Zone *__restrict__ zones, int ntile, double cut,
                                                const double *__restrict__ Tk, int K, double base, const double *__restrict__ extra,
-                                               double *__restrict__ sigma, int accumulate)
+                                               double *__restrict__ sigma, int accumulate, const PhIWin *__restrict__ fine, int ishift, int inner_voigt,
+                                               int dbg)
 {
+    // inner_voigt: the pairs within 3 cm^-1 (chi = 1) are left to the Voigt kernels that follow with that cut-off (wavewin_body)
+    // fine != NULL: the region-uniform ranges of the tile's interval (tile >> ishift at the smallest interval size) are in sigma
+    // already, carried there from the node sums of k_phco2_nodes -- the tile's uniform sets shrink to what lies outside them
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int tile = (int)blockIdx.x * 4 + wv;
     if (tile >= ntile) return;
@@ -1847,70 +2023,99 @@ __global__ __launch_bounds__(256) void k_phco2(const double *__restrict__ nu, in
     const PhWin w = pw[tile];
     const Zone z = zones[(size_t)k * ntile + tile];
     const FarK c = load_fark();
-    const double T = Tk[k];
-    const double B1 = 0.0888 - 0.16 * exp(-0.0041 * T), B2 = 0.0526 * exp(-0.00152 * T), B3 = 0.0232;
-    // chi in region r: exp(a_r - b_r dnu) with a_1 = 3 B1, a_2 = -27 B1 + 30 B2, a_3 = -27 B1 - 90 B2 + 120 B3 (line_shapes.jl:467-481)
-    const double a1 = 3.0 * B1, a2 = -27.0 * B1 + 30.0 * B2, a3 = -27.0 * B1 - 90.0 * B2 + 120.0 * B3;
+    const PhCoef pc = ph_coef(Tk[k]);
     const double dc = v - nu_c;
+    // per-lane factors of chi, left (line below the point) and right, r = 1..3
+    double gL[3], gR[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) { gL[r] = exp(pc.a[r] - pc.b[r] * dc); gR[r] = exp(pc.a[r] + pc.b[r] * dc); }
+    const double *__restrict__ fL[3] = {phfac + 0 * KL + (size_t)k * L, phfac + 1 * KL + (size_t)k * L, phfac + 2 * KL + (size_t)k * L};
+    const double *__restrict__ fR[3] = {phfac + 3 * KL + (size_t)k * L, phfac + 4 * KL + (size_t)k * L, phfac + 5 * KL + (size_t)k * L};
+    PhIWin x;   // what the intervals took (empty ranges at the sets' upper ends: nothing)
+    if (fine) x = fine[tile >> ishift];
+    const int slo[6] = {w.W0, w.L2a, w.L1a, w.R1, w.R2, w.R3}, shi[6] = {w.L3, w.L2, w.L1, w.R1b, w.R2b, w.W1};
     double acc = 0.0;
     // uniform sets: region r, side; inside [Q0,Q1) (k_zones) the 4-term series, outside the 2-/3-term body; cut-off edges with the
     // predicate (they sit in region 3: the launcher only takes this kernel for cut-offs beyond 130 cm^-1)
-    {
-        const double *f = phfac + 2 * KL + (size_t)k * L;   // exp(+B3 (nul - nu_c)), left side
-        const double g = exp(a3 - B3 * dc);
-        const int e = min(max(w.E0, w.W0), w.L3), q = min(max(z.Q0, e), w.L3);
-        acc = ph_segment<true, false>(acc, v, g, hk, f, w.W0, e, cut, c);
-        acc = ph_segment<false, false>(acc, v, g, hk, f, e, q, cut, c);
-        acc = ph_segment<false, true>(acc, v, g, hk, f, q, w.L3, cut, c);
+#pragma unroll
+    for (int s = 0; s < 6; s++) {
+        if (dbg & 1) break;
+        const bool left = s < 3;
+        const int r = left ? 2 - s : s - 3;
+        const double *__restrict__ f = left ? fL[r] : fR[r];
+        const double g = left ? gL[r] : gR[r];
+        const int lo = slo[s], hi = shi[s];
+        const int xa = fine ? min(max(x.a[s], lo), hi) : hi, xb = fine ? min(max(x.b[s], xa), hi) : hi;
+        for (int piece = 0; piece < 2; piece++) {
+            const int p0 = piece ? xb : lo, p1 = piece ? hi : xa;
+            if (p0 >= p1) continue;
+#define LO(x) max((x), p0)
+#define HI(x) min((x), p1)
+            if (left) {
+                // [lo, e) cut-off edge (r = 3 only) | [e, q) far | [q, hi) 4-term
+                const int e = s == 0 ? min(max(w.E0, lo), hi) : lo, q = min(max(z.Q0, e), hi);
+                if (s == 0) acc = ph_segment<true, false>(acc, v, g, hk, f, LO(lo), HI(e), cut, c);
+                acc = ph_segment<false, false>(acc, v, g, hk, f, LO(e), HI(q), cut, c);
+                acc = ph_segment<false, true>(acc, v, g, hk, f, LO(q), HI(hi), cut, c);
+            } else {
+                const int e = s == 5 ? max(min(w.E1, hi), lo) : hi, q = min(max(z.Q1, lo), e);
+                acc = ph_segment<false, true>(acc, v, g, hk, f, LO(lo), HI(q), cut, c);
+                acc = ph_segment<false, false>(acc, v, g, hk, f, LO(q), HI(e), cut, c);
+                if (s == 5) acc = ph_segment<true, false>(acc, v, g, hk, f, LO(e), HI(hi), cut, c);
+            }
+#undef LO
+#undef HI
+        }
     }
-    {
-        const double *f = phfac + 1 * KL + (size_t)k * L;
-        const double g = exp(a2 - B2 * dc);
-        const int q = min(max(z.Q0, w.L2a), w.L2);
-        acc = ph_segment<false, false>(acc, v, g, hk, f, w.L2a, q, cut, c);
-        acc = ph_segment<false, true>(acc, v, g, hk, f, q, w.L2, cut, c);
-    }
-    {
-        const double *f = phfac + 0 * KL + (size_t)k * L;
-        const double g = exp(a1 - B1 * dc);
-        const int q = min(max(z.Q0, w.L1a), w.L1);
-        acc = ph_segment<false, false>(acc, v, g, hk, f, w.L1a, q, cut, c);
-        acc = ph_segment<false, true>(acc, v, g, hk, f, q, w.L1, cut, c);
-    }
-    {
-        const double *f = phfac + 3 * KL + (size_t)k * L;   // exp(-B1 (nul - nu_c)), right side
-        const double g = exp(a1 + B1 * dc);
-        const int q = min(max(z.Q1, w.R1), w.R1b);
-        acc = ph_segment<false, true>(acc, v, g, hk, f, w.R1, q, cut, c);
-        acc = ph_segment<false, false>(acc, v, g, hk, f, q, w.R1b, cut, c);
-    }
-    {
-        const double *f = phfac + 4 * KL + (size_t)k * L;
-        const double g = exp(a2 + B2 * dc);
-        const int q = min(max(z.Q1, w.R2), w.R2b);
-        acc = ph_segment<false, true>(acc, v, g, hk, f, w.R2, q, cut, c);
-        acc = ph_segment<false, false>(acc, v, g, hk, f, q, w.R2b, cut, c);
-    }
-    {
-        const double *f = phfac + 5 * KL + (size_t)k * L;
-        const double g = exp(a3 + B3 * dc);
-        const int e = max(min(w.E1, w.W1), w.R3), q = min(max(z.Q1, w.R3), e);
-        acc = ph_segment<false, true>(acc, v, g, hk, f, w.R3, q, cut, c);
-        acc = ph_segment<false, false>(acc, v, g, hk, f, q, e, cut, c);
-        acc = ph_segment<true, false>(acc, v, g, hk, f, e, w.W1, cut, c);
-    }
-    // generic sets: per-lane chi and the full Faddeeva (line_shapes.jl:496-499)
-    const int gl[5] = {w.L3, w.L2, w.L1, w.R1b, w.R2b}, gh[5] = {w.L2a, w.L1a, w.R1, w.R2, w.R3};
-    for (int r = 0; r < 5; r++)
-        for (int j = gl[r]; j < gh[r]; j++) {
-            const LineHot h = hk[j];
-            const double dv = v - h.nul;
-            if (!(fabs(dv) > cut)) {
-                const LineCold cc = ck[j];
-                const double chi = chi_phco2(fabs(dv), B1, B2);
-                acc = __builtin_fma(cc.A, fad_re(dv * h.p1, chi * cc.y), acc);
+    // boundary sets: a region boundary D = 120 or 30 cm^-1 crosses the tile -- the lane picks the side's factorised chi of its own
+    // region; all of these lines are far (4-term body)
+    if (!(dbg & 2)) {
+        const int bl[4] = {w.L3, w.L2, w.R1b, w.R2b}, bh[4] = {w.L2a, w.L1a, w.R2, w.R3};
+        const double D[4] = {120.0, 30.0, 30.0, 120.0};
+        const int rn[4] = {1, 0, 0, 1};   // region (0-based) on the near side of the boundary; the far side is rn + 1
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const bool left = b < 2;
+            const double gn = left ? gL[rn[b]] : gR[rn[b]], gf = left ? gL[rn[b] + 1] : gR[rn[b] + 1];
+            const double *__restrict__ fn = left ? fL[rn[b]] : fR[rn[b]], *__restrict__ ff = left ? fL[rn[b] + 1] : fR[rn[b] + 1];
+#pragma unroll 2
+            for (int j = bl[b]; j < bh[b]; j++) {
+                const LineHot h = hk[j];
+                const double chi = fabs(v - h.nul) < D[b] ? gn * fn[j] : gf * ff[j];
+                acc += ph_term<true, true>(h, chi, v, cut, c);
             }
         }
+    }
+    // core [L1, R1): lines within 3 cm^-1 of some lane -- chi = 1 there, region 1 beyond; the full Faddeeva (line_shapes.jl:496-499)
+    // only for the lines that have a lane inside s < 1e4 (wave-uniform test), the 4-term body for the others
+    if (inner_voigt) {
+        // [L1, C0) and [C1, R1): lines with lanes on both sides of 3 cm^-1 -- the lanes beyond it here ([C0, C1): every lane inside)
+        // (the side is the lane's own: on a tile wider than 3 cm^-1 such a line can lie inside it)
+        for (int half = 0; half < 2; half++) {
+            const int j0 = half ? max(w.C1, w.C0) : w.L1, j1 = half ? w.R1 : w.C0;
+#pragma unroll 2
+            for (int j = (dbg & 4) ? j1 : j0; j < j1; j++) {
+                const LineHot h = hk[j];
+                const double dv = v - h.nul;
+                const double t = ph_term<false, true>(h, dv > 0.0 ? gL[0] * fL[0][j] : gR[0] * fR[0][j], v, cut, c);
+                acc += fabs(dv) > 3.0 ? t : 0.0;
+            }
+        }
+    } else
+    for (int j = (dbg & 4) ? w.R1 : w.L1; j < w.R1; j++) {
+        const LineHot h = hk[j];
+        const double dv = v - h.nul;
+        const double chi = fabs(dv) < 3.0 ? 1.0 : (dv > 0.0 ? gL[0] * fL[0][j] : gR[0] * fR[0][j]);
+        const double xx = dv * h.p1;
+        const bool nearl = __builtin_fma(xx, xx, (h.p2 * chi) * chi) < 1.0e4;
+        if (!(dbg & 8) && __builtin_amdgcn_ballot_w64(nearl) != 0ull) {
+            const LineCold cc = ck[j];
+            const double t = cc.A * fad_re(xx, chi * cc.y);
+            acc += (fabs(dv) > cut) ? 0.0 : t;
+        } else {
+            acc += ph_term<true, true>(h, chi, v, cut, c);
+        }
+    }
     if (i < nnu) {
         const size_t o = (size_t)k * nnu + i;
         const double prev = accumulate ? sigma[o] : (base + (extra ? extra[o] : 0.0));

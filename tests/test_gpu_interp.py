@@ -248,6 +248,48 @@ def test_phco2_fast_path(cs, O, lines, ctx_on):
     assert relerr(col.sigma_nodes(), r["sigma"], floor=1e-300) < 2e-11
 
 
+def test_phco2_interpolated_wings(cs, O, lines, ctx_on, ctx_off):
+    """PHCO2 far wings through the Chebyshev machinery (k_phco2_nodes): inside one chi-region and on one side of a line the term is
+    analytic in nu, so the lines that are region-uniform for a whole interval of 128 .. 2048 points are summed at its 64 nodes
+    (own ranges minus the parent's) and carried to the grid; k_phco2 keeps the tile's sets minus the smallest interval's, the
+    boundary sets (two-way chi select) and the core (Faddeeva only next to a line).  Same cross-sections as with every pair summed
+    per point (5e-13: different summation orders) and as the oracle (2e-11), on a dense table and the sparse fixture, on grids that
+    end inside an interval, for interval size ranges that leave one or five levels, and in a column."""
+    dense = cs.SpectralLines.synthetic(2, 8000, 91, numin=200.0, numax=1400.0)
+    T, P, Pp = map(list, zip(*STATES))
+    for sl, lo, hi, n in ((dense, 640.0, 800.0, 6401), (dense, 655.0, 700.0, 3119), (lines("CO2"), 2200.0, 2420.0, 7001)):
+        nu = np.linspace(lo, hi, n)
+        a = cs.shape_batch(sl, "PHCO2", nu, T, P, Pp, 500.0, ctx_on)
+        b = cs.shape_batch(sl, "PHCO2", nu, T, P, Pp, 500.0, ctx_off)
+        assert np.array_equal(a == 0, b == 0)
+        assert relerr(a, b, floor=1e-250) < 5e-13
+        for k in (1, 3):
+            so = O.shape_bang("PHCO2", nu, sl, T[k], P[k], Pp[k], 500.0)
+            assert relerr(a[k], so, floor=1e-250) < 2e-11
+    nu = np.linspace(640.0, 800.0, 6401)
+    ref = cs.shape_batch(dense, "PHCO2", nu, T[:2], P[:2], Pp[:2], 500.0, ctx_off)
+    for smin, smax in ((128, 128), (2048, 2048), (256, 1024)):
+        c = cs.Context(0)
+        c.set_interp_plan(size_min=smin, size_max=smax)
+        a = cs.shape_batch(dense, "PHCO2", nu, T[:2], P[:2], Pp[:2], 500.0, c)
+        c.close()
+        assert relerr(a, ref, floor=1e-250) < 5e-13
+    # a column: two PHCO2 gases on the same grid (the levels are built once per column setup) beside a Voigt gas
+    Pl = cs.pressuregrid(10.0, 1e5, 9)
+    Tl = np.linspace(210.0, 290.0, 9)
+    res = []
+    for ctx in (ctx_on, ctx_off):
+        g1 = cs.DirectGas(dense, 0.3, nu, shape="PHCO2")
+        g2 = cs.DirectGas(lines("CO2"), 0.2, nu, shape="PHCO2")
+        g3 = cs.DirectGas(lines("H2O"), 1e-3, nu)
+        col = cs.Column(Pl, 9.8, Tl, 0.04, 0.0, 0.0, g3, g1, g2, core=cs.Discretized(5, 2), ctx=ctx)
+        col.run()
+        col.run()
+        res.append((col.sigma_nodes(), col.fetch()))
+    assert relerr(res[0][0], res[1][0], floor=1e-300) < 5e-13
+    assert abs(res[0][1][0][0] - res[1][1][0][0]) < 1e-12 * res[1][1][0][0]
+
+
 def test_matrix_core_node_sums_on_off(cs, O, lines):
     """K2d, K2e, K2f: far lines inside the validity range of the 4-term series in 1/dnu^2 are summed as matrix products on
     v_mfma_f64_16x16x4 -- at the interpolation nodes (k_cheb_nodes_mx) and, for the window ends of the per-point sum with the
