@@ -250,10 +250,17 @@ struct PhScratch {
     struct Dens { const void *tab; uint64_t gen, grid; bool ok; };
     std::vector<Dens> dens;                  // check_near_density() per (table, grid), a few kept
     double nu_lo = 0.0, nu_hi = 0.0, nu_c = 0.0, max_span = 0.0, margin = kChebMargin;
-    int itp_on = 0, itp_min = 128, itp_max = 2048, dbg = 0;
+    int itp_on = 0, itp_min = 128, itp_max = 2048, own_core = 0;   // own_core: cs_set_tuning key 9
     uint64_t grid_id = 0;
-    ChebGrid cheb;
-    uint64_t built_id = 0; int64_t built_nnu = 0; double built_cut = 0.0; int built_min = 0, built_max = 0;
+    double lev_span[8] = {};   // widest interval of 8192 >> i points on this grid (ph_set_grid)
+    int force64 = 0;           // cs_set_tuning key 10: 64 nodes for every interval (bit 0), tiles as 64-point intervals too (bit 1)
+    // interval sizes in use (descending) and the virtual levels on them (PhVLevels); nodes [sum nI x nc], Cm[v] [nI][nc][itv]
+    struct Grid {
+        PhLevels lv; PhVLevels vl; PhFine fine;
+        int nnodes = 0, nslots = 0;
+        DevBuf nodes, Cm[CS_MAX_ALEVEL];
+    } grid;
+    uint64_t built_id = 0; int64_t built_nnu = 0; double built_cut = 0.0, built_margin = 0.0; int built_min = 0, built_max = 0, built_force = 0;
 };
 
 // what cs_fluxes_discretized_multi keeps between calls (in its first context)
@@ -294,7 +301,14 @@ void ph_set_grid(const cs_ctx *ctx, PhScratch &ph, const double *nu, int64_t nnu
     ph.grid_id = grid_id;
     ph.itp_on = ctx->interp; ph.itp_min = ctx->itp_min; ph.itp_max = ctx->itp_max;
     ph.margin = ctx->tune[3] > 0 ? 0.01 * ctx->tune[3] : kChebMargin;
-    ph.dbg = ctx->tune[9];
+    ph.own_core = ctx->tune[9];
+    ph.force64 = ctx->tune[10];
+    for (int i = 0; i < 8; i++) {
+        const int64_t sz = 8192 >> i;
+        double w = 0.0;
+        for (int64_t i0 = 0; i0 < nnu; i0 += sz) w = std::max(w, nu[std::min(i0 + sz - 1, nnu - 1)] - nu[i0]);
+        ph.lev_span[i] = w;
+    }
 }
 
 namespace {
@@ -650,7 +664,7 @@ int cheb_build_range(ChebGrid &g, double nu_lo, double nu_hi, const double *dnu,
     HIPCHK(g.nodes.reserve((size_t)g.nItot * CS_NC * sizeof(double)));
     for (int l = 0; l < g.nlev; l++) {
         HIPCHK(g.Cm[l].reserve((size_t)g.nI[l] * CS_NC * g.itv[l] * sizeof(double)));
-        CS_LAUNCH(k_cheb_setup, dim3(g.nI[l]), dim3(256), 0, s, dnu, nnu, g.itv[l], g.nI[l],
+        CS_LAUNCH(k_cheb_setup, dim3(g.nI[l]), dim3(256), 0, s, dnu, nnu, g.itv[l], g.nI[l], CS_NC,
                            g.nodes.as<double>() + (size_t)g.ioff[l] * CS_NC, g.Cm[l].as<double>());
         HIPCHK(hipGetLastError());
     }
@@ -735,7 +749,7 @@ Interp interp_view(const ChebGrid &g, const GasInterp &gi, int K, IZone *iz_over
 }
 
 void launch_apply(hipStream_t s, const ChebApply &A, int Kpad, int64_t nnu, int kn, double base, const double *extra, double *sigma,
-                  int accumulate)
+                  int accumulate, bool varnc = false)
 {
     const int nt64 = (int)((nnu + 63) / 64);
 #ifdef CS_APPLY_VALU   // the vector-unit version (kept for A/B builds)
@@ -755,12 +769,15 @@ void launch_apply(hipStream_t s, const ChebApply &A, int Kpad, int64_t nnu, int 
 #ifndef CS_APPLY_NSUB
 #define CS_APPLY_NSUB 2
 #endif
-    if ((int64_t)nt64 * ((nst + CS_APPLY_NSUB - 1) / CS_APPLY_NSUB) >= 2048)   // enough (tile, state chunk) waves to fill 1024 SIMDs twice
-        CS_LAUNCH(k_cheb_apply_mfma<CS_APPLY_NSUB>, dim3(tb8 * (unsigned)((nst + CS_APPLY_NSUB - 1) / CS_APPLY_NSUB)), dim3(256), 0, s, A, Kpad, nnu, nt64, kn, base,
-                           extra, sigma, accumulate);
-    else
-        CS_LAUNCH(k_cheb_apply_mfma<1>, dim3(tb8 * (unsigned)nst), dim3(256), 0, s, A, Kpad, nnu, nt64, kn, base, extra, sigma,
-                           accumulate);
+    const bool big = (int64_t)nt64 * ((nst + CS_APPLY_NSUB - 1) / CS_APPLY_NSUB) >= 2048;   // enough (tile, state chunk) waves to fill 1024 SIMDs twice
+    const dim3 gridb(tb8 * (unsigned)((nst + CS_APPLY_NSUB - 1) / CS_APPLY_NSUB)), grids(tb8 * (unsigned)nst);
+    if (varnc) {
+        if (big) CS_LAUNCH((k_cheb_apply_mfma<CS_APPLY_NSUB, true>), gridb, dim3(256), 0, s, A, Kpad, nnu, nt64, kn, base, extra, sigma, accumulate);
+        else CS_LAUNCH((k_cheb_apply_mfma<1, true>), grids, dim3(256), 0, s, A, Kpad, nnu, nt64, kn, base, extra, sigma, accumulate);
+    } else {
+        if (big) CS_LAUNCH((k_cheb_apply_mfma<CS_APPLY_NSUB, false>), gridb, dim3(256), 0, s, A, Kpad, nnu, nt64, kn, base, extra, sigma, accumulate);
+        else CS_LAUNCH((k_cheb_apply_mfma<1, false>), grids, dim3(256), 0, s, A, Kpad, nnu, nt64, kn, base, extra, sigma, accumulate);
+    }
 #endif
 }
 
@@ -784,19 +801,114 @@ bool phco2_fast_ok(const GasTable &G, int64_t nnu, double cut, int kn, PhScratch
 // the grid of the coming launch_gas calls (host copy `nu`), and the context's interpolation settings
 static std::atomic<uint64_t> g_grid_counter{0};
 // interpolation levels of the PHCO2 far wings on that grid; false: none (k_phco2 sums every pair per point)
+static int ph_plan(PhScratch *ph, int64_t nnu, double cut)
+{
+    PhScratch::Grid &g = ph->grid;
+    memset(&g.lv, 0, sizeof g.lv);
+    memset(&g.vl, 0, sizeof g.vl);
+    for (int r = 0; r < 3; r++) { g.fine.off[r] = -1; g.fine.shift[r] = 0; }
+    g.nnodes = g.nslots = 0;
+    if (nnu < 128) return 0;
+    const double dnu = (ph->nu_hi - ph->nu_lo) / (double)(nnu - 1);
+    // (cs_set_interp_plan's limits of 128 and 2048 points are the Voigt path's; left there, the wide PHCO2 window also takes 4096 and
+    //  8192 points; key 10 bit 1: also the tiles themselves as 64-point intervals with 16 or 32 nodes -- measured a tie at C3 size: 1.2 ms
+    //  more in k_phco2_nodes, whose smallest waves are a chain of short batches, for 1.3 ms less in k_phco2)
+    const int szmax = ph->itp_max >= 2048 ? 8192 : ph->itp_max, szmin = (ph->itp_min <= 128 && (ph->force64 & 2)) ? 64 : ph->itp_min;
+    const double Dn[3] = {3.0, 30.0, 120.0}, Df[3] = {30.0, 120.0, cut};
+    int need[8][3];   // per size and region: node count, 0 = not carried
+    int nreal = 0, real_of[8];
+    for (int i = 0; i < 8; i++) {
+        const int sz = 8192 >> i;
+        real_of[i] = -1;
+        if (!(sz <= szmax && sz >= szmin && 2.3 * sz * dnu <= 1.5 * cut && sz / 2 <= nnu && sz * dnu > 1e-8 * std::fabs(ph->nu_hi))) continue;
+        const double span = ph->lev_span[i], h = 0.5 * span;
+        bool any = false;
+        for (int r = 0; r < 3; r++) {
+            const double dn = std::max(Dn[r], ph->margin * h);
+            need[i][r] = 0;
+            if (!(Df[r] - dn - sz * dnu >= 0.05 * (Df[r] - Dn[r]))) continue;   // (next to) nothing to hold at this size
+            const double x0 = 1.0 + std::max(Dn[r] / h, ph->margin), lr = std::log10(x0 + std::sqrt(x0 * x0 - 1.0));
+            need[i][r] = (ph->force64 & 1) ? 64 : (15.0 * lr >= 18.0 ? 16 : (31.0 * lr >= 18.0 ? 32 : 64));
+            any = true;
+        }
+        if (!any) continue;
+        real_of[i] = nreal;
+        g.lv.itv[nreal] = sz;
+        g.lv.nI[nreal] = (int)((nnu + sz - 1) / sz);
+        g.lv.ioff[nreal] = g.lv.nItot;
+        g.lv.nItot += g.lv.nI[nreal];
+        nreal++;
+    }
+    g.lv.nlev = nreal;
+    if (nreal == 0) return 0;
+    // virtual levels; more than CS_MAX_ALEVEL of them: the regions of a size join its larger node count
+    for (;;) {
+        int nv = 0;
+        for (int i = 0; i < 8; i++) {
+            if (real_of[i] < 0) continue;
+            for (int nc = 64; nc >= 16; nc >>= 1) {
+                int mask = 0;
+                for (int r = 0; r < 3; r++) if (need[i][r] == nc) mask |= 1 << r;
+                if (mask) nv++;
+            }
+        }
+        if (nv <= CS_MAX_ALEVEL) break;
+        bool changed = false;
+        for (int i = 7; i >= 0 && !changed; i--)
+            for (int r = 0; r < 3 && !changed; r++)
+                if (real_of[i] >= 0 && need[i][r] > 0 && need[i][r] < 64) { need[i][r] *= 2; changed = true; }
+        if (!changed) break;
+    }
+    int nv = 0, last[3] = {-1, -1, -1};   // last[r]: the size above that carries region r
+    for (int i = 0; i < 8; i++) {
+        if (real_of[i] < 0) continue;
+        for (int nc = 64; nc >= 16; nc >>= 1) {
+            int mask = 0;
+            for (int r = 0; r < 3; r++) if (need[i][r] == nc) mask |= 1 << r;
+            if (!mask || nv >= CS_MAX_ALEVEL) continue;
+            g.vl.rl[nv] = real_of[i]; g.vl.nc[nv] = nc; g.vl.rmask[nv] = mask;
+            g.vl.noff[nv] = g.nnodes; g.vl.boff[nv] = g.nslots;
+            for (int r = 0; r < 3; r++) g.vl.par[nv][r] = last[r];
+            g.nnodes += g.lv.nI[real_of[i]] * nc;
+            g.nslots += g.lv.nI[real_of[i]];
+            nv++;
+        }
+        for (int r = 0; r < 3; r++)
+            if (need[i][r] > 0) {
+                last[r] = real_of[i];
+                g.fine.off[r] = g.lv.ioff[real_of[i]];
+                g.fine.shift[r] = 0;
+                for (int x = (8192 >> i) / 64; x > 1; x >>= 1) g.fine.shift[r]++;
+            }
+    }
+    g.vl.nv = nv;
+    g.vl.boff[nv] = g.nslots;
+    return nv;
+}
 bool ph_interp_ready(PhScratch *ph, const double *dnu, int64_t nnu, double cut, int kn, hipStream_t s)
 {
     if (!ph->itp_on) return false;
+    PhScratch::Grid &g = ph->grid;
     if (!(ph->built_id == ph->grid_id && ph->built_nnu == nnu && ph->built_cut == cut && ph->built_min == ph->itp_min &&
-          ph->built_max == ph->itp_max)) {
+          ph->built_max == ph->itp_max && ph->built_margin == ph->margin && ph->built_force == ph->force64)) {
         ph->built_id = 0;
-        // (cs_set_interp_plan's upper limit of 2048 points is the Voigt path's largest size; left there, the wide PHCO2 window also takes 4096 and 8192)
-        if (cheb_build_range(ph->cheb, ph->nu_lo, ph->nu_hi, dnu, nnu, cut, ph->itp_min, ph->itp_max >= 2048 ? 8192 : ph->itp_max, s) != CS_OK) { ph->cheb.nlev = 0; return false; }
+        const int nv = ph_plan(ph, nnu, cut);
+        if (nv > 0) {
+            if (g.nodes.reserve((size_t)g.nnodes * sizeof(double)) != hipSuccess) return false;
+            for (int v = 0; v < nv; v++) {
+                const int rl = g.vl.rl[v], nc = g.vl.nc[v];
+                if (g.Cm[v].reserve((size_t)g.lv.nI[rl] * nc * g.lv.itv[rl] * sizeof(double)) != hipSuccess) return false;
+                CS_LAUNCH(k_cheb_setup, dim3(g.lv.nI[rl]), dim3(256), 0, s, dnu, nnu, g.lv.itv[rl], g.lv.nI[rl], nc,
+                          g.nodes.as<double>() + g.vl.noff[v], g.Cm[v].as<double>());
+            }
+            if (hipGetLastError() != hipSuccess) return false;
+        }
         ph->built_id = ph->grid_id; ph->built_nnu = nnu; ph->built_cut = cut; ph->built_min = ph->itp_min; ph->built_max = ph->itp_max;
+        ph->built_margin = ph->margin; ph->built_force = ph->force64;
     }
-    if (ph->cheb.nlev == 0) return false;
-    if (ph->piw.reserve((size_t)ph->cheb.nItot * sizeof(PhIWin)) != hipSuccess) return false;
-    const size_t fb = (size_t)ph->cheb.nItot * CS_NC * cheb_kpad(kn) * sizeof(double);
+    if (g.vl.nv == 0) return false;
+    if (ph->piw.reserve((size_t)g.lv.nItot * sizeof(PhIWin)) != hipSuccess) return false;
+    const size_t fb = (size_t)g.nnodes * cheb_kpad(kn) * sizeof(double);
     if (ph->F.bytes < fb) {
         if (ph->F.reserve(fb) != hipSuccess) return false;
         if (hipMemsetAsync(ph->F.p, 0, ph->F.bytes, s) != hipSuccess) return false;   // padding states stay finite
@@ -964,6 +1076,8 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
                 A.shift[l] = 0;
                 for (int r = itp.itv[l] / 64; r > 1; r >>= 1) A.shift[l]++;
                 A.ioff[l] = itp.ioff[l];
+                A.nc[l] = CS_NC;
+                A.noff[l] = itp.ioff[l] * CS_NC;
                 A.Cm[l] = itp.Cm[l];
             }
             fuse = defer && itp.fuse_apply && use_edge && defer->ngas == 0;   // (then k_voigt_edge_mx below carries this group's node sums to the grid)
@@ -1085,7 +1199,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
         memset(&P, 0, sizeof P);
         CS_LAUNCH(k_gas_setup, dim3(nb_prep + nb_zones), dim3(256), 0, s, nb_prep, nb_zones, pa, za, P, (IZone *)nullptr);
         const bool use_itp = ph_interp_ready(ph, dnu, nnu, cut, kn, s);
-        const ChebGrid &cg = ph->cheb;
+        const PhScratch::Grid &pg = ph->grid;
         PhArgs pw;
         pw.nu = dnu; pw.nul = G.nu.as<double>(); pw.nnu = nnu; pw.ntile = nt64; pw.J0 = (int32_t)jlo; pw.J1 = (int32_t)jhi; pw.cut = cut;
         pw.tol = 1e-9 * (std::max(std::fabs(ph->nu_lo), std::fabs(ph->nu_hi)) + cut + 1.0);
@@ -1094,14 +1208,13 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
         memset(&ia, 0, sizeof ia);
         if (use_itp) {
             ia.nu = dnu; ia.nul = pw.nul; ia.nnu = nnu; ia.J0 = pw.J0; ia.J1 = pw.J1; ia.cut = cut; ia.tol = pw.tol; ia.margin = ph->margin;
-            ia.lv.nlev = cg.nlev; ia.lv.nItot = cg.nItot;
-            for (int l = 0; l < cg.nlev; l++) { ia.lv.itv[l] = cg.itv[l]; ia.lv.nI[l] = cg.nI[l]; ia.lv.ioff[l] = cg.ioff[l]; }
+            ia.lv = pg.lv;
             ia.out = ph->piw.as<PhIWin>();
         }
         // the pairs within 3 cm^-1 (chi = 1: plain Voigt, every near-line pair among them) through the Voigt kernels, where their
         // near-line hand-off takes this table (check_near_density; else k_phco2's own core loop)
         bool inner = false;
-        if (ranges && !(ph->dbg & 16)) {
+        if (ranges && !ph->own_core) {
             const PhScratch::Dens *hit = nullptr;
             for (auto &d : ph->dens) if (d.tab == (const void *)&G && d.gen == G.generation && d.grid == ph->grid_id) hit = &d;
             if (!hit) {
@@ -1122,29 +1235,33 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
         const unsigned nb_tiles = (unsigned)((nt64 + 255) / 256), nb_itv = (unsigned)((ia.lv.nItot + 255) / 256);
         CS_LAUNCH(k_phwin, dim3(nb_tiles + nb_itv + (inner ? nb_tiles : 0u)), dim3(256), 0, s, nb_tiles, nb_itv, pw, ia, wa);
         if (evg) (void)hipEventRecord(evg[0], s);
-        const PhIWin *fine = nullptr;
-        int ishift = 0;
+        const PhIWin *piw = nullptr;
+        PhFine fine;
+        memset(&fine, 0, sizeof fine);
         if (use_itp) {   // far wings of the region-uniform lines: node sums, carried to the grid (sigma = base + extra + them)
             const int Kpad = cheb_kpad(kn);
-            CS_LAUNCH(k_phco2_nodes, dim3((unsigned)cg.nItot * (unsigned)((kn + 3) / 4)), dim3(256), 0, s, cg.nodes.as<double>(), G.L, hot,
-                      ph->fac.as<double>(), ph->nu_c, ph->piw.as<PhIWin>(), ia.lv, kn, Kpad, Tk, cut, gbound, G.mu_min, G.mu_max, far_s, ph->F.as<double>());
+            CS_LAUNCH(k_phco2_nodes, dim3((unsigned)pg.nslots * (unsigned)((kn + 3) / 4)), dim3(256), 0, s, pg.nodes.as<double>(), G.L, hot,
+                      ph->fac.as<double>(), ph->nu_c, ph->piw.as<PhIWin>(), pg.lv, pg.vl, kn, Kpad, Tk, cut, gbound, G.mu_min, G.mu_max, far_s,
+                      ph->F.as<double>());
             if (evg) (void)hipEventRecord(evg[1], s);
             ChebApply A;
             memset(&A, 0, sizeof A);
-            A.nlev = cg.nlev; A.ngas = 1; A.F[0] = ph->F.as<double>(); A.l0[0] = 0;
-            for (int l = 0; l < cg.nlev; l++) {
-                for (int r = cg.itv[l] / 64; r > 1; r >>= 1) A.shift[l]++;
-                A.ioff[l] = cg.ioff[l];
-                A.Cm[l] = cg.Cm[l].as<double>();
+            A.nlev = pg.vl.nv; A.ngas = 1; A.F[0] = ph->F.as<double>(); A.l0[0] = 0;
+            for (int v = 0; v < pg.vl.nv; v++) {
+                for (int r = pg.lv.itv[pg.vl.rl[v]] / 64; r > 1; r >>= 1) A.shift[v]++;
+                A.ioff[v] = pg.vl.boff[v];
+                A.nc[v] = pg.vl.nc[v];
+                A.noff[v] = pg.vl.noff[v];
+                A.Cm[v] = pg.Cm[v].as<double>();
             }
-            launch_apply(s, A, Kpad, nnu, kn, base, extra, sigma, accumulate);
+            launch_apply(s, A, Kpad, nnu, kn, base, extra, sigma, accumulate, true);
             accumulate = 1;
             if (evg) (void)hipEventRecord(evg[2], s);
-            fine = ph->piw.as<PhIWin>() + cg.ioff[cg.nlev - 1];
-            ishift = A.shift[cg.nlev - 1];
+            piw = ph->piw.as<PhIWin>();
+            fine = pg.fine;
         } else if (evg) { (void)hipEventRecord(evg[1], s); (void)hipEventRecord(evg[2], s); }
         CS_LAUNCH(k_phco2, dim3((unsigned)((nt64 + 3) / 4), kn), dim3(256), 0, s, dnu, nnu, G.L, hot, cold, ph->fac.as<double>(), ph->nu_c,
-                           ph->win.as<PhWin>(), zones, nt64, cut, Tk, kn, base, extra, sigma, accumulate, fine, ishift, inner ? 1 : 0, ph->dbg);
+                           ph->win.as<PhWin>(), zones, nt64, cut, Tk, kn, base, extra, sigma, accumulate, piw, fine, inner ? 1 : 0);
         if (evg) (void)hipEventRecord(evg[3], s);
         if (inner) {
             const int nt4 = (nt64 + 3) / 4 * 4, per = ((nt4 / 4 + 7) / 8) * 4;   // (wave_windows' stretch length)
@@ -2252,7 +2369,8 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
         HIPCHK(dranges.reserve((size_t)kc * c.nnu * sizeof(int2) + (size_t)2 * kc * ((c.nnu + 63) / 64) * sizeof(int)));
         if (ctx->mixed) HIPCHK(ctx->hot32.reserve(((size_t)kc * maxL + 4) * sizeof(LineF32)));
     }
-    ph_set_grid(ctx, ctx->ph, c.h_nu.data(), c.nnu, c.grid_id);
+    for (auto &cg : c.gas)
+        if (cg.shape == SH_PHCO2) { ph_set_grid(ctx, ctx->ph, c.h_nu.data(), c.nnu, c.grid_id); break; }
     for (size_t qi = 0; qi < c.gas.size(); qi++) {
         ColGas &cg = c.gas[qi];
         const GasTable &G = *cg.tab;
@@ -2392,7 +2510,8 @@ static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e, bool *
     }
     ChebApply apply;
     apply.ngas = 0;
-    ph_set_grid(ctx, ctx->ph, c.h_nu.data(), c.nnu, c.grid_id);
+    for (auto &cg : c.gas)
+        if (cg.shape == SH_PHCO2) { ph_set_grid(ctx, ctx->ph, c.h_nu.data(), c.nnu, c.grid_id); break; }
     int n_itp = 0;
     for (auto &cg : c.gas) n_itp += cg.itp.nlev > 0 ? 1 : 0;
     // cs_set_tuning key 2: node sums on a side stream -- 1: where the grid is short (fewer than 16384 (tile, state) waves), 2: always

@@ -506,7 +506,8 @@ __device__ __forceinline__ int tile_block(const int32_t *__restrict__ xc, int ti
 // EVERY point of the interval qualify (the cut-off makes the others discontinuous in nu); lines nearer than
 // max(dA, 0.3 h) and the cut-off edges are left to the next smaller interval size, and finally to the per-point kernels.
 #define CS_NC 64
-#define CS_MAX_LEVEL 7   // (Voigt: 2048 .. 128 points, five sizes; PHCO2 with its 500 cm^-1 cut-off: from 8192)
+#define CS_MAX_LEVEL 5
+#define CS_MAX_ALEVEL 16  // levels one apply launch can carry (PHCO2 with its 500 cm^-1 cut-off: 8192 .. 64 points, some sizes with two node counts)
 constexpr double kChebMargin = 0.3;   // default of ZoneArgs::margin
 // per (state, interval): own set = [E0,Z0) U [Z1,E1), cut into the 2-/3-/4-term zones of the far body; [P0,P1) and [P2,P3)
 // is the part of it the parent interval (next level up) has already summed.
@@ -517,7 +518,9 @@ constexpr double kChebMargin = 0.3;   // default of ZoneArgs::margin
 struct __attribute__((aligned(16))) IZone { int32_t E0, Q0, M0, Z0, Z1, M1, Q1, E1, P0, P1, P2, P3, S0, S1, pad0, pad1; };
 
 // nodes[T][m] = centre + h cos(pi m/63) and C[T][m][i] = l_m(nu_i): Lagrange basis of the extrema, barycentric form
-__global__ __launch_bounds__(256) void k_cheb_setup(const double *__restrict__ nu, int64_t nnu, int itv, int nI,
+// nc <= CS_NC nodes per interval (64 everywhere on the Voigt path; 16 or 32 where the lines of a set are many half-widths away:
+// k_phco2_nodes)
+__global__ __launch_bounds__(256) void k_cheb_setup(const double *__restrict__ nu, int64_t nnu, int itv, int nI, int nc,
                                                      double *__restrict__ nodes, double *__restrict__ Cm)
 {
     const int T = blockIdx.x;
@@ -525,19 +528,19 @@ __global__ __launch_bounds__(256) void k_cheb_setup(const double *__restrict__ n
     const double vlo = nu[i0], vhi = nu[i1];
     const double cen = 0.5 * (vlo + vhi), h = 0.5 * (vhi - vlo);
     __shared__ double xm[CS_NC], wm[CS_NC];
-    if (threadIdx.x < CS_NC) {
-        const double x = cen + h * cos(kPi * threadIdx.x / (CS_NC - 1));
+    if ((int)threadIdx.x < nc) {
+        const double x = cen + h * cos(kPi * threadIdx.x / (nc - 1));
         xm[threadIdx.x] = x;
-        nodes[(size_t)T * CS_NC + threadIdx.x] = x;
+        nodes[(size_t)T * nc + threadIdx.x] = x;
     }
     __syncthreads();
     // barycentric weights of the nodes AS ROUNDED: w_m = 1 / prod_{j != m} (x_m - x_j).  The closed form (-1)^m {1/2,1,..,1,1/2}
     // belongs to the exact extrema; nodes near nu ~ 1e3 are rounded by ~1e-13 / h of the interval, and the mismatch shows up
     // as a 1e-13..1e-12 error of the interpolant (tools/cheb_proto.py).  Differences of nodes are exact in fp64.
-    if (threadIdx.x < CS_NC) {
+    if ((int)threadIdx.x < nc) {
         double prod = 1.0;
         const double x = xm[threadIdx.x], ih = h > 0.0 ? 1.0 / h : 1.0;
-        for (int j = 0; j < CS_NC; j++)
+        for (int j = 0; j < nc; j++)
             if (j != threadIdx.x) prod *= 2.0 * (x - xm[j]) * ih;   // factor 2: keeps the product near 1e2 instead of 1e-17
         wm[threadIdx.x] = 1.0 / prod;
     }
@@ -547,15 +550,15 @@ __global__ __launch_bounds__(256) void k_cheb_setup(const double *__restrict__ n
         const double v = nu[i < nnu ? i : nnu - 1];
         double den = 0.0;
         int hit = -1;
-        for (int m = 0; m < CS_NC; m++) {
+        for (int m = 0; m < nc; m++) {
             const double d = v - xm[m];
             if (d == 0.0) hit = m;
             den += (d == 0.0) ? 0.0 : wm[m] / d;
         }
-        for (int m = 0; m < CS_NC; m++) {
+        for (int m = 0; m < nc; m++) {
             const double d = v - xm[m];
-            const double c = (hit >= 0) ? (m == hit ? 1.0 : 0.0) : (wm[m] / d) / den;   // (one-point interval: all nodes coincide, hit = 63)
-            Cm[((size_t)T * CS_NC + m) * itv + p] = c;
+            const double c = (hit >= 0) ? (m == hit ? 1.0 : 0.0) : (wm[m] / d) / den;   // (one-point interval: all nodes coincide, hit = the last)
+            Cm[((size_t)T * nc + m) * itv + p] = c;
         }
     }
 }
@@ -1056,9 +1059,11 @@ __global__ __launch_bounds__(256) void k_cheb_nodes_mx(const double *__restrict_
 // wave-uniform scalar operands.
 struct ChebApply {
     int nlev, ngas;
-    int shift[CS_MAX_LEVEL];   // log2(interval size / 64)
-    int ioff[CS_MAX_LEVEL];    // offset of the level in the concatenated interval list
-    const double *Cm[CS_MAX_LEVEL];
+    int shift[CS_MAX_ALEVEL];   // log2(interval size / 64)
+    int ioff[CS_MAX_ALEVEL];    // offset of the level in the concatenated interval list
+    int nc[CS_MAX_ALEVEL];      // nodes per interval of the level (CS_NC on the Voigt path)
+    int noff[CS_MAX_ALEVEL];    // offset of the level's first node in F (ioff x CS_NC there)
+    const double *Cm[CS_MAX_ALEVEL];
     const double *F[16];       // node sums of up to CS_MAX_GAS gases: C is read once for all of them
     int l0[16];                // first level each gas uses
 };
@@ -1083,10 +1088,11 @@ __global__ __launch_bounds__(256) void k_cheb_apply(ChebApply A, int Kpad, int64
             const int sh = A.shift[l];
             const int T = tile >> sh, sub = tile & ((1 << sh) - 1);
             const size_t itv = (size_t)64 << sh;
-            const double *__restrict__ Cp = A.Cm[l] + (size_t)T * CS_NC * itv + (size_t)sub * 64 + lane;
-            const double *__restrict__ Fp = Fg + (size_t)(A.ioff[l] + T) * CS_NC * Kpad + k0;
+            const int nc = A.nc[l];
+            const double *__restrict__ Cp = A.Cm[l] + (size_t)T * nc * itv + (size_t)sub * 64 + lane;
+            const double *__restrict__ Fp = Fg + ((size_t)A.noff[l] + (size_t)T * nc) * Kpad + k0;
 #pragma unroll 4   // (2 is 10 % faster on the bench workload but 20-40 % slower on nu-shards and on five levels x four gases)
-            for (int m = 0; m < CS_NC; m++) {
+            for (int m = 0; m < nc; m++) {
                 const double cv = Cp[(size_t)m * itv];
                 const double *__restrict__ fr = Fp + (size_t)m * Kpad;
 #pragma unroll
@@ -1127,10 +1133,11 @@ __global__ __launch_bounds__(256) void k_cheb_apply_split(ChebApply A, int Kpad,
             const int sh = A.shift[l];
             const int T = tile >> sh, sub = tile & ((1 << sh) - 1);
             const size_t itv = (size_t)64 << sh;
-            const double *__restrict__ Cp = A.Cm[l] + (size_t)T * CS_NC * itv + (size_t)sub * 64 + lane;
-            const double *__restrict__ Fp = Fg + (size_t)(A.ioff[l] + T) * CS_NC * Kpad + k0;
+            const int nc = A.nc[l], nq = nc >> 2;   // (a quarter of the level's nodes per wave)
+            const double *__restrict__ Cp = A.Cm[l] + (size_t)T * nc * itv + (size_t)sub * 64 + lane;
+            const double *__restrict__ Fp = Fg + ((size_t)A.noff[l] + (size_t)T * nc) * Kpad + k0;
 #pragma unroll 4
-            for (int m = 16 * wv; m < 16 * wv + 16; m++) {
+            for (int m = nq * wv; m < nq * wv + nq; m++) {
                 const double cv = Cp[(size_t)m * itv];
                 const double *__restrict__ fr = Fp + (size_t)m * Kpad;
 #pragma unroll
@@ -1165,7 +1172,7 @@ __global__ __launch_bounds__(256) void k_cheb_apply_split(ChebApply A, int Kpad,
 // version is (64 dependent FMA steps per (level, gas), one scalar F stream per 16 states).  NSUB = 4 for full grids, 1 for small
 // ones (a nu-shard), where 4x more, 4x shorter waves fill the chip.
 typedef double v4f64 __attribute__((ext_vector_type(4)));
-template <int NSUB>
+template <int NSUB, bool VARNC = false>   // VARNC: node counts per level from A.nc (k_phco2_nodes' levels); else CS_NC everywhere
 __global__ __launch_bounds__(256, NSUB >= 4 ? 2 : 4) void k_cheb_apply_mfma(ChebApply A, int Kpad, int64_t nnu, int ntile, int K, double base,
                                                           const double *__restrict__ extra, double *__restrict__ sigma, int accumulate)
 {
@@ -1190,10 +1197,11 @@ __global__ __launch_bounds__(256, NSUB >= 4 ? 2 : 4) void k_cheb_apply_mfma(Cheb
             const int sh = A.shift[l];
             const int T = tile >> sh, sub = tile & ((1 << sh) - 1);
             const size_t itv = (size_t)64 << sh;
-            const double *__restrict__ Cp = A.Cm[l] + ((size_t)T * CS_NC + lq) * itv + (size_t)sub * 64 + lr;          // node lq, point lr
-            const double *__restrict__ Fp = Fg + ((size_t)(A.ioff[l] + T) * CS_NC + lq) * Kpad + (size_t)s0 * 16 + lr;  // node lq, state lr
+            const int nc = VARNC ? A.nc[l] : CS_NC;
+            const double *__restrict__ Cp = A.Cm[l] + ((size_t)T * nc + lq) * itv + (size_t)sub * 64 + lr;                         // node lq, point lr
+            const double *__restrict__ Fp = Fg + ((size_t)A.noff[l] + (size_t)T * nc + lq) * Kpad + (size_t)s0 * 16 + lr;        // node lq, state lr
 #pragma unroll 2
-            for (int m = 0; m < CS_NC; m += 4) {
+            for (int m = 0; m < nc; m += 4) {
                 double b[4], a[NSUB];
 #pragma unroll
                 for (int jt = 0; jt < 4; jt++) b[jt] = Cp[(size_t)m * itv + jt * 16];
@@ -1803,7 +1811,20 @@ __device__ __forceinline__ void phwin_body(unsigned bid, const PhArgs &a)
 // The ranges of an interval contain those of its parent (next size up) and are contained in those of its tiles (PhWin): a level
 // sums its ranges minus its parent's, and k_phco2 the tile's minus the smallest interval's.
 struct PhIWin { int32_t a[6], b[6]; };
-struct PhLevels { int nlev, nItot; int itv[CS_MAX_LEVEL], nI[CS_MAX_LEVEL], ioff[CS_MAX_LEVEL]; };
+struct PhLevels { int nlev, nItot; int itv[CS_MAX_ALEVEL], nI[CS_MAX_ALEVEL], ioff[CS_MAX_ALEVEL]; };
+// How many nodes an interval needs depends on how far its lines are in half-widths h: a set that stays D away converges like rho^-n,
+// rho = x0 + sqrt(x0^2 - 1), x0 = 1 + D/h -- 64 nodes at the margin (rho = 2.1), but 16 or 32 for the far regions of the smaller
+// intervals (region 3 from a 1024-point interval: D/h >= 9).  A "virtual level" is (interval size, node count, regions summed with
+// it); a region that could hold nothing at a size is not carried there, and par[] names the next larger size that does carry it
+// (the level whose ranges this one's are reduced by).
+struct PhVLevels {
+    int nv;
+    int rl[CS_MAX_ALEVEL], nc[CS_MAX_ALEVEL], rmask[CS_MAX_ALEVEL];   // interval size (index into PhLevels), nodes per interval, regions (bit r = region r + 1)
+    int noff[CS_MAX_ALEVEL], boff[CS_MAX_ALEVEL + 1];                // first node in F / in the node array, first interval slot in the launch
+    int par[CS_MAX_ALEVEL][3];                                      // per region: the size above that carries it (-1: none)
+};
+// what k_phco2 leaves out of a tile's uniform sets, per region: the ranges of the smallest interval size that carries it
+struct PhFine { int off[3], shift[3]; };                           // first PhIWin of that size (-1: none), log2(size / 64)
 struct PhIArgs { const double *nu, *nul; int64_t nnu; int32_t J0, J1; double cut, tol, margin; PhLevels lv; PhIWin *out; };
 __device__ __forceinline__ void phiwin_body(unsigned bid, const PhIArgs &A)
 {
@@ -1920,33 +1941,74 @@ __device__ __forceinline__ PhCoef ph_coef(double T)
     return p;
 }
 
-// one wave = the 64 nodes of one interval x one state: F[interval][node][state] = sum over the interval's own ranges (its
-// region-uniform ranges minus its parent's), every line with the 4-term far body (all of them are >= 3 cm^-1 >= 100 Doppler
+// one wave = one interval (of one virtual level) x one state: F[node][state] = sum over the interval's own ranges (its
+// region-uniform ranges minus those of the size above), every line with the far body (all of them are >= 3 cm^-1 >= 100 Doppler
 // widths away: phco2_fast_ok) and chi = (node factor) x (tabulated line factor).  Both sides are summed towards the interval.
+// With nc = 64 nodes a lane is a node and the line records arrive as scalar loads; with 32 (16) the wave holds 2 (4) copies of the
+// nodes, each taking a contiguous half (quarter) of every piece through vector loads, and the copies are added at the end.
+#define CS_PH_PITCH 68   // doubles per record field in a wave's staging area: 4 parts x (16 + 1) or 2 parts x (32 + 1)
+// the lines [j0, j1) for a wave that holds nparts = 2 or 4 copies of its nodes: 64 records at a time are fetched one per lane
+// (coalesced) and laid out in LDS by (part, position) -- line i of the batch belongs to part i % nparts -- then every copy walks its
+// own lines with broadcast reads (the parts' addresses fall on different banks).  Per-lane global loads of the records instead cost
+// more than they save: four waves per CU x (2 x 16 B + 8 B) x 64 lanes per evaluation keep the CU's one address path busy longer
+// than the arithmetic takes (measured: 32 / 16 nodes no faster than 64).
+template <bool FOUR>
+__device__ __forceinline__ double ph_segment_lds(double acc, double v, double glane, const LineHot *__restrict__ hk, const double *__restrict__ fk,
+                                                 int j0, int j1, int part, int nparts, bool rev, double cut, const FarK &c, double *__restrict__ st)
+{
+    if (j1 <= j0) return acc;   // (wave-uniform)
+    const int lane = threadIdx.x & 63;
+    const int per = 64 / nparts, pitch = per + 1;
+    const int wslot = (lane % nparts) * pitch + lane / nparts;   // where this lane's record goes
+    for (int base = j0; base < j1; base += 64) {
+        const int n = min(64, j1 - base);
+        const int j = min(base + lane, j1 - 1);
+        const LineHot h = hk[j];
+        const double fj = fk[j];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();     // (the reads of the previous batch are done)
+        st[0 * CS_PH_PITCH + wslot] = h.nul;
+        st[1 * CS_PH_PITCH + wslot] = h.p1;
+        st[2 * CS_PH_PITCH + wslot] = h.p2;
+        st[3 * CS_PH_PITCH + wslot] = h.p3;
+        st[4 * CS_PH_PITCH + wslot] = fj;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        const int tmax = (n + nparts - 1) / nparts;          // positions in use (part 0 has them all)
+        const int cnt = (n - part + nparts - 1) / nparts;    // ... and this part: lines part, part + nparts, ...
+#pragma unroll 2
+        for (int t = 0; t < tmax; t++) {
+            const int pos = rev ? tmax - 1 - t : t;
+            const int idx = part * pitch + pos;
+            LineHot hh;
+            hh.nul = st[0 * CS_PH_PITCH + idx]; hh.p1 = st[1 * CS_PH_PITCH + idx]; hh.p2 = st[2 * CS_PH_PITCH + idx]; hh.p3 = st[3 * CS_PH_PITCH + idx];
+            const double term = ph_term<false, FOUR>(hh, glane * st[4 * CS_PH_PITCH + idx], v, cut, c);
+            acc += pos < cnt ? term : 0.0;
+        }
+    }
+    return acc;
+}
 __global__ __launch_bounds__(256) void k_phco2_nodes(const double *__restrict__ nodes, int64_t L, const LineHot *__restrict__ hot,
                                                       const double *__restrict__ phfac, double nu_c, const PhIWin *__restrict__ piw,
-                                                      PhLevels lv, int K, int Kpad, const double *__restrict__ Tk, double cut,
+                                                      PhLevels lv, PhVLevels vl, int K, int Kpad, const double *__restrict__ Tk, double cut,
                                                       const double *__restrict__ gbound, double mu_min, double mu_max, double far_s,
                                                       double *__restrict__ F)
 {
+    __shared__ double stage[4][5 * CS_PH_PITCH];
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int nsb = (K + 3) >> 2;
-    const int T = (int)(blockIdx.x / nsb);
+    const int slot = (int)(blockIdx.x / nsb);
+    int vi = 0;
+    while (vi + 1 < vl.nv && slot >= vl.boff[vi + 1]) vi++;
+    const int T = slot - vl.boff[vi], rl = vl.rl[vi], nc = vl.nc[vi], rmask = vl.rmask[vi];
     const int k = (int)((blockIdx.x % nsb + T) % nsb) * 4 + wv;   // (rotated: see k_cheb_nodes)
     if (k >= K) return;
-    int l = 0;
-    while (l + 1 < lv.nlev && T >= lv.ioff[l + 1]) l++;
-    const PhIWin w = piw[T];
-    PhIWin p = w;
-    const bool par = l > 0;
-    if (par) {
-        int pshift = 0;
-        for (int r = lv.itv[l - 1] / lv.itv[l]; r > 1; r >>= 1) pshift++;
-        p = piw[lv.ioff[l - 1] + ((T - lv.ioff[l]) >> pshift)];
-    }
+    const int node = lane & (nc - 1), nparts = 64 / nc, part = lane / nc;
+    const PhIWin w = piw[lv.ioff[rl] + T];
     const LineHot *__restrict__ hk = hot + (size_t)k * L;
     const size_t KL = (size_t)K * L;
-    const double v = nodes[(size_t)T * CS_NC + lane];
+    const size_t n0 = (size_t)vl.noff[vi] + (size_t)T * nc;
+    const double v = nodes[n0 + node];
     const FarK c = load_fark();
     const PhCoef pc = ph_coef(Tk[k]);
     const double dc = v - nu_c;
@@ -1954,7 +2016,7 @@ __global__ __launch_bounds__(256) void k_phco2_nodes(const double *__restrict__ 
     // (zones_body), with the widest Doppler width of the window for x and the narrowest for y (chi <= 1 only shrinks y)
     bool two[3];
     {
-        const double vhi = nodes[(size_t)T * CS_NC], vlo = nodes[(size_t)T * CS_NC + CS_NC - 1];   // nodes run from the upper end down
+        const double vhi = nodes[n0], vlo = nodes[n0 + nc - 1];   // nodes run from the upper end down
         const double vth = sqrt(2.0 * kRgas * Tk[k]);
         const double amax = ((vhi + cut) / kC) * vth / sqrt(mu_min);
         const double vmin = w.b[5] > w.a[0] ? fmax(vlo - cut, hk[w.a[0]].nul) : vlo - cut;   // (the lowest line any range holds)
@@ -1969,48 +2031,52 @@ __global__ __launch_bounds__(256) void k_phco2_nodes(const double *__restrict__ 
     }
     double accL = 0.0, accR = 0.0;
 #pragma unroll
-    for (int s = 0; s < 3; s++) {   // left of the interval: r = 3, 2, 1, ascending lines
-        const int r = 2 - s;
-        const double *__restrict__ f = phfac + (size_t)r * KL + (size_t)k * L;   // exp(+b_r (nul - nu_c))
-        const double g = exp(pc.a[r] - pc.b[r] * dc);
-        const int lo = w.a[s], hi = w.b[s];
-        const int pa = par ? min(max(p.a[s], lo), hi) : hi, pb = par ? min(max(p.b[s], pa), hi) : hi;
-        if (two[r]) {
-            accL = ph_segment<false, false>(accL, v, g, hk, f, lo, pa, cut, c);
-            accL = ph_segment<false, false>(accL, v, g, hk, f, pb, hi, cut, c);
-        } else {
-            accL = ph_segment<false, true>(accL, v, g, hk, f, lo, pa, cut, c);
-            accL = ph_segment<false, true>(accL, v, g, hk, f, pb, hi, cut, c);
+    for (int s = 0; s < 6; s++) {   // left of the interval: r = 3, 2, 1 with ascending lines; then right of it: r = 3, 2, 1, descending
+        const bool left = s < 3;
+        const int q = left ? s : 8 - s;           // set in line order: 0, 1, 2, 5, 4, 3
+        const int r = left ? 2 - s : q - 3;
+        if (!((rmask >> r) & 1)) continue;       // (wave-uniform)
+        const double *__restrict__ f = phfac + (size_t)(left ? r : 3 + r) * KL + (size_t)k * L;   // exp(+-b_r (nul - nu_c))
+        const double g = exp(left ? pc.a[r] - pc.b[r] * dc : pc.a[r] + pc.b[r] * dc);
+        const int lo = w.a[q], hi = w.b[q];
+        int pa = hi, pb = hi;
+        const int prl = vl.par[vi][r];
+        if (prl >= 0) {
+            int pshift = 0;
+            for (int x = lv.itv[prl] / lv.itv[rl]; x > 1; x >>= 1) pshift++;
+            const PhIWin p = piw[lv.ioff[prl] + (T >> pshift)];
+            pa = min(max(p.a[q], lo), hi);
+            pb = min(max(p.b[q], pa), hi);
+        }
+        // far end first: [lo, pa) then [pb, hi) on the left, [pb, hi) then [lo, pa) on the right
+        for (int piece = 0; piece < 2; piece++) {
+            const bool first = (piece == 0) == left;
+            const int j0 = first ? lo : pb, j1 = first ? pa : hi;
+            double &acc = left ? accL : accR;
+            if (nc == CS_NC) {
+                if (left) acc = two[r] ? ph_segment<false, false>(acc, v, g, hk, f, j0, j1, cut, c) : ph_segment<false, true>(acc, v, g, hk, f, j0, j1, cut, c);
+                else      acc = two[r] ? ph_segment_rev<false, false>(acc, v, g, hk, f, j0, j1, cut, c) : ph_segment_rev<false, true>(acc, v, g, hk, f, j0, j1, cut, c);
+            } else {
+                acc = two[r] ? ph_segment_lds<false>(acc, v, g, hk, f, j0, j1, part, nparts, !left, cut, c, stage[wv])
+                             : ph_segment_lds<true>(acc, v, g, hk, f, j0, j1, part, nparts, !left, cut, c, stage[wv]);
+            }
         }
     }
-#pragma unroll
-    for (int s = 5; s >= 3; s--) {  // right of it: r = 3, 2, 1, descending lines
-        const int r = s - 3;
-        const double *__restrict__ f = phfac + (size_t)(3 + r) * KL + (size_t)k * L;   // exp(-b_r (nul - nu_c))
-        const double g = exp(pc.a[r] + pc.b[r] * dc);
-        const int lo = w.a[s], hi = w.b[s];
-        const int pa = par ? min(max(p.a[s], lo), hi) : hi, pb = par ? min(max(p.b[s], pa), hi) : hi;
-        if (two[r]) {
-            accR = ph_segment_rev<false, false>(accR, v, g, hk, f, pb, hi, cut, c);
-            accR = ph_segment_rev<false, false>(accR, v, g, hk, f, lo, pa, cut, c);
-        } else {
-            accR = ph_segment_rev<false, true>(accR, v, g, hk, f, pb, hi, cut, c);
-            accR = ph_segment_rev<false, true>(accR, v, g, hk, f, lo, pa, cut, c);
-        }
-    }
-    F[((size_t)T * CS_NC + lane) * Kpad + k] = accL + accR;
+    double acc = accL + accR;
+    if (nc <= 32) acc += __shfl_xor(acc, 32);
+    if (nc <= 16) acc += __shfl_xor(acc, 16);
+    if (lane < nc) F[(n0 + lane) * Kpad + k] = acc;
 }
 
 __global__ __launch_bounds__(256) void k_phco2(const double *__restrict__ nu, int64_t nnu, int64_t L, const LineHot *__restrict__ hot,
                                                const LineCold *__restrict__ cold, const double *__restrict__ phfac, double nu_c,
                                                const PhWin *__restrict__ pw, const Zone *__restrict__ zones, int ntile, double cut,
                                                const double *__restrict__ Tk, int K, double base, const double *__restrict__ extra,
-                                               double *__restrict__ sigma, int accumulate, const PhIWin *__restrict__ fine, int ishift, int inner_voigt,
-                                               int dbg)
+                                               double *__restrict__ sigma, int accumulate, const PhIWin *__restrict__ piw, PhFine fine, int inner_voigt)
 {
     // inner_voigt: the pairs within 3 cm^-1 (chi = 1) are left to the Voigt kernels that follow with that cut-off (wavewin_body)
-    // fine != NULL: the region-uniform ranges of the tile's interval (tile >> ishift at the smallest interval size) are in sigma
-    // already, carried there from the node sums of k_phco2_nodes -- the tile's uniform sets shrink to what lies outside them
+    // piw != NULL: the region-uniform ranges of the tile's interval (at the smallest interval size that carries the region: fine) are
+    // in sigma already, carried there from the node sums of k_phco2_nodes -- the tile's uniform sets shrink to what lies outside them
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int tile = (int)blockIdx.x * 4 + wv;
     if (tile >= ntile) return;
@@ -2031,21 +2097,23 @@ __global__ __launch_bounds__(256) void k_phco2(const double *__restrict__ nu, in
     for (int r = 0; r < 3; r++) { gL[r] = exp(pc.a[r] - pc.b[r] * dc); gR[r] = exp(pc.a[r] + pc.b[r] * dc); }
     const double *__restrict__ fL[3] = {phfac + 0 * KL + (size_t)k * L, phfac + 1 * KL + (size_t)k * L, phfac + 2 * KL + (size_t)k * L};
     const double *__restrict__ fR[3] = {phfac + 3 * KL + (size_t)k * L, phfac + 4 * KL + (size_t)k * L, phfac + 5 * KL + (size_t)k * L};
-    PhIWin x;   // what the intervals took (empty ranges at the sets' upper ends: nothing)
-    if (fine) x = fine[tile >> ishift];
+    PhIWin x[3];   // what the intervals took, per region
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+        if (piw && fine.off[r] >= 0) x[r] = piw[fine.off[r] + (tile >> fine.shift[r])];
     const int slo[6] = {w.W0, w.L2a, w.L1a, w.R1, w.R2, w.R3}, shi[6] = {w.L3, w.L2, w.L1, w.R1b, w.R2b, w.W1};
     double acc = 0.0;
     // uniform sets: region r, side; inside [Q0,Q1) (k_zones) the 4-term series, outside the 2-/3-term body; cut-off edges with the
     // predicate (they sit in region 3: the launcher only takes this kernel for cut-offs beyond 130 cm^-1)
 #pragma unroll
     for (int s = 0; s < 6; s++) {
-        if (dbg & 1) break;
         const bool left = s < 3;
         const int r = left ? 2 - s : s - 3;
         const double *__restrict__ f = left ? fL[r] : fR[r];
         const double g = left ? gL[r] : gR[r];
         const int lo = slo[s], hi = shi[s];
-        const int xa = fine ? min(max(x.a[s], lo), hi) : hi, xb = fine ? min(max(x.b[s], xa), hi) : hi;
+        const bool took = piw && fine.off[r] >= 0;
+        const int xa = took ? min(max(x[r].a[s], lo), hi) : hi, xb = took ? min(max(x[r].b[s], xa), hi) : hi;
         for (int piece = 0; piece < 2; piece++) {
             const int p0 = piece ? xb : lo, p1 = piece ? hi : xa;
             if (p0 >= p1) continue;
@@ -2069,7 +2137,7 @@ __global__ __launch_bounds__(256) void k_phco2(const double *__restrict__ nu, in
     }
     // boundary sets: a region boundary D = 120 or 30 cm^-1 crosses the tile -- the lane picks the side's factorised chi of its own
     // region; all of these lines are far (4-term body)
-    if (!(dbg & 2)) {
+    {
         const int bl[4] = {w.L3, w.L2, w.R1b, w.R2b}, bh[4] = {w.L2a, w.L1a, w.R2, w.R3};
         const double D[4] = {120.0, 30.0, 30.0, 120.0};
         const int rn[4] = {1, 0, 0, 1};   // region (0-based) on the near side of the boundary; the far side is rn + 1
@@ -2094,7 +2162,7 @@ __global__ __launch_bounds__(256) void k_phco2(const double *__restrict__ nu, in
         for (int half = 0; half < 2; half++) {
             const int j0 = half ? max(w.C1, w.C0) : w.L1, j1 = half ? w.R1 : w.C0;
 #pragma unroll 2
-            for (int j = (dbg & 4) ? j1 : j0; j < j1; j++) {
+            for (int j = j0; j < j1; j++) {
                 const LineHot h = hk[j];
                 const double dv = v - h.nul;
                 const double t = ph_term<false, true>(h, dv > 0.0 ? gL[0] * fL[0][j] : gR[0] * fR[0][j], v, cut, c);
@@ -2102,13 +2170,13 @@ __global__ __launch_bounds__(256) void k_phco2(const double *__restrict__ nu, in
             }
         }
     } else
-    for (int j = (dbg & 4) ? w.R1 : w.L1; j < w.R1; j++) {
+    for (int j = w.L1; j < w.R1; j++) {
         const LineHot h = hk[j];
         const double dv = v - h.nul;
         const double chi = fabs(dv) < 3.0 ? 1.0 : (dv > 0.0 ? gL[0] * fL[0][j] : gR[0] * fR[0][j]);
         const double xx = dv * h.p1;
         const bool nearl = __builtin_fma(xx, xx, (h.p2 * chi) * chi) < 1.0e4;
-        if (!(dbg & 8) && __builtin_amdgcn_ballot_w64(nearl) != 0ull) {
+        if (__builtin_amdgcn_ballot_w64(nearl) != 0ull) {
             const LineCold cc = ck[j];
             const double t = cc.A * fad_re(xx, chi * cc.y);
             acc += (fabs(dv) > cut) ? 0.0 : t;

@@ -129,7 +129,11 @@ int cs_set_merge(cs_ctx *ctx, int on);
  *          main stream, into sigma;
  *   key 8: a far line joins a state group's matrix-core node piece when at least this many of the group's 16 states are beyond their
  *          own series radius (the others' coefficients are masked, the vector unit sums them) -- default 7; 16 = the group's widest
- *          line decides (round 2), 1 = its narrowest.
+ *          line decides (round 2), 1 = its narrowest;
+ *   key 9: PHCO2: the pairs within 3 cm^-1 of a line (chi = 1 there: the plain Voigt profile, every near-line pair among them) go
+ *          through the Voigt kernels with a 3 cm^-1 cut-off after k_phco2 (0, default), or through k_phco2's own core loop (1);
+ *   key 10: PHCO2 interpolation levels: bit 0 = 64 nodes on every interval (default: 16 or 32 where a region's lines are many
+ *          half-widths from the intervals of a size), bit 1 = the 64-point tiles themselves as the smallest interval size.
  * Applies to every later cs_column_setup / cs_column_run of the context. */
 int cs_set_tuning(cs_ctx *ctx, int key, int value);
 

@@ -251,8 +251,9 @@ def test_phco2_fast_path(cs, O, lines, ctx_on):
 def test_phco2_interpolated_wings(cs, O, lines, ctx_on, ctx_off):
     """PHCO2 far wings through the Chebyshev machinery (k_phco2_nodes): inside one chi-region and on one side of a line the term is
     analytic in nu, so the lines that are region-uniform for a whole interval of 128 .. 2048 points are summed at its 64 nodes
-    (own ranges minus the parent's) and carried to the grid; k_phco2 keeps the tile's sets minus the smallest interval's, the
-    boundary sets (two-way chi select) and the core (Faddeeva only next to a line).  Same cross-sections as with every pair summed
+    (own ranges minus the parent's; 16 or 32 nodes where the lines are many half-widths away) and carried to the grid; k_phco2
+    keeps the tile's sets minus the smallest interval's and the boundary sets (two-way chi select); the pairs within 3 cm^-1, where
+    chi = 1, go through the Voigt kernels with that cut-off.  Same cross-sections as with every pair summed
     per point (5e-13: different summation orders) and as the oracle (2e-11), on a dense table and the sparse fixture, on grids that
     end inside an interval, for interval size ranges that leave one or five levels, and in a column."""
     dense = cs.SpectralLines.synthetic(2, 8000, 91, numin=200.0, numax=1400.0)
@@ -268,9 +269,12 @@ def test_phco2_interpolated_wings(cs, O, lines, ctx_on, ctx_off):
             assert relerr(a[k], so, floor=1e-250) < 2e-11
     nu = np.linspace(640.0, 800.0, 6401)
     ref = cs.shape_batch(dense, "PHCO2", nu, T[:2], P[:2], Pp[:2], 500.0, ctx_off)
-    for smin, smax in ((128, 128), (2048, 2048), (256, 1024)):
+    for smin, smax, tune in ((128, 128, {}), (2048, 2048, {}), (256, 1024, {}), (128, 2048, {10: 1}), (128, 2048, {10: 2}), (128, 2048, {10: 3}),
+                             (128, 2048, {9: 1})):
         c = cs.Context(0)
         c.set_interp_plan(size_min=smin, size_max=smax)
+        for key, val in tune.items():   # 64 nodes everywhere / tiles as 64-point intervals / k_phco2's own core loop
+            c.set_tuning(key, val)
         a = cs.shape_batch(dense, "PHCO2", nu, T[:2], P[:2], Pp[:2], 500.0, c)
         c.close()
         assert relerr(a, ref, floor=1e-250) < 5e-13
