@@ -160,11 +160,12 @@ struct ColCia {
 struct ChebGrid {
     int nlev = 0, nItot = 0;
     int itv[CS_MAX_LEVEL] = {}, nI[CS_MAX_LEVEL] = {}, ioff[CS_MAX_LEVEL] = {};
+    double span[CS_MAX_LEVEL] = {};   // widest interval of the level (cheb_build; 0: not known)
     DevBuf nodes;               // [nItot][64]
     DevBuf Cm[CS_MAX_LEVEL];    // [nI][64][itv]
 };
 // per gas on that grid: windows per level, zones [K][nItot], node sums F [nItot][64][Kpad]
-struct GasInterp { int nlev = 0, l0 = 0; DevBuf iwin[CS_MAX_LEVEL], iz, F, sep, edge; };   // levels l0 .. nlev-1 of the grid are in use; sep: SepZone [K/16][nItot]
+struct GasInterp { int nlev = 0, l0 = 0; int nfar[CS_MAX_LEVEL] = {}; DevBuf iwin[CS_MAX_LEVEL], iz, F, sep, edge; };   // nfar: nodes for a level's far pieces (far_node_count)   // levels l0 .. nlev-1 of the grid are in use; sep: SepZone [K/16][nItot]
                                                                                           // (matrix-core node sums), edge: EdgeZone [K/16][tiles] (matrix-core pieces of the per-point sum)
 
 // a gas of the column as the caller named it (conc is laid out [ngas, K] over these)
@@ -290,6 +291,7 @@ struct cs_ctx {
     int tune[CS_NTUNE] = {0, 1, 2, 0, 0, 1, 0, 1, 7, 0, 0, 0};   // ... [8] states of a group that must be able to use a line for it to join the group's matrix-core node piece   // [6] split levels of k_cheb_nodes_mx, [7] near-line kernels on a second side stream   // ... [3] interpolation margin (per cent), [4] hipGraph replay, [5] k_rt_streams on short grids
     std::vector<std::unique_ptr<GasTable>> merged;   // merged tables (keyed by their members' (slot, generation)), a few kept
     double far_s = 1e6;
+    DevBuf reinterp;        // [64][32] then [64][16]: values at the 64 nodes of an interval from those at its 32 / 16 nodes (build_reinterp)
     DevBuf hot32;
     DevBuf tmpA, tmpB, tmpC;
 };
@@ -621,12 +623,23 @@ struct Interp {
     bool core = true;         // cs_set_matrix_cores(ctx, on | 4) switches the sub-tile treatment of the window core (k_voigt_sub) off
     double margin = kChebMargin;   // cs_set_tuning key 3 (per cent): distance of an interval's interpolated set, in half-widths
     int mx_min_states = 7;    // cs_set_tuning key 8
+    int nfar[CS_MAX_LEVEL] = {};   // nodes for the far pieces of a level in k_cheb_nodes_mx (16, 32; 64 = as the near pieces)
+    const double *R = nullptr;     // the context's re-interpolation matrices (cs_ctx::reinterp); NULL: every piece on 64 nodes (cs_set_tuning key 11)
     int nsplit_levels = 1;    // cs_set_tuning key 6: interval sizes (largest first) whose node sums four waves share in k_cheb_nodes_mx
     bool small_mx = false;    // cs_set_tuning key 1: the matrix-core kernels on short grids too (their four-waves-per-item variants)
     bool fuse_apply = false;  // the column's only interpolating group: k_voigt_edge_mx may carry the node sums to the grid itself
     double core4 = 0.0;       // the core takes the 4-term series where its radius is below core4 x the tile's span, else the 8-term one
                               // (0: always the 8-term one -- measured at C3 with 0.75 / 0.3 / 0: 2.61 / 2.55 / 2.52 ms)
 };
+
+static void interp_settings(const cs_ctx *ctx, Interp &itp)   // the cs_set_tuning keys an Interp view carries
+{
+    itp.small_mx = ctx->tune[1] != 0;
+    itp.margin = ctx->tune[3] > 0 ? 0.01 * ctx->tune[3] : kChebMargin;
+    itp.nsplit_levels = ctx->tune[6] > 0 ? ctx->tune[6] : 1;
+    itp.mx_min_states = ctx->tune[8] > 0 ? ctx->tune[8] : 7;
+    itp.R = ctx->tune[11] ? nullptr : ctx->reinterp.as<double>();
+}
 
 // interval sizes worth using on this grid: an interval of width W leaves lines over (2 cut - 2.3 W) to interpolate
 int choose_levels(double nu_lo, double nu_hi, int64_t nnu, double cut, int *itv, int szmin = 128, int szmax = 2048)
@@ -649,7 +662,20 @@ int choose_levels(const double *nu, int64_t nnu, double cut, int *itv, int szmin
 int cheb_build_range(ChebGrid &g, double nu_lo, double nu_hi, const double *dnu, int64_t nnu, double cut, int szmin, int szmax, hipStream_t s);
 int cheb_build(const cs_ctx *ctx, ChebGrid &g, const double *h_nu, const double *dnu, int64_t nnu, double cut, hipStream_t s)
 {
-    return cheb_build_range(g, h_nu[0], h_nu[nnu - 1], dnu, nnu, cut, ctx->itp_min, ctx->itp_max, s);
+    const int rc = cheb_build_range(g, h_nu[0], h_nu[nnu - 1], dnu, nnu, cut, ctx->itp_min, ctx->itp_max, s);
+    for (int l = 0; l < g.nlev; l++) {
+        g.span[l] = 0.0;
+        for (int64_t i0 = 0; i0 < nnu; i0 += g.itv[l]) g.span[l] = std::max(g.span[l], h_nu[std::min<int64_t>(i0 + g.itv[l] - 1, nnu - 1)] - h_nu[i0]);
+    }
+    return rc;
+}
+// nodes for a set of lines that stays `dist` away from intervals of half-width h: the interpolation error falls like rho^-(n-1),
+// rho = x0 + sqrt(x0^2 - 1), x0 = 1 + dist / h; 1e-18 asked for (64 nodes at the margin of 0.3: rho = 2.1, 5e-21)
+int far_node_count(double dist, double h)
+{
+    if (!(dist > 0.0) || !(h > 0.0)) return CS_NC;
+    const double x0 = 1.0 + dist / h, lr = std::log10(x0 + std::sqrt(x0 * x0 - 1.0));
+    return 15.0 * lr >= 18.0 ? 16 : (31.0 * lr >= 18.0 ? 32 : CS_NC);
 }
 int cheb_build_range(ChebGrid &g, double nu_lo, double nu_hi, const double *dnu, int64_t nnu, double cut, int szmin, int szmax, hipStream_t s)
 {
@@ -712,6 +738,9 @@ int gas_interp_build(const cs_ctx *ctx, GasInterp &gi, ChebGrid &g, const std::v
         if (ctx->itp_first >= 0) gi.l0 = std::min(ctx->itp_first, g.nlev);
         if (gi.l0 >= g.nlev) { gi.nlev = 0; gi.l0 = 0; return CS_OK; }   // too few lines: every pair directly
     }
+    // far pieces of a level (the lines beyond its parent's set): at least cut-off minus the parent's width from the interval
+    for (int l = 0; l < g.nlev; l++)
+        gi.nfar[l] = (l > gi.l0 && g.span[l - 1] > 0.0 && g.span[l] > 0.0) ? far_node_count(cut - g.span[l - 1], 0.5 * g.span[l]) : CS_NC;
     for (int l = 0; l < g.nlev; l++) {
         std::vector<WaveWin> iwin;
         wave_windows(nul, g0, g1, nu, nnu, cut, iwin, g.itv[l]);
@@ -742,6 +771,7 @@ Interp interp_view(const ChebGrid &g, const GasInterp &gi, int K, IZone *iz_over
     v.edge = gi.edge.as<EdgeZone>();
     for (int l = 0; l < gi.nlev; l++) {
         v.itv[l] = g.itv[l]; v.nI[l] = g.nI[l]; v.ioff[l] = g.ioff[l];
+        v.nfar[l] = gi.nfar[l];
         v.Cm[l] = g.Cm[l].as<double>();
         v.iwin[l] = gi.iwin[l].as<WaveWin>();
     }
@@ -1059,8 +1089,14 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
                 for (int l = itp.l0; l < std::min(itp.nlev, itp.l0 + itp.nsplit_levels); l++) nsplit += itp.nI[l];
                 if (!mx_big(nq, kn, 2048) || nsplit > nq) nsplit = nq;
                 const unsigned nblk_mx = (unsigned)(nsplit * ngrp) + (unsigned)(((int64_t)(nq - nsplit) * ngrp + 3) / 4);
+                MxFar mf;
+                memset(&mf, 0, sizeof mf);
+                mf.nlev = itp.nlev;
+                for (int l = 0; l < itp.nlev; l++) { mf.ioff[l] = itp.ioff[l]; mf.nfar[l] = itp.nfar[l] > 0 ? itp.nfar[l] : CS_NC; }
+                mf.ioff[itp.nlev] = itp.nItot;
+                mf.R = itp.R;
                 CS_LAUNCH(k_cheb_nodes_mx, dim3(nblk_mx), dim3(256), 0, s, itp.nodes, G.L, hot, itp.sep, itp.nItot, q0, nsplit, kn,
-                                   itp.Kpad, ngrp, itp.F, itp.iz);
+                                   itp.Kpad, ngrp, itp.F, itp.iz, mf);
             }
             if (s != sm) {
                 (void)hipEventRecord(fork->ev_join, s);
@@ -1335,6 +1371,30 @@ int cs_create(int device, cs_ctx **out)
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_far3, hipEventDisableTiming);
     if (e != hipSuccess) { cs_destroy(c); return fail(CS_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    {   // R_n[m][j] = l_j(x_m): Lagrange basis of the n extrema cos(pi j / (n - 1)) at the 64 extrema cos(pi m / 63), barycentric form
+        std::vector<double> R((size_t)CS_NC * 48);
+        const long double pi = 3.14159265358979323846264338327950288L;
+        for (int n : {32, 16}) {
+            double *Rn = R.data() + (n == 32 ? 0 : CS_NC * 32);
+            std::vector<long double> x(n), w(n);
+            for (int j = 0; j < n; j++) { x[j] = cosl(pi * j / (n - 1)); w[j] = ((j & 1) ? -1.0L : 1.0L) * ((j == 0 || j == n - 1) ? 0.5L : 1.0L); }
+            for (int m = 0; m < CS_NC; m++) {
+                const long double xm = cosl(pi * m / (CS_NC - 1));
+                int hit = -1;
+                long double den = 0.0L;
+                for (int j = 0; j < n; j++) {
+                    const long double d = xm - x[j];
+                    if (fabsl(d) < 1e-17L) hit = j; else den += w[j] / d;
+                }
+                for (int j = 0; j < n; j++)
+                    Rn[(size_t)m * n + j] = hit >= 0 ? (j == hit ? 1.0 : 0.0) : (double)((w[j] / (xm - x[j])) / den);
+            }
+        }
+        if (upload(c->reinterp, R.data(), R.size(), c->stream) != CS_OK || hipStreamSynchronize(c->stream) != hipSuccess) {
+            cs_destroy(c);
+            return fail(CS_EHIP, "upload of the re-interpolation matrices failed");
+        }
+    }
     *out = c;
     return CS_OK;
 }
@@ -1620,7 +1680,7 @@ static int shape_impl(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t 
         itp = interp_view(cheb, ginterp, kc);
         if (!ctx->matrix_nodes) itp.sep = nullptr, itp.edge = nullptr;
         itp.sep_always = ctx->matrix_nodes == 2;
-        itp.small_mx = ctx->tune[1] != 0; itp.margin = ctx->tune[3] > 0 ? 0.01 * ctx->tune[3] : kChebMargin; itp.nsplit_levels = ctx->tune[6] > 0 ? ctx->tune[6] : 1; itp.mx_min_states = ctx->tune[8] > 0 ? ctx->tune[8] : 7;
+        interp_settings(ctx, itp);
         itp.core = ctx->matrix_core != 0;
     }
     for (int k0 = 0; k0 < K; k0 += kc) {
@@ -1708,7 +1768,7 @@ int cs_bake(cs_ctx *ctx, int gas_slot, int table_slot, int shape, double dnu_cut
         itp = interp_view(cheb, ginterp, kc);
         if (!ctx->matrix_nodes) itp.sep = nullptr, itp.edge = nullptr;
         itp.sep_always = ctx->matrix_nodes == 2;
-        itp.small_mx = ctx->tune[1] != 0; itp.margin = ctx->tune[3] > 0 ? 0.01 * ctx->tune[3] : kChebMargin; itp.nsplit_levels = ctx->tune[6] > 0 ? ctx->tune[6] : 1; itp.mx_min_states = ctx->tune[8] > 0 ? ctx->tune[8] : 7;
+        interp_settings(ctx, itp);
         itp.core = ctx->matrix_core != 0;
     }
     for (int k0 = 0; k0 < M; k0 += kc) {
@@ -2411,7 +2471,7 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
             itp.sep = ctx->matrix_nodes ? dsep.as<SepZone>() : nullptr;
             itp.edge = ctx->matrix_nodes ? dedge.as<EdgeZone>() : nullptr;
             itp.sep_always = ctx->matrix_nodes == 2;
-            itp.small_mx = ctx->tune[1] != 0; itp.margin = ctx->tune[3] > 0 ? 0.01 * ctx->tune[3] : kChebMargin; itp.nsplit_levels = ctx->tune[6] > 0 ? ctx->tune[6] : 1; itp.mx_min_states = ctx->tune[8] > 0 ? ctx->tune[8] : 7;
+            interp_settings(ctx, itp);
             itp.core = ctx->matrix_core != 0;
         }
         for (int64_t k0 = 0; k0 < BK; k0 += kc) {
@@ -2534,7 +2594,7 @@ static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e, bool *
         itp.F = c.chebF.as<double>();
         if (!ctx->matrix_nodes) itp.sep = nullptr, itp.edge = nullptr;
         itp.sep_always = ctx->matrix_nodes == 2;
-        itp.small_mx = ctx->tune[1] != 0; itp.margin = ctx->tune[3] > 0 ? 0.01 * ctx->tune[3] : kChebMargin; itp.nsplit_levels = ctx->tune[6] > 0 ? ctx->tune[6] : 1; itp.mx_min_states = ctx->tune[8] > 0 ? ctx->tune[8] : 7;
+        interp_settings(ctx, itp);
         itp.core = ctx->matrix_core != 0;
         itp.fuse_apply = ctx->tune[0] != 0 && n_itp == 1;
         launch_gas(s, cg.shape, G, cg.jlo, cg.jhi, K, c.Tk.as<double>(), c.Pk.as<double>(), cg.Pp.as<double>(), cg.conc.as<double>(), K,
@@ -2813,6 +2873,21 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
         HIPCHK(hipMemcpy(zn.data(), g.zones.p, zn.size() * sizeof(Zone), hipMemcpyDeviceToHost));
         std::vector<IZone> iz;
         const int nlev = g.itp.nlev, nItot = c.cheb.nItot;
+        // nodes a piece of interval q is summed on in k_cheb_nodes_mx: 16 or 32 for the far pieces (p = 0, 3) of the intervals that are
+        // not shared by the four waves of a block, 64 otherwise (the carry to the 64 nodes, 2 x 64 x n per state, is not counted)
+        int nsplit_w = 0;
+        if (nlev > 0) {
+            const int q0w = c.cheb.ioff[g.itp.l0], nqw = nItot - q0w;
+            for (int l = g.itp.l0; l < std::min(nlev, g.itp.l0 + (ctx->tune[6] > 0 ? ctx->tune[6] : 1)); l++) nsplit_w += c.cheb.nI[l];
+            if (!mx_big(nqw, K, 2048) || nsplit_w > nqw) nsplit_w = nqw;
+            nsplit_w += q0w;   // intervals below this index are split
+        }
+        auto far_nodes = [&](int q, int p) {
+            if (ctx->tune[11] || (p != 0 && p != 3) || q < nsplit_w) return (int)CS_NC;
+            int l = 0;
+            while (l + 1 < nlev && q >= c.cheb.ioff[l + 1]) l++;
+            return g.itp.nfar[l] > 0 ? g.itp.nfar[l] : (int)CS_NC;
+        };
         if (nlev > 0) {
             iz.resize((size_t)K * nItot);
             HIPCHK(hipMemcpy(iz.data(), g.itp.iz.p, iz.size() * sizeof(IZone), hipMemcpyDeviceToHost));
@@ -2839,7 +2914,7 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
                                 const int n3 = p < 2 ? std::max(0, std::min(s4.m[p], pb) - pa) : std::max(0, pb - std::max(s4.m[p], pa));
                                 mx3 += (int64_t)CS_NC * n3;
                                 mx3n += (int64_t)CS_NC * n3;
-                                fl_nodes_useful += 2.0 * CS_NC * (3.0 * n3 + 4.0 * ((pb - pa) - n3));
+                                fl_nodes_useful += 2.0 * far_nodes(q, p) * (3.0 * n3 + 4.0 * ((pb - pa) - n3));
                             }
                         }
                     }
@@ -2867,7 +2942,7 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
                             if (z.b[p] <= z.a[p]) continue;
                             const int n3 = p < 2 ? z.m[p] - z.a[p] : z.b[p] - z.m[p], n4 = (z.b[p] - z.a[p]) - n3;
                             (void)ns;   // (useful flops: per state, above -- a state takes part only beyond its own series radius)
-                            fl_nodes_issued += 2.0 * CS_NC * 16 * (3.0 * ((n3 + 3) / 4 * 4) + 4.0 * ((n4 + 3) / 4 * 4));
+                            fl_nodes_issued += 2.0 * far_nodes(q, p) * 16 * (3.0 * ((n3 + 3) / 4 * 4) + 4.0 * ((n4 + 3) / 4 * 4));
                         }
                     }
                 }

@@ -828,9 +828,9 @@ typedef double v4f64_sep __attribute__((ext_vector_type(4)));
 // one step of the matrix-core sums: 4 lines x 64 columns (nodes or points) x 16 states.  The lane's record as (state lr, line lq)
 // gives the NT coefficients (A operands) and, as (column lr, line lq), the line position; vn[st] = the lane's column of sub-tile
 // st.  MASK: w = 0 beyond the cut-off (line_shapes.jl:10).  4 NT matrix instructions.
-template <int NT, int MASK>   // MASK 1: w = 0 beyond the cut-off; 2: also inside the radius rin (those pairs are k_voigt_sub's)
-__device__ __forceinline__ void sep_step(v4f64_sep (&acc)[4], const double (&vn)[4], const LineHot &h, bool valid, double cut, double rin = 0.0)
-{
+template <int NT, int MASK, int NST = 4>   // MASK 1: w = 0 beyond the cut-off; 2: also inside the radius rin (those pairs are k_voigt_sub's)
+__device__ __forceinline__ void sep_step(v4f64_sep (&acc)[NST], const double (&vn)[NST], const LineHot &h, bool valid, double cut, double rin = 0.0)
+{   // NST sub-tiles of 16 columns (4: a 64-point tile or the 64 nodes of an interval; 1, 2: a far piece on 16 or 32 nodes)
     const double id2 = rcp_nr1(h.p1 * h.p1);
     const double y2 = h.p2;
     // a_n = (A y / sqrt(pi)) c_n(y^2) / d^(2n), c_n from tools/voigt_series.py (exact rationals, all representable)
@@ -849,7 +849,7 @@ __device__ __forceinline__ void sep_step(v4f64_sep (&acc)[4], const double (&vn)
                                                                                           -42229.6875), 88682.34375), -73901.953125), 15836.1328125);
     }
 #pragma unroll
-    for (int st = 0; st < 4; st++) {
+    for (int st = 0; st < NST; st++) {
         const double dv = vn[st] - h.nul;
         const double s2 = dv * dv;
         double w = rcp_fast(s2);
@@ -871,8 +871,8 @@ __device__ __forceinline__ void sep_step(v4f64_sep (&acc)[4], const double (&vn)
 // matrix instructions of step t and waited for after them
 // [jlo_ok, jhi_ok): the lines of the run this LANE's state takes part in (its coefficients are zero for the others: a state whose own
 // series radius excludes a line of the group's piece leaves it to the vector-unit kernel)
-template <int NT, int MASK>
-__device__ __forceinline__ void sep_run(v4f64_sep (&acc)[4], const double (&vn)[4], const LineHot *__restrict__ hk, int ja, int jb, bool asc,
+template <int NT, int MASK, int NST = 4>
+__device__ __forceinline__ void sep_run(v4f64_sep (&acc)[NST], const double (&vn)[NST], const LineHot *__restrict__ hk, int ja, int jb, bool asc,
                                         int lq, double cut, double rin = 0.0, int jlo_ok = -0x7fffffff, int jhi_ok = 0x7fffffff)
 {
     if (ja >= jb) return;
@@ -884,7 +884,7 @@ __device__ __forceinline__ void sep_run(v4f64_sep (&acc)[4], const double (&vn)[
     for (int t = 0; t < nst; t++) {
         const LineHot nxt = rec(t + 1);      // (past the end: a harmless re-read of an end record, never used)
         __builtin_amdgcn_sched_barrier(0);   // keep the load here: the scheduler would sink it behind the matrix instructions
-        sep_step<NT, MASK>(acc, vn, cur, ok(t), cut, rin);
+        sep_step<NT, MASK, NST>(acc, vn, cur, ok(t), cut, rin);
         __builtin_amdgcn_sched_barrier(0);   // ... and the wait for it there
         cur = nxt;
     }
@@ -975,9 +975,57 @@ __device__ __forceinline__ void sepzones_body(unsigned bid, const SepArgs &a)
 // (Tried: the vector part of the same (interval, group) in the same block, four states per wave, so that both pipes work side by
 // side -- the matrix and vector phases do overlap, but the vector loop lives on eight waves per SIMD hiding its scalar loads, and
 // this kernel's registers and LDS allow four: 0.94 ms for a quarter of the vector work, profiles/r02_notes.md.)
+// Far pieces on fewer nodes.  The pieces p = 0 and p = 3 of an interval -- the lines beyond its parent's set -- are at least
+// cut-off minus the parent's width away: 3.8 half-widths for the 256-point intervals of the bench grid, 11.6 for the 128-point ones,
+// against 0.3 for the sets next to an interval.  Their sum converges like rho^-n (rho = x0 + sqrt(x0^2 - 1), x0 = 1 + distance in
+// half-widths), so 32 resp. 16 nodes carry it to rounding where the near pieces need 64: two resp. one 16-node sub-tile per matrix
+// step instead of four.  The values at those nodes are then carried to the interval's 64 nodes -- polynomial interpolation again, a
+// fixed 64 x n matrix in the interval's own coordinate (R: [64][32] then [64][16], built by the host in extended precision), one more
+// small matrix product per (interval, state group) -- and F, the apply kernel and everything after them never know.
+struct MxFar { int nlev, ioff[CS_MAX_LEVEL + 1], nfar[CS_MAX_LEVEL]; const double *R; };   // nfar[l]: 16, 32 or 64 (= as before); R = NULL: 64 everywhere
+template <int NST>
+__device__ __forceinline__ void mx_far_pieces(v4f64_sep (&acc)[4], const SepZone &z, const LineHot *__restrict__ hk, double vlo, double vhi,
+                                              int lr, int lq, int S0k, int S1k, const double *__restrict__ R, double (*__restrict__ tr)[CS_MX_PITCH])
+{
+    constexpr int n = 16 * NST;
+    const double cen = 0.5 * (vlo + vhi), h = 0.5 * (vhi - vlo);
+    double vf[NST];
+    v4f64_sep af[NST];
+#pragma unroll
+    for (int st = 0; st < NST; st++) {
+        vf[st] = cen + h * cospi((double)(st * 16 + lr) / (double)(n - 1));   // extrema of T_(n-1), from the upper end down like the 64
+        af[st] = v4f64_sep{0.0, 0.0, 0.0, 0.0};
+    }
+    if (z.b[0] > z.a[0]) {   // left of the interval, ascending: the 3-term part (the far end) first
+        if (z.m[0] > z.a[0]) sep_run<3, 0, NST>(af, vf, hk, z.a[0], z.m[0], true, lq, 0.0, 0.0, -0x7fffffff, S0k);
+        if (z.b[0] > z.m[0]) sep_run<4, 0, NST>(af, vf, hk, z.m[0], z.b[0], true, lq, 0.0, 0.0, -0x7fffffff, S0k);
+    }
+    if (z.b[3] > z.a[3]) {   // right of it, descending
+        if (z.b[3] > z.m[3]) sep_run<3, 0, NST>(af, vf, hk, z.m[3], z.b[3], false, lq, 0.0, 0.0, S1k);
+        if (z.m[3] > z.a[3]) sep_run<4, 0, NST>(af, vf, hk, z.a[3], z.m[3], false, lq, 0.0, 0.0, S1k);
+    }
+    // acc[state][m] += sum_j af[state][j] R[m][j]: af goes through LDS from the D layout (state 4r + lq, node lr) to the A layout
+    // (state lr, node lq of a group of four)
+#pragma unroll
+    for (int st = 0; st < NST; st++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) tr[4 * r + lq][st * 16 + lr] = af[st][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const double *__restrict__ Rn = R + (NST == 2 ? 0 : CS_NC * 32);
+#pragma unroll 2
+    for (int kk = 0; kk < 4 * NST; kk++) {
+        const double a = tr[lr][4 * kk + lq];
+#pragma unroll
+        for (int st2 = 0; st2 < 4; st2++)
+            acc[st2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Rn[(size_t)(16 * st2 + lr) * n + 4 * kk + lq], acc[st2], 0, 0, 0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
 __global__ __launch_bounds__(256) void k_cheb_nodes_mx(const double *__restrict__ nodes, int64_t L, const LineHot *__restrict__ hot,
                                                        const SepZone *__restrict__ sep, int nItot, int q0, int nsplit, int K, int Kpad,
-                                                       int ngrp, double *__restrict__ F, const IZone *__restrict__ iz)
+                                                       int ngrp, double *__restrict__ F, const IZone *__restrict__ iz, MxFar far)
 {
     // the first nsplit intervals (the largest interval size in use: several hundred lines per piece) are shared by the four waves
     // of a block as described; the rest (a few dozen lines, ~10 steps) go one (interval, group) per wave -- no LDS, no barrier
@@ -1017,10 +1065,22 @@ __global__ __launch_bounds__(256) void k_cheb_nodes_mx(const double *__restrict_
             ja = asc ? pa + wv * run : max(pb - (wv + 1) * run, pa);
             jb = asc ? min(ja + run, pb) : pb - wv * run;
         };
+        bool far_done = false;
+        if (!split && far.R) {   // (wave-uniform) the far pieces on 16 or 32 nodes where the interval's size allows
+            int l = 0;
+            while (l + 1 < far.nlev && T >= far.ioff[l + 1]) l++;
+            const int nf = far.nfar[l];
+            if (nf < CS_NC && (z.b[0] > z.a[0] || z.b[3] > z.a[3])) {
+                const double vhi = nodes[(size_t)T * CS_NC], vlo = nodes[(size_t)T * CS_NC + CS_NC - 1];
+                if (nf == 16) mx_far_pieces<1>(acc, z, hk, vlo, vhi, lr, lq, S0k, S1k, far.R, part[wv]);
+                else mx_far_pieces<2>(acc, z, hk, vlo, vhi, lr, lq, S0k, S1k, far.R, part[wv]);
+                far_done = true;
+            }
+        }
         for (int pp = 0; pp < 4; pp++) {
             const int p = pp < 2 ? pp : 5 - pp;          // 0, 1, 3, 2
             const bool asc = pp < 2;
-            if (z.b[p] <= z.a[p]) continue;
+            if (z.b[p] <= z.a[p] || (far_done && (p == 0 || p == 3))) continue;
             int ja, jb;
             if (asc) {
                 if (z.m[p] > z.a[p]) { quarter(z.a[p], z.m[p], true, ja, jb); sep_run<3, 0>(acc, vn, hk, ja, jb, true, lq, 0.0, 0.0, -0x7fffffff, S0k); }

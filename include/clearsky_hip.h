@@ -133,7 +133,9 @@ int cs_set_merge(cs_ctx *ctx, int on);
  *   key 9: PHCO2: the pairs within 3 cm^-1 of a line (chi = 1 there: the plain Voigt profile, every near-line pair among them) go
  *          through the Voigt kernels with a 3 cm^-1 cut-off after k_phco2 (0, default), or through k_phco2's own core loop (1);
  *   key 10: PHCO2 interpolation levels: bit 0 = 64 nodes on every interval (default: 16 or 32 where a region's lines are many
- *          half-widths from the intervals of a size), bit 1 = the 64-point tiles themselves as the smallest interval size.
+ *          half-widths from the intervals of a size), bit 1 = the 64-point tiles themselves as the smallest interval size;
+ *   key 11: the far pieces of an interval's matrix-core node sums (the lines beyond its parent's set: 3.8 .. 12 half-widths away on
+ *          the bench grid) are summed on 32 or 16 nodes and carried to the interval's 64 (0, default), or on all 64 (1).
  * Applies to every later cs_column_setup / cs_column_run of the context. */
 int cs_set_tuning(cs_ctx *ctx, int key, int value);
 
