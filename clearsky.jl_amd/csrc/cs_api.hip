@@ -163,6 +163,7 @@ struct ChebGrid {
     double span[CS_MAX_LEVEL] = {};   // widest interval of the level (cheb_build; 0: not known)
     DevBuf nodes;               // [nItot][64]
     DevBuf Cm[CS_MAX_LEVEL];    // [nI][64][itv]
+    DevBuf Rc[CS_MAX_LEVEL];    // level l >= 1: [nI][64][64], the parent's node values carried to the nodes of an interval (k_cheb_cascade)
 };
 // per gas on that grid: windows per level, zones [K][nItot], node sums F [nItot][64][Kpad]
 struct GasInterp { int nlev = 0, l0 = 0; int nfar[CS_MAX_LEVEL] = {}; DevBuf iwin[CS_MAX_LEVEL], iz, F, sep, edge; };   // nfar: nodes for a level's far pieces (far_node_count)   // levels l0 .. nlev-1 of the grid are in use; sep: SepZone [K/16][nItot]
@@ -243,7 +244,7 @@ static void drop_graph(Column &c)
 }
 
 // workspace of the PHCO2 fast path (k_phco2): per-(state, line) chi factors and per-tile region windows
-constexpr int CS_NTUNE = 12;
+constexpr int CS_NTUNE = 16;
 // nu_lo .. grid_id: the grid of the call, set by the caller (ph_set_grid); cheb, piw, F: the interpolation levels of that grid for the
 // PHCO2 cut-off (k_phco2_nodes), rebuilt when the key (grid_id, nnu, cut) changes
 struct PhScratch {
@@ -288,7 +289,7 @@ struct cs_ctx {
     int merge = 1;          // cs_set_merge: gases of a column with the same shape and cut-off share one merged line table
     // cs_set_tuning: [0] interpolated wings applied inside k_voigt_edge_mx where one launch group has them, [1] matrix-core kernels on
     // short grids (four waves per item), [2] node sums on a side stream (1: short grids only, 2: always)
-    int tune[CS_NTUNE] = {0, 1, 2, 0, 0, 1, 0, 1, 7, 0, 0, 0};   // ... [8] states of a group that must be able to use a line for it to join the group's matrix-core node piece   // [6] split levels of k_cheb_nodes_mx, [7] near-line kernels on a second side stream   // ... [3] interpolation margin (per cent), [4] hipGraph replay, [5] k_rt_streams on short grids
+    int tune[CS_NTUNE] = {0, 1, 2, 0, 0, 1, 0, 1, 7, 0, 0, 0, 0, 0, 0, 0};   // ... [8] states of a group that must be able to use a line for it to join the group's matrix-core node piece   // [6] split levels of k_cheb_nodes_mx, [7] near-line kernels on a second side stream   // ... [3] interpolation margin (per cent), [4] hipGraph replay, [5] k_rt_streams on short grids
     std::vector<std::unique_ptr<GasTable>> merged;   // merged tables (keyed by their members' (slot, generation)), a few kept
     double far_s = 1e6;
     DevBuf reinterp;        // [64][32] then [64][16]: values at the 64 nodes of an interval from those at its 32 / 16 nodes (build_reinterp)
@@ -624,6 +625,8 @@ struct Interp {
     double margin = kChebMargin;   // cs_set_tuning key 3 (per cent): distance of an interval's interpolated set, in half-widths
     int mx_min_states = 7;    // cs_set_tuning key 8
     int nfar[CS_MAX_LEVEL] = {};   // nodes for the far pieces of a level in k_cheb_nodes_mx (16, 32; 64 = as the near pieces)
+    const double *Rc[CS_MAX_LEVEL] = {};   // ChebGrid::Rc
+    int cascade = 0;               // cs_set_tuning key 12: 0 = where it pays (cascade_pays), 1 = always, 2 = never
     const double *R = nullptr;     // the context's re-interpolation matrices (cs_ctx::reinterp); NULL: every piece on 64 nodes (cs_set_tuning key 11)
     int nsplit_levels = 1;    // cs_set_tuning key 6: interval sizes (largest first) whose node sums four waves share in k_cheb_nodes_mx
     bool small_mx = false;    // cs_set_tuning key 1: the matrix-core kernels on short grids too (their four-waves-per-item variants)
@@ -639,6 +642,7 @@ static void interp_settings(const cs_ctx *ctx, Interp &itp)   // the cs_set_tuni
     itp.nsplit_levels = ctx->tune[6] > 0 ? ctx->tune[6] : 1;
     itp.mx_min_states = ctx->tune[8] > 0 ? ctx->tune[8] : 7;
     itp.R = ctx->tune[11] ? nullptr : ctx->reinterp.as<double>();
+    itp.cascade = ctx->tune[12];
 }
 
 // interval sizes worth using on this grid: an interval of width W leaves lines over (2 cut - 2.3 W) to interpolate
@@ -692,6 +696,13 @@ int cheb_build_range(ChebGrid &g, double nu_lo, double nu_hi, const double *dnu,
         HIPCHK(g.Cm[l].reserve((size_t)g.nI[l] * CS_NC * g.itv[l] * sizeof(double)));
         CS_LAUNCH(k_cheb_setup, dim3(g.nI[l]), dim3(256), 0, s, dnu, nnu, g.itv[l], g.nI[l], CS_NC,
                            g.nodes.as<double>() + (size_t)g.ioff[l] * CS_NC, g.Cm[l].as<double>());
+        HIPCHK(hipGetLastError());
+    }
+    for (int l = 1; l < g.nlev; l++) {
+        int pshift = 0;
+        for (int r = g.itv[l - 1] / g.itv[l]; r > 1; r >>= 1) pshift++;
+        HIPCHK(g.Rc[l].reserve((size_t)g.nI[l] * CS_NC * CS_NC * sizeof(double)));
+        CS_LAUNCH(k_cascade_setup, dim3(g.nI[l]), dim3(256), 0, s, g.nodes.as<double>(), g.ioff[l - 1], g.ioff[l], pshift, g.Rc[l].as<double>());
         HIPCHK(hipGetLastError());
     }
     return CS_OK;
@@ -773,13 +784,39 @@ Interp interp_view(const ChebGrid &g, const GasInterp &gi, int K, IZone *iz_over
         v.itv[l] = g.itv[l]; v.nI[l] = g.nI[l]; v.ioff[l] = g.ioff[l];
         v.nfar[l] = gi.nfar[l];
         v.Cm[l] = g.Cm[l].as<double>();
+        v.Rc[l] = g.Rc[l].as<double>();
         v.iwin[l] = gi.iwin[l].as<WaveWin>();
     }
     return v;
 }
 
 void launch_apply(hipStream_t s, const ChebApply &A, int Kpad, int64_t nnu, int kn, double base, const double *extra, double *sigma,
-                  int accumulate, bool varnc = false)
+                  int accumulate, bool varnc = false);
+// the node sums of ONE F (levels l0 ..) to the grid: level by level into the next smaller one, then the smallest (k_cheb_cascade), or
+// every level by itself
+// (measured: five levels, BASELINE configs[4]: apply 1.31 -> 1.12 ms; three levels, the bench column: 0.092 -> 0.100 ms, a 1/8 shard
+//  of it 0.029 -> 0.037 ms -- F goes through memory once more per level, and each level is one more launch)
+static bool cascade_pays(int nlevels_in_use) { return nlevels_in_use >= 4; }
+void launch_apply_cascade(hipStream_t s, ChebApply A, const double *const *Rc, const int *itv, const int *nI, int mode, int Kpad, int64_t nnu,
+                          int kn, double base, const double *extra, double *sigma, int accumulate)
+{
+    const int l0 = A.l0[0];
+    const bool on = A.ngas == 1 && A.nlev - l0 >= 2 && mode != 2 && (mode == 1 || cascade_pays(A.nlev - l0));
+    if (on) {
+        const int nst = cheb_kpad(kn) / 16;
+        double *F = const_cast<double *>(A.F[0]);
+        for (int l = l0 + 1; l < A.nlev; l++) {
+            int pshift = 0;
+            for (int r = itv[l - 1] / itv[l]; r > 1; r >>= 1) pshift++;
+            CS_LAUNCH(k_cheb_cascade, dim3((unsigned)(((int64_t)nI[l] * nst + 3) / 4)), dim3(256), 0, s, Rc[l], F, A.ioff[l - 1], A.ioff[l], pshift,
+                      nI[l], Kpad, nst);
+        }
+        A.l0[0] = A.nlev - 1;
+    }
+    launch_apply(s, A, Kpad, nnu, kn, base, extra, sigma, accumulate);
+}
+void launch_apply(hipStream_t s, const ChebApply &A, int Kpad, int64_t nnu, int kn, double base, const double *extra, double *sigma,
+                  int accumulate, bool varnc)
 {
     const int nt64 = (int)((nnu + 63) / 64);
 #ifdef CS_APPLY_VALU   // the vector-unit version (kept for A/B builds)
@@ -1129,7 +1166,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
                 A.F[A.ngas++] = itp.F;
             }
             if (!defer) {   // sigma = base + extra + interpolated far wings now; the per-point kernels add the rest
-                launch_apply(s, A, itp.Kpad, nnu, kn, base, extra, sigma, accumulate);
+                launch_apply_cascade(s, A, itp.Rc, itp.itv, itp.nI, itp.cascade, itp.Kpad, nnu, kn, base, extra, sigma, accumulate);
                 accumulate = 1;
             }               // (deferred: the caller applies the node sums of all its gases in one launch, after the last gas)
             const int low = itp.nlev - 1;
@@ -2607,7 +2644,11 @@ static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e, bool *
     }
     fork_join(&fk, s, true, false);   // the node sums; the near-line kernels may run on beside what follows (none of it touches their plane)
     // interpolated far wings of all gases: sigma += sum_level C (sum_gas F)  (one pass over C and sigma)
-    if (apply.ngas > 0) launch_apply(s, apply, cheb_kpad(K), c.nnu, K, 0.0, nullptr, sig, 1);
+    if (apply.ngas > 0) {
+        const double *Rc[CS_MAX_LEVEL];
+        for (int l = 0; l < CS_MAX_LEVEL; l++) Rc[l] = c.cheb.Rc[l].as<double>();
+        launch_apply_cascade(s, apply, Rc, c.cheb.itv, c.cheb.nI, ctx->tune[12], cheb_kpad(K), c.nnu, K, 0.0, nullptr, sig, 1);
+    }
     for (auto &t : c.tab) {  // baked gases: sigma += fC * exp(Phi(T, ln P))
         TableDev &tb = ctx->tab[t.slot];
         int rc2;
@@ -2986,7 +3027,7 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
             }
         }
         if (nlev > 0)   // the contraction that carries the node sums to the grid (k_cheb_apply_mfma, or fused into k_voigt_edge_mx)
-            fl_apply += 2.0 * CS_NC * 64.0 * 16.0 * ((K + 15) / 16) * (double)nt64 * (nlev - g.itp.l0);
+            fl_apply += 2.0 * CS_NC * 64.0 * 16.0 * ((K + 15) / 16) * (double)nt64 * (nlev - g.itp.l0);   // (per group; with the cascade: cs_column_info)
         for (int k = 0; k < K; k++)
             for (int t = 0; t < nt64; t++) {
                 WaveWin w = win[t];

@@ -1223,6 +1223,72 @@ __global__ __launch_bounds__(256) void k_cheb_apply_split(ChebApply A, int Kpad,
     }
 }
 
+// ---- cascade: the node sums of a level carried to the nodes of the next smaller one ----------------------------------------------
+// The interpolant of an interval is a polynomial of degree 63; its values at the 64 nodes of a child interval define the same
+// polynomial there.  So instead of carrying every level to the grid (levels x 64 x 64 multiply-adds per point and 16 states, and one
+// pass over every level's [64][points] matrix), each level is added into the next smaller one -- F_child += Rc F_parent, a 64 x 64
+// matrix per child interval, built like Cm from the nodes as rounded -- and only the smallest interval size is carried to the grid:
+// 64 x 64 x (1 + 1/2 + 1/4 + ...) per point instead of 64 x 64 x levels.  Exact up to rounding (same polynomials).
+// Rc[T][j][m] = l_j^parent(x_m^child)
+__global__ __launch_bounds__(256) void k_cascade_setup(const double *__restrict__ nodes, int ioff_p, int ioff_c, int pshift, double *__restrict__ Rc)
+{
+    const int T = blockIdx.x;
+    const double *__restrict__ xp = nodes + (size_t)(ioff_p + (T >> pshift)) * CS_NC, *__restrict__ xc = nodes + (size_t)(ioff_c + T) * CS_NC;
+    __shared__ double xm[CS_NC], wm[CS_NC];
+    if (threadIdx.x < CS_NC) xm[threadIdx.x] = xp[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x < CS_NC) {   // barycentric weights of the parent's nodes as rounded (k_cheb_setup)
+        const double h = 0.5 * (xm[0] - xm[CS_NC - 1]), ih = h > 0.0 ? 1.0 / h : 1.0, x = xm[threadIdx.x];
+        double prod = 1.0;
+        for (int j = 0; j < CS_NC; j++)
+            if (j != (int)threadIdx.x) prod *= 2.0 * (x - xm[j]) * ih;
+        wm[threadIdx.x] = 1.0 / prod;
+    }
+    __syncthreads();
+    const int m = threadIdx.x & (CS_NC - 1), jq = threadIdx.x >> 6;   // child node m, a quarter of the parent's nodes
+    const double v = xc[m];
+    double den = 0.0;
+    int hit = -1;
+    for (int j = 0; j < CS_NC; j++) {
+        const double d = v - xm[j];
+        if (d == 0.0) hit = j;
+        den += (d == 0.0) ? 0.0 : wm[j] / d;
+    }
+    for (int j = jq * 16; j < jq * 16 + 16; j++) {
+        const double d = v - xm[j];
+        Rc[((size_t)T * CS_NC + j) * CS_NC + m] = (hit >= 0) ? (j == hit ? 1.0 : 0.0) : (wm[j] / d) / den;
+    }
+}
+// one wave = one child interval x 16 states: D(16 child nodes x 16 states) += A(16 child nodes x 4 parent nodes) B(4 parent nodes x
+// 16 states), operands as in k_cheb_apply_mfma -- both loads and the read-modify-write of F are 128-byte runs (F is state-fastest)
+__global__ __launch_bounds__(256) void k_cheb_cascade(const double *__restrict__ Rc, double *__restrict__ F, int ioff_p, int ioff_c, int pshift,
+                                                      int nIc, int Kpad, int nst)
+{
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int item = (int)blockIdx.x * 4 + wv;
+    const int T = item / nst, sidx = item - T * nst;
+    if (T >= nIc) return;
+    const int lr = lane & 15, lq = lane >> 4;
+    const double *__restrict__ Fp = F + (size_t)(ioff_p + (T >> pshift)) * CS_NC * Kpad + (size_t)sidx * 16 + lr;
+    double *__restrict__ Fc = F + (size_t)(ioff_c + T) * CS_NC * Kpad + (size_t)sidx * 16 + lr;
+    const double *__restrict__ R = Rc + (size_t)T * CS_NC * CS_NC + lr;
+    typedef double v4 __attribute__((ext_vector_type(4)));
+    v4 acc[4];
+#pragma unroll
+    for (int st = 0; st < 4; st++) acc[st] = v4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int kk = 0; kk < CS_NC / 4; kk++) {
+        const int j = 4 * kk + lq;
+        const double b = Fp[(size_t)j * Kpad];
+#pragma unroll
+        for (int st = 0; st < 4; st++) acc[st] = __builtin_amdgcn_mfma_f64_16x16x4f64(R[(size_t)j * CS_NC + 16 * st], b, acc[st], 0, 0, 0);
+    }
+#pragma unroll
+    for (int st = 0; st < 4; st++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) Fc[(size_t)(16 * st + 4 * r + lq) * Kpad] += acc[st][r];
+}
+
 // The same contraction on the matrix cores: v_mfma_f64_16x16x4_f64 computes D(16 states x 16 nu) += A(16 states x 4 nodes) *
 // B(4 nodes x 16 nu).  Operand layout on gfx950 (tools/ubench/mfma_f64_layout.hip): lane l holds A[l%16][l/16], B[l/16][l%16] and,
 // in register r, D[4r + l/16][l%16] -- with states as the rows of D a store of one register is four 128-byte runs of consecutive

@@ -14,6 +14,8 @@ run c3_nomerge --no-merge
 run c3_nomatrix --matrix-cores 0
 run lorentz --shape lorentz
 run doppler --shape doppler
+run phco2 --shape PHCO2 --steps 10 --warmup 2
+run phco2_pointwise --shape PHCO2 --steps 3 --warmup 1 --no-interp
 run shard0 --emulate-shard 0/8
 run shard3 --emulate-shard 3/8
 run shard7 --emulate-shard 7/8
