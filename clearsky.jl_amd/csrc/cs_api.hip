@@ -626,6 +626,7 @@ struct Interp {
     int mx_min_states = 7;    // cs_set_tuning key 8
     int nfar[CS_MAX_LEVEL] = {};   // nodes for the far pieces of a level in k_cheb_nodes_mx (16, 32; 64 = as the near pieces)
     const double *Rc[CS_MAX_LEVEL] = {};   // ChebGrid::Rc
+    int nodes_split = 0;           // cs_set_tuning key 13: k_cheb_nodes with four waves per (interval, state)
     int cascade = 0;               // cs_set_tuning key 12: 0 = where it pays (cascade_pays), 1 = always, 2 = never
     const double *R = nullptr;     // the context's re-interpolation matrices (cs_ctx::reinterp); NULL: every piece on 64 nodes (cs_set_tuning key 11)
     int nsplit_levels = 1;    // cs_set_tuning key 6: interval sizes (largest first) whose node sums four waves share in k_cheb_nodes_mx
@@ -643,6 +644,7 @@ static void interp_settings(const cs_ctx *ctx, Interp &itp)   // the cs_set_tuni
     itp.mx_min_states = ctx->tune[8] > 0 ? ctx->tune[8] : 7;
     itp.R = ctx->tune[11] ? nullptr : ctx->reinterp.as<double>();
     itp.cascade = ctx->tune[12];
+    itp.nodes_split = ctx->tune[13];
 }
 
 // interval sizes worth using on this grid: an interval of width W leaves lines over (2 cut - 2.3 W) to interpolate
@@ -1080,7 +1082,9 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
             const int q0 = itp.ioff[itp.l0];
             // deferred apply: the gases of a column add their node sums into ONE F (levels an earlier gas has written accumulate)
             const int q_acc = (defer && defer->ngas > 0 && defer->l0[0] < itp.nlev) ? itp.ioff[defer->l0[0]] : itp.nItot;
-            const dim3 gridn((unsigned)((kn + 3) / 4) * (unsigned)(itp.nItot - q0));
+            // short grids: four waves per (interval, state) (cs_set_tuning key 13: 0 = below 16384 waves, 1 = always, 2 = never)
+            const bool nsplit4 = itp.nodes_split == 1 || (itp.nodes_split == 0 && (int64_t)(itp.nItot - q0) * kn < 16384);
+            const dim3 gridn(nsplit4 ? (unsigned)kn * (unsigned)(itp.nItot - q0) : (unsigned)((kn + 3) / 4) * (unsigned)(itp.nItot - q0));
             const int ngrp = (kn + 15) / 16;
             const bool use_sep = sep_in_use(itp.sep != nullptr, itp.sep_always, itp.nItot - q0, kn, lor, hot32 != nullptr, itp.small_mx);
             use_edge = edge_in_use(itp.edge != nullptr, itp.sep_always, nt64, kn, lor, hot32 != nullptr, jhi - jlo, itp.small_mx);
@@ -1108,15 +1112,16 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
                 (void)hipStreamWaitEvent(fork->s2, fork->ev_fork, 0);
                 s = fork->s2;     // the two node kernels below run beside what follows them on the main stream
             }
+#define NODES_LAUNCH(M, L_, M4, L4, S4) do { if (nsplit4) CS_LAUNCH((k_cheb_nodes<M4, L4, S4>), gridn, dim3(256), 0, s, itp.nodes, G.L, hot, hot32, G.nu.as<double>(), itp.iz, \
+                                   itp.nItot, q0, q_acc, kn, itp.Kpad, cut, itp.F, sepz); \
+            else CS_LAUNCH((k_cheb_nodes<M, L_>), gridn, dim3(256), 0, s, itp.nodes, G.L, hot, hot32, G.nu.as<double>(), itp.iz, \
+                                   itp.nItot, q0, q_acc, kn, itp.Kpad, cut, itp.F, sepz); } while (0)
             if (lor)
-                CS_LAUNCH((k_cheb_nodes<false, true>), gridn, dim3(256), 0, s, itp.nodes, G.L, hot, hot32, G.nu.as<double>(), itp.iz,
-                                   itp.nItot, q0, q_acc, kn, itp.Kpad, cut, itp.F, sepz);
+                NODES_LAUNCH(false, true, false, true, 4);
             else if (hot32)
-                CS_LAUNCH((k_cheb_nodes<true, false>), gridn, dim3(256), 0, s, itp.nodes, G.L, hot, hot32, G.nu.as<double>(), itp.iz,
-                                   itp.nItot, q0, q_acc, kn, itp.Kpad, cut, itp.F, sepz);
+                NODES_LAUNCH(true, false, true, false, 4);
             else
-                CS_LAUNCH((k_cheb_nodes<false, false>), gridn, dim3(256), 0, s, itp.nodes, G.L, hot, hot32, G.nu.as<double>(), itp.iz,
-                                   itp.nItot, q0, q_acc, kn, itp.Kpad, cut, itp.F, sepz);
+                NODES_LAUNCH(false, false, false, false, 4);
             if (evg) (void)hipEventRecord(evg[1], s);
             if (use_sep) {
                 const int nq = itp.nItot - q0;

@@ -706,13 +706,16 @@ struct __attribute__((aligned(16))) EdgeZone { int32_t eL, mL0, mL1, mR0, mR1, e
 template <bool MIXED, bool LOR>
 __device__ __forceinline__ double node_sum_valu(double v, const LineHot *__restrict__ hk, const LineF32 *__restrict__ hf,
                                                 const double *__restrict__ gnul, const IZone &z, const int (&sa)[4], const int (&sb)[4],
-                                                double cut, const FarK &c)
+                                                double cut, const FarK &c, int part = 0, int nparts = 1)
 {
+    // part / nparts: this wave's share of every window (short grids: the waves of a block split the lines of one (interval, state))
     double accL = 0.0, accR = 0.0;
     {
         const int wl[4] = {z.E0, sb[0], z.P1, sb[1]}, wh[4] = {sa[0], z.P0, sa[1], z.Z0};
         for (int cw = 0; cw < 4; cw++) {
-            const int p0 = wl[cw], p1 = wh[cw];
+            const int w0 = wl[cw], w1 = wh[cw];
+            if (w0 >= w1) continue;
+            const int p0 = w0 + (int)((int64_t)(w1 - w0) * part / nparts), p1 = w0 + (int)((int64_t)(w1 - w0) * (part + 1) / nparts);
             if (p0 >= p1) continue;
 #define LO(x) max((x), p0)
 #define HI(x) min((x), p1)
@@ -729,7 +732,9 @@ __device__ __forceinline__ double node_sum_valu(double v, const LineHot *__restr
     {
         const int wl[4] = {sb[3], z.P3, sb[2], z.Z1}, wh[4] = {z.E1, sa[3], z.P2, sa[2]};   // far end first
         for (int cw = 0; cw < 4; cw++) {
-            const int p0 = wl[cw], p1 = wh[cw];
+            const int w0 = wl[cw], w1 = wh[cw];
+            if (w0 >= w1) continue;
+            const int p0 = w0 + (int)((int64_t)(w1 - w0) * part / nparts), p1 = w0 + (int)((int64_t)(w1 - w0) * (part + 1) / nparts);
             if (p0 >= p1) continue;
             if (MIXED) {
                 accR = far_segment32_rev<false, 0>(accR, v, gnul, hf, LO(z.Q1), HI(z.E1), cut);
@@ -746,7 +751,7 @@ __device__ __forceinline__ double node_sum_valu(double v, const LineHot *__restr
     return accL + accR;
 }
 
-template <bool MIXED, bool LOR>
+template <bool MIXED, bool LOR, int S = 1>   // S = 4 (short grids): the four waves of a block share ONE (interval, state), a quarter of every window each
 __global__ __launch_bounds__(256) void k_cheb_nodes(const double *__restrict__ nodes, int64_t L, const LineHot *__restrict__ hot,
                                                      const LineF32 *__restrict__ hot32, const double *__restrict__ gnul,
                                                      const IZone *__restrict__ iz, int nItot, int q0, int q_acc, int K, int Kpad, double cut,
@@ -756,16 +761,18 @@ __global__ __launch_bounds__(256) void k_cheb_nodes(const double *__restrict__ n
     // is linear, so k_cheb_apply then carries the SUM over gases to the grid in one pass per level instead of one per (gas, level).
     // 1-D grid (an interval list can exceed the 65535 limit of gridDim.y): block = interval * nsb + state block, state fastest;
     // intervals q0 .. nItot-1 (the levels this gas uses)
+    __shared__ double red[S > 1 ? 3 : 1][64];
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int nsb = (K + 3) >> 2;
+    const int nsb = S > 1 ? K : (K + 3) >> 2;
     const int T = q0 + (int)(blockIdx.x / nsb);
     // state block rotated by the interval: workgroups go round-robin to the 8 XCDs, and with the matrix cores taking most far lines
     // of the low-pressure states the work left here sits in the last state blocks -- unrotated, on half of the XCDs.
     // (Tried in round 3: one contiguous stretch of every level's intervals per XCD, cut at equal sums of window sizes, so that the ~5
     // neighbouring intervals that read a record share an L2 -- FETCH_SIZE 336 -> 291 MB here, 470 -> 448 MB in k_cheb_nodes_mx, but
     // 0.37 -> 0.43 ms: the in-flight footprint of an XCD's blocks is several times its 4 MB L2 either way, profiles/r03_notes.md.)
-    const int k = (int)((blockIdx.x % nsb + (sep ? T : 0)) % nsb) * 4 + wv;   // (unrotated, a state block stays on one XCD: its records stay in that L2)
-    if (k >= K) return;
+    const int k = S > 1 ? (int)((blockIdx.x % nsb + (sep ? T : 0)) % nsb)
+                        : (int)((blockIdx.x % nsb + (sep ? T : 0)) % nsb) * 4 + wv;   // (unrotated, a state block stays on one XCD: its records stay in that L2)
+    if (S == 1 && k >= K) return;
     const LineHot *__restrict__ hk = hot + (size_t)k * L;
     const LineF32 *__restrict__ hf = MIXED ? hot32 + (size_t)k * L : nullptr;
     const double v = nodes[(size_t)T * CS_NC + lane];
@@ -782,7 +789,13 @@ __global__ __launch_bounds__(256) void k_cheb_nodes(const double *__restrict__ n
             if (pb > pa) { sa[p] = pa; sb[p] = pb; }
         }
     }
-    const double acc = node_sum_valu<MIXED, LOR>(v, hk, hf, gnul, z, sa, sb, cut, c);
+    double acc = node_sum_valu<MIXED, LOR>(v, hk, hf, gnul, z, sa, sb, cut, c, S > 1 ? wv : 0, S);
+    if (S > 1) {   // partial sums added in wave order (bitwise repeatable)
+        if (wv > 0) red[wv - 1][lane] = acc;
+        __syncthreads();
+        if (wv > 0) return;
+        acc = ((acc + red[0][lane]) + red[1][lane]) + red[2][lane];
+    }
     double *__restrict__ Fo = F + ((size_t)T * CS_NC + lane) * Kpad + k;
     *Fo = T >= q_acc ? *Fo + acc : acc;
 }

@@ -137,7 +137,9 @@ int cs_set_merge(cs_ctx *ctx, int on);
  *   key 11: the far pieces of an interval's matrix-core node sums (the lines beyond its parent's set: 3.8 .. 12 half-widths away on
  *          the bench grid) are summed on 32 or 16 nodes and carried to the interval's 64 (0, default), or on all 64 (1);
  *   key 12: the node sums of a level are added into the next smaller level's (a 64 x 64 matrix per interval) and only the smallest
- *          interval size is carried to the grid (k_cheb_cascade) -- 0 (default) with four or more levels in use, 1 always, 2 never.
+ *          interval size is carried to the grid (k_cheb_cascade) -- 0 (default) with four or more levels in use, 1 always, 2 never;
+ *   key 13: the vector-unit node kernel with four waves per (interval, state), a quarter of every window each -- 0 (default) on
+ *          grids of fewer than 16384 (interval, state) waves (a nu-shard), 1 always, 2 never.
  * Applies to every later cs_column_setup / cs_column_run of the context. */
 int cs_set_tuning(cs_ctx *ctx, int key, int value);
 
