@@ -294,6 +294,24 @@ def test_phco2_interpolated_wings(cs, O, lines, ctx_on, ctx_off):
     assert abs(res[0][1][0][0] - res[1][1][0][0]) < 1e-12 * res[1][1][0][0]
 
 
+def test_phco2_ragged_grids(cs, O, lines, ctx_on, ctx_off):
+    """PHCO2 interval machinery on grids that are not the bench's: geometric spacing (interval widths differ along the grid, so the
+    node counts follow the widest interval of a size and a region may be carried at one size and not the next), a grid that starts
+    below the cut-off (no lower bound on the Doppler width: four-term body everywhere), a grid shorter than one interval (every pair per
+    point) and one with tiles wider than a region (the generic kernel) -- each against the per-point path and the oracle."""
+    dense = cs.SpectralLines.synthetic(2, 6000, 17, numin=1.0, numax=1500.0)
+    T, P, Pp = map(list, zip(*STATES[:3]))
+    grids = (np.geomspace(400.0, 900.0, 9001), np.linspace(5.0, 260.0, 10201), np.linspace(700.0, 702.0, 90),
+             np.linspace(100.0, 1300.0, 2400))
+    for nu in grids:
+        a = cs.shape_batch(dense, "PHCO2", nu, T, P, Pp, 500.0, ctx_on)
+        b = cs.shape_batch(dense, "PHCO2", nu, T, P, Pp, 500.0, ctx_off)
+        assert np.array_equal(a == 0, b == 0)
+        assert relerr(a, b, floor=1e-250) < 5e-13
+        so = O.shape_bang("PHCO2", nu, dense, T[1], P[1], Pp[1], 500.0)
+        assert relerr(a[1], so, floor=1e-250) < 2e-11
+
+
 def test_matrix_core_node_sums_on_off(cs, O, lines):
     """K2d, K2e, K2f: far lines inside the validity range of the 4-term series in 1/dnu^2 are summed as matrix products on
     v_mfma_f64_16x16x4 -- at the interpolation nodes (k_cheb_nodes_mx) and, for the window ends of the per-point sum with the
