@@ -287,9 +287,13 @@ struct cs_ctx {
     int matrix_nodes = 1;   // cs_set_matrix_cores: separable far-wing node sums on v_mfma_f64 (k_cheb_nodes_mx)
     int matrix_core = 1;    // ... and the window core on sub-tiles (k_voigt_sub + the second mask of k_voigt_edge_mx)
     int merge = 1;          // cs_set_merge: gases of a column with the same shape and cut-off share one merged line table
-    // cs_set_tuning: [0] interpolated wings applied inside k_voigt_edge_mx where one launch group has them, [1] matrix-core kernels on
-    // short grids (four waves per item), [2] node sums on a side stream (1: short grids only, 2: always)
-    int tune[CS_NTUNE] = {0, 1, 2, 0, 0, 1, 0, 1, 7, 0, 0, 0, 0, 0, 0, 0};   // ... [8] states of a group that must be able to use a line for it to join the group's matrix-core node piece   // [6] split levels of k_cheb_nodes_mx, [7] near-line kernels on a second side stream   // ... [3] interpolation margin (per cent), [4] hipGraph replay, [5] k_rt_streams on short grids
+    // cs_set_tuning (include/clearsky_hip.h has the full descriptions): [0] interpolated wings applied inside k_voigt_edge_mx, [1]
+    // matrix-core kernels on short grids, [2] node sums on a side stream, [3] interpolation margin (per cent), [4] hipGraph replay, [5]
+    // k_rt_streams on short grids, [6] split levels of k_cheb_nodes_mx, [7] near-line kernels on a second side stream, [8] states of a
+    // group that must be able to use a line for it to join the group's matrix-core node piece, [9] PHCO2 core in k_phco2 itself, [10]
+    // PHCO2 node counts / 64-point intervals, [11] far pieces of the node sums on all 64 nodes, [12] level cascade, [13] k_cheb_nodes
+    // with four waves per (interval, state)
+    int tune[CS_NTUNE] = {0, 1, 2, 0, 0, 1, 0, 1, 7, 0, 0, 0, 0, 0, 0, 0};
     std::vector<std::unique_ptr<GasTable>> merged;   // merged tables (keyed by their members' (slot, generation)), a few kept
     double far_s = 1e6;
     DevBuf reinterp;        // [64][32] then [64][16]: values at the 64 nodes of an interval from those at its 32 / 16 nodes (build_reinterp)
