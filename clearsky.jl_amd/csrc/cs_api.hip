@@ -292,7 +292,7 @@ struct cs_ctx {
     // k_rt_streams on short grids, [6] split levels of k_cheb_nodes_mx, [7] near-line kernels on a second side stream, [8] states of a
     // group that must be able to use a line for it to join the group's matrix-core node piece, [9] PHCO2 core in k_phco2 itself, [10]
     // PHCO2 node counts / 64-point intervals, [11] far pieces of the node sums on all 64 nodes, [12] level cascade, [13] k_cheb_nodes
-    // with four waves per (interval, state)
+    // with four waves per (interval, state), [14] cut-off edges of k_voigt_edge_mx without the sub-tile phases
     int tune[CS_NTUNE] = {0, 1, 2, 0, 0, 1, 0, 1, 7, 0, 0, 0, 0, 0, 0, 0};
     std::vector<std::unique_ptr<GasTable>> merged;   // merged tables (keyed by their members' (slot, generation)), a few kept
     double far_s = 1e6;
@@ -630,6 +630,7 @@ struct Interp {
     int mx_min_states = 7;    // cs_set_tuning key 8
     int nfar[CS_MAX_LEVEL] = {};   // nodes for the far pieces of a level in k_cheb_nodes_mx (16, 32; 64 = as the near pieces)
     const double *Rc[CS_MAX_LEVEL] = {};   // ChebGrid::Rc
+    int edge_phases = 1;           // cs_set_tuning key 14: k_voigt_edge_mx cuts a cut-off edge by the sub-tiles its lines reach (0: off)
     int nodes_split = 0;           // cs_set_tuning key 13: k_cheb_nodes with four waves per (interval, state)
     int cascade = 0;               // cs_set_tuning key 12: 0 = where it pays (cascade_pays), 1 = always, 2 = never
     const double *R = nullptr;     // the context's re-interpolation matrices (cs_ctx::reinterp); NULL: every piece on 64 nodes (cs_set_tuning key 11)
@@ -649,6 +650,7 @@ static void interp_settings(const cs_ctx *ctx, Interp &itp)   // the cs_set_tuni
     itp.R = ctx->tune[11] ? nullptr : ctx->reinterp.as<double>();
     itp.cascade = ctx->tune[12];
     itp.nodes_split = ctx->tune[13];
+    itp.edge_phases = ctx->tune[14] ? 0 : 1;
 }
 
 // interval sizes worth using on this grid: an interval of width W leaves lines over (2 cut - 2.3 W) to interpolate
@@ -1258,10 +1260,10 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
             if (fuse) fork_join(fork, s);   // (it reads F)
             if (mx_big(nt64, kn, 1024))
                 CS_LAUNCH(k_voigt_edge_mx<1>, dim3((unsigned)((nt64 + 3) / 4), (unsigned)((kn + 15) / 16)), dim3(256), 0, s, dnu, nnu, G.L, hot, win,
-                          itp.edge, nt64, kn, cut, sigma, fuse ? 1 : 0, Afuse, itp.Kpad);
+                          itp.edge, nt64, kn, cut, sigma, fuse ? 1 : 0, Afuse, itp.Kpad, G.nu.as<double>(), itp.edge_phases);
             else   // short grid: four waves per (tile, group)
                 CS_LAUNCH(k_voigt_edge_mx<4>, dim3((unsigned)nt64, (unsigned)((kn + 15) / 16)), dim3(256), 0, s, dnu, nnu, G.L, hot, win,
-                          itp.edge, nt64, kn, cut, sigma, fuse ? 1 : 0, Afuse, itp.Kpad);
+                          itp.edge, nt64, kn, cut, sigma, fuse ? 1 : 0, Afuse, itp.Kpad, G.nu.as<double>(), itp.edge_phases);
         }
         if (evg) (void)hipEventRecord(evg[5], s);
         if (!lor && !near_fork) launch_near(s, sigma);
@@ -3027,8 +3029,36 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
                         }
                         fl_edge_useful += 2.0 * nt * cols * ns;
                     };
-                    piece(w.W0, e.eL, (e.far3 & 1) ? 3 : 4, 1);
-                    piece(e.eR, w.W1, (e.far3 & 2) ? 3 : 4, 1);
+                    // the cut-off edges, cut where the next sub-tile comes into reach (k_voigt_edge_mx's phases: one wave per (tile, group) only)
+                    const bool phased = !ctx->tune[14] && mx_big(nt64, K, 1024);
+                    auto end_piece = [&](int ja, int jb, int nt, bool left) {
+                        if (jb <= ja) return;
+                        if (!phased || jb - ja < 48) { piece(ja, jb, nt, 1); return; }
+                        const double issued0 = fl_edge_issued;
+                        piece(ja, jb, nt, 1);              // (for the useful flops)
+                        fl_edge_issued = issued0;
+                        const double tolc = 1e-9 * (std::fabs(v0[0]) + g.cut + 1.0);
+                        int cutp[5];
+                        if (left) {
+                            cutp[0] = ja; cutp[4] = jb;
+                            for (int q = 0; q < 3; q++) {
+                                const double *col = vv + std::min<int64_t>((int64_t)t * 64 + 16 * (q + 1), c.nnu - 1);
+                                cutp[q + 1] = (int)(std::lower_bound(nl + ja, nl + jb, *col - g.cut - tolc) - nl);
+                            }
+                            for (int q = 1; q < 5; q++) cutp[q] = std::max(cutp[q], cutp[q - 1]);
+                            for (int q = 0; q < 4; q++) fl_edge_issued += 2.0 * nt * 16.0 * (q + 1) * 16.0 * ((cutp[q + 1] - cutp[q] + 3) / 4 * 4);
+                        } else {
+                            cutp[0] = ja; cutp[4] = jb;
+                            for (int q = 0; q < 3; q++) {
+                                const double *col = vv + std::min<int64_t>((int64_t)t * 64 + 16 * q + 15, c.nnu - 1);
+                                cutp[q + 1] = (int)(std::upper_bound(nl + ja, nl + jb, *col + g.cut + tolc) - nl);
+                            }
+                            for (int q = 1; q < 5; q++) cutp[q] = std::max(cutp[q], cutp[q - 1]);
+                            for (int q = 0; q < 4; q++) fl_edge_issued += 2.0 * nt * 16.0 * (4 - q) * 16.0 * ((cutp[q + 1] - cutp[q] + 3) / 4 * 4);
+                        }
+                    };
+                    end_piece(w.W0, e.eL, (e.far3 & 1) ? 3 : 4, true);
+                    end_piece(e.eR, w.W1, (e.far3 & 2) ? 3 : 4, false);
                     if (e.mL1 > e.mL0) { piece(e.mL0, e.mL3, 3, 1); piece(e.mL3, e.mL1, 4, 1); }
                     if (e.mR1 > e.mR0) { piece(e.mR3, e.mR1, 3, 1); piece(e.mR0, e.mR3, 4, 1); }
                     if (e.cR > e.cL) piece(e.cL, e.cR, (e.far3 & 4) ? 8 : 4, 2);

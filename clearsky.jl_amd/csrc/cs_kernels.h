@@ -841,9 +841,11 @@ typedef double v4f64_sep __attribute__((ext_vector_type(4)));
 // one step of the matrix-core sums: 4 lines x 64 columns (nodes or points) x 16 states.  The lane's record as (state lr, line lq)
 // gives the NT coefficients (A operands) and, as (column lr, line lq), the line position; vn[st] = the lane's column of sub-tile
 // st.  MASK: w = 0 beyond the cut-off (line_shapes.jl:10).  4 NT matrix instructions.
-template <int NT, int MASK, int NST = 4>   // MASK 1: w = 0 beyond the cut-off; 2: also inside the radius rin (those pairs are k_voigt_sub's)
-__device__ __forceinline__ void sep_step(v4f64_sep (&acc)[NST], const double (&vn)[NST], const LineHot &h, bool valid, double cut, double rin = 0.0)
-{   // NST sub-tiles of 16 columns (4: a 64-point tile or the 64 nodes of an interval; 1, 2: a far piece on 16 or 32 nodes)
+template <int NT, int MASK, int NST = 4, int ST0 = 0, int NA = 4>   // MASK 1: w = 0 beyond the cut-off; 2: also inside the radius rin (those pairs are k_voigt_sub's)
+__device__ __forceinline__ void sep_step(v4f64_sep (&acc)[NA], const double (&vn)[NA], const LineHot &h, bool valid, double cut, double rin = 0.0)
+{   // the NST sub-tiles of 16 columns from ST0 on (4: a 64-point tile or the 64 nodes of an interval; 1, 2: a far piece on 16 or 32
+    // nodes; 1 .. 3 from either end: a cut-off edge whose far lines reach only the first or last columns of the tile)
+    static_assert(ST0 + NST <= NA, "sub-tile range");
     const double id2 = rcp_nr1(h.p1 * h.p1);
     const double y2 = h.p2;
     // a_n = (A y / sqrt(pi)) c_n(y^2) / d^(2n), c_n from tools/voigt_series.py (exact rationals, all representable)
@@ -862,7 +864,7 @@ __device__ __forceinline__ void sep_step(v4f64_sep (&acc)[NST], const double (&v
                                                                                           -42229.6875), 88682.34375), -73901.953125), 15836.1328125);
     }
 #pragma unroll
-    for (int st = 0; st < NST; st++) {
+    for (int st = ST0; st < ST0 + NST; st++) {
         const double dv = vn[st] - h.nul;
         const double s2 = dv * dv;
         double w = rcp_fast(s2);
@@ -884,8 +886,8 @@ __device__ __forceinline__ void sep_step(v4f64_sep (&acc)[NST], const double (&v
 // matrix instructions of step t and waited for after them
 // [jlo_ok, jhi_ok): the lines of the run this LANE's state takes part in (its coefficients are zero for the others: a state whose own
 // series radius excludes a line of the group's piece leaves it to the vector-unit kernel)
-template <int NT, int MASK, int NST = 4>
-__device__ __forceinline__ void sep_run(v4f64_sep (&acc)[NST], const double (&vn)[NST], const LineHot *__restrict__ hk, int ja, int jb, bool asc,
+template <int NT, int MASK, int NST = 4, int ST0 = 0, int NA = 4>
+__device__ __forceinline__ void sep_run(v4f64_sep (&acc)[NA], const double (&vn)[NA], const LineHot *__restrict__ hk, int ja, int jb, bool asc,
                                         int lq, double cut, double rin = 0.0, int jlo_ok = -0x7fffffff, int jhi_ok = 0x7fffffff)
 {
     if (ja >= jb) return;
@@ -897,7 +899,7 @@ __device__ __forceinline__ void sep_run(v4f64_sep (&acc)[NST], const double (&vn
     for (int t = 0; t < nst; t++) {
         const LineHot nxt = rec(t + 1);      // (past the end: a harmless re-read of an end record, never used)
         __builtin_amdgcn_sched_barrier(0);   // keep the load here: the scheduler would sink it behind the matrix instructions
-        sep_step<NT, MASK, NST>(acc, vn, cur, ok(t), cut, rin);
+        sep_step<NT, MASK, NST, ST0, NA>(acc, vn, cur, ok(t), cut, rin);
         __builtin_amdgcn_sched_barrier(0);   // ... and the wait for it there
         cur = nxt;
     }
@@ -1010,12 +1012,12 @@ __device__ __forceinline__ void mx_far_pieces(v4f64_sep (&acc)[4], const SepZone
         af[st] = v4f64_sep{0.0, 0.0, 0.0, 0.0};
     }
     if (z.b[0] > z.a[0]) {   // left of the interval, ascending: the 3-term part (the far end) first
-        if (z.m[0] > z.a[0]) sep_run<3, 0, NST>(af, vf, hk, z.a[0], z.m[0], true, lq, 0.0, 0.0, -0x7fffffff, S0k);
-        if (z.b[0] > z.m[0]) sep_run<4, 0, NST>(af, vf, hk, z.m[0], z.b[0], true, lq, 0.0, 0.0, -0x7fffffff, S0k);
+        if (z.m[0] > z.a[0]) sep_run<3, 0, NST, 0, NST>(af, vf, hk, z.a[0], z.m[0], true, lq, 0.0, 0.0, -0x7fffffff, S0k);
+        if (z.b[0] > z.m[0]) sep_run<4, 0, NST, 0, NST>(af, vf, hk, z.m[0], z.b[0], true, lq, 0.0, 0.0, -0x7fffffff, S0k);
     }
     if (z.b[3] > z.a[3]) {   // right of it, descending
-        if (z.b[3] > z.m[3]) sep_run<3, 0, NST>(af, vf, hk, z.m[3], z.b[3], false, lq, 0.0, 0.0, S1k);
-        if (z.m[3] > z.a[3]) sep_run<4, 0, NST>(af, vf, hk, z.a[3], z.m[3], false, lq, 0.0, 0.0, S1k);
+        if (z.b[3] > z.m[3]) sep_run<3, 0, NST, 0, NST>(af, vf, hk, z.m[3], z.b[3], false, lq, 0.0, 0.0, S1k);
+        if (z.m[3] > z.a[3]) sep_run<4, 0, NST, 0, NST>(af, vf, hk, z.a[3], z.m[3], false, lq, 0.0, 0.0, S1k);
     }
     // acc[state][m] += sum_j af[state][j] R[m][j]: af goes through LDS from the D layout (state 4r + lq, node lr) to the A layout
     // (state lr, node lq of a group of four)
@@ -1678,8 +1680,13 @@ __global__ __launch_bounds__(256) void k_mxzones(unsigned nb_sep, SepArgs sa, Ed
 template <int SPLIT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_voigt_edge_mx(const double *__restrict__ nu, int64_t nnu, int64_t L, const LineHot *__restrict__ hot,
                                                        const WaveWin *__restrict__ win, const EdgeZone *__restrict__ edge, int ntile, int K,
-                                                       double cut, double *__restrict__ sigma, int fuse, ChebApply A, int Kpad)
+                                                       double cut, double *__restrict__ sigma, int fuse, ChebApply A, int Kpad,
+                                                       const double *__restrict__ gnul, int phases)
 {
+    // phases (SPLIT = 1): the far lines of a cut-off edge reach only the first (left end) or last (right end) columns of the tile, and
+    // the reach grows with the line index -- so the window end is cut where the next 16-column sub-tile comes into reach, and each
+    // part multiplies only the sub-tiles it can reach (a per-step test of "sub-tile all masked" cost what it saved; these are four
+    // loops with the sub-tile count fixed at compile time).  gnul: the table's line positions (state-independent).
     __shared__ double part[SPLIT > 1 ? 4 : 1][SPLIT > 1 ? 16 : 1][SPLIT > 1 ? CS_MX_PITCH : 1];
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     // (2-D grid, tile blocks fastest: consecutive blocks are neighbouring tiles of ONE state group, whose pieces overlap by half --
@@ -1730,14 +1737,73 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     };
     int ja, jb;
     // left pieces ascending, right pieces descending: far lines first; three terms where they do
-    run(w.W0, e.eL, true, ja, jb);
-    if (e.far3 & 1) sep_run<3, 1>(acc, vn, hk, ja, jb, true, lq, cut); else sep_run<4, 1>(acc, vn, hk, ja, jb, true, lq, cut);
+    const bool ph = SPLIT == 1 && phases && gnul;
+    const double tolc = 1e-9 * (fabs(__shfl(vn[0], 0)) + cut + 1.0);
+    if (ph && e.eL - w.W0 >= 48) {   // (shorter ends: the four partial loops and their step fill cost more than the skipped sub-tiles -- C5: 0.350 -> 0.386 ms)
+        // J[q]: first line of [W0, eL) whose cut-off reaches sub-tile q + 1 (its first column): one vector load per 64 lines and ballots
+        const int p0 = w.W0, p1 = e.eL;
+        int J[3] = {p1, p1, p1};
+        const double a0 = __shfl(vn[1], 0) - cut - tolc, a1 = __shfl(vn[2], 0) - cut - tolc, a2 = __shfl(vn[3], 0) - cut - tolc;
+        for (int base = p0; base < p1; base += 64) {
+            const int j = base + lane;
+            const double x = gnul[j < p1 ? j : p1 - 1];
+            const uint64_t m0 = __builtin_amdgcn_ballot_w64(j < p1 && x >= a0), m1 = __builtin_amdgcn_ballot_w64(j < p1 && x >= a1),
+                           m2 = __builtin_amdgcn_ballot_w64(j < p1 && x >= a2);
+            if (m0 != 0 && J[0] == p1) J[0] = base + __builtin_ctzll(m0);
+            if (m1 != 0 && J[1] == p1) J[1] = base + __builtin_ctzll(m1);
+            if (m2 != 0 && J[2] == p1) J[2] = base + __builtin_ctzll(m2);
+        }
+        J[1] = max(J[1], J[0]); J[2] = max(J[2], J[1]);
+        if (e.far3 & 1) {
+            sep_run<3, 1, 1, 0>(acc, vn, hk, p0, J[0], true, lq, cut);
+            sep_run<3, 1, 2, 0>(acc, vn, hk, J[0], J[1], true, lq, cut);
+            sep_run<3, 1, 3, 0>(acc, vn, hk, J[1], J[2], true, lq, cut);
+            sep_run<3, 1, 4, 0>(acc, vn, hk, J[2], p1, true, lq, cut);
+        } else {
+            sep_run<4, 1, 1, 0>(acc, vn, hk, p0, J[0], true, lq, cut);
+            sep_run<4, 1, 2, 0>(acc, vn, hk, J[0], J[1], true, lq, cut);
+            sep_run<4, 1, 3, 0>(acc, vn, hk, J[1], J[2], true, lq, cut);
+            sep_run<4, 1, 4, 0>(acc, vn, hk, J[2], p1, true, lq, cut);
+        }
+    } else {
+        run(w.W0, e.eL, true, ja, jb);
+        if (e.far3 & 1) sep_run<3, 1>(acc, vn, hk, ja, jb, true, lq, cut); else sep_run<4, 1>(acc, vn, hk, ja, jb, true, lq, cut);
+    }
     if (e.mL1 > e.mL0) {
         run(e.mL0, e.mL3, true, ja, jb); sep_run<3, 1>(acc, vn, hk, ja, jb, true, lq, cut);
         run(e.mL3, e.mL1, true, ja, jb); sep_run<4, 1>(acc, vn, hk, ja, jb, true, lq, cut);
     }
-    run(e.eR, w.W1, false, ja, jb);
-    if (e.far3 & 2) sep_run<3, 1>(acc, vn, hk, ja, jb, false, lq, cut); else sep_run<4, 1>(acc, vn, hk, ja, jb, false, lq, cut);
+    if (ph && w.W1 - e.eR >= 48) {
+        // U[q]: first line of [eR, W1) whose cut-off no longer reaches sub-tile q (its last column); lines from U[q] on need the
+        // sub-tiles q + 1 .. 3 only
+        const int p0 = e.eR, p1 = w.W1;
+        int U[3] = {p1, p1, p1};
+        const double b0 = __shfl(vn[0], 15) + cut + tolc, b1 = __shfl(vn[1], 15) + cut + tolc, b2 = __shfl(vn[2], 15) + cut + tolc;
+        for (int base = p0; base < p1; base += 64) {
+            const int j = base + lane;
+            const double x = gnul[j < p1 ? j : p1 - 1];
+            const uint64_t m0 = __builtin_amdgcn_ballot_w64(j < p1 && x > b0), m1 = __builtin_amdgcn_ballot_w64(j < p1 && x > b1),
+                           m2 = __builtin_amdgcn_ballot_w64(j < p1 && x > b2);
+            if (m0 != 0 && U[0] == p1) U[0] = base + __builtin_ctzll(m0);
+            if (m1 != 0 && U[1] == p1) U[1] = base + __builtin_ctzll(m1);
+            if (m2 != 0 && U[2] == p1) U[2] = base + __builtin_ctzll(m2);
+        }
+        U[1] = max(U[1], U[0]); U[2] = max(U[2], U[1]);
+        if (e.far3 & 2) {
+            sep_run<3, 1, 1, 3>(acc, vn, hk, U[2], p1, false, lq, cut);
+            sep_run<3, 1, 2, 2>(acc, vn, hk, U[1], U[2], false, lq, cut);
+            sep_run<3, 1, 3, 1>(acc, vn, hk, U[0], U[1], false, lq, cut);
+            sep_run<3, 1, 4, 0>(acc, vn, hk, p0, U[0], false, lq, cut);
+        } else {
+            sep_run<4, 1, 1, 3>(acc, vn, hk, U[2], p1, false, lq, cut);
+            sep_run<4, 1, 2, 2>(acc, vn, hk, U[1], U[2], false, lq, cut);
+            sep_run<4, 1, 3, 1>(acc, vn, hk, U[0], U[1], false, lq, cut);
+            sep_run<4, 1, 4, 0>(acc, vn, hk, p0, U[0], false, lq, cut);
+        }
+    } else {
+        run(e.eR, w.W1, false, ja, jb);
+        if (e.far3 & 2) sep_run<3, 1>(acc, vn, hk, ja, jb, false, lq, cut); else sep_run<4, 1>(acc, vn, hk, ja, jb, false, lq, cut);
+    }
     if (e.mR1 > e.mR0) {
         run(e.mR3, e.mR1, false, ja, jb); sep_run<3, 1>(acc, vn, hk, ja, jb, false, lq, cut);
         run(e.mR0, e.mR3, false, ja, jb); sep_run<4, 1>(acc, vn, hk, ja, jb, false, lq, cut);

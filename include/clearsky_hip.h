@@ -139,7 +139,9 @@ int cs_set_merge(cs_ctx *ctx, int on);
  *   key 12: the node sums of a level are added into the next smaller level's (a 64 x 64 matrix per interval) and only the smallest
  *          interval size is carried to the grid (k_cheb_cascade) -- 0 (default) with four or more levels in use, 1 always, 2 never;
  *   key 13: the vector-unit node kernel with four waves per (interval, state), a quarter of every window each -- 0 (default) on
- *          grids of fewer than 16384 (interval, state) waves (a nu-shard), 1 always, 2 never.
+ *          grids of fewer than 16384 (interval, state) waves (a nu-shard), 1 always, 2 never;
+ *   key 14: k_voigt_edge_mx cuts a cut-off edge where the next 16-column sub-tile of the tile comes into the lines' reach and
+ *          multiplies only the sub-tiles a part can reach (0, default), or all four for every line (1).
  * Applies to every later cs_column_setup / cs_column_run of the context. */
 int cs_set_tuning(cs_ctx *ctx, int key, int value);
 

@@ -165,7 +165,7 @@ def test_merged_shards_add_up(cs, O, lines):
     ctx.close()
 
 
-@pytest.mark.parametrize("tune", [{0: 1}, {1: 0}, {2: 0}, {2: 1}, {0: 1, 2: 0}, {3: 20}, {4: 1}, {5: 0}, {6: 2}, {7: 0}, {7: 2}, {2: 0, 7: 2}, {8: 16}, {11: 1}, {12: 1}, {12: 2}, {13: 1}, {13: 2}])
+@pytest.mark.parametrize("tune", [{0: 1}, {1: 0}, {2: 0}, {2: 1}, {0: 1, 2: 0}, {3: 20}, {4: 1}, {5: 0}, {6: 2}, {7: 0}, {7: 2}, {2: 0, 7: 2}, {8: 16}, {11: 1}, {12: 1}, {12: 2}, {13: 1}, {13: 2}, {14: 1}])
 def test_tuning_switches_same_results(cs, O, lines, tune):
     """cs_set_tuning: interpolated wings applied inside k_voigt_edge_mx (0), matrix-core kernels on short grids through their
     four-waves-per-item variants (1), node sums on a side stream (2), interpolation margin (3), the step as one hipGraph (4) -- none
