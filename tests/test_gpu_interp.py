@@ -124,6 +124,43 @@ def test_column_interp_on_off(cs, lines):
     assert relerr(np.asarray(Bon[0])[0], Fon.Fup) < 1e-13      # batch member 0 = the resident state
 
 
+@pytest.mark.parametrize("seed", list(range(1, 13)))
+def test_random_columns_on_off(cs, seed):
+    """Seeded random columns off the bench's beaten track -- geometric and uniform grids that end inside an interval, cut-offs of
+    8 .. 60 cm^-1 (two to five interval sizes, the cascade from four up), 5 .. 40 layers (ragged state groups), dense and thin
+    synthetic tables merged into one launch group, two or three Lobatto nodes per layer: the cross-sections of the full machinery
+    (interpolated wings, low-order far pieces, matrix-core pieces with phased cut-off edges, sub-tile cores, side streams) against
+    every pair evaluated per point on the vector unit."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(9000, 40000))
+    lo = float(rng.uniform(200.0, 1500.0))
+    hi = lo + float(rng.uniform(60.0, 400.0))
+    nu = np.geomspace(lo, hi, n) if seed % 2 else np.linspace(lo, hi, n)
+    cut = float(rng.choice([8.0, 15.0, 25.0, 40.0, 60.0]))
+    nlay = int(rng.integers(5, 41))
+    P = cs.pressuregrid(float(rng.uniform(0.5, 50.0)), float(rng.uniform(2e4, 2e5)), nlay + 1)
+    T = cs.AtmosphericProfile(P, np.linspace(float(rng.uniform(180.0, 230.0)), float(rng.uniform(260.0, 320.0)), nlay + 1))
+    dens = cs.SpectralLines.synthetic(2, int(rng.integers(4000, 30000)), 50 + seed, numin=lo - 80.0, numax=hi + 80.0)
+    thin = cs.SpectralLines.synthetic(1, int(rng.integers(50, 800)), 80 + seed, numin=lo - 80.0, numax=hi + 80.0)
+    conc = float(rng.uniform(1e-4, 1e-2))
+    res = []
+    for on in (True, False):
+        c = cs.Context(0)
+        c.set_interp(on)
+        if not on:
+            c.set_matrix_cores(0)
+        g1 = cs.DirectGas(dens, conc, nu, dnu_cut=cut)
+        g2 = cs.DirectGas(thin, 3e-3, nu, dnu_cut=cut)
+        col = cs.Column(P, 9.8, T, 0.029, 0.0, 0.0, g1, g2, core=cs.Discretized(4, 2 + seed % 2), ctx=c)
+        col.run()
+        res.append((col.sigma_nodes(), col.fetch(), col.work()))
+        c.close()
+    assert res[0][2]["levels"] >= 1 and res[0][2]["node_evals"] > 0 and res[1][2]["levels"] == 0
+    assert np.array_equal(res[0][0] == 0, res[1][0] == 0)
+    assert relerr(res[0][0], res[1][0], floor=1e-300) < 2e-13
+    assert relerr(res[0][1][0], res[1][1][0]) < 1e-12
+
+
 def test_bake_with_interp(cs, O, lines, ctx_on, ctx_off):
     nu = np.linspace(640.0, 700.0, 6000)
     Om = cs.AtmosphericDomain((180.0, 320.0), 4, (10.0, 1e5), 5)
