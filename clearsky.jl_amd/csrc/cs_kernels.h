@@ -1410,7 +1410,9 @@ __global__ __launch_bounds__(256) CS_FAR_ATTR void k_voigt_far(const double *__r
     const int part = wv % S;                                                                     // line records stay scalar loads
     const bool work = in_stretch && tb < nblk && tile < ntile;
     if (S == 1 && !work) return;
-    const int k = blockIdx.y;
+    // states from the last (the surface: highest pressure, widest lines, by far the longest waves of this kernel) to the first: the
+    // grid is dealt out y-slowest, and the long waves must not be the tail
+    const int k = (int)(gridDim.y - 1 - blockIdx.y);
     const int64_t i = (int64_t)tile * 64 + lane;
     double acc = 0.0;
     int bl = 0x3fffffff, bh = -1, cl = 0x3fffffff, ch = -1;
