@@ -349,6 +349,28 @@ def test_phco2_ragged_grids(cs, O, lines, ctx_on, ctx_off):
         assert relerr(a[1], so, floor=1e-250) < 2e-11
 
 
+@pytest.mark.parametrize("seed", list(range(1, 9)))
+def test_phco2_random_on_off(cs, ctx_on, ctx_off, seed):
+    """Seeded random PHCO2 evaluations -- uniform and geometric grids of 3e3 .. 3e4 points anywhere between 20 and 3000 cm^-1,
+    cut-offs of 150 .. 600 cm^-1 (which interval sizes exist, which regions they carry and with how many nodes all follow from these),
+    tables of 2e2 .. 2e4 lines, cold / warm, thin / thick states: interval machinery against every pair per point."""
+    rng = np.random.default_rng(4000 + seed)
+    n = int(rng.integers(3000, 30000))
+    lo = float(rng.uniform(20.0, 2500.0))
+    hi = lo + float(rng.uniform(30.0, 500.0))
+    nu = np.geomspace(lo, hi, n) if seed % 2 else np.linspace(lo, hi, n)
+    cut = float(rng.choice([150.0, 250.0, 500.0, 600.0]))
+    sl = cs.SpectralLines.synthetic(2, int(rng.integers(200, 20000)), 300 + seed, numin=max(lo - cut, 1.0), numax=hi + cut)
+    K = int(rng.integers(1, 7))
+    T = rng.uniform(160.0, 340.0, K).tolist()
+    P = (10.0 ** rng.uniform(0.0, 5.2, K)).tolist()
+    Pp = [float(p * rng.uniform(0.0, 1.0)) for p in P]
+    a = cs.shape_batch(sl, "PHCO2", nu, T, P, Pp, cut, ctx_on)
+    b = cs.shape_batch(sl, "PHCO2", nu, T, P, Pp, cut, ctx_off)
+    assert np.array_equal(a == 0, b == 0)
+    assert relerr(a, b, floor=1e-250) < 5e-13
+
+
 def test_matrix_core_node_sums_on_off(cs, O, lines):
     """K2d, K2e, K2f: far lines inside the validity range of the 4-term series in 1/dnu^2 are summed as matrix products on
     v_mfma_f64_16x16x4 -- at the interpolation nodes (k_cheb_nodes_mx) and, for the window ends of the per-point sum with the
