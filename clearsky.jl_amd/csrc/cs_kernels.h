@@ -1963,16 +1963,18 @@ __global__ __launch_bounds__(4096 / SW) void k_voigt_sub(const double *__restric
 // cm^-1 -- all but a few hundred of them far enough from the whole 64-point tile to (i) sit in ONE region r and on one side for
 // every lane and (ii) take the asymptotic far-wing body.  For those, chi = [exp(a_r -+ b_r (nu - nu_c))] x [exp(+- b_r (nul - nu_c))]:
 // a per-lane factor formed once per wave and a per-(state, line) factor k_prep tabulates, so a pair costs the far body + 4
-// multiplies, with wave-uniform scalar loads -- no exponential per pair.  What is left (lines within 3 cm^-1 of the tile, and those
-// whose region boundary or cut-off edge... falls inside the tile) goes through the generic per-lane body.
-// Per 64-point tile (state-independent): line indices of the region boundaries, computed in k_gas_setup.
+// multiplies, with wave-uniform scalar loads -- no exponential per pair.  What is left: the lines whose region boundary falls inside
+// the tile (the lane picks the factorised chi of its own side: "boundary sets"), and the lines within 3 cm^-1 of the tile (chi = 1:
+// handed to the Voigt kernels with that cut-off, or k_phco2's own core loop).  With the far wings interpolated (k_phco2_nodes,
+// further down) the uniform sets shrink to what the smallest interval leaves of them.
+// Per 64-point tile (state-independent): line indices of the region boundaries, computed by k_phwin.
 struct PhWin {
     int32_t W0, L3, L2a, L2, L1a, L1, C0, C1, R1, R1b, R2, R2b, R3, W1;
     // uniform sets: [W0,L3) r=3 left | [L2a,L2) r=2 left | [L1a,L1) r=1 left | [R1,R1b) r=1 right | [R2,R2b) r=2 right | [R3,W1) r=3 right
-    // generic sets: [L3,L2a), [L2,L1a), [L1,R1) (contains the chi = 1 core [C0,C1)), [R1b,R2), [R2b,R3)
+    // boundary sets: [L3,L2a), [L2,L1a), [R1b,R2), [R2b,R3); core [L1,R1) (contains [C0,C1): every lane within 3 cm^-1)
     int32_t E0, E1;   // lines inside the cut-off of every lane (as WaveWin)
 };
-struct PhArgs { const double *nu, *nul; int64_t nnu; int ntile; int32_t J0, J1; double cut, tol; PhWin *out; };   // tol: one value per grid (phi_tol)
+struct PhArgs { const double *nu, *nul; int64_t nnu; int ntile; int32_t J0, J1; double cut, tol; PhWin *out; };   // tol: one value per grid
 __device__ __forceinline__ void phwin_body(unsigned bid, const PhArgs &a)
 {
     const int t = bid * blockDim.x + threadIdx.x;
