@@ -70,6 +70,7 @@ SIGNATURES = {
     "cs_column_counts": (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "cs_column_work": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
     "cs_interp_plan": (C.c_int, [C.c_int64, _dp, C.c_double, _ip]),
+    "cs_phco2_plan": (C.c_int, [C.c_int64, _dp, C.c_double, C.c_int, _ip, _ip, _ip]),
     "cs_column_batch": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
     "cs_shape_points": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_int64, _dp, C.c_int, _dp, _dp, _dp, _dp, C.c_int64]),
     "cs_column_sigma_run": (C.c_int, [_vp, _vp]),

@@ -206,6 +206,17 @@ def interp_plan(nu, cut=25.0):
     return [out[i] for i in range(n)]
 
 
+def phco2_plan(nu, cut=500.0):
+    """The levels PHCO2's far wings are interpolated on (default settings): [(interval size, nodes per interval, chi-regions)], regions
+    as a tuple out of (1, 2, 3) = 3-30, 30-120, 120-cut-off cm^-1.  [] = every pair evaluated per point.  Host only."""
+    nu = np.ascontiguousarray(nu, dtype=np.float64)
+    sz, nd, rg = (C.c_int * 16)(), (C.c_int * 16)(), (C.c_int * 16)()
+    n = lib().cs_phco2_plan(nu.size, nu.ctypes.data_as(C.POINTER(C.c_double)), float(cut), 16, sz, nd, rg)
+    if n < 0:
+        check(n)
+    return [(sz[i], nd[i], tuple(r + 1 for r in range(3) if (rg[i] >> r) & 1)) for i in range(n)]
+
+
 class Context:
     """One HIP context (cs_ctx) = one device + stream + resident gas tables.  Not re-entrant."""
 

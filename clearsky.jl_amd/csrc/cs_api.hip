@@ -2900,6 +2900,21 @@ int cs_interp_plan(int64_t nnu, const double *nu, double dnu_cut, int *interval_
     return choose_levels(nu, nnu, dnu_cut, interval_sizes);   // (default size range; a context's cs_set_interp_plan may narrow it)
 }
 
+int cs_phco2_plan(int64_t nnu, const double *nu, double dnu_cut, int cap, int *interval_sizes, int *nodes, int *regions)
+{
+    if (!nu || nnu < 1 || !interval_sizes || !nodes || !regions || cap < 1) return fail(CS_EINVAL, "bad arguments");
+    cs_ctx defaults;          // (host data only: the default interpolation settings)
+    PhScratch ph;
+    ph_set_grid(&defaults, ph, nu, nnu, 1);
+    const int nv = ph_plan(&ph, nnu, dnu_cut);
+    for (int v = 0; v < std::min(nv, cap); v++) {
+        interval_sizes[v] = ph.grid.lv.itv[ph.grid.vl.rl[v]];
+        nodes[v] = ph.grid.vl.nc[v];
+        regions[v] = ph.grid.vl.rmask[v];
+    }
+    return nv;
+}
+
 int cs_column_work(cs_ctx *ctx, int64_t *out)
 {
     if (!ctx || !ctx->col.ready || !out) return fail(CS_ESTATE, "no resident column");

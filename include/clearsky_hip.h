@@ -301,6 +301,11 @@ int cs_column_work(cs_ctx *ctx, int64_t *out);
 /* interval sizes (descending, <= 5, each 128..2048 points) cs_set_interp(on) would use for this grid and cut-off; returns
  * their number (0: the grid is too coarse for the cut-off -- every pair is evaluated directly) */
 int cs_interp_plan(int64_t nnu, const double *nu, double dnu_cut, int *interval_sizes);
+/* the same for PHCO2! (line_shapes.jl:467-540) with the default settings: the "virtual levels" its far wings are interpolated on --
+ * interval size (8192 .. 128 points), Chebyshev nodes per interval (64, 32 or 16: by how many half-widths the region's lines stay
+ * away) and the chi-regions summed with that node count (bit 0: 3-30 cm^-1, bit 1: 30-120, bit 2: 120-cut-off).  Host only.  Returns
+ * their number (at most 16; 0: every pair per point); the arrays hold `cap` entries. */
+int cs_phco2_plan(int64_t nnu, const double *nu, double dnu_cut, int cap, int *interval_sizes, int *nodes, int *regions);
 /* update only the temperature-dependent inputs of a resident column (RCM stepping, radiative_convective.jl:109-144) */
 int cs_column_update_state(cs_ctx *ctx, const double *T_nodes, const double *mu_nodes, const double *T_levels,
                            const double *conc, const double *conc_tab);

@@ -209,6 +209,35 @@ def test_missing_library_fails_loudly(cs, monkeypatch, tmp_path):
         lib_mod.lib()
 
 
+def test_phco2_plan_host_logic(cs):
+    """cs_phco2_plan is pure host code: which interval sizes PHCO2's far wings use, with how many Chebyshev nodes and for which
+    chi-regions.  A region is carried at a size while it can hold lines there (30 - 3, 120 - 30, cut-off - 120 cm^-1 minus the
+    interval's width); the node count follows from the distance in half-widths h: rho = x0 + sqrt(x0^2 - 1), x0 = 1 + dist / h, and
+    (n - 1) log10(rho) >= 18 for n = 16, 32, else 64."""
+    nu = np.linspace(1, 2500, 100000)                     # the bench grid: 0.025 cm^-1 per point
+    plan = cs.phco2_plan(nu, 500.0)
+    assert [p[0] for p in plan] == sorted((p[0] for p in plan), reverse=True) and plan[0][0] == 8192 and plan[-1][0] == 128
+    by = {}
+    for size, n, regions in plan:
+        for r in regions:
+            assert (size, r) not in by
+            by[(size, r)] = n
+    # region 3 (>= 120 cm^-1 away) everywhere, on 32 nodes down to 2048 points and 16 below; region 2 from 2048 points on; region 1
+    # from 512 points on, never on 16 nodes (3 cm^-1 is only 1.9 half-widths of a 128-point interval)
+    assert {s for (s, r) in by if r == 3} == {8192, 4096, 2048, 1024, 512, 256, 128}
+    assert [by[(s, 3)] for s in (8192, 4096, 2048, 1024, 512, 256, 128)] == [32, 32, 32, 16, 16, 16, 16]
+    assert {s for (s, r) in by if r == 2} == {2048, 1024, 512, 256, 128} and by[(256, 2)] == 16 and by[(2048, 2)] == 32
+    assert {s for (s, r) in by if r == 1} == {512, 256, 128} and by[(512, 1)] == 64 and by[(128, 1)] == 32
+    for (size, r), n in by.items():       # the rule itself
+        h = 0.5 * (size - 1) * 0.025
+        x0 = 1.0 + max({1: 3.0, 2: 30.0, 3: 120.0}[r] / h, 0.3)
+        lr = np.log10(x0 + np.sqrt(x0 * x0 - 1.0))
+        assert n == (16 if 15 * lr >= 18 else 32 if 31 * lr >= 18 else 64), (size, r, n)
+    assert cs.phco2_plan(np.linspace(600, 700, 100), 500.0) == []          # fewer than 128 points: every pair per point
+    short = cs.phco2_plan(np.linspace(600, 640, 1601), 500.0)              # 40 cm^-1: no interval larger than the grid / 2
+    assert short and max(p[0] for p in short) <= 2048
+
+
 def test_interp_plan_host_logic(cs):
     """cs_interp_plan is pure host code (no GPU call): interval sizes follow 2.3 N dnu <= 1.5 cut, descending, <= 5 levels."""
     for nu, cut, want in ((np.linspace(1, 2500, 100000), 25.0, [512, 256, 128]),      # the bench grid
