@@ -13,7 +13,6 @@ import argparse
 import hashlib
 import json
 import os
-import socket
 import subprocess
 import sys
 import time
@@ -71,11 +70,9 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, as fresh child processes, BEFORE anything
         # in this process touches the GPU (no exec of a GPU-initialised process), and exit with the launcher's code
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
-               "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        # (--standalone: the launcher's own c10d store picks a free port and keeps it -- no probe-close-reuse of a port number)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+               f"--nproc-per-node={args.gpus}", os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -98,14 +95,14 @@ def main():
     use_dist = N > 1 or args.force_dist
     if use_dist:
         import torch.distributed as dist
-        if "RANK" not in os.environ:     # --force-dist without a launcher: a one-rank group on a free local port
-            with socket.socket() as sk:
-                sk.bind(("127.0.0.1", 0))
-                os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        init = {}
+        if "RANK" not in os.environ:     # --force-dist without a launcher: a one-rank group rendezvousing through a file (no port to pick)
+            import tempfile
+            init = dict(init_method="file://" + os.path.join(tempfile.mkdtemp(prefix="cs_bench_"), "rdzv"), rank=0, world_size=1)
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev), **init)
         else:
-            dist.init_process_group(args.dist_backend)
+            dist.init_process_group(args.dist_backend, **init)
 
     cfg = W.config(args.config, nnu=args.nnu, lines_kind=args.lines, shape=args.shape)
     nu, nl = cfg["nu"], cfg["nl"]
@@ -273,7 +270,13 @@ def main():
         ub = json.load(open(os.path.join(_ROOT, "profiles", "r03_ubench.json")))
     except Exception:
         pass
-    roofline = dict(bound="mfma" if D["bound"] == "mfma" else ("hbm" if D["bound"] == "hbm" else "mfma"), kernel=dom, achieved=r_ach, peak=r_peak,
+    # the step as a whole: every class's fraction of the roof that binds IT, weighted by its time (the classes of cs_column_profile)
+    tw_num = sum((kern[k_]["frac"] or 0.0) * prof.get(cls[k_], 0.0) for k_ in cls)
+    tw_den = sum(prof.get(cls[k_], 0.0) for k_ in cls)
+    if "k_cheb_apply_mfma" in kern:
+        tw_num += kern["k_cheb_apply_mfma"]["frac"] * prof["apply"]
+        tw_den += prof["apply"]
+    roofline = dict(bound=D["bound"], kernel=dom, achieved=r_ach, peak=r_peak,
                     unit=r_unit, frac=r_ach / r_peak if r_peak else None, traffic=traffic, traffic_note=traffic_note,
                     traffic_bytes_per_step=traffic_step, launches_per_step=D["launches_per_step"], avg_launch_ms=D["ms_per_launch"],
                     algorithmic_flops_per_launch=D.get("useful_flops_per_launch"), issued_flops_per_launch=D.get("issued_flops_per_launch"),
@@ -283,7 +286,9 @@ def main():
                           "matrix path of MI355X has the vector unit's peak (78.6 TFLOP/s) and shares its pipe; measured_rates holds what "
                           "tools/ubench sustains"),
                     measured_rates=ub, kernels=kern, kernel_ms=prof, reference_pair_evals=cnt["pair_evals"], interp_levels=work["levels"],
-                    whole_step=dict(algorithmic_bytes=24.0 * col.nnu * col.nl + 58.0 * lines_total + 8.0 * col.nnu,
+                    whole_step=dict(time_weighted_frac=(tw_num / tw_den) if tw_den > 0 else None,
+                                    time_weighted_note="sum over kernel classes of (fraction of the roof that binds the class) x (its time), over the sum of the times",
+                                    algorithmic_bytes=24.0 * col.nnu * col.nl + 58.0 * lines_total + 8.0 * col.nnu,
                                     hbm_frac=(24.0 * col.nnu * col.nl + 58.0 * lines_total + 8.0 * col.nnu) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                     note="SURVEY 8d: 24 B per spectral point + 58 B per line + 8 B per nu over the whole step, against 8 TB/s -- "
                                          "small by construction: the path is fp64-issue-bound"))
@@ -326,7 +331,7 @@ def main():
         O.use_native_build()
         cia_data = [cs.readcia(x.x.filename) for x in col.U.cia] if col.U.cia else []
         # calibrate on a thin sample, then size the sample for roughly 15 s of CPU work
-        def run_cpu(stride):
+        def run_cpu(stride, want_sigma=False):
             sub = np.ascontiguousarray(nu[::stride])
             t1 = time.perf_counter()
             extra = None
@@ -338,18 +343,42 @@ def main():
                                                 extrapolate=x.x.extrapolate, singles=x.x.singles)
             ref = O.fluxes_discretized(sub, cfg["P"], cfg["g"], cfg["core"].nlobatto, col.Tn, col.mun, col.Tlev,
                                        [g.sl for g in col.gases], [g.shape for g in col.gases], [g.dnu_cut for g in col.gases],
-                                       col.conc, sigma_extra=extra, theta_s=cfg["theta_s"], nstream=cfg["core"].nstream)
+                                       col.conc, sigma_extra=extra, theta_s=cfg["theta_s"], nstream=cfg["core"].nstream,
+                                       want_sigma=want_sigma)
             return sub, ref, time.perf_counter() - t1
         if args.cpu_stride > 0:
             stride = args.cpu_stride
         else:
             sub, ref, tc = run_cpu(64)
             stride = int(min(max(1, round(tc * 64 / 15.0)), 64))
-        sub, ref, tc = run_cpu(stride)
+        sub, ref, tc = run_cpu(stride, want_sigma=(stride == 1))
         cpu = dict(value=len(sub) * nl / tc, unit="spectral-points/s", cores=O.num_threads(), kind="port",
                    sample=f"every {stride}th wavenumber of the same column ({len(sub)} x {nl} points, {tc:.1f} s)",
                    olr_sample=float(ref["Fup"][0]),
                    olr_abs_err_wm2=(abs(olr - float(ref["Fup"][0])) if stride == 1 else None))
+        if stride == 1:
+            # the whole grid against the CPU port, EVERY element of what radiate! returns (fluxes.jl:357-383: tau, M+, M-, F+, F-) and of
+            # the node cross-sections behind them: the step that was timed above, fetched now
+            col.run(stream)
+            torch.cuda.synchronize()
+            tau_g = np.zeros((col.nl, col.nnu), order="F"); Mu_g = np.zeros((col.np, col.nnu), order="F"); Md_g = np.zeros((col.np, col.nnu), order="F")
+            Fu_g, Fd_g = col.fetch(tau_g, Mu_g, Md_g)
+            sig_g = col.sigma_nodes()
+            sig_c = ref["sigma"]
+            pos = sig_c > 0
+            Mmax = float(max(np.max(ref["Mup"]), np.max(ref["Mdn"])))
+            Fmax = float(np.max(ref["Fup"]))
+            cpu.update(
+                max_rel_sigma=float(np.max(np.abs(sig_g[pos] - sig_c[pos]) / sig_c[pos])) if pos.any() else 0.0,
+                sigma_zero_where_cpu_zero=bool(np.all(sig_g[~pos] == 0.0)),
+                max_rel_tau=float(np.max(np.abs(tau_g - ref["tau"]) / ref["tau"])),
+                max_abs_M_over_max=float(max(np.max(np.abs(Mu_g - ref["Mup"])), np.max(np.abs(Md_g - ref["Mdn"]))) / Mmax),
+                max_rel_F=float(max(np.max(np.abs(Fu_g - ref["Fup"])), np.max(np.abs(Fd_g - ref["Fdn"]))) / Fmax),
+                max_rel_Fup=float(np.max(np.abs(Fu_g - ref["Fup"]) / ref["Fup"])),
+                accuracy_note=("GPU vs CPU port on the full grid, every element: sigma [K, nnu] relative (where the CPU value is "
+                               "non-zero), tau [nl, nnu] relative, M+ and M- [np, nnu] absolute over the column maximum, F+ and F- [np] "
+                               "over max F+ (F-[1] = 0 at the top of the atmosphere), F+ also element-wise relative"))
+            del tau_g, Mu_g, Md_g, sig_g, sig_c
 
     if rank == 0:
         out = dict(metric="spectral-points/s (nu x layers), whole-column LBL flux evaluation", value=value,

@@ -273,12 +273,13 @@ class Context:
         low-order far pieces, level cascade, split node kernel -- include/clearsky_hip.h describes each."""
         check(lib().cs_set_tuning(self._h, int(key), int(value)))
 
-    def slot_of(self, sl: SpectralLines) -> int:
-        """Upload `sl` (once) and return its gas slot."""
+    def slot_of(self, sl: SpectralLines, keep=()) -> int:
+        """Upload `sl` (once) and return its gas slot.  `keep`: tables that must stay where they are (the other gases of the call this
+        one belongs to): with every slot taken, the oldest table NOT among them makes room."""
         key = id(sl)
         if key in self._slots:
             return self._slots[key][0]
-        slot = self._take_slot()
+        slot = self._take_slot(keep)
         iso = np.ascontiguousarray(sl.I, dtype=np.int16)
         ncheb = np.ascontiguousarray(sl.ncheb, dtype=np.int32)
         cheb = as_f64(sl.cheb)
@@ -291,10 +292,17 @@ class Context:
         return slot
 
 
-    def _take_slot(self):
-        if len(self._slots) >= CS_MAX_GAS:   # evict the oldest table
-            old = next(iter(self._slots))
-            return self._slots.pop(old)[0]
+    def slots_of(self, tables):
+        """Slots of all the line tables of ONE call: none of them is evicted to make room for another of them."""
+        return [self.slot_of(sl, keep=tables) for sl in tables]
+
+    def _take_slot(self, keep=()):
+        if len(self._slots) >= CS_MAX_GAS:   # evict the oldest table that the current call does not use
+            pinned = {id(x) for x in keep}
+            for old in self._slots:
+                if old not in pinned:
+                    return self._slots.pop(old)[0]
+            raise ClearSkyHIPError(-1, f"all {CS_MAX_GAS} gas slots hold tables of the current call")
         slot = self._next
         self._next += 1
         return slot
@@ -374,10 +382,13 @@ class MultiContext:
         self.ctxs = [Context(int(d)) for d in devices]
         assert len(self.ctxs) >= 1
 
-    def slot_of(self, sl: SpectralLines) -> int:
-        slots = [c.slot_of(sl) for c in self.ctxs]
+    def slot_of(self, sl: SpectralLines, keep=()) -> int:
+        slots = [c.slot_of(sl, keep) for c in self.ctxs]
         assert all(s_ == slots[0] for s_ in slots), "contexts of a MultiContext must be used together from the start"
         return slots[0]
+
+    def slots_of(self, tables):
+        return [self.slot_of(sl, keep=tables) for sl in tables]
 
     def handles(self):
         return (C.c_void_p * len(self.ctxs))(*[c.handle.value for c in self.ctxs])
@@ -972,7 +983,7 @@ class Column:
         for g_ in U.gas:
             if not isinstance(g_, (DirectGas, GrayGas, Gas)):
                 raise TypeError(f"unsupported gas type {type(g_).__name__} for the HIP Discretized core")
-        self.slots = np.array([self.ctx.slot_of(g_.sl) for g_ in self.gases], dtype=np.int32)
+        self.slots = np.array(self.ctx.slots_of([g_.sl for g_ in self.gases]), dtype=np.int32)
         self.shapes = np.array([SHAPES[g_.shape] for g_ in self.gases], dtype=np.int32)
         self.cuts = as_f64([g_.dnu_cut for g_ in self.gases])
         self.want_tau, self.want_M = bool(want_tau), bool(want_M)
@@ -1230,36 +1241,42 @@ def _fluxes_discretized(col: "Column", tau, Mup, Mdn):
             col.core.nstream, fp(tau), fp(Mup), fp(Mdn), dptr(Fup), dptr(Fdn)))
         return Fup, Fdn
     col.ctx._resident = None           # the call replaces (or re-uses) the context's resident column on the C side
-    check(lib().cs_fluxes_discretized(
-        col.ctx.handle, col.nnu, dptr(col.nu), col.np, dptr(col.P), col.g, col.core.nlobatto,
-        dptr(np.asfortranarray(col.Tn).ravel(order="F").copy()), dptr(np.asfortranarray(col.mun).ravel(order="F").copy()),
-        dptr(col.Tlev), len(col.gases), ip(col.slots), ip(col.shapes), dptr(col.cuts) if len(col.cuts) else None,
-        dptr(col.conc.ravel(order="F").copy()) if col.conc.size else None, col.sigma_gray,
-        dptr(col.sigma_extra) if col.sigma_extra is not None else None, dptr(col.S_toa), dptr(col.albedo), col.theta_s,
-        col.core.nstream, fp(tau), fp(Mup), fp(Mdn), dptr(Fup), dptr(Fdn)))
+    # members beyond the line-by-line gases go by slot (cs_fluxes_discretized_members; without any it is cs_fluxes_discretized)
+    tslots = np.array([g_.slot for g_ in col.baked], dtype=np.int32)
+    cslots = np.array([col.ctx.cia_slot(x.x) for x in col.U.cia], dtype=np.int32)
+    cflags = np.array([int(x.x.extrapolate) | (int(x.x.singles) << 1) for x in col.U.cia], dtype=np.int32)
+    args = (col.ctx.handle, col.nnu, dptr(col.nu), col.np, dptr(col.P), col.g, col.core.nlobatto,
+            dptr(np.asfortranarray(col.Tn).ravel(order="F").copy()), dptr(np.asfortranarray(col.mun).ravel(order="F").copy()),
+            dptr(col.Tlev), len(col.gases), ip(col.slots), ip(col.shapes), dptr(col.cuts) if len(col.cuts) else None,
+            dptr(col.conc.ravel(order="F").copy()) if col.conc.size else None)
+    tail = (col.sigma_gray, dptr(col.sigma_extra) if col.sigma_extra is not None else None, dptr(col.S_toa), dptr(col.albedo),
+            col.theta_s, col.core.nstream, fp(tau), fp(Mup), fp(Mdn), dptr(Fup), dptr(Fdn))
+    if len(tslots) or len(cslots) or col.accel is not None:
+        check(lib().cs_fluxes_discretized_members(
+            *args, len(tslots), ip(tslots), dptr(col.conc_tab.ravel(order="F").copy()) if len(tslots) else None,
+            len(cslots), ip(cslots), ip(cflags), dptr(col.cia_P1.ravel(order="F").copy()) if len(cslots) else None,
+            dptr(col.cia_P2.ravel(order="F").copy()) if len(cslots) else None, col.accel.slot if col.accel is not None else -1, *tail))
+    else:
+        check(lib().cs_fluxes_discretized(*args, *tail))
     return Fup, Fdn
 
 
 def _b3(P, g, T, mu, fS, fa, absorbers, core, theta_s, ctx, tau, Mup, Mdn):
-    """The B3 boundary: columns of line-by-line / gray / function absorbers go through cs_fluxes_discretized (host pointers,
-    what the Julia glue calls); baked Gas objects, CIA pairs and an AcceleratedAbsorber need the resident-column calls
-    (cs_column_set_tables / _set_cia / _set_accel)."""
+    """The B3 boundary, as the Julia method monochromaticfluxes!(…, core::HIPDiscretized, …) calls it: ONE host-pointer call per
+    evaluation -- cs_fluxes_discretized for columns of line-by-line / gray / function absorbers, cs_fluxes_discretized_members when
+    baked Gas objects, CIA pairs or an AcceleratedAbsorber are among the members (B2)."""
     direct = Column(P, g, T, mu, fS, fa, *absorbers, core=core, theta_s=theta_s, want_tau=tau is not None,
                     want_M=Mup is not None or Mdn is not None, ctx=ctx, _setup=False)
-    if not direct.baked and not direct.U.cia and direct.accel is None:
-        bufs = [None if a is None else (a if (a.flags["F_CONTIGUOUS"] and a.dtype == np.float64) else np.zeros(a.shape, order="F"))
-                for a in (tau, Mup, Mdn)]
-        F = _fluxes_discretized(direct, *bufs)
-        for a, b in zip((tau, Mup, Mdn), bufs):
-            if a is not None and b is not a:
-                a[...] = b
-        return F
-    if isinstance(direct.ctx, MultiContext):
+    if isinstance(direct.ctx, MultiContext) and (direct.baked or direct.U.cia or direct.accel is not None):
         raise TypeError("baked Gas objects, CIA pairs and accelerated absorbers live on ONE context: a MultiContext takes line-by-line, "
                         "gray and function absorbers")
-    direct._setup()
-    direct.run()
-    return direct.fetch(tau, Mup, Mdn)
+    bufs = [None if a is None else (a if (a.flags["F_CONTIGUOUS"] and a.dtype == np.float64) else np.zeros(a.shape, order="F"))
+            for a in (tau, Mup, Mdn)]
+    F = _fluxes_discretized(direct, *bufs)
+    for a, b in zip((tau, Mup, Mdn), bufs):
+        if a is not None and b is not a:
+            a[...] = b
+    return F
 
 
 def monochromaticfluxes_(Mup, Mdn, tau, core: Discretized, P, g, T, mu, fS, fa, *absorbers, theta_s=0.841, ctx=None):

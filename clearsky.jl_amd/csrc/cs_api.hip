@@ -182,7 +182,8 @@ struct UserGas {
 // instead of one per gas, and windows as dense as the column's lines together
 struct ColGas {
     std::vector<int> mem;     // indices into Column::ugas
-    const GasTable *tab = nullptr;   // ctx->gas[slot], or a merged table owned by the context
+    const GasTable *tab = nullptr;   // ctx->gas[slot], or a merged table ...
+    std::shared_ptr<const GasTable> hold;   // ... which the column shares with the context's cache (an eviction there cannot free it)
     int shape = 0;
     double cut = 25.0;
     DevBuf conc, Pp, J0, J1;  // [nmem][K], [nmem][K], [ntile], [ntile]
@@ -222,6 +223,8 @@ struct Column {
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     int runs_since_change = 0;
+    bool graph_near_live = false;   // what the captured run left in near_live / launches: a replay leaves the same
+    int graph_launches = 0;
     std::vector<ColTab> tab;
     std::vector<ColCia> cia;
     ColAccel accel;
@@ -233,6 +236,9 @@ struct Column {
 };
 
 }  // namespace
+
+static std::atomic<int> g_live_ctx{0};   // contexts alive in this process (the last cs_destroy stops the worker pool)
+static void pool_stop();
 
 static void drop_graph(Column &c)
 {
@@ -272,6 +278,7 @@ struct cs_ctx {
     PhScratch ph;
     MultiPlan mplan;
     int device = 0;
+    bool counted = false;   // cs_create finished: the context counts in g_live_ctx
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;            // side stream: node sums beside the per-point kernels (cs_set_tuning key 2)
     hipStream_t stream3 = nullptr;            // side stream: near-line kernels beside the matrix-core per-point kernel (key 7)
@@ -294,7 +301,7 @@ struct cs_ctx {
     // PHCO2 node counts / 64-point intervals, [11] far pieces of the node sums on all 64 nodes, [12] level cascade, [13] k_cheb_nodes
     // with four waves per (interval, state), [14] cut-off edges of k_voigt_edge_mx without the sub-tile phases
     int tune[CS_NTUNE] = {0, 1, 2, 0, 0, 1, 0, 1, 7, 0, 0, 0, 0, 0, 0, 0};
-    std::vector<std::unique_ptr<GasTable>> merged;   // merged tables (keyed by their members' (slot, generation)), a few kept
+    std::vector<std::shared_ptr<GasTable>> merged;   // merged tables (keyed by their members' (slot, generation)), least recently used first
     double far_s = 1e6;
     DevBuf reinterp;        // [64][32] then [64][16]: values at the 64 nodes of an interval from those at its 32 / 16 nodes (build_reinterp)
     DevBuf hot32;
@@ -1444,12 +1451,15 @@ int cs_create(int device, cs_ctx **out)
         }
     }
     *out = c;
+    c->counted = true;
+    g_live_ctx++;
     return CS_OK;
 }
 
 void cs_destroy(cs_ctx *ctx)
 {
     if (!ctx) return;
+    if (ctx->counted && --g_live_ctx == 0) pool_stop();
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
@@ -1492,9 +1502,9 @@ static int table_to_device(GasTable &G, hipStream_t s)
     return CS_OK;
 }
 
-static uint64_t next_generation()
+static uint64_t next_generation()   // (cs_fluxes_discretized_multi sets columns up on one host thread per context)
 {
-    static uint64_t g = 0;
+    static std::atomic<uint64_t> g{0};
     return ++g;
 }
 
@@ -1530,18 +1540,26 @@ int cs_gas_upload(cs_ctx *ctx, int slot, int64_t L, const double *nu, const doub
 // One sorted table out of the tables of `slots` (stable merge by wavenumber: lines of equal position keep member order), each
 // line tagged with its member index; isotopologue numbers are offset into the concatenated Chebyshev tables.  Kept by the context
 // (a handful, keyed by the members' upload generations) so that re-setting a column up does not merge again.
-static int merged_table(cs_ctx *ctx, const std::vector<int> &slots, const GasTable **out)
+static int merged_table(cs_ctx *ctx, const std::vector<int> &slots, std::shared_ptr<const GasTable> *out)
 {
     std::vector<std::pair<int, uint64_t>> key;
     for (int sl : slots) key.emplace_back(sl, ctx->gas[sl].generation);
-    for (auto &m : ctx->merged)
-        if (m->members == key) { *out = m.get(); return CS_OK; }
-    if (ctx->merged.size() >= 4) ctx->merged.erase(ctx->merged.begin());   // (no column is resident while one is being set up)
+    for (size_t i = 0; i < ctx->merged.size(); i++)
+        if (ctx->merged[i]->members == key) {   // a hit becomes the most recently used entry
+            std::shared_ptr<GasTable> m = ctx->merged[i];
+            ctx->merged.erase(ctx->merged.begin() + i);
+            ctx->merged.push_back(m);
+            *out = m;
+            return CS_OK;
+        }
+    // the cache only bounds what the CONTEXT keeps: a column shares ownership of the tables of its launch groups (ColGas::hold), so
+    // evicting the least recently used entry can never free a table a column still runs on, however many groups that column has
+    if (ctx->merged.size() >= CS_MAX_GAS / 2) ctx->merged.erase(ctx->merged.begin());
     int64_t L = 0;
     int niso = 0;
     for (int sl : slots) { L += ctx->gas[sl].L; niso += ctx->gas[sl].niso; }
     if (L >= ((int64_t)1 << 26)) return fail(CS_EINVAL, "merged line table too long (%lld lines; the limit is 2^26 - 1)", (long long)L);
-    std::unique_ptr<GasTable> M(new GasTable());
+    std::shared_ptr<GasTable> M(new GasTable());
     GasTable &G = *M;
     G.L = L;
     G.niso = niso;
@@ -1576,7 +1594,7 @@ static int merged_table(cs_ctx *ctx, const std::vector<int> &slots, const GasTab
     int rc;
     if ((rc = table_to_device(G, ctx->stream))) return rc;
     G.generation = next_generation();
-    *out = M.get();
+    *out = M;
     ctx->merged.push_back(std::move(M));
     return CS_OK;
 }
@@ -2309,7 +2327,8 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
         } else {
             std::vector<int> slots;
             for (int m : cg.mem) slots.push_back(c.ugas[m].slot);
-            if ((rc = merged_table(ctx, slots, &cg.tab))) return rc;
+            if ((rc = merged_table(ctx, slots, &cg.hold))) return rc;
+            cg.tab = cg.hold.get();
         }
         const GasTable &G = *cg.tab;
         if (cg.shape == SH_VOIGT && (rc = check_near_density(G, nu, nnu, cg.cut))) return rc;
@@ -2737,6 +2756,11 @@ int cs_column_run(cs_ctx *ctx, void *stream)
         for (auto &ug : c.ugas)
             if (!ctx->gas[ug.slot].present || ctx->gas[ug.slot].generation != ug.generation) { drop_graph(c); return run_impl(ctx, s, nullptr); }
         HIPCHK(hipGraphLaunch(c.graph_exec, s));
+        // the replayed kernels wrote the near-line plane again and ran on THIS stream: what cs_column_sigma_fetch / cs_column_fetch /
+        // cs_column_info read must say so, as after an eager run
+        c.near_live = c.graph_near_live;
+        c.launches = c.graph_launches;
+        c.last_stream = s;
         return CS_OK;
     }
     if (c.runs_since_change++ == 0) return run_impl(ctx, s, nullptr);   // first run after a change: eager (workspaces may still grow)
@@ -2751,6 +2775,8 @@ int cs_column_run(cs_ctx *ctx, void *stream)
         return run_impl(ctx, s, nullptr);   // (capture refused: run eagerly)
     }
     c.graph = g;
+    c.graph_near_live = c.near_live;   // (set by the captured run_impl)
+    c.graph_launches = c.launches;
     if (hipGraphInstantiate(&c.graph_exec, g, nullptr, nullptr, 0) != hipSuccess) { c.graph_exec = nullptr; drop_graph(c); return run_impl(ctx, s, nullptr); }
     HIPCHK(hipGraphLaunch(c.graph_exec, s));
     return CS_OK;
@@ -3188,14 +3214,21 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
 
 // true when the resident column was set up for exactly this grid, pressure levels, rule orders and gas line-up: only the
 // thermal state and the per-call spectra differ, so a call can skip the window / interpolation-matrix / workspace setup
+// (the members beyond line-by-line gases -- baked tables, CIA pairs, an accelerated absorber -- are named by their slots: ntab / ncia
+//  = 0 and accel_slot = -1 for a column without them)
 static bool column_matches(cs_ctx *ctx, int64_t nnu, const double *nu, int np, const double *P, double g, int nlobatto, int ngas,
                            const int *gas_slots, const int *shapes, const double *dnu_cuts, double sigma_gray, double theta_s,
-                           int nstream, bool want_tau, bool want_M, int64_t g_nnu = 0, int64_t g_start = 0, double g_left = 0.0, double g_right = 0.0)
+                           int nstream, bool want_tau, bool want_M, int64_t g_nnu = 0, int64_t g_start = 0, double g_left = 0.0, double g_right = 0.0,
+                           int ntab = 0, const int *table_slots = nullptr, int ncia = 0, const int *cia_slots = nullptr, int accel_slot = -1)
 {
     const Column &c = ctx->col;
     const bool shard_ok = g_nnu > 0 ? (!c.default_wts && c.g_nnu == g_nnu && c.g_start == g_start && c.g_left == g_left && c.g_right == g_right)
                                     : c.default_wts;
-    if (!c.ready || c.accel.slot >= 0 || !shard_ok || c.interp != interp_key(ctx) || !c.tab.empty() || !c.cia.empty()) return false;
+    if (!c.ready || c.accel.slot != accel_slot || !shard_ok || c.interp != interp_key(ctx) || (int)c.tab.size() != ntab || (int)c.cia.size() != ncia) return false;
+    for (int t = 0; t < ntab; t++)
+        if (c.tab[t].slot != table_slots[t]) return false;
+    for (int t = 0; t < ncia; t++)
+        if (c.cia[t].slot != cia_slots[t]) return false;
     if (c.nnu != nnu || c.np != np || c.nlob != nlobatto || c.nstream != nstream || c.ngas != ngas) return false;
     if (c.g != g || c.sigma_gray != sigma_gray || c.theta_s != theta_s) return false;
     if (c.want_tau != want_tau || c.want_M != want_M) return false;
@@ -3214,13 +3247,32 @@ int cs_fluxes_discretized(cs_ctx *ctx, int64_t nnu, const double *nu, int np, co
                           double sigma_gray, const double *sigma_extra, const double *S_toa, const double *albedo,
                           double theta_s, int nstream, double *tau, double *Mup, double *Mdn, double *Fup, double *Fdn)
 {
+    return cs_fluxes_discretized_members(ctx, nnu, nu, np, P, g, nlobatto, T_nodes, mu_nodes, T_levels, ngas, gas_slots, shapes, dnu_cuts, conc,
+                                         0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, -1, sigma_gray, sigma_extra, S_toa, albedo,
+                                         theta_s, nstream, tau, Mup, Mdn, Fup, Fdn);
+}
+
+int cs_fluxes_discretized_members(cs_ctx *ctx, int64_t nnu, const double *nu, int np, const double *P, double g, int nlobatto,
+                                  const double *T_nodes, const double *mu_nodes, const double *T_levels, int ngas,
+                                  const int *gas_slots, const int *shapes, const double *dnu_cuts, const double *conc,
+                                  int ntab, const int *table_slots, const double *conc_tab,
+                                  int ncia, const int *cia_slots, const int *cia_flags, const double *cia_P1, const double *cia_P2,
+                                  int accel_slot, double sigma_gray, const double *sigma_extra, const double *S_toa, const double *albedo,
+                                  double theta_s, int nstream, double *tau, double *Mup, double *Mdn, double *Fup, double *Fdn)
+{
     if (!ctx) return fail(CS_EINVAL, "ctx is NULL");
     if (!nu || !P || nnu < 1 || np < 2) return fail(CS_EINVAL, "bad grid arguments");
+    if (ntab < 0 || ntab > CS_MAX_TABLE || (ntab > 0 && (!table_slots || !conc_tab))) return fail(CS_EINVAL, "bad opacity-table arguments");
+    if (ncia < 0 || ncia > CS_MAX_CIA || (ncia > 0 && (!cia_slots || !cia_P1 || !cia_P2))) return fail(CS_EINVAL, "bad CIA arguments");
+    if (accel_slot >= 0 && (ngas > 0 || ntab > 0 || ncia > 0))   // unifyabsorbers(::Tuple{AcceleratedAbsorber}), absorbers.jl:216
+        return fail(CS_EINVAL, "a column over an accelerated absorber has no other absorbers");
+    if (accel_slot < -1) accel_slot = -1;
     int rc;
     // radiate! is called once per time step / Jacobian column on an unchanged grid (radiative_convective.jl:109-171): keep the
-    // column of the previous call resident and refresh only what a call can change -- node states, fS, fa, sigma_extra
+    // column of the previous call resident and refresh only what a call can change -- node states, fS, fa, sigma_extra, and the
+    // per-node inputs of the tables / CIA pairs / accelerated absorber it names
     if (column_matches(ctx, nnu, nu, np, P, g, nlobatto, ngas, gas_slots, shapes, dnu_cuts, sigma_gray, theta_s, nstream,
-                       tau != nullptr, Mup || Mdn)) {
+                       tau != nullptr, Mup || Mdn, 0, 0, 0.0, 0.0, ntab, table_slots, ncia, cia_slots, accel_slot)) {
         Column &c = ctx->col;
         HIPCHK(hipSetDevice(ctx->device));
         hipStream_t s = ctx->stream;
@@ -3232,15 +3284,88 @@ int cs_fluxes_discretized(cs_ctx *ctx, int64_t nnu, const double *nu, int np, co
         if (c.has_extra && (rc = upload(c.extra, sigma_extra, (size_t)nnu * c.K, s))) return rc;
         if (c.has_S && (rc = upload(c.S_toa, S_toa, nnu, s))) return rc;
         if (c.has_alb && (rc = upload(c.albedo, albedo, nnu, s))) return rc;
-        if ((rc = cs_column_update_state(ctx, T_nodes, mu_nodes, T_levels, conc, nullptr))) return rc;
+        // (a table baked again into its slot since the last call may have another (T, P) grid: cs_column_set_tables re-checks it)
+        if (ntab > 0 && (rc = cs_column_set_tables(ctx, ntab, table_slots, conc_tab))) return rc;
+        if ((rc = cs_column_update_state(ctx, T_nodes, mu_nodes, T_levels, conc, ntab > 0 ? conc_tab : nullptr))) return rc;
     } else {
         rc = cs_column_setup(ctx, nnu, nu, nullptr, np, P, g, nlobatto, T_nodes, mu_nodes, T_levels, ngas, gas_slots,
                              shapes, dnu_cuts, conc, sigma_gray, sigma_extra, S_toa, albedo, theta_s, nstream,
                              tau != nullptr, (Mup || Mdn) ? 1 : 0);
         if (rc) return rc;
+        if (ntab > 0 && (rc = cs_column_set_tables(ctx, ntab, table_slots, conc_tab))) return rc;
     }
+    // per-node partial pressures of the CIA pairs and the knot cells of the accelerated absorber follow the node states: every call
+    if (ncia > 0 && (rc = cs_column_set_cia(ctx, ncia, cia_slots, cia_flags, cia_P1, cia_P2))) return rc;
+    if (accel_slot >= 0 && (rc = cs_column_set_accel(ctx, accel_slot))) return rc;
     if ((rc = cs_column_run(ctx, nullptr))) return rc;
     return cs_column_fetch(ctx, nnu, np, tau, Mup, Mdn, Fup, Fdn);
+}
+
+// ---- host-held reference objects handed over as they are ---------------------------------------------------------------------
+int cs_table_upload(cs_ctx *ctx, int table_slot, int64_t nnu, const double *nu, int nT, const double *T, int nP, const double *P,
+                    const double *lnsigma)
+{
+    if (!ctx) return fail(CS_EINVAL, "ctx is NULL");
+    if (table_slot < 0 || table_slot >= CS_MAX_TABLE) return fail(CS_EINVAL, "table slot %d out of range", table_slot);
+    if (nT < 2 || nP < 2 || !T || !P || !lnsigma) return fail(CS_EINVAL, "need at least 2 x 2 grid points");
+    int rc;
+    if ((rc = check_ascending(nu, nnu))) return rc;
+    for (int i = 1; i < nT; i++)
+        if (!(T[i] > T[i - 1])) return fail(CS_EORDER, "table temperatures must be ascending");
+    for (int j = 0; j < nP; j++)
+        if (!(P[j] > 0) || (j > 0 && !(P[j] > P[j - 1]))) return fail(CS_EORDER, "table pressures must be positive and ascending");
+    const size_t n = (size_t)nT * nP * nnu;
+    for (size_t i = 0; i < n; i++)
+        if (!std::isfinite(lnsigma[i])) return fail(CS_EINVAL, "ln sigma must be finite (OpacityTable stores ln(floatmin) for empty rows, gases.jl:76-80)");
+    HIPCHK(hipSetDevice(ctx->device));
+    TableDev &tb = ctx->tab[table_slot];
+    tb.present = false;
+    if ((rc = upload(tb.Z, lnsigma, n, ctx->stream))) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    tb.nnu = nnu; tb.nT = nT; tb.nP = nP;
+    tb.T.assign(T, T + nT);
+    tb.lnP.resize(nP);
+    for (int j = 0; j < nP; j++) tb.lnP[j] = std::log(P[j]);
+    tb.nu.assign(nu, nu + nnu);
+    tb.present = true;
+    return CS_OK;
+}
+
+int cs_accel_upload(cs_ctx *ctx, int accel_slot, int64_t nnu, const double *nu, int nk, const double *P_knots, const double *lnsigma)
+{
+    if (!ctx) return fail(CS_EINVAL, "ctx is NULL");
+    if (accel_slot < 0 || accel_slot >= CS_MAX_ACCEL) return fail(CS_EINVAL, "accelerated-absorber slot %d out of range", accel_slot);
+    if (nk < 2 || !P_knots || !lnsigma) return fail(CS_EINVAL, "need at least two pressure knots");
+    int rc;
+    if ((rc = check_ascending(nu, nnu))) return rc;
+    for (int k = 0; k < nk; k++)
+        if (!(P_knots[k] > 0) || (k > 0 && !(P_knots[k] > P_knots[k - 1]))) return fail(CS_EORDER, "knot pressures must be positive and strictly ascending");
+    HIPCHK(hipSetDevice(ctx->device));
+    AccelDev &ad = ctx->accel[accel_slot];
+    const bool resident_here = ctx->col.ready && ctx->col.accel.slot == accel_slot;
+    if (resident_here && (ad.nk != nk || ad.nnu != nnu)) ctx->col.ready = false;   // (its knot cells belong to the old knots)
+    ad.present = false;
+    if ((rc = upload(ad.L, lnsigma, (size_t)nk * nnu, ctx->stream))) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ad.nnu = nnu;
+    ad.nk = nk;
+    ad.nu.assign(nu, nu + nnu);
+    ad.lnP.resize(nk);
+    for (int k = 0; k < nk; k++) ad.lnP[k] = std::log(P_knots[k]);
+    ad.present = true;
+    return CS_OK;
+}
+
+int cs_accel_fetch(cs_ctx *ctx, int accel_slot, int64_t nnu, int nk, double *lnsigma)
+{
+    if (!ctx || accel_slot < 0 || accel_slot >= CS_MAX_ACCEL || !ctx->accel[accel_slot].present) return fail(CS_EINVAL, "accelerated-absorber slot is empty");
+    const AccelDev &ad = ctx->accel[accel_slot];
+    if (!lnsigma || nnu != ad.nnu || nk != ad.nk)
+        return fail(CS_ESTATE, "the slot holds %lld wavenumbers x %d knots, caller expects %lld x %d", (long long)ad.nnu, ad.nk, (long long)nnu, nk);
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemcpyAsync(lnsigma, ad.L.p, (size_t)nk * nnu * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return CS_OK;
 }
 
 namespace {
@@ -3423,7 +3548,8 @@ class WorkerPool {
         std::mutex m;
         std::condition_variable cv;
         std::function<void()> job;
-        bool ready = false, done = true;
+        bool ready = false, done = true, quit = false;
+        std::thread th;
     };
     std::vector<std::unique_ptr<Worker>> w_;
     std::mutex run_m_;
@@ -3431,7 +3557,8 @@ class WorkerPool {
     {
         for (;;) {
             std::unique_lock<std::mutex> lk(w->m);
-            w->cv.wait(lk, [&] { return w->ready; });
+            w->cv.wait(lk, [&] { return w->ready || w->quit; });
+            if (w->quit) return;
             w->ready = false;
             std::function<void()> job = std::move(w->job);
             lk.unlock();
@@ -3446,9 +3573,9 @@ public:
     void run(int n, const std::function<void(int)> &f)
     {
         std::lock_guard<std::mutex> g(run_m_);
-        while ((int)w_.size() < n - 1) {
+        while ((int)w_.size() < n - 1) {   // (parked on their condition variables between calls; joined by stop())
             w_.emplace_back(new Worker());
-            std::thread(loop, w_.back().get()).detach();   // (parked on its condition variable until the process ends)
+            w_.back()->th = std::thread(loop, w_.back().get());
         }
         for (int i = 1; i < n; i++) {
             Worker *w = w_[i - 1].get();
@@ -3465,13 +3592,25 @@ public:
             w->cv.wait(lk, [&] { return w->done; });
         }
     }
+    // end and join every worker (cs_destroy of the process's last context: a long-lived host session does not keep parked threads
+    // that have touched the GPU; the next multi-context call starts new ones)
+    void stop()
+    {
+        std::lock_guard<std::mutex> g(run_m_);
+        for (auto &w : w_) {
+            { std::lock_guard<std::mutex> lk(w->m); w->quit = true; w->cv.notify_all(); }
+            if (w->th.joinable()) w->th.join();
+        }
+        w_.clear();
+    }
 };
 WorkerPool &worker_pool()
 {
-    static WorkerPool *p = new WorkerPool();   // (never destroyed: its threads outlive static destruction)
+    static WorkerPool *p = new WorkerPool();   // (never destroyed itself: no static-destruction order to get wrong)
     return *p;
 }
 }  // namespace
+static void pool_stop() { worker_pool().stop(); }
 
 int cs_balanced_ranges(int64_t nnu, const double *nu, int ngas, const int64_t *nlines, const double *const *line_nu, int nparts, int64_t *ranges)
 {

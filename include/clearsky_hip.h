@@ -176,6 +176,11 @@ int cs_shape_points(cs_ctx *ctx, int slot, int shape, double dnu_cut, int64_t nn
 int cs_bake(cs_ctx *ctx, int gas_slot, int table_slot, int shape, double dnu_cut, int64_t nnu, const double *nu, int nT,
             const double *T, int nP, const double *P, const double *conc, double *lnsigma_out);
 int cs_table_clear(cs_ctx *ctx, int table_slot);
+/* A table the HOST baked -- the reference's own Gas object (gases.jl:205-249), whatever shape! filled it: lnsigma[nnu, nT, nP]
+ * column-major (nu fastest) = the knot values ln sigma of its OpacityTables (gases.jl:75-82; finite: ln(floatmin) for empty rows) on
+ * T[nT] x P[nP] = Omega.T, Omega.P.  The slot then behaves exactly as one filled by cs_bake. */
+int cs_table_upload(cs_ctx *ctx, int table_slot, int64_t nnu, const double *nu, int nT, const double *T, int nP, const double *P,
+                    const double *lnsigma);
 /* sigma(nu[i0..i0+n), T, P) of a baked table WITHOUT the concentration factor: rawsigma(g, T, P) gases.jl:256-263 */
 int cs_table_eval(cs_ctx *ctx, int table_slot, double T, double P, int64_t i0, int64_t n, double *sigma_out);
 
@@ -229,6 +234,26 @@ int cs_fluxes_discretized_multi(cs_ctx *const *ctxs, int nctx, int64_t nnu, cons
                                 const int *shapes, const double *dnu_cuts, const double *conc, double sigma_gray, const double *sigma_extra,
                                 const double *S_toa, const double *albedo, double theta_s, int nstream, double *tau, double *Mup,
                                 double *Mdn, double *Fup, double *Fdn);
+/*
+ * B3 for every member an AbstractAbsorber can hold (B2): monochromaticfluxes!(M+, M-, tau, core::Discretized, ...,
+ * absorbers...) fluxes.jl:238-279 + intF! shared.jl:125-137 with the sigma-chain of absorbers.jl:84-95 on the device -- line-by-line
+ * gases (gas_slots, as cs_fluxes_discretized), baked Gas objects (gases.jl:205-281: table_slots of cs_bake / cs_table_upload with
+ * conc_tab[ntab, K] = fC_t(T_k, P_k)), CIA pairs (collision_induced_absorption.jl:431-465: cia_slots of cs_cia_begin / cs_cia_band,
+ * cia_flags bit 0 = extrapolate, bit 1 = singles, cia_P1 / cia_P2 [ncia, K] = P_k * concentration(g1 / g2, T_k, P_k), :378-382), the
+ * gray term and host-evaluated functions (sigma_gray, sigma_extra) -- or, instead of all of these, an AcceleratedAbsorber
+ * (absorbers.jl:114-203, what heating! hands radiate!, radiative_convective.jl:112-113): accel_slot >= 0 with ngas = ntab = ncia = 0;
+ * accel_slot = -1 otherwise.  Everything else as cs_fluxes_discretized, which is this call without tables, CIA pairs and accelerated
+ * absorber.  Repeated calls on an unchanged grid, level set and member line-up keep the column resident and refresh only the node
+ * states, spectra and per-node member inputs (the RCM loop).
+ */
+int cs_fluxes_discretized_members(cs_ctx *ctx, int64_t nnu, const double *nu, int np, const double *P, double g, int nlobatto,
+                                  const double *T_nodes, const double *mu_nodes, const double *T_levels, int ngas,
+                                  const int *gas_slots, const int *shapes, const double *dnu_cuts, const double *conc,
+                                  int ntab, const int *table_slots, const double *conc_tab,
+                                  int ncia, const int *cia_slots, const int *cia_flags, const double *cia_P1, const double *cia_P2,
+                                  int accel_slot, double sigma_gray, const double *sigma_extra, const double *S_toa, const double *albedo,
+                                  double theta_s, int nstream, double *tau, double *Mup, double *Mdn, double *Fup, double *Fdn);
+
 /* The partition of the above (host only, no GPU needed): nparts contiguous ranges [ranges[2r], ranges[2r+1]) of the grid with equal
  * estimated device time -- a fixed cost per wavenumber plus, per gas, its local line density times a factor growing with nu
  * (near-line pairs scale with the Doppler width); edges on multiples of 64 points where the grid is long enough; every range
@@ -365,6 +390,14 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
  */
 int cs_accel_store(cs_ctx *ctx, int accel_slot);
 int cs_accel_clear(cs_ctx *ctx, int accel_slot);
+/*   cs_accel_upload  : an AcceleratedAbsorber the HOST holds (the reference's struct as RCM keeps it, radiative_convective.jl:18,95):
+ *                      lnsigma[nnu, nk] column-major (nu fastest) = the knot values of its interpolators phi_i (absorbers.jl:116,195)
+ *                      on P_knots[nk] = A.P (ascending) -- whatever its members were.  The slot then behaves as one filled by
+ *                      cs_accel_store.
+ *   cs_accel_fetch   : the knot values of a slot back to the host, same layout (so that a device-side update! can keep the
+ *                      reference's host struct current); nnu, nk = what the caller's buffer was allocated for. */
+int cs_accel_upload(cs_ctx *ctx, int accel_slot, int64_t nnu, const double *nu, int nk, const double *P_knots, const double *lnsigma);
+int cs_accel_fetch(cs_ctx *ctx, int accel_slot, int64_t nnu, int nk, double *lnsigma);
 int cs_accel_eval(cs_ctx *ctx, int accel_slot, double P, int64_t i0, int64_t n, double *sigma_out);
 int cs_column_set_accel(cs_ctx *ctx, int accel_slot);
 

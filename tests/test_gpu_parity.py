@@ -237,6 +237,27 @@ def test_c3_sparse_parity_vs_oracle(cs, O, c3):
     assert np.max(np.abs(F.Mup[:, idx] - r["Mup"])) < 1e-11 * sm and np.max(np.abs(F.Mdn[:, idx] - r["Mdn"])) < 1e-11 * sm
 
 
+def test_c3_full_grid_every_element_vs_oracle(cs, O, c3):
+    """BASELINE configs[2] at FULL size, every element of what radiate! returns (fluxes.jl:357-383) and of the node cross-sections:
+    the oracle evaluates the whole 1e5-point column (a few seconds on the GPU box's host cores).  An error confined to one interval
+    or tile of the full grid cannot hide in a sample of columns or in the band integral.  Tolerance 1e-11 (sigma, tau relative; M+,
+    M- over the column maximum; F over max F+) -- observed ~1e-13."""
+    cfg, col, F = c3
+    r = O.fluxes_discretized(cfg["nu"], cfg["P"], cfg["g"], 2, col.Tn, col.mun, col.Tlev, [g.sl for g in col.gases],
+                             ["voigt"] * 2, [25.0] * 2, col.conc, want_sigma=True)
+    col.run()
+    sig = col.sigma_nodes()
+    pos = r["sigma"] > 0
+    assert np.all(sig[~pos] == 0.0)
+    assert float(np.max(np.abs(sig[pos] - r["sigma"][pos]) / r["sigma"][pos])) < 1e-11
+    assert relerr(F.tau, r["tau"]) < 1e-11
+    sm = max(r["Mup"].max(), r["Mdn"].max())
+    assert np.max(np.abs(F.Mup - r["Mup"])) < 1e-11 * sm and np.max(np.abs(F.Mdn - r["Mdn"])) < 1e-11 * sm
+    fm = r["Fup"].max()
+    assert np.max(np.abs(F.Fup - r["Fup"])) < 1e-11 * fm and np.max(np.abs(F.Fdn - r["Fdn"])) < 1e-11 * fm
+    assert abs(F.Fup[0] - r["Fup"][0]) < 1e-9          # OLR error [W/m^2]
+
+
 def test_c3_band_integral_and_boundaries(cs, c3):
     cfg, col, F = c3
     w = cs.trapz_weights(cfg["nu"])
