@@ -29,6 +29,9 @@ VALU_PER_LINE = dict(t2=13, t2_cut=17, t3=16, t3_cut=20, t4=20, t4_cut=24, near_
 # k_voigt_near, per (nu, line, state) pair: the evaluation block of the ISA (basic block of the trip loop: 64 VALU in tier 0, 407 in
 # tier 1) + 41 for the queue write, the record fetch of the next trip and the ordered per-lane sum (profiles/r03_notes.md)
 VALU_NEAR = dict(tier0_eval=64, tier1_eval=407, per_candidate=41)
+# the flux sweeps per (wavenumber, layer), ISA of k_rt<5, true> (tools/isa_loops.py): 334 VALU in the downward loop (optical depth, Planck, five
+# exp + layerplanck, wave reduction), 286 in the upward one; other stream counts: 60 + 55 per stream and sweep
+VALU_RT = dict(down=334, up=286, per_stream=55, fixed=60)
 VALU_ISSUE_PEAK = 256 * 4 * 16 * 2.4e9     # fp64-rate lane-instructions per second: 256 CU x 4 SIMD x 16 lanes x 2.4 GHz
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
@@ -230,9 +233,19 @@ def main():
                                note="58 B per line read + 48 B per (state, line) record written + zone tables; the time includes k_mxzones")
     rt_bytes = 8.0 * col.nnu * (K + (col.nl if col.want_tau else 0) + (2 * col.np if col.want_M else 0) + 2)
     t = prof["rt"] * 1e-3
-    kern["k_rt"] = dict(bound="hbm", ms_per_launch=t * 1e3, launches_per_step=1, algorithmic_bytes_per_launch=rt_bytes,
-                        achieved=rt_bytes / t / 1e9 if t > 0 else 0.0, peak=HBM_PEAK_GBS, unit="GB/s", frac=rt_bytes / t / 1e9 / HBM_PEAK_GBS if t > 0 else 0.0,
-                        note="reads sigma [K][nnu], writes tau, M+, M- when asked for; 2 ns + 1 exponentials per (nu, layer) make it VALU-bound on full grids")
+    ns_ = cfg["core"].nstream
+    rt_valu = (VALU_RT["down"] + VALU_RT["up"]) if ns_ == 5 else 2 * (VALU_RT["fixed"] + VALU_RT["per_stream"] * ns_)
+    rt_lane_instr = float(col.nnu) * col.nl * rt_valu
+    flux_name = {0: "k_rt", 1: "k_flux_streams", 2: "k_flux_chunk"}[int(info.get("flux_form", 0))]
+    kern["k_rt"] = dict(bound="valu_issue", kernel=flux_name, ms_per_launch=t * 1e3, launches_per_step=1, lane_instructions_per_launch=rt_lane_instr,
+                        valu_per_point_layer=rt_valu, achieved=rt_lane_instr / t if t > 0 else 0.0, peak=VALU_ISSUE_PEAK,
+                        unit="fp64-rate lane-instructions/s", frac=rt_lane_instr / t / VALU_ISSUE_PEAK if t > 0 else 0.0,
+                        algorithmic_bytes_per_launch=rt_bytes, hbm_achieved_gbs=rt_bytes / t / 1e9 if t > 0 else 0.0,
+                        hbm_frac=rt_bytes / t / 1e9 / HBM_PEAK_GBS if t > 0 else 0.0,
+                        note="the flux sweeps: 2 ns + 1 exponentials (own 20-instruction exp), layerplanck and a wave reduction per (nu, layer) and sweep -- "
+                             "priced against the fp64 issue peak from the ISA's loop bodies; the HBM figure beside it (cross-sections read, tau, M+, M- "
+                             "written when asked for).  k_flux_* also finish the cross-sections on chip (interpolated wings on the matrix cores, CIA "
+                             "pairs, near-line plane): that work is overhead in this fraction")
     # the dominant kernel = the class with the largest time per step
     cls = dict(k_voigt_edge_mx="far_mx", k_cheb_nodes_mx="nodes_mx", k_voigt_far="far", k_cheb_nodes="nodes", k_voigt_sub="sub",
                k_voigt_near="near", k_gas_setup="prep", k_rt="rt")

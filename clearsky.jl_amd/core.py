@@ -1174,7 +1174,7 @@ class Column:
         self._require_resident("info")
         out = (C.c_int64 * 8)()
         check(lib().cs_column_info(self.ctx.handle, out))
-        return dict(groups=out[0], launches=out[1], lines=out[2], merge=out[3], max_members=out[4])
+        return dict(groups=out[0], launches=out[1], lines=out[2], merge=out[3], max_members=out[4], flux_form=out[5])
 
     def work(self):
         """Evaluations the last run issued for its Voigt gases: per-point, at interpolation nodes; levels in use."""

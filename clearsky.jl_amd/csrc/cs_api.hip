@@ -147,13 +147,20 @@ struct CiaBandHost {
 };
 struct CiaDev {
     bool present = false;
+    uint64_t generation = 0;   // bumped whenever the slot's bands change (a resident column's per-grid tables belong to one generation)
     std::vector<CiaBandHost> bands;
     int filled = 0;
 };
 struct ColCia {
     int slot = 0, flags = 0;
     DevBuf bands, st, rho1, rho2, rhoa;
+    DevBuf fac;           // k_cia_tab: [K] Lo^2 rho1 rho2 / rhoa
+    DevBuf tab, toff;     // k_cia_tab: ln k of every band at the temperature of every node state, [toff[b] + k * nb + c]
+    DevBuf tband, cell, fx;   // k_flux: per 64-point tile the bands that reach it [ntile][CS_CIA_ACT] (-1: none), and per (slot, wavenumber)
+                              // the sample cell of that band (-1: outside it) and the position in the cell -- the grid's, not the state's
+    uint64_t generation = 0;  // of the CIA slot these per-grid tables were built from
     int nband = 0;
+    int max_overlap = 0;  // bands of this object reaching one 64-point tile of the column's grid, at most (k_flux holds CS_CIA_ACT)
 };
 
 // interpolated far wings: interval levels of a nu grid (descending interval size; intervals of all levels form one list)
@@ -223,7 +230,7 @@ struct Column {
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     int runs_since_change = 0;
-    bool graph_near_live = false;   // what the captured run left in near_live / launches: a replay leaves the same
+    bool graph_near_live = false, graph_sigma_partial = false;   // what the captured run left in near_live / sigma_partial / launches: a replay leaves the same
     int graph_launches = 0;
     std::vector<ColTab> tab;
     std::vector<ColCia> cia;
@@ -231,6 +238,9 @@ struct Column {
     std::vector<double> h_Tk;
     DevBuf nu, wts, P, Pk, Tk, muk, Tlev, extra, S_toa, albedo;
     DevBuf hot, cold, sigma, sigma2, tau, Mup, Mdn, partial, F, stage, ranges;   // sigma2: the near-line plane (k_voigt_near on a side stream)
+    DevBuf ticket;             // k_flux: blocks finished (the last one adds the block partials up)
+    int flux_form_last = 0;      // which flux kernel the last run used (flux_form)
+    bool sigma_partial = false;  // the last run finished the cross-sections on chip (k_flux): cs_column_sigma_fetch evaluates them again, in HBM
     ChebGrid cheb;             // interpolation levels of the nu grid (nlev = 0: off)
     DevBuf chebF;              // node sums F [nItot][64][Kpad], summed over the column's gases (k_cheb_nodes accumulates)
 };
@@ -299,7 +309,8 @@ struct cs_ctx {
     // k_rt_streams on short grids, [6] split levels of k_cheb_nodes_mx, [7] near-line kernels on a second side stream, [8] states of a
     // group that must be able to use a line for it to join the group's matrix-core node piece, [9] PHCO2 core in k_phco2 itself, [10]
     // PHCO2 node counts / 64-point intervals, [11] far pieces of the node sums on all 64 nodes, [12] level cascade, [13] k_cheb_nodes
-    // with four waves per (interval, state), [14] cut-off edges of k_voigt_edge_mx without the sub-tile phases
+    // with four waves per (interval, state), [14] cut-off edges of k_voigt_edge_mx without the sub-tile phases, [15] the flux kernel
+    // finishes the cross-sections on chip (k_flux): 0 = where it pays, 1 = never, 2 = always
     int tune[CS_NTUNE] = {0, 1, 2, 0, 0, 1, 0, 1, 7, 0, 0, 0, 0, 0, 0, 0};
     std::vector<std::shared_ptr<GasTable>> merged;   // merged tables (keyed by their members' (slot, generation)), least recently used first
     double far_s = 1e6;
@@ -477,6 +488,53 @@ void launch_rt(int ns, const RtGeom &g, int B, hipStream_t s, const RtParams &p,
         CS_RT_CASE(9) CS_RT_CASE(10) CS_RT_CASE(11) CS_RT_CASE(12) CS_RT_CASE(13) CS_RT_CASE(14) CS_RT_CASE(15) CS_RT_CASE(16)
     }
 #undef CS_RT_CASE
+}
+
+// which form of the flux kernel a step of the resident column uses: 0 = k_rt / k_rt_streams reading finished cross-sections from HBM,
+// 1 = k_flux_streams (short grids), 2 = k_flux_chunk (long grids)
+int flux_form(const cs_ctx *ctx, const Column &c, size_t *shmem, int *nblk, int *threads)
+{
+    if ((ctx->tune[15] & 3) == 1 || !c.tab.empty() || c.gas.empty()) return 0;   // (baked tables are added between wings and CIA pairs: own pass)
+    for (auto &cc : c.cia)
+        if (cc.max_overlap > CS_CIA_ACT) return 0;
+    const int np = c.np, ns = c.nstream, K = c.K;
+    const size_t lim = 160 * 1024 - 4096;
+    if (c.rtg.streams) {
+        const size_t sh = ((size_t)K * 64 + (size_t)(2 * np - 1) * 64 + (size_t)4 * ns * 64 + (size_t)2 * np + 64) * sizeof(double);
+        if (sh > lim) return 0;
+        *shmem = sh; *nblk = c.rtg.nblk; *threads = 2 * ns * 64;
+        return 1;
+    }
+    // long grids: where k_rt runs one wave per tile for both sweeps (>= 4096 tiles) the chunked form saves the passes over the plane; in
+    // between (the bench column at full size: 1563 tiles, two waves per tile) the separate kernels are as fast (profiles/r04_notes.md)
+    const int nt64 = (int)((c.nnu + 63) / 64);
+    if ((ctx->tune[15] & 3) != 2 && c.rtg.ud) return 0;
+    const int nw = 4, R = 16 + c.nlob - 1;
+    const size_t sh = ((size_t)2 * np * nw + (size_t)nw * R * 64) * sizeof(double);
+    if (sh > lim) return 0;
+    *shmem = sh; *nblk = (nt64 + nw - 1) / nw; *threads = nw * 64;
+    return 2;
+}
+
+template <int NS>
+void launch_flux_ns(int form, size_t shmem, int nblk, int threads, hipStream_t s, const RtParams &p, const double *nu, const double *wts,
+                           int64_t nnu, const double *sigma, const double *muk, const double *P, const double *Tlev, const double *S,
+                           const double *alb, double *tau, double *Mup, double *Mdn, double *partial, const FluxFuse &f, bool three_waves = true)
+{
+    if (form == 1) {
+        if constexpr (NS >= 2 && NS <= 8) {
+            if (shmem > 65536) (void)hipFuncSetAttribute((const void *)k_flux_streams<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+            CS_LAUNCH((k_flux_streams<NS>), dim3(nblk), dim3(threads), shmem, s, p, nu, wts, nnu, sigma, muk, P, Tlev, S, alb, tau, Mup, Mdn, partial, f);
+        }
+    } else if (three_waves) {
+        if (shmem > 65536) (void)hipFuncSetAttribute((const void *)k_flux_chunk3<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        CS_LAUNCH((k_flux_chunk3<NS>), dim3(nblk), dim3(threads), shmem, s, p, nu, wts, nnu, sigma, muk, P, Tlev, S, alb, tau, Mup, Mdn, partial, f,
+                  (int)((nnu + 63) / 64));
+    } else {
+        if (shmem > 65536) (void)hipFuncSetAttribute((const void *)k_flux_chunk<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        CS_LAUNCH((k_flux_chunk<NS>), dim3(nblk), dim3(threads), shmem, s, p, nu, wts, nnu, sigma, muk, P, Tlev, S, alb, tau, Mup, Mdn, partial, f,
+                  (int)((nnu + 63) / 64));
+    }
 }
 
 // includedlines(::Vector) line_shapes.jl:18-22 -> [g0, g1) ; strict = 0 keeps every line (scalar-nu method :12-16)
@@ -813,7 +871,8 @@ void launch_apply(hipStream_t s, const ChebApply &A, int Kpad, int64_t nnu, int 
 //  of it 0.029 -> 0.037 ms -- F goes through memory once more per level, and each level is one more launch)
 static bool cascade_pays(int nlevels_in_use) { return nlevels_in_use >= 4; }
 void launch_apply_cascade(hipStream_t s, ChebApply A, const double *const *Rc, const int *itv, const int *nI, int mode, int Kpad, int64_t nnu,
-                          int kn, double base, const double *extra, double *sigma, int accumulate)
+                          int kn, double base, const double *extra, double *sigma, int accumulate, ChebApply *carry = nullptr /* != NULL: the
+                          cascade only; *carry = what is still to be carried to the grid (k_flux does that) */)
 {
     const int l0 = A.l0[0];
     const bool on = A.ngas == 1 && A.nlev - l0 >= 2 && mode != 2 && (mode == 1 || cascade_pays(A.nlev - l0));
@@ -828,6 +887,7 @@ void launch_apply_cascade(hipStream_t s, ChebApply A, const double *const *Rc, c
         }
         A.l0[0] = A.nlev - 1;
     }
+    if (carry) { *carry = A; return; }
     launch_apply(s, A, Kpad, nnu, kn, base, extra, sigma, accumulate);
 }
 void launch_apply(hipStream_t s, const ChebApply &A, int Kpad, int64_t nnu, int kn, double base, const double *extra, double *sigma,
@@ -1978,6 +2038,7 @@ int cs_cia_begin(cs_ctx *ctx, int cia_slot, int nband)
     if (nband < 1 || nband > CS_MAX_CIA_BAND) return fail(CS_EINVAL, "a CIA object holds 1..%d bands", CS_MAX_CIA_BAND);
     ctx->cia[cia_slot] = CiaDev();
     ctx->cia[cia_slot].bands.resize(nband);
+    ctx->cia[cia_slot].generation = next_generation();
     return CS_OK;
 }
 
@@ -2000,6 +2061,7 @@ int cs_cia_band(cs_ctx *ctx, int cia_slot, int band, int nb, const double *nu_b,
     HIPCHK(hipStreamSynchronize(ctx->stream));
     cd.filled++;
     cd.present = cd.filled >= (int)cd.bands.size();
+    cd.generation = next_generation();
     return CS_OK;
 }
 
@@ -2069,34 +2131,88 @@ int cs_column_set_cia(cs_ctx *ctx, int ncia, const int *cia_slots, const int *fl
     if (ncia < 0 || ncia > CS_MAX_CIA) return fail(CS_EINVAL, "ncia out of range");
     Column &c = ctx->col;
     HIPCHK(hipSetDevice(ctx->device));
-    drop_graph(c);
-    c.cia.clear();
-    c.cia.resize(ncia);
+    for (int t = 0; t < ncia; t++)
+        if (cia_slots[t] < 0 || cia_slots[t] >= CS_MAX_CIA || !ctx->cia[cia_slots[t]].present) {
+            c.cia.clear();
+            return fail(CS_EINVAL, "CIA slot %d is empty", cia_slots[t]);
+        }
+    // what depends on the grid and the tables alone (band descriptors, sample cells of every wavenumber) is kept while the pairs named
+    // are the ones the column already holds: an RCM loop re-sets its pairs on every call for the partial pressures only
+    bool same = (int)c.cia.size() == ncia;
+    for (int t = 0; t < ncia && same; t++)
+        same = c.cia[t].slot == cia_slots[t] && c.cia[t].generation == ctx->cia[cia_slots[t]].generation;
+    if (!same) {
+        drop_graph(c);
+        c.cia.clear();
+        c.cia.resize(ncia);
+    }
     int rc;
+    const int nt64 = (int)((c.nnu + 63) / 64);
     for (int t = 0; t < ncia; t++) {
         ColCia &cc = c.cia[t];
         cc.slot = cia_slots[t];
         cc.flags = flags ? flags[t] : 0;
-        if (cc.slot < 0 || cc.slot >= CS_MAX_CIA || !ctx->cia[cc.slot].present) { c.cia.clear(); return fail(CS_EINVAL, "CIA slot %d is empty", cc.slot); }
         CiaDev &cd = ctx->cia[cc.slot];
-        cc.nband = (int)cd.bands.size();
-        std::vector<CiaBand> hb(cc.nband);
-        for (int b = 0; b < cc.nband; b++) {
-            hb[b].nu = cd.bands[b].dnu.as<double>();
-            hb[b].lnk = cd.bands[b].dlnk.as<double>();
-            hb[b].nb = (int)cd.bands[b].nu.size();
-            hb[b].nt = (int)cd.bands[b].T.size();
+        if (!same) {
+            cc.generation = cd.generation;
+            cc.nband = (int)cd.bands.size();
+            std::vector<CiaBand> hb(cc.nband);
+            for (int b = 0; b < cc.nband; b++) {
+                hb[b].nu = cd.bands[b].dnu.as<double>();
+                hb[b].lnk = cd.bands[b].dlnk.as<double>();
+                hb[b].nb = (int)cd.bands[b].nu.size();
+                hb[b].nt = (int)cd.bands[b].T.size();
+            }
+            // k_flux: room for ln k at every state's temperature; per tile the bands that reach it; per wavenumber its cell in each
+            std::vector<int64_t> toff(cc.nband);
+            int64_t tot = 0;
+            for (int b = 0; b < cc.nband; b++) { toff[b] = tot; tot += (int64_t)c.K * hb[b].nb; }
+            std::vector<int32_t> tband((size_t)nt64 * CS_CIA_ACT, -1);
+            cc.max_overlap = 0;
+            for (int ti = 0; ti < nt64; ti++) {
+                const double vlo = c.h_nu[(int64_t)ti * 64], vhi = c.h_nu[std::min<int64_t>((int64_t)ti * 64 + 63, c.nnu - 1)];
+                int n = 0;
+                for (int b = 0; b < cc.nband; b++)
+                    if (cd.bands[b].nu.front() <= vhi && cd.bands[b].nu.back() >= vlo) {
+                        if (n < CS_CIA_ACT) tband[(size_t)ti * CS_CIA_ACT + n] = b;
+                        n++;
+                    }
+                cc.max_overlap = std::max(cc.max_overlap, n);
+            }
+            const int nslot = std::min(std::max(cc.max_overlap, 1), (int)CS_CIA_ACT);
+            std::vector<int32_t> cell((size_t)nslot * c.nnu, -1);
+            std::vector<double> fx((size_t)nslot * c.nnu, 0.0);
+            for (int ti = 0; ti < nt64; ti++)
+                for (int q = 0; q < nslot; q++) {
+                    const int b = tband[(size_t)ti * CS_CIA_ACT + q];
+                    if (b < 0) continue;
+                    const std::vector<double> &g = cd.bands[b].nu;
+                    for (int64_t i = (int64_t)ti * 64; i < std::min<int64_t>((int64_t)ti * 64 + 64, c.nnu); i++) {
+                        const double v = c.h_nu[i];
+                        if (!(g.front() <= v && v <= g.back())) continue;      // Phi.G.xa <= nu <= Phi.G.xb, :255
+                        int lo = 0, hi = (int)g.size() - 1;                      // cell with g[lo] <= v < g[lo + 1] (the last one for v == g.back()): k_cia's search
+                        while (hi - lo > 1) { const int m = (lo + hi) >> 1; if (g[m] <= v) lo = m; else hi = m; }
+                        cell[(size_t)q * c.nnu + i] = lo;
+                        fx[(size_t)q * c.nnu + i] = (v - g[lo]) / (g[lo + 1] - g[lo]);
+                    }
+                }
+            if ((rc = upload(cc.bands, hb.data(), hb.size(), ctx->stream)) || (rc = upload(cc.toff, toff.data(), toff.size(), ctx->stream)) ||
+                (rc = upload(cc.tband, tband.data(), tband.size(), ctx->stream)) || (rc = upload(cc.cell, cell.data(), cell.size(), ctx->stream)) ||
+                (rc = upload(cc.fx, fx.data(), fx.size(), ctx->stream))) {
+                c.cia.clear();
+                return rc;
+            }
+            HIPCHK(cc.tab.reserve((size_t)tot * sizeof(double)));
+            HIPCHK(cc.fac.reserve((size_t)c.K * sizeof(double)));
+            HIPCHK(hipStreamSynchronize(ctx->stream));   // (the host vectors are locals)
         }
-        if ((rc = upload(cc.bands, hb.data(), hb.size(), ctx->stream)) || (rc = upload_cia_state(ctx, cc, P1, P2, ncia, t))) {
-            c.cia.clear();
-            return rc;
-        }
+        if ((rc = upload_cia_state(ctx, cc, P1, P2, ncia, t))) { c.cia.clear(); return rc; }
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return CS_OK;
 }
 
-static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e, bool *near_plane_live = nullptr);
+static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e, bool *near_plane_live = nullptr, FluxFuse *fuse = nullptr);
 static int column_current(cs_ctx *ctx);
 
 // ---- AcceleratedAbsorber (absorbers.jl:114-203) -------------------------------------------------------------------------
@@ -2365,12 +2481,16 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
     for (auto &cg : c.gas) any_voigt = any_voigt || cg.shape == SH_VOIGT;
     if (any_voigt) HIPCHK(c.sigma2.reserve((size_t)K * nnu * sizeof(double)));
     if (ngas > 0) HIPCHK(c.ranges.reserve((size_t)K * nnu * sizeof(int2) + (size_t)2 * K * ((nnu + 63) / 64) * sizeof(int)));   // + per-(tile, state) flags
-    if (c.want_tau) HIPCHK(c.tau.reserve((size_t)nl * nnu * sizeof(double)));   // (band fluxes only: no optical depth is stored)
+    HIPCHK(c.tau.reserve((size_t)nl * nnu * sizeof(double)));   // the caller's output, or k_flux_chunk's scratch between its two sweeps
+    if (!c.ticket.p) {
+        HIPCHK(c.ticket.reserve((size_t)(1 + 512 / CS_FLUX_GROUP) * sizeof(unsigned)));
+        HIPCHK(hipMemsetAsync(c.ticket.p, 0, c.ticket.bytes, s));
+    }
     if (c.want_M) {
         HIPCHK(c.Mup.reserve((size_t)np * nnu * sizeof(double)));
         HIPCHK(c.Mdn.reserve((size_t)np * nnu * sizeof(double)));
     }
-    HIPCHK(c.partial.reserve((size_t)c.rtg.nblk * 2 * np * sizeof(double)));
+    HIPCHK(c.partial.reserve(((size_t)c.rtg.nblk + 512 / CS_FLUX_GROUP) * 2 * np * sizeof(double)));   // + k_flux's group sums
     HIPCHK(c.F.reserve((size_t)2 * np * sizeof(double)));
     HIPCHK(hipStreamSynchronize(s));
     c.ready = true;  // state upload below needs the sizes
@@ -2612,7 +2732,9 @@ int cs_column_batch(cs_ctx *ctx, int B, const double *T_nodes, const double *mu_
 // (Sigma(A, i, T, P) of absorbers.jl:95 for every i and node).  ev: see run_impl; e counts the events recorded.
 // near_plane_live: NULL = the cross-sections themselves are the result (the near-line plane is folded into sigma before returning);
 // else the caller (run_impl) hands both planes to k_rt and is told here whether the second one is in use this step
-static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e, bool *near_plane_live)
+// fuse != NULL: the interpolated wings are not carried to the grid and the CIA pairs are not added here -- *fuse says what the flux
+// kernel still has to add (k_flux; near_plane_live must be given too: the near-line plane is not folded in either)
+static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e, bool *near_plane_live, FluxFuse *fuse)
 {
     Column &c = ctx->col;
     const int K = c.K;
@@ -2674,21 +2796,38 @@ static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e, bool *
     }
     fork_join(&fk, s, true, false);   // the node sums; the near-line kernels may run on beside what follows (none of it touches their plane)
     // interpolated far wings of all gases: sigma += sum_level C (sum_gas F)  (one pass over C and sigma)
+    if (fuse) { fuse->apply = 0; fuse->ncia = 0; fuse->Kpad = cheb_kpad(K); }
     if (apply.ngas > 0) {
         const double *Rc[CS_MAX_LEVEL];
         for (int l = 0; l < CS_MAX_LEVEL; l++) Rc[l] = c.cheb.Rc[l].as<double>();
-        launch_apply_cascade(s, apply, Rc, c.cheb.itv, c.cheb.nI, ctx->tune[12], cheb_kpad(K), c.nnu, K, 0.0, nullptr, sig, 1);
+        launch_apply_cascade(s, apply, Rc, c.cheb.itv, c.cheb.nI, ctx->tune[12], cheb_kpad(K), c.nnu, K, 0.0, nullptr, sig, 1,
+                             fuse ? &fuse->A : nullptr);
+        if (fuse) fuse->apply = 1;
     }
     for (auto &t : c.tab) {  // baked gases: sigma += fC * exp(Phi(T, ln P))
         TableDev &tb = ctx->tab[t.slot];
         int rc2;
         if ((rc2 = launch_table_eval(s, tb.Z.as<double>(), tb.nT * tb.nP, c.nnu, t.W.as<double>(), K, t.conc.as<double>(), sig))) return rc2;
     }
-    for (auto &cc : c.cia)  // CIA pairs
+    for (auto &cc : c.cia) {  // CIA pairs
+        if (fuse) {   // the temperature half of the interpolation per (band, state, sample); k_flux does the rest per point
+            CiaPairDev &pd = fuse->cia[fuse->ncia++];
+            pd.nband = cc.nband; pd.bands = cc.bands.as<CiaBand>(); pd.st = cc.st.as<CiaState>(); pd.tab = cc.tab.as<double>();
+            pd.toff = cc.toff.as<int64_t>(); pd.rho1 = cc.rho1.as<double>(); pd.rho2 = cc.rho2.as<double>(); pd.rhoa = cc.rhoa.as<double>();
+            pd.tband = cc.tband.as<int32_t>(); pd.cell = cc.cell.as<int32_t>(); pd.fx = cc.fx.as<double>();
+            pd.nslot = std::min(std::max(cc.max_overlap, 1), (int)CS_CIA_ACT);
+            pd.fac = cc.fac.as<double>();
+            int maxnb = 0;
+            for (auto &b : ctx->cia[cc.slot].bands) maxnb = std::max(maxnb, (int)b.nu.size());
+            CS_LAUNCH(k_cia_tab, dim3((unsigned)((maxnb + 255) / 256), (unsigned)K, (unsigned)cc.nband), dim3(256), 0, s, pd, K);
+            continue;
+        }
         CS_LAUNCH(k_cia, dim3((unsigned)c.ntile), dim3(256), 0, s, cc.nband, cc.bands.as<CiaBand>(), cc.st.as<CiaState>(),
                            c.nu.as<double>(), c.nnu, K, cc.rho1.as<double>(), cc.rho2.as<double>(), cc.rhoa.as<double>(), sig);
+    }
     fork_join(&fk, s);
     c.near_live = false;
+    c.sigma_partial = fuse != nullptr;
     if (near_plane_live) *near_plane_live = fk.live;
     else if (fk.live) {
         const int64_t tot = (int64_t)K * c.nnu;
@@ -2720,17 +2859,43 @@ static int run_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev)
     c.last_stream = s;
     if (ev) HIPCHK(hipEventRecord(ev[e++], s));
     bool near_live = false;
-    if ((rc = sigma_impl(ctx, s, ev, e, &near_live))) return rc;
+    size_t fsh = 0;
+    int fblk = 0, fthr = 0;
+    const int form = flux_form(ctx, c, &fsh, &fblk, &fthr);
+    FluxFuse fuse;
+    memset(&fuse, 0, sizeof fuse);
+    if ((rc = sigma_impl(ctx, s, ev, e, &near_live, form ? &fuse : nullptr))) return rc;
     c.near_live = near_live;
+    c.sigma_partial = form != 0;
+    c.flux_form_last = form;
     if (ev) HIPCHK(hipEventRecord(ev[e++], s));
-    launch_rt(c.nstream, c.rtg, 1, s, c.rt, c.nu.as<double>(), c.wts.as<double>(),
-              c.nnu, sig, c.muk.as<double>(), c.P.as<double>(), c.Tlev.as<double>(),
-              c.has_S ? c.S_toa.as<double>() : nullptr, c.has_alb ? c.albedo.as<double>() : nullptr, c.want_tau ? c.tau.as<double>() : nullptr,
-              c.want_M ? c.Mup.as<double>() : nullptr, c.want_M ? c.Mdn.as<double>() : nullptr, c.partial.as<double>(), 0,
-              near_live ? c.sigma2.as<double>() : nullptr);
+    const double *dS = c.has_S ? c.S_toa.as<double>() : nullptr, *dA = c.has_alb ? c.albedo.as<double>() : nullptr;
+    double *dMu = c.want_M ? c.Mup.as<double>() : nullptr, *dMd = c.want_M ? c.Mdn.as<double>() : nullptr;
+    bool reduced = false;
+    if (form) {
+        fuse.sigma2 = near_live ? c.sigma2.as<double>() : nullptr;
+        fuse.F = c.F.as<double>();
+        // up to 512 blocks the last ones to finish add the block partials (two stages of 16 and <= 32 terms); longer grids keep k_freduce
+        fuse.ticket = (fblk <= 512 && !(ctx->tune[15] & 4)) ? c.ticket.as<unsigned>() : nullptr;   // (| 4: k_freduce always, for A/B)
+        fuse.gpartial = c.partial.as<double>() + (size_t)c.rtg.nblk * 2 * c.np;
+        reduced = fuse.ticket != nullptr;
+        // the chunked form always writes the layer optical depths (its upward sweep reads them back): into the caller's plane or scratch
+        double *dtau = (c.want_tau || form == 2) ? c.tau.as<double>() : nullptr;
+#define CS_FLUX_CASE(N) case N: launch_flux_ns<N>(form, fsh, fblk, fthr, s, c.rt, c.nu.as<double>(), c.wts.as<double>(), c.nnu, sig, c.muk.as<double>(), \
+                                                  c.P.as<double>(), c.Tlev.as<double>(), dS, dA, dtau, dMu, dMd, c.partial.as<double>(), fuse, (ctx->tune[15] & 8) == 0); break;
+        switch (c.nstream) {
+            CS_FLUX_CASE(1) CS_FLUX_CASE(2) CS_FLUX_CASE(3) CS_FLUX_CASE(4) CS_FLUX_CASE(5) CS_FLUX_CASE(6) CS_FLUX_CASE(7) CS_FLUX_CASE(8)
+            CS_FLUX_CASE(9) CS_FLUX_CASE(10) CS_FLUX_CASE(11) CS_FLUX_CASE(12) CS_FLUX_CASE(13) CS_FLUX_CASE(14) CS_FLUX_CASE(15) CS_FLUX_CASE(16)
+        }
+#undef CS_FLUX_CASE
+    } else {
+        launch_rt(c.nstream, c.rtg, 1, s, c.rt, c.nu.as<double>(), c.wts.as<double>(),
+                  c.nnu, sig, c.muk.as<double>(), c.P.as<double>(), c.Tlev.as<double>(), dS, dA, c.want_tau ? c.tau.as<double>() : nullptr,
+                  dMu, dMd, c.partial.as<double>(), 0, near_live ? c.sigma2.as<double>() : nullptr);
+    }
     if (ev) HIPCHK(hipEventRecord(ev[e++], s));
-    CS_LAUNCH(k_freduce, dim3(2 * c.np), dim3(256), 0, s, c.partial.as<double>(), c.rtg.nblk, 2 * c.np,
-                       c.F.as<double>());
+    if (!reduced)
+        CS_LAUNCH(k_freduce, dim3(2 * c.np), dim3(256), 0, s, c.partial.as<double>(), form ? fblk : c.rtg.nblk, 2 * c.np, c.F.as<double>());
     if (ev) HIPCHK(hipEventRecord(ev[e++], s));
     c.launches = g_nlaunch;
     HIPCHK(hipGetLastError());
@@ -2759,6 +2924,7 @@ int cs_column_run(cs_ctx *ctx, void *stream)
         // the replayed kernels wrote the near-line plane again and ran on THIS stream: what cs_column_sigma_fetch / cs_column_fetch /
         // cs_column_info read must say so, as after an eager run
         c.near_live = c.graph_near_live;
+        c.sigma_partial = c.graph_sigma_partial;
         c.launches = c.graph_launches;
         c.last_stream = s;
         return CS_OK;
@@ -2776,6 +2942,7 @@ int cs_column_run(cs_ctx *ctx, void *stream)
     }
     c.graph = g;
     c.graph_near_live = c.near_live;   // (set by the captured run_impl)
+    c.graph_sigma_partial = c.sigma_partial;
     c.graph_launches = c.launches;
     if (hipGraphInstantiate(&c.graph_exec, g, nullptr, nullptr, 0) != hipSuccess) { c.graph_exec = nullptr; drop_graph(c); return run_impl(ctx, s, nullptr); }
     HIPCHK(hipGraphLaunch(c.graph_exec, s));
@@ -2882,6 +3049,14 @@ int cs_column_sigma_fetch(cs_ctx *ctx, int64_t nnu, int K, double *sigma)
                     (long long)nnu, K);
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipDeviceSynchronize());
+    if (c.sigma_partial) {   // the run finished the cross-sections on chip (k_flux): evaluate them once more, all the way into HBM
+        int e = 0;
+        const int rc = sigma_impl(ctx, ctx->stream, nullptr, e);
+        if (rc) return rc;
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        c.sigma_partial = false;
+        c.near_live = false;
+    }
     if (c.near_live) {   // the run handed k_rt two planes: the total is their sum (folded in once)
         const int64_t tot = (int64_t)c.K * c.nnu;
         CS_LAUNCH(k_fold, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, tot, c.sigma.as<double>(), c.sigma2.as<double>());
@@ -2917,6 +3092,7 @@ int cs_column_info(cs_ctx *ctx, int64_t *out)
     out[1] = c.launches;
     for (auto &g : c.gas) { out[2] += g.tab->L; out[4] = std::max<int64_t>(out[4], (int64_t)g.mem.size()); }
     out[3] = c.merge;
+    out[5] = c.flux_form_last;
     return CS_OK;
 }
 

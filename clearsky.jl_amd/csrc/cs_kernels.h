@@ -4,7 +4,10 @@
 //   K3 k_rt        tau (Lobatto), Planck, multi-stream sweeps,  discretized.jl:76-87,136-177,249-326; radiation.jl:48-54
 //                  per-block nu-trapezoid partial sums          shared.jl:125-137, util.jl:26-33
 //   K4 k_freduce   fixed-order reduction of the block partials
-// Paths are relative to the reference root.  No MFMA: nothing here is a contraction.
+//   K5 k_flux      K3 + K4 with the last additions to the cross-sections on chip (interpolated wings, CIA, near-line plane)
+// Paths are relative to the reference root.  Near a line the sum is elementwise on the vector unit; far from it the Voigt term is a
+// short power series in 1/dnu^2 whose coefficients carry the state, so the sum over lines for 16 states is a matrix product on
+// v_mfma_f64_16x16x4_f64 (k_cheb_nodes_mx, k_voigt_edge_mx), as is the carry of the node sums to the grid.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -3132,6 +3135,560 @@ __global__ __launch_bounds__(256) void k_cia(int nband, const CiaBand *__restric
         if (ktot != 0.0) sigma[(size_t)k * nnu + i] += (ktot * Lo2) * rho1[k] * rho2[k] / rhoa[k];
     }
 }
+
+// ---- K5: the flux kernel with the cross-sections finished on chip -------------------------------------------------------------
+// fluxes.jl:270-277 does depth and flux of a wavenumber in one loop body.  Here the line kernels leave their sums in sigma (far,
+// matrix-core pieces) and sigma2 (sub-tile cores, near-line pairs); what is still missing of Sigma(U, i, T_k, P_k) (absorbers.jl:84-95)
+// -- the interpolated far wings sum_level C_l F (k_cheb_apply_mfma's product), the CIA pairs (k_cia) and the sum of the two planes
+// (k_fold) -- used to be three read-modify-write passes over the [K][nnu] plane plus k_rt's read of both planes.  k_flux does all of
+// it for ONE 64-point tile per block: phase A builds sigma_total[K][64] in LDS (matrix cores for the wings, every wave of the block),
+// phase B is k_rt's / k_rt_streams' arithmetic, instruction for instruction, reading the cross-sections from LDS; the block partials
+// of the nu-trapezoid are added by the last block to finish (a ticket), in k_freduce's order.  Nothing of sigma_total, of the
+// optical depths or of the Planck values touches HBM unless the caller asks for tau.
+struct CiaPairDev {
+    int nband;
+    const CiaBand *bands;      // [nband]
+    const CiaState *st;        // [nband][K]
+    const double *tab;         // ln k of band b interpolated to the temperature of state k: tab[toff[b] + k * nb + c]   (k_cia_tab)
+    const int64_t *toff;       // [nband]
+    const double *rho1, *rho2, *rhoa;   // [K]
+    double *fac;               // [K] Lo^2 rho1 rho2 / rhoa of cia(k, T, Pa, P1, P2), :295-303 (k_cia_tab)
+    // per grid (built once at cs_column_set_cia): the bands reaching each 64-point tile, [ntile][CS_CIA_ACT] (-1: none); the sample cell
+    // of wavenumber i in the band of slot q, cell[q * nnu + i] (-1: outside the band), and its position in the cell, fx[q * nnu + i]
+    const int32_t *tband, *cell;
+    const double *fx;
+    int nslot;
+};
+#define CS_CIA_ACT 4           // bands of one CIA object that may overlap one 64-point tile (checked on the host)
+struct FluxFuse {
+    int apply;                 // node sums to carry to the grid (A, Kpad valid)
+    int Kpad;
+    int ncia;
+    ChebApply A;
+    CiaPairDev cia[8];
+    const double *sigma2;      // near-line plane (NULL: none)
+    unsigned *ticket;          // NULL: k_freduce adds the block partials; else [1 + groups] counters, zero between launches
+    double *gpartial;          // [groups][2 np] sums of the partials of 16 consecutive blocks
+    double *F;                 // [2 np] band fluxes
+};
+#define CS_FLUX_GROUP 16
+
+// tab[toff[b] + k*nb + c] = (1 - y) z0[c] + y z1[c]: the temperature half of the bilinear interpolation of ln k (BilinearInterpolator,
+// collision_induced_absorption.jl:207,259) for state k -- wave-uniform in k_cia, so done once per (band, state, sample) instead of
+// once per (wavenumber, state).  Single-temperature ranges (nt = 1) are copied.
+__global__ __launch_bounds__(256) void k_cia_tab(CiaPairDev p, int K)
+{
+    const int b = blockIdx.z, k = blockIdx.y;
+    const CiaBand B = p.bands[b];
+    const int c = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (b == 0 && c == 0) p.fac[k] = 7.21879268e38 * p.rho1[k] * p.rho2[k] / p.rhoa[k];      // Lo^2 (constants.jl:18) x number densities
+    if (c >= B.nb) return;
+    const CiaState s = p.st[(size_t)b * K + k];
+    double v;
+    if (B.nt == 1) v = B.lnk[c];
+    else if (!s.use) v = 0.0;
+    else {
+        const double *z0 = B.lnk + (size_t)s.jT * B.nb, *z1 = z0 + B.nb;
+        v = (1.0 - s.fT) * z0[c] + s.fT * z1[c];
+    }
+    const_cast<double *>(p.tab)[p.toff[b] + (int64_t)k * B.nb + c] = v;
+}
+
+// the CIA terms of one object for the lane's wavenumber at the states k = k0, k0 + kstep, ... (n of them, n <= 16), added into
+// dst[(k % R) * 64]: for every band that reaches the tile, exp(ln k) x Lo^2 rho1 rho2 / rhoa (cia(k, T, Pa, P1, P2), :295-303) with ln k
+// the linear interpolation in nu of the band's samples at the state's temperature (tab).  Written for memory-level parallelism: what
+// depends on the band alone is loaded once, the two samples of eight states are requested together, nothing in the state loop waits
+// for a load that depends on another load.  (Where two bands overlap their terms are added one after the other.)
+__device__ __forceinline__ void cia_add(const CiaPairDev &p, int tile, int64_t ii, int64_t nnu, double v, int K, int k0, int kstep, int n,
+                                        double *__restrict__ dst, int R)
+{
+    const int4 bands4 = *reinterpret_cast<const int4 *>(p.tband + (size_t)tile * CS_CIA_ACT);      // wave-uniform
+    const int bq[CS_CIA_ACT] = {bands4.x, bands4.y, bands4.z, bands4.w};
+#pragma unroll
+    for (int q = 0; q < CS_CIA_ACT; q++) {
+        const int b = bq[q];
+        if (q >= p.nslot || b < 0) continue;                      // (wave-uniform)
+        const int cc = p.cell[(size_t)q * nnu + ii];              // -1: the lane's wavenumber is outside the band
+        const double x = p.fx[(size_t)q * nnu + ii];
+        const CiaBand B = p.bands[b];
+        const double *__restrict__ tb = p.tab + p.toff[b] + max(cc, 0);
+        const CiaState *__restrict__ stb = p.st + (size_t)b * K;
+        for (int h0 = 0; h0 < n; h0 += 8) {
+            double t0[8], t1[8];
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                const int k = min(k0 + (h0 + s) * kstep, K - 1);
+                t0[s] = tb[(int64_t)k * B.nb];
+                t1[s] = tb[(int64_t)k * B.nb + 1];
+            }
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                const int k = k0 + (h0 + s) * kstep;
+                if (h0 + s >= n || k >= K) break;
+                if (!stb[k].use) continue;                        // (wave-uniform)
+                double e;
+                if (B.nt == 1) {     // single-temperature range (`singles`): samples may be ln 0 = -inf, the library exponential keeps the reference's inf / NaN rules
+                    const int c1 = max(cc, 0);
+                    e = exp((v - B.nu[c1]) * (t1[s] - t0[s]) / (B.nu[c1 + 1] - B.nu[c1]) + t0[s]);
+                } else {             // finite samples (floatmin-clamped, :205): the flux kernel's own exponential (<= 2 ulp, tests/test_gpu_kat.py)
+                    e = exp_rt((1.0 - x) * t0[s] + x * t1[s]);
+                }
+                if (cc >= 0) dst[(size_t)(k % R) * 64] += e * p.fac[k];
+            }
+        }
+    }
+}
+
+// phase A: sig[k][lane] = Sigma(U, i, T_k, P_k) of the block's tile for every node state k, in the order the separate kernels add
+// it up: ((sigma + interpolated wings) + CIA pairs, one after the other) + sigma2
+__device__ __forceinline__ void flux_sigma_tile(const FluxFuse &f, int K, int64_t nnu, int tile, const double *__restrict__ sigma,
+                                                const double *__restrict__ nu, double *__restrict__ sig, int wave, int nwaves, int lane)
+{
+    const int64_t i = (int64_t)tile * 64 + lane;
+    const int64_t ii = i < nnu ? i : nnu - 1;      // lanes past a ragged end repeat the last column (their trapezoid weight is 0)
+    const bool fold2 = f.sigma2 != nullptr && f.ncia == 0;      // the near-line plane goes in with the store (no CIA terms come between)
+    if (f.apply) {
+        // items = (16-state group, half of the tile's points): D(16 states x 16 points) += A(16 states x 4 nodes: F) B(4 nodes x 16
+        // points: C), operands as in k_cheb_apply_mfma; an item is one wave's, so no sums cross waves.  A short grid is a chain of
+        // latencies: all operands of a level are requested before its first matrix instruction, and the item's cross-sections before that
+        const int nst = (K + 15) >> 4;
+        const int lr = lane & 15, lq = lane >> 4;
+        for (int item = wave; item < 2 * nst; item += nwaves) {
+            const int sgrp = item >> 1, h = item & 1;
+            double s1[2][4], s2[2][4];
+#pragma unroll
+            for (int jt = 0; jt < 2; jt++) {
+                const int64_t ic = (int64_t)tile * 64 + h * 32 + jt * 16 + lr;
+                const int64_t icc = ic < nnu ? ic : nnu - 1;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int k = min(sgrp * 16 + 4 * r + lq, K - 1);
+                    s1[jt][r] = sigma[(size_t)k * nnu + icc];
+                    s2[jt][r] = fold2 ? f.sigma2[(size_t)k * nnu + icc] : 0.0;
+                }
+            }
+            v4f64 acc[2] = {v4f64{0.0, 0.0, 0.0, 0.0}, v4f64{0.0, 0.0, 0.0, 0.0}};
+            for (int g = 0; g < f.A.ngas; g++) {
+                const double *__restrict__ Fg = f.A.F[g];
+                for (int l = f.A.l0[g]; l < f.A.nlev; l++) {
+                    const int sh = f.A.shift[l];
+                    const int T = tile >> sh, sub = tile & ((1 << sh) - 1);
+                    const size_t itv = (size_t)64 << sh;
+                    const double *__restrict__ Cp = f.A.Cm[l] + ((size_t)T * CS_NC + lq) * itv + (size_t)sub * 64 + (size_t)h * 32 + lr;
+                    const double *__restrict__ Fp = Fg + ((size_t)f.A.noff[l] + (size_t)T * CS_NC + lq) * f.Kpad + (size_t)sgrp * 16 + lr;
+                    double a[CS_NC / 4], b0[CS_NC / 4], b1[CS_NC / 4];
+#pragma unroll
+                    for (int st = 0; st < CS_NC / 4; st++) {
+                        a[st] = Fp[(size_t)(4 * st) * f.Kpad];
+                        b0[st] = Cp[(size_t)(4 * st) * itv];
+                        b1[st] = Cp[(size_t)(4 * st) * itv + 16];
+                    }
+#pragma unroll
+                    for (int st = 0; st < CS_NC / 4; st++) {
+                        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[st], b0[st], acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[st], b1[st], acc[1], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int jt = 0; jt < 2; jt++) {
+                const int col = h * 32 + jt * 16 + lr;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int k = sgrp * 16 + 4 * r + lq;
+                    if (k < K) sig[(size_t)k * 64 + col] = fold2 ? (s1[jt][r] + acc[jt][r]) + s2[jt][r] : s1[jt][r] + acc[jt][r];
+                }
+            }
+        }
+    } else {
+        for (int k = wave; k < K; k += nwaves)
+            sig[(size_t)k * 64 + lane] = fold2 ? sigma[(size_t)k * nnu + ii] + f.sigma2[(size_t)k * nnu + ii] : sigma[(size_t)k * nnu + ii];
+    }
+    if (f.ncia == 0) return;
+    __syncthreads();
+    const double v = nu[ii];
+    for (int pq = 0; pq < f.ncia; pq++)
+        for (int k0 = wave; k0 < K; k0 += 16 * nwaves)        // this wave's states k0, k0 + nwaves, ..., sixteen at a time
+            cia_add(f.cia[pq], tile, ii, nnu, v, K, k0, nwaves, 16, sig + lane, K);
+    if (f.sigma2)
+        for (int k = wave; k < K; k += nwaves) sig[(size_t)k * 64 + lane] += f.sigma2[(size_t)k * nnu + ii];
+}
+
+// the band fluxes from the block partials without another launch (f.ticket != NULL: grids of up to a few hundred blocks).  Blocks form
+// groups of CS_FLUX_GROUP consecutive ones: the last block of a group to arrive adds the group's partials in block order into
+// gpartial[group]; the last GROUP to finish adds the group sums in group order into F.  Who arrives last varies, what is added in
+// which order does not: the band fluxes are bitwise repeatable like k_freduce's.  Every thread's loads of a stage are independent
+// (requested together), so the tail of the kernel is two memory latencies, not one per block.
+// (The partials cross XCDs, whose L2s are not coherent with each other.  A device-scope fence per block would write back and
+//  invalidate the whole L2 of the block's XCD -- measured: +40 us on a 157-block grid -- so the partials and group sums travel as
+//  device-scope relaxed atomic stores and loads instead (write-through / L2-bypassing accesses to just those words), ordered by
+//  waiting for the stores before the ticket and by the ticket's own device-scope atomicity.)
+__device__ __forceinline__ void flux_store_dev(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double flux_load_dev(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void flux_last_block_reduce(const FluxFuse &f, const double *__restrict__ partial, int nblk, int n2)
+{
+    __shared__ unsigned last;
+    const int grp = (int)blockIdx.x / CS_FLUX_GROUP, ngrp = (nblk + CS_FLUX_GROUP - 1) / CS_FLUX_GROUP;
+    const int b0 = grp * CS_FLUX_GROUP, nb = min(CS_FLUX_GROUP, nblk - b0);
+    __builtin_amdgcn_s_waitcnt(0);      // this thread's partials (device-scope stores) have left before the block takes its ticket
+    __syncthreads();
+    if (threadIdx.x == 0) last = (__hip_atomic_fetch_add(f.ticket + 1 + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nb - 1u) ? 1u : 0u;
+    __syncthreads();
+    if (!last) return;
+    for (int e = threadIdx.x; e < n2; e += blockDim.x) {
+        double v[CS_FLUX_GROUP];
+#pragma unroll
+        for (int q = 0; q < CS_FLUX_GROUP; q++) v[q] = q < nb ? flux_load_dev(&partial[(size_t)(b0 + q) * n2 + e]) : 0.0;
+        double t = v[0];
+#pragma unroll
+        for (int q = 1; q < CS_FLUX_GROUP; q++) t += v[q];       // (absent blocks add +0.0: no change)
+        flux_store_dev(&f.gpartial[(size_t)grp * n2 + e], t);
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(f.ticket + 1 + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch (stream order)
+        last = (__hip_atomic_fetch_add(f.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)ngrp - 1u) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!last) return;
+    for (int e = threadIdx.x; e < n2; e += blockDim.x) {
+        double t = 0.0;
+        for (int g0 = 0; g0 < ngrp; g0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) v[q] = g0 + q < ngrp ? flux_load_dev(&f.gpartial[(size_t)(g0 + q) * n2 + e]) : 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; q++) t += v[q];
+        }
+        f.F[e] = t;
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(f.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// K5 on short grids (a nu-shard, a small column: up to ~400 tiles): k_rt_streams with phase A in front -- one block = one 64-point
+// tile, 2 NS waves.  Phase A: every wave takes (state group, half tile) items of the interpolation product and states of the CIA /
+// near-line sums -> sig[K][64] in LDS.  Phase 0 and 1 are k_rt_streams' (same operations in the same order: same rounding).
+template <int NS>
+__global__ __launch_bounds__(2 * NS * 64) void k_flux_streams(RtParams p, const double *__restrict__ nu, const double *__restrict__ wts,
+                                                              int64_t nnu, const double *__restrict__ sigma, const double *__restrict__ muk,
+                                                              const double *__restrict__ P, const double *__restrict__ Tlev,
+                                                              const double *__restrict__ S_toa, const double *__restrict__ albedo,
+                                                              double *__restrict__ tau, double *__restrict__ Mup, double *__restrict__ Mdn,
+                                                              double *__restrict__ partial, FluxFuse f)
+{
+    extern __shared__ double sh[];   // sig[K][64] | Blev[np][64] | tl[nl][64] | xch[2 buffers][2 roles][NS][64] | red[2 np] | msurf[64]
+    const int np = p.np, nl = np - 1, nlob = p.nlobatto, K = p.K;
+    double *sig = sh, *Blev = sig + (size_t)K * 64, *tl = Blev + (size_t)np * 64, *xch = tl + (size_t)nl * 64, *red = xch + (size_t)2 * 2 * NS * 64,
+           *msurf = red + 2 * np;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool up = wave >= NS;
+    const int k = up ? wave - NS : wave;
+    const int64_t j = (int64_t)blockIdx.x * 64 + lane;
+    const bool live = j < nnu;
+    const int64_t jj = live ? j : nnu - 1;
+    flux_sigma_tile(f, K, nnu, (int)blockIdx.x, sigma, nu, sig, wave, 2 * NS, lane);
+    __syncthreads();
+    const double v = nu[jj];
+    const double w = live ? wts[jj] : 0.0;
+    const double fS = S_toa ? S_toa[jj] : 0.0;
+    const double fa = albedo ? albedo[jj] : 0.0;
+    const double c = p.cos_ts;
+    for (int i = wave; i < np; i += 2 * NS) {
+        Blev[(size_t)i * 64 + lane] = planck(v, Tlev[i]);
+        if (i < nl) {   // optical depth of layer i exactly as k_rt forms it (dDepth!, discretized.jl:136-177): beta at the layer's nodes, 1e-6 floor
+            const double dP = P[i + 1] - P[i];
+            const int kl = i * (nlob - 1);
+            auto sg = [&](int kk) { return sig[(size_t)kk * 64 + lane]; };
+            double ti = (dP * p.ws[0]) * (p.C * (sg(kl) / muk[kl]));
+            for (int n = 1; n < nlob - 1; n++) ti += (dP * p.ws[n]) * (p.C * (sg(kl + n) / muk[kl + n]));
+            ti += (dP * p.ws[nlob - 1]) * (p.C * (sg(kl + nlob - 1) / muk[kl + nlob - 1]));
+            const double t = ti > 1e-6 ? ti : 1e-6;
+            tl[(size_t)i * 64 + lane] = t;
+            if (tau && live) tau[(size_t)i * nnu + j] = t;
+        }
+    }
+    __syncthreads();
+    const bool serial = albedo != nullptr;           // (block-uniform) the upward sweep waits for the surface downward flux
+    const double mk = p.m[k], imk = p.im[k], Wk = p.W[k];
+    auto slot = [&](int buf, int role, int kk) { return xch + (((size_t)buf * 2 + role) * NS + kk) * 64 + lane; };
+    double I = 0.0, Ms = c * fS;
+    if (!up && k == 0) {   // level 0: M-[1] = c fS(nu), discretized.jl:299
+        const double r = wave_sum(w * Ms);
+        if (lane == 0) red[np + 0] = r;
+        if (Mdn && live) Mdn[j] = Ms;
+    }
+    double Iu = 0.0;
+    if (up && !serial) {   // surface: Planck emission only (no reflected part without an albedo), discretized.jl:309-310
+        Iu = Blev[(size_t)(np - 1) * 64 + lane];
+        if (k == 0) {
+            const double Mu = Iu * kPi;
+            const double r = wave_sum(w * Mu);
+            if (lane == 0) red[np - 1] = r;
+            if (Mup && live) Mup[(size_t)(np - 1) * nnu + j] = Mu;
+        }
+    }
+    for (int s = 0; s < nl; s++) {
+        const int buf = s & 1;
+        if (!up) {
+            const double t = tl[(size_t)s * 64 + lane];
+            const double tr = exp_rt(-(t * mk));
+            const double Be = layerplanck_inv(Blev[(size_t)s * 64 + lane], Blev[(size_t)(s + 1) * 64 + lane], (1.0 / t) * imk, tr);
+            I = I * tr + Be;
+            *slot(buf, 0, k) = Wk * I;
+            if (k == 0 && S_toa) Ms *= exp(-t / c);
+        } else if (!serial) {
+            const int i = nl - 1 - s;
+            const double t = tl[(size_t)i * 64 + lane];
+            const double tr = exp_rt(-(t * mk));
+            const double Be = layerplanck_inv(Blev[(size_t)(i + 1) * 64 + lane], Blev[(size_t)i * 64 + lane], (1.0 / t) * imk, tr);
+            Iu = Iu * tr + Be;
+            *slot(buf, 1, k) = Wk * Iu;
+        }
+        __syncthreads();
+        if (k == 0 && (!up || !serial)) {   // the role's sum over the streams, in stream order
+            const int role = up ? 1 : 0;
+            double M = 0.0;
+#pragma unroll
+            for (int kk = 0; kk < NS; kk++) M += *slot(buf, role, kk);
+            if (!up) {
+                M += Ms;
+                const double r = wave_sum(w * M);
+                if (lane == 0) red[np + s + 1] = r;
+                if (Mdn && live) Mdn[(size_t)(s + 1) * nnu + j] = M;
+                if (serial && s == nl - 1) msurf[lane] = M;
+            } else {
+                const int i = nl - 1 - s;
+                const double r = wave_sum(w * M);
+                if (lane == 0) red[i] = r;
+                if (Mup && live) Mup[(size_t)i * nnu + j] = M;
+            }
+        }
+    }
+    if (serial) {   // ---- upward sweep after the downward one: Lambertian reflection + Planck emission at the surface
+        __syncthreads();
+        if (up) {
+            Iu = msurf[lane] * fa / kPi + Blev[(size_t)(np - 1) * 64 + lane];
+            if (k == 0) {
+                const double Mu = Iu * kPi;
+                const double r = wave_sum(w * Mu);
+                if (lane == 0) red[np - 1] = r;
+                if (Mup && live) Mup[(size_t)(np - 1) * nnu + j] = Mu;
+            }
+        }
+        for (int s = 0; s < nl; s++) {
+            const int buf = s & 1, i = nl - 1 - s;
+            if (up) {
+                const double t = tl[(size_t)i * 64 + lane];
+                const double tr = exp_rt(-(t * mk));
+                const double Be = layerplanck_inv(Blev[(size_t)(i + 1) * 64 + lane], Blev[(size_t)i * 64 + lane], (1.0 / t) * imk, tr);
+                Iu = Iu * tr + Be;
+                *slot(buf, 1, k) = Wk * Iu;
+            }
+            __syncthreads();
+            if (up && k == 0) {
+                double M = 0.0;
+#pragma unroll
+                for (int kk = 0; kk < NS; kk++) M += *slot(buf, 1, kk);
+                const double r = wave_sum(w * M);
+                if (lane == 0) red[i] = r;
+                if (Mup && live) Mup[(size_t)i * nnu + j] = M;
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * np; e += blockDim.x) {
+        if (f.ticket) flux_store_dev(&partial[(size_t)blockIdx.x * 2 * np + e], red[e]);
+        else partial[(size_t)blockIdx.x * 2 * np + e] = red[e];
+    }
+    if (f.ticket) flux_last_block_reduce(f, partial, (int)gridDim.x, 2 * np);
+}
+
+// K5 on long grids (thousands of tiles): one WAVE = one 64-point tile, both sweeps (k_rt<NS, false>'s arithmetic), four tiles per
+// block.  The cross-sections are finished 16 node states at a time -- one matrix-core state group -- into a ring of 16 + nlobatto - 1
+// rows of LDS per wave, just ahead of the downward sweep that consumes them: the interpolation product of the chunk (4 matrix
+// instructions per 4-node step: one F operand, four C operands), sigma and sigma2 of the chunk, its CIA terms.  The layer optical
+// depths go to `tau` (the caller's output, or scratch) for the upward sweep, as in k_rt.  LDS: 8.7 KB per wave with nlobatto = 2.
+template <int NS>
+__device__ __forceinline__ void flux_chunk_body(const RtParams &p, const double *__restrict__ nu, const double *__restrict__ wts, int64_t nnu,
+                                                const double *__restrict__ sigma, const double *__restrict__ muk, const double *__restrict__ P,
+                                                const double *__restrict__ Tlev, const double *__restrict__ S_toa,
+                                                const double *__restrict__ albedo, double *__restrict__ tau, double *__restrict__ Mup,
+                                                double *__restrict__ Mdn, double *__restrict__ partial, const FluxFuse &f, int ntile)
+{
+    extern __shared__ double sh[];   // red[2 np][nw] | ring[nw][R][64]
+    const int nw = blockDim.x >> 6;
+    const int np = p.np, nl = np - 1, nlob = p.nlobatto, K = p.K;
+    const int R = 16 + nlob - 1;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double *red = sh, *ring = sh + (size_t)2 * np * nw + (size_t)wv * R * 64;
+    const int tile = (int)blockIdx.x * nw + wv;
+    const bool wave_live = tile < ntile;
+    const int tl_ = wave_live ? tile : ntile - 1;     // (a wave past the last tile repeats it with zero weights: barriers stay uniform)
+    const int64_t j = (int64_t)tl_ * 64 + lane;
+    const bool live = wave_live && j < nnu;
+    const int64_t jj = j < nnu ? j : nnu - 1;
+    const double v = nu[jj];
+    const double w = live ? wts[jj] : 0.0;
+    const double fS = S_toa ? S_toa[jj] : 0.0;
+    const double fa = albedo ? albedo[jj] : 0.0;
+    const double c = p.cos_ts;
+    const int lr = lane & 15, lq = lane >> 4;
+    int chunk_next = 0;                // first node state not yet in the ring
+    auto load_chunk = [&]() {          // node states [chunk_next, chunk_next + 16) -> ring rows k % R
+        const int k0 = chunk_next, sgrp = k0 >> 4;
+        if (f.apply) {
+            v4f64 acc[4];
+#pragma unroll
+            for (int jt = 0; jt < 4; jt++) acc[jt] = v4f64{0.0, 0.0, 0.0, 0.0};
+            for (int g = 0; g < f.A.ngas; g++) {
+                const double *__restrict__ Fg = f.A.F[g];
+                for (int l = f.A.l0[g]; l < f.A.nlev; l++) {
+                    const int sh_ = f.A.shift[l];
+                    const int T = tl_ >> sh_, sub = tl_ & ((1 << sh_) - 1);
+                    const size_t itv = (size_t)64 << sh_;
+                    const double *__restrict__ Cp = f.A.Cm[l] + ((size_t)T * CS_NC + lq) * itv + (size_t)sub * 64 + lr;
+                    const double *__restrict__ Fp = Fg + ((size_t)f.A.noff[l] + (size_t)T * CS_NC + lq) * f.Kpad + (size_t)sgrp * 16 + lr;
+#pragma unroll 4
+                    for (int m = 0; m < CS_NC; m += 4) {
+                        const double a = Fp[(size_t)m * f.Kpad];
+                        double b[4];
+#pragma unroll
+                        for (int jt = 0; jt < 4; jt++) b[jt] = Cp[(size_t)m * itv + jt * 16];
+#pragma unroll
+                        for (int jt = 0; jt < 4; jt++) acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[jt], acc[jt], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int jt = 0; jt < 4; jt++) {
+                const int col = jt * 16 + lr;
+                const int64_t ic = (int64_t)tl_ * 64 + col;
+                const int64_t icc = ic < nnu ? ic : nnu - 1;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int k = k0 + 4 * r + lq;
+                    if (k < K) ring[(size_t)(k % R) * 64 + col] = sigma[(size_t)k * nnu + icc] + acc[jt][r];
+                }
+            }
+        } else {
+            for (int k = k0; k < min(k0 + 16, K); k++) ring[(size_t)(k % R) * 64 + lane] = sigma[(size_t)k * nnu + jj];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int pq = 0; pq < f.ncia; pq++) cia_add(f.cia[pq], tl_, jj, nnu, v, K, k0, 1, 16, ring + lane, R);
+        if (f.sigma2)
+            for (int k = k0; k < min(k0 + 16, K); k++) ring[(size_t)(k % R) * 64 + lane] += f.sigma2[(size_t)k * nnu + jj];
+        chunk_next = k0 + 16;
+    };
+    auto sg = [&](int k) { return ring[(size_t)(k % R) * 64 + lane]; };
+
+    double I[NS];
+#pragma unroll
+    for (int k = 0; k < NS; k++) I[k] = 0.0;
+    load_chunk();
+    double b1 = p.C * (sg(0) / muk[0]);  // beta at node 0, discretized.jl:150
+    double Ms = c * fS;                   // M-[1] = c*fS(nu), discretized.jl:299
+    double Md = Ms;
+    double Bprev = planck(v, Tlev[0]);
+    {
+        const double r = wave_sum(w * Md);
+        if (lane == 0) red[(np + 0) * nw + wv] = r;
+        if (Mdn && live) Mdn[j] = Md;
+    }
+    for (int i = 0; i < nl; i++) {
+        const int ke = (i + 1) * (nlob - 1);
+        while (ke >= chunk_next) load_chunk();      // (wave-uniform)
+        const double dP = P[i + 1] - P[i];
+        double ti = (dP * p.ws[0]) * b1;
+        for (int n = 1; n < nlob - 1; n++) {
+            const int k = i * (nlob - 1) + n;
+            ti += (dP * p.ws[n]) * (p.C * (sg(k) / muk[k]));
+        }
+        const double bn = p.C * (sg(ke) / muk[ke]);
+        ti += (dP * p.ws[nlob - 1]) * bn;
+        b1 = bn;
+        const double t = ti > 1e-6 ? ti : 1e-6;  // floor, discretized.jl:147,174
+        if (live) tau[(size_t)i * nnu + j] = t;
+        const double Bnext = planck(v, Tlev[i + 1]);
+        Md = 0.0;
+        const double it = 1.0 / t;
+#pragma unroll
+        for (int k = 0; k < NS; k++) {
+            const double tk = t * p.m[k];
+            const double tr = exp_rt(-tk);
+            const double Be = layerplanck_inv(Bprev, Bnext, it * p.im[k], tr);
+            I[k] = I[k] * tr + Be;
+            Md += p.W[k] * I[k];
+        }
+        if (S_toa) Ms *= exp(-t / c);   // (wave-uniform; without a stellar beam Ms stays 0)
+        Md += Ms;
+        Bprev = Bnext;
+        const double r = wave_sum(w * Md);
+        if (lane == 0) red[(np + i + 1) * nw + wv] = r;
+        if (Mdn && live) Mdn[(size_t)(i + 1) * nnu + j] = Md;
+    }
+    {
+        // surface: Lambertian reflection + Planck emission, discretized.jl:309-310
+        const double Is = Md * fa / kPi + Bprev;
+        double Mu = Is * kPi;
+        {
+            const double r = wave_sum(w * Mu);
+            if (lane == 0) red[(np - 1) * nw + wv] = r;
+            if (Mup && live) Mup[(size_t)(np - 1) * nnu + j] = Mu;
+        }
+#pragma unroll
+        for (int k = 0; k < NS; k++) I[k] = Is;
+        double Bhi = Bprev;  // B at level i+1
+        double t_next = live ? tau[(size_t)(nl - 1) * nnu + j] : 1.0;      // (this lane's own store, same address: program order)
+        for (int i = nl - 1; i >= 0; i--) {
+            const double t = t_next;
+            if (i > 0) t_next = live ? tau[(size_t)(i - 1) * nnu + j] : 1.0;   // one layer ahead
+            const double Blo = planck(v, Tlev[i]);
+            Mu = 0.0;
+            const double it = 1.0 / t;
+#pragma unroll
+            for (int k = 0; k < NS; k++) {
+                const double tk = t * p.m[k];
+                const double tr = exp_rt(-tk);
+                const double Be = layerplanck_inv(Bhi, Blo, it * p.im[k], tr);
+                I[k] = I[k] * tr + Be;
+                Mu += p.W[k] * I[k];
+            }
+            Bhi = Blo;
+            const double r = wave_sum(w * Mu);
+            if (lane == 0) red[i * nw + wv] = r;
+            if (Mup && live) Mup[(size_t)i * nnu + j] = Mu;
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * np; e += blockDim.x) {
+        const double *q = red + e * nw;
+        double t = q[0];
+        for (int x = 1; x < nw; x++) t += q[x];
+        if (f.ticket) flux_store_dev(&partial[(size_t)blockIdx.x * 2 * np + e], t);
+        else partial[(size_t)blockIdx.x * 2 * np + e] = t;
+    }
+    if (f.ticket) flux_last_block_reduce(f, partial, (int)gridDim.x, 2 * np);
+}
+
+// (the register budget decides how many waves a SIMD holds: 168 registers = 3 waves, nothing spilled -- the default; 128 = 4 waves with a
+//  few values in scratch: BASELINE configs[4] 1.59 vs 2.58 ms (profiles/r04_notes.md).  Both are kept for A/B, cs_set_tuning key 15 | 8)
+#define CS_FLUX_CHUNK_KERNEL(NAME, WAVES)                                                                                                       \
+    template <int NS>                                                                                                                           \
+    __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void NAME(                                              \
+        RtParams p, const double *__restrict__ nu, const double *__restrict__ wts, int64_t nnu, const double *__restrict__ sigma,               \
+        const double *__restrict__ muk, const double *__restrict__ P, const double *__restrict__ Tlev, const double *__restrict__ S_toa,         \
+        const double *__restrict__ albedo, double *__restrict__ tau, double *__restrict__ Mup, double *__restrict__ Mdn,                         \
+        double *__restrict__ partial, FluxFuse f, int ntile)                                                                                    \
+    {                                                                                                                                           \
+        flux_chunk_body<NS>(p, nu, wts, nnu, sigma, muk, P, Tlev, S_toa, albedo, tau, Mup, Mdn, partial, f, ntile);                             \
+    }
+CS_FLUX_CHUNK_KERNEL(k_flux_chunk, 4)
+CS_FLUX_CHUNK_KERNEL(k_flux_chunk3, 3)
+#undef CS_FLUX_CHUNK_KERNEL
 
 // ---- AcceleratedAbsorber (absorbers.jl:114-203): per-wavenumber ln sigma on pressure knots, linear in ln P -----------------
 // update!: L[i][nu] = max(ln sigma[i][nu], ln floatmin)  (absorbers.jl:185-196)

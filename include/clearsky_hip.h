@@ -141,7 +141,12 @@ int cs_set_merge(cs_ctx *ctx, int on);
  *   key 13: the vector-unit node kernel with four waves per (interval, state), a quarter of every window each -- 0 (default) on
  *          grids of fewer than 16384 (interval, state) waves (a nu-shard), 1 always, 2 never;
  *   key 14: k_voigt_edge_mx cuts a cut-off edge where the next 16-column sub-tile of the tile comes into the lines' reach and
- *          multiplies only the sub-tiles a part can reach (0, default), or all four for every line (1).
+ *          multiplies only the sub-tiles a part can reach (0, default), or all four for every line (1);
+ *   key 15: the flux kernel finishes the cross-sections on chip (k_flux: the interpolated wings as a matrix product, the CIA pairs and
+ *          the near-line plane are added per 64-point tile in LDS instead of by read-modify-write passes over the [K][nnu] plane, and
+ *          the last block adds the band-flux partials; fluxes.jl:270-277 does depth and flux of a wavenumber in one loop body) -- 0
+ *          (default) where it pays: grids of up to 400 tiles (a nu-shard, a small column) and of 4096 tiles or more, 1 never, 2 always;
+ *          | 4: the block partials are always added by k_freduce's own launch, | 8: the long-grid form with four waves per SIMD (A/B).
  * Applies to every later cs_column_setup / cs_column_run of the context. */
 int cs_set_tuning(cs_ctx *ctx, int key, int value);
 
@@ -303,7 +308,8 @@ int cs_column_fetch(cs_ctx *ctx, int64_t nnu, int np, double *tau, double *Mup, 
 int cs_column_sigma_fetch(cs_ctx *ctx, int64_t nnu, int K, double *sigma);
 int cs_column_counts(cs_ctx *ctx, int64_t *pair_evals, int64_t *lines_in_range);
 /* measurement hook, out[8]: out[0] = launch groups of the resident column (merged gases count once), out[1] = kernel launches of
- * the last cs_column_run, out[2] = lines of all groups, out[3] = cs_set_merge at setup time, out[4] = gases in the largest group */
+ * the last cs_column_run, out[2] = lines of all groups, out[3] = cs_set_merge at setup time, out[4] = gases in the largest group,
+ * out[5] = the flux kernel of the last run: 0 = k_rt / k_rt_streams on finished cross-sections, 1 = k_flux_streams, 2 = k_flux_chunk */
 int cs_column_info(cs_ctx *ctx, int64_t *out);
 /* line-shape evaluations the last cs_column_run actually issued for its Voigt gases (measurement hook): out[0] = per-point
  * evaluations of k_voigt_far/k_voigt_near (64 lanes x lines per wave), out[1] = node evaluations of k_cheb_nodes,

@@ -1,0 +1,135 @@
+"""k_flux: the flux kernel that finishes the cross-sections on chip (interpolated wings as a matrix product, CIA pairs, near-line plane)
+and adds the block partials itself -- fluxes.jl:270-277 does depth and flux of a wavenumber in one loop body -- against the separate
+kernels (k_cheb_apply_mfma, k_cia, k_fold, k_rt / k_rt_streams, k_freduce: cs_set_tuning key 15 = 1) and against the oracle.
+
+Both forms run the separate kernels' operations in the same order, so optical depths and monochromatic fluxes of line-by-line columns
+must come out BITWISE equal; band fluxes differ by the order in which block partials are added (1e-15), CIA terms by the order of the
+bilinear interpolation (1e-14 of the CIA term).  Tolerances vs the oracle as everywhere: 1e-11.
+"""
+import numpy as np
+import pytest
+
+import workloads as W
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(cs, ctx, P, T, absorbers, core, fS=0.0, fa=0.0, **kw):
+    col = cs.Column(P, 9.8, T, 0.029, fS, fa, *absorbers, core=core, ctx=ctx, **kw)
+    col.run()
+    tau = np.zeros((col.nl, col.nnu), order="F")
+    Mu = np.zeros((col.np, col.nnu), order="F")
+    Md = np.zeros((col.np, col.nnu), order="F")
+    Fup, Fdn = col.fetch(tau, Mu, Md)
+    return col, dict(tau=tau, Mup=Mu, Mdn=Md, Fup=Fup, Fdn=Fdn, launches=col.info()["launches"])
+
+
+def _ctx(cs, key15):
+    c = cs.Context(0)
+    c.set_tuning(15, key15)
+    return c
+
+
+@pytest.mark.parametrize("nnu,nlob,ns,fS,fa", [(6000, 2, 5, 0.0, 0.0), (6001, 3, 4, 0.3, 0.2), (2500, 4, 8, 0.0, 0.15), (20000, 2, 5, 0.0, 0.0)])
+def test_streams_form_bitwise_vs_separate_kernels(cs, O, lines, nnu, nlob, ns, fS, fa):
+    """short grids (k_flux_streams): line-by-line H2O + CO2, with and without stellar beam / albedo, ragged last tile"""
+    nu = np.linspace(580.0, 780.0, nnu)
+    P = cs.pressuregrid(5.0, 1e5, 14)
+    T = W.earth_temperature(P)
+    gases = (cs.DirectGas(lines("H2O"), W.fC_h2o, nu), cs.DirectGas(lines("CO2"), 400e-6, nu))
+    core = cs.Discretized(ns, nlob)
+    a_ctx, b_ctx = _ctx(cs, 0), _ctx(cs, 1)
+    col, a = _run(cs, a_ctx, P, T, gases, core, fS, fa)
+    _, b = _run(cs, b_ctx, P, T, gases, core, fS, fa)
+    assert a["launches"] < b["launches"]          # wings, plane fold, sweeps and the band sum in one launch
+    assert np.array_equal(a["tau"], b["tau"]) and np.array_equal(a["Mup"], b["Mup"]) and np.array_equal(a["Mdn"], b["Mdn"])
+    fm = np.max(b["Fup"])
+    assert np.max(np.abs(a["Fup"] - b["Fup"])) < 1e-14 * fm and np.max(np.abs(a["Fdn"] - b["Fdn"])) < 1e-14 * fm
+    r = O.fluxes_discretized(nu, P, 9.8, nlob, col.Tn, col.mun, col.Tlev, [g.sl for g in col.gases], ["voigt"] * 2, [25.0] * 2, col.conc,
+                             S_toa=col.S_toa, albedo=col.albedo, nstream=ns)
+    assert relerr(a["tau"], r["tau"]) < 1e-11
+    sm = max(r["Mup"].max(), r["Mdn"].max())
+    assert np.max(np.abs(a["Mup"] - r["Mup"])) < 1e-11 * sm and np.max(np.abs(a["Mdn"] - r["Mdn"])) < 1e-11 * sm
+    assert np.max(np.abs(a["Fup"] - r["Fup"])) < 1e-11 * r["Fup"].max()
+    # repeatable bit for bit (the last block adds the partials in a fixed order), also after a state update and back
+    col.update(T + 2.0)
+    col.run()
+    col.update(T)
+    col.run()
+    F2 = col.fetch()
+    assert np.array_equal(F2[0], a["Fup"]) and np.array_equal(F2[1], a["Fdn"])
+    # the node cross-sections are still there for whoever asks (evaluated again, all the way into HBM)
+    sig = col.sigma_nodes()
+    bcol = cs.Column(P, 9.8, T, 0.029, fS, fa, *gases, core=core, ctx=b_ctx)
+    bcol.run()
+    assert relerr(sig, bcol.sigma_nodes(), floor=1e-300) < 5e-13
+    a_ctx.close(); b_ctx.close()
+
+
+@pytest.mark.parametrize("nnu,nlob,fa", [(40000, 2, 0.0), (30011, 3, 0.25)])
+def test_chunk_form_bitwise_vs_separate_kernels(cs, lines, nnu, nlob, fa):
+    """long-grid form (k_flux_chunk), forced on a mid-size grid: one wave per tile, cross-sections finished 16 states at a time"""
+    nu = np.linspace(560.0, 800.0, nnu)
+    P = cs.pressuregrid(5.0, 1e5, 22)                 # K = 22 or 43: more than one 16-state chunk, a partial last chunk
+    T = W.earth_temperature(P)
+    gases = (cs.DirectGas(lines("H2O"), W.fC_h2o, nu), cs.DirectGas(lines("CO2"), 400e-6, nu))
+    core = cs.Discretized(5, nlob)
+    a_ctx, b_ctx = _ctx(cs, 2), _ctx(cs, 1)
+    _, a = _run(cs, a_ctx, P, T, gases, core, 0.0, fa)
+    _, b = _run(cs, b_ctx, P, T, gases, core, 0.0, fa)
+    assert a["launches"] < b["launches"]
+    assert np.array_equal(a["tau"], b["tau"]) and np.array_equal(a["Mup"], b["Mup"]) and np.array_equal(a["Mdn"], b["Mdn"])
+    fm = np.max(b["Fup"])
+    assert np.max(np.abs(a["Fup"] - b["Fup"])) < 1e-14 * fm and np.max(np.abs(a["Fdn"] - b["Fdn"])) < 1e-14 * fm
+    # band fluxes only (no tau / M outputs): the optical depths go through scratch
+    col = cs.Column(P, 9.8, T, 0.029, 0.0, fa, *gases, core=core, ctx=a_ctx, want_tau=False, want_M=False)
+    col.run()
+    F = col.fetch()
+    assert np.array_equal(F[0], a["Fup"]) and np.array_equal(F[1], a["Fdn"])
+    a_ctx.close(); b_ctx.close()
+
+
+@pytest.mark.parametrize("key15,nnu", [(0, 9000), (2, 36000)])
+def test_fused_cia_and_gray_vs_separate_and_oracle(cs, O, lines, key15, nnu):
+    """CO2 + CH4 line-by-line with both CIA pairs of the fixtures (CO2-CO2: several bands; CO2-CH4), a gray term and a function absorber:
+    CIA terms inside the flux kernel (temperature half of the interpolation per band sample, the rest per point) vs k_cia, vs the oracle"""
+    nu = np.linspace(1.0, 2200.0, nnu)
+    P = cs.pressuregrid(50.0, 1e5, 19)
+    T = W.earth_temperature(P)
+    members = (cs.DirectGas(lines("CO2"), 0.9, nu), cs.DirectGas(lines("CH4"), 0.02, nu), cs.CIATables(W.fixture("CO2-CO2_2018.cia")),
+               cs.CIATables(W.fixture("CO2-CH4_2018.cia")), cs.GrayGas(2e-28, nu), lambda v, T_, P_: 1e-28 * (P_ / 1e5) * np.asarray(v) / 1000.0)
+    core = cs.Discretized(5, 2)
+    a_ctx, b_ctx = _ctx(cs, key15), _ctx(cs, 1)
+    col, a = _run(cs, a_ctx, P, T, members, core)
+    _, b = _run(cs, b_ctx, P, T, members, core)
+    assert a["launches"] < b["launches"]
+    assert relerr(a["tau"], b["tau"]) < 1e-12
+    sm = max(b["Mup"].max(), b["Mdn"].max())
+    assert np.max(np.abs(a["Mup"] - b["Mup"])) < 1e-12 * sm and np.max(np.abs(a["Mdn"] - b["Mdn"])) < 1e-12 * sm
+    d = [cs.readcia(W.fixture(f)) for f in ("CO2-CO2_2018.cia", "CO2-CH4_2018.cia")]
+    extra = np.zeros((col.K, col.nnu))
+    for k in range(col.K):
+        for ci, x in enumerate(col.U.cia):
+            extra[k] += O.cia_sigma(d[ci], nu, col.Tk[k], col.Pk[k], col.cia_P1[ci, k], col.cia_P2[ci, k])
+        extra[k] += col.sigma_extra[k]
+    r = O.fluxes_discretized(nu, P, 9.8, 2, col.Tn, col.mun, col.Tlev, [g.sl for g in col.gases], ["voigt"] * 2, [25.0] * 2, col.conc,
+                             sigma_gray=col.sigma_gray, sigma_extra=extra)
+    assert relerr(a["tau"], r["tau"]) < 1e-10
+    assert np.max(np.abs(a["Fup"] - r["Fup"])) < 1e-10 * r["Fup"].max()
+    a_ctx.close(); b_ctx.close()
+
+
+def test_long_grid_default_is_chunk_form(cs, lines):
+    """>= 4096 tiles: the chunked form is the default; against the separate kernels (key 15 = 1) on a 300 000-point grid"""
+    nu = np.linspace(600.0, 780.0, 300000)
+    P = cs.pressuregrid(100.0, 1e5, 7)
+    T = W.earth_temperature(P)
+    gases = (cs.DirectGas(lines("CO2"), 400e-6, nu),)
+    a_ctx, b_ctx = _ctx(cs, 0), _ctx(cs, 1)
+    _, a = _run(cs, a_ctx, P, T, gases, cs.Discretized(5, 2))
+    _, b = _run(cs, b_ctx, P, T, gases, cs.Discretized(5, 2))
+    assert a["launches"] < b["launches"]
+    assert np.array_equal(a["tau"], b["tau"]) and np.array_equal(a["Mup"], b["Mup"]) and np.array_equal(a["Mdn"], b["Mdn"])
+    assert np.max(np.abs(a["Fup"] - b["Fup"])) < 1e-14 * np.max(b["Fup"])
+    a_ctx.close(); b_ctx.close()
