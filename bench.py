@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL, default) | gloo (rehearsal of N>1 on fewer GPUs)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and all-reduce the band fluxes even with one rank "
                     "(rehearsal of the RCCL path on a one-GPU box)")
+    ap.add_argument("--nu-range", default=None, help="a:b -- time only the wavenumbers [a, b) of the grid, with the global trapezoid weights (rehearsal of one shard)")
+    ap.add_argument("--no-calibrate", action="store_true", help="N > 1: keep the cost model's partition instead of re-cutting it from the shards' measured times")
     ap.add_argument("--cpu-stride", type=int, default=0, help="cpu_baseline evaluates every n-th wavenumber (0 = size the sample for ~15 s)")
     args = ap.parse_args()
 
@@ -113,6 +115,8 @@ def main():
     if args.emulate_shard:
         r_, n_ = map(int, args.emulate_shard.split("/"))
         ranges = [W.balanced_ranges(nu, cfg["absorbers"], n_)[r_]]
+    if args.nu_range:
+        ranges = [tuple(int(x) for x in args.nu_range.split(":"))]
     ctx = cs.Context(dev)
     ctx.set_precision(args.precision, args.far_s)
     ctx.set_interp(not args.no_interp)
@@ -121,11 +125,60 @@ def main():
     ctx.set_merge(not args.no_merge)
     for kv in filter(None, args.tune.split(",")):
         ctx.set_tuning(*map(int, kv.split("=")))
+    def make_column(rng):
+        return cs.Column(cfg["P"], cfg["g"], cfg["T"], cfg["mu"], cfg["fS"], cfg["fa"], *cfg["absorbers"], core=cfg["core"],
+                         theta_s=cfg["theta_s"], want_tau=True, want_M=True, nu_range=rng, ctx=ctx)
+
+    def shard_ms(c, reps=8):
+        for _ in range(3):
+            c.run()
+        c.sync()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            c.run()
+        c.sync()
+        return (time.perf_counter() - t1) * 1e3 / reps
+
     t_setup = time.perf_counter()
-    col = cs.Column(cfg["P"], cfg["g"], cfg["T"], cfg["mu"], cfg["fS"], cfg["fa"], *cfg["absorbers"], core=cfg["core"],
-                    theta_s=cfg["theta_s"], want_tau=True, want_M=True, nu_range=ranges[rank], ctx=ctx)
+    col = make_column(ranges[rank])
     col.sync()
     setup_ms = (time.perf_counter() - t_setup) * 1e3   # one-off: closures, windows, interpolation matrices, workspaces, uploads
+    # N > 1: the partition came from a cost model whose constants were fitted to BASELINE configs[2]; before the timed region it is re-cut
+    # ONCE from what the shards are measured to take on THIS column (cs_rebalance_ranges; one all-reduce of N doubles at setup time -- the
+    # path's only per-step collective stays the band-flux all-reduce).  --emulate-shard r/N measures all N shards on the one GPU for that.
+    partition = None
+    n_parts = N if not args.emulate_shard else int(args.emulate_shard.split("/")[1])
+    if n_parts > 1 and not args.no_calibrate:
+        try:
+            base = W.balanced_ranges(nu, cfg["absorbers"], n_parts)
+            if args.emulate_shard:
+                me = int(args.emulate_shard.split("/")[0])
+                times = []
+                for r_i in range(n_parts):
+                    if r_i == me:
+                        times.append(shard_ms(col))
+                    else:
+                        tmp_ctx = cs.Context(dev)
+                        tmp = cs.Column(cfg["P"], cfg["g"], cfg["T"], cfg["mu"], cfg["fS"], cfg["fa"], *cfg["absorbers"], core=cfg["core"],
+                                        theta_s=cfg["theta_s"], want_tau=True, want_M=True, nu_range=base[r_i], ctx=tmp_ctx)
+                        times.append(shard_ms(tmp))
+                        del tmp
+                        tmp_ctx.close()
+            else:
+                me = rank
+                tv = torch.zeros(n_parts, dtype=torch.float64, device=(f"cuda:{dev}" if args.dist_backend == "nccl" else "cpu"))
+                tv[rank] = shard_ms(col)
+                dist.all_reduce(tv)
+                times = [float(x) for x in tv.cpu()]
+            lines_pos = [a.sl.nu for a in cfg["absorbers"] if isinstance(a, cs.DirectGas)]
+            recut = cs.rebalance_ranges(nu, lines_pos, base, times, fixed_time=0.3 * min(times))
+            partition = dict(model_ranges=base, model_shard_ms=times, ranges=recut, calibrated=recut != base)
+            if recut[me] != base[me]:
+                del col
+                col = make_column(recut[me])
+                col.sync()
+        except Exception as exc:     # (a failed calibration keeps the model's partition: the step itself does not depend on it)
+            partition = dict(calibrated=False, error=repr(exc))
     # one explicit torch stream carries the kernels, the D2D copy of the band fluxes and the collective, so they are
     # ordered by the stream (torch's default stream has handle 0, which the C ABI reads as "use the context's stream")
     tstream = torch.cuda.Stream(device=dev)
@@ -258,7 +311,7 @@ def main():
     try:
         pm = json.load(open(os.path.join(_ROOT, "profiles", "pmc_traffic.json")))
         default_wl = (args.nnu is None and args.lines is None and args.shape == "voigt" and N == 1 and interp_on and args.precision == "fp64"
-                      and not args.emulate_shard and args.tune in ("", "2=0", "2=0,7=0") and not args.no_merge)
+                      and not args.emulate_shard and not args.nu_range and args.tune in ("", "2=0", "2=0,7=0") and not args.no_merge)
         if pm.get("source_sha16") != source_stamp():
             traffic_note = f"profiles/pmc_traffic.json belongs to build {pm.get('source_sha16')}, the loaded library is {source_stamp()}"
         elif pm.get("config") != args.config or not default_wl:
@@ -309,7 +362,7 @@ def main():
     # the drop-in entry point (cs_fluxes_discretized: host pointers in, host arrays out, what the Julia method calls per
     # radiate!), PCIe-inclusive -- reported beside ms_per_step, never as `value`
     host_ptr = None
-    if rank == 0 and N == 1 and not args.emulate_shard and not col.baked and not col.U.cia:
+    if rank == 0 and N == 1 and not args.emulate_shard and not args.nu_range and not col.baked and not col.U.cia:
         from clearsky_jl_amd.core import _fluxes_discretized
         d = cs.Column(cfg["P"], cfg["g"], cfg["T"], cfg["mu"], cfg["fS"], cfg["fa"], *cfg["absorbers"], core=cfg["core"],
                       theta_s=cfg["theta_s"], ctx=ctx, _setup=False)
@@ -404,7 +457,7 @@ def main():
                                nnu=len(nu), layers=nl, lines=lines_total, parallelism=f"nu-shard x{N}"),
                    collective=(f"{args.dist_backend} all_reduce of {2 * col.np} doubles per step" if use_dist else None),
                    olr_wm2=olr, setup_ms=setup_ms, launches_per_step=int(info["launches"]), launch_groups=int(info["groups"]), host_pointer_ms=host_ptr, kernel_source_sha16=source_stamp(),
-                   roofline=roofline, cpu_baseline=cpu)
+                   partition=partition, roofline=roofline, cpu_baseline=cpu)
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

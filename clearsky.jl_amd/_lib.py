@@ -64,6 +64,8 @@ SIGNATURES = {
     "cs_accel_upload": (C.c_int, [_vp, C.c_int, C.c_int64, _dp, C.c_int, _dp, _dp]),
     "cs_accel_fetch": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_int, _dp]),
     "cs_balanced_ranges": (C.c_int, [C.c_int64, _dp, C.c_int, C.POINTER(C.c_int64), C.POINTER(_dp), C.c_int, C.POINTER(C.c_int64)]),
+    "cs_rebalance_ranges": (C.c_int, [C.c_int64, _dp, C.c_int, C.POINTER(C.c_int64), C.POINTER(_dp), C.c_int, C.POINTER(C.c_int64), _dp, C.c_double,
+                                     C.POINTER(C.c_int64)]),
     "cs_column_setup": (C.c_int, [_vp, C.c_int64, _dp, _dp, C.c_int, _dp, C.c_double, C.c_int, _dp, _dp, _dp, C.c_int,
                                   _ip, _ip, _dp, _dp, C.c_double, _dp, _dp, _dp, C.c_double, C.c_int, C.c_int, C.c_int]),
     "cs_column_run": (C.c_int, [_vp, _vp]),

@@ -414,6 +414,21 @@ def balanced_ranges(nu, line_positions, nparts: int):
     return [(int(out[2 * r]), int(out[2 * r + 1])) for r in range(nparts)]
 
 
+def rebalance_ranges(nu, line_positions, prev_ranges, prev_time, fixed_time: float = 0.0):
+    """cs_rebalance_ranges: the partition `prev_ranges` re-cut from the times its ranges were measured to take (balance the
+    work, not the wavenumbers).  Host only."""
+    nu = as_f64(nu)
+    tabs = [as_f64(a) for a in line_positions]
+    nparts = len(prev_ranges)
+    n = (C.c_int64 * max(len(tabs), 1))(*[len(a) for a in tabs])
+    ptrs = (C.POINTER(C.c_double) * max(len(tabs), 1))(*[dptr(a) for a in tabs])
+    prev = (C.c_int64 * (2 * nparts))(*[int(x) for r in prev_ranges for x in r])
+    t = as_f64(prev_time)
+    out = (C.c_int64 * (2 * nparts))()
+    check(lib().cs_rebalance_ranges(len(nu), dptr(nu), len(tabs), n, ptrs, nparts, prev, dptr(t), float(fixed_time), out))
+    return [(int(out[2 * r]), int(out[2 * r + 1])) for r in range(nparts)]
+
+
 _default_ctx = {}
 
 

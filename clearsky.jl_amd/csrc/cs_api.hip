@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -3788,14 +3789,13 @@ WorkerPool &worker_pool()
 }  // namespace
 static void pool_stop() { worker_pool().stop(); }
 
-int cs_balanced_ranges(int64_t nnu, const double *nu, int ngas, const int64_t *nlines, const double *const *line_nu, int nparts, int64_t *ranges)
+// cost per wavenumber, as a running sum: a fixed part (flux sweeps, interpolation carry, setup) + per gas its local line density rho
+// [lines per cm^-1 within +-2 cm^-1] x (0.011 + 1.1e-6 nu) -- near-line pairs grow with the Doppler width.  The constants were fitted
+// to the kernel times of the eight 1/8 shards of BASELINE configs[2] (profiles/r02_notes.md, r03_notes.md); a column whose balance
+// they miss is re-cut from measured times (cs_rebalance_ranges).
+static void model_cost_sum(int64_t nnu, const double *nu, int ngas, const int64_t *nlines, const double *const *line_nu, std::vector<double> &cum)
 {
-    if (!nu || nnu < 1 || nparts < 1 || !ranges || ngas < 0 || (ngas > 0 && (!nlines || !line_nu))) return fail(CS_EINVAL, "bad arguments");
-    if (nparts > nnu) return fail(CS_EINVAL, "more parts (%d) than wavenumbers (%lld)", nparts, (long long)nnu);
-    // cost per wavenumber, fitted to the per-class kernel times of the eight 1/8 shards of BASELINE configs[2] (profiles/r02_notes.md;
-    // re-checked on the merged kernels, profiles/r03_notes.md): a fixed part (flux sweeps, interpolation apply, setup) + per gas its
-    // local line density rho [lines per cm^-1 within +-2 cm^-1] x (0.011 + 1.1e-6 nu) -- near-line pairs grow with the Doppler width
-    std::vector<double> cum((size_t)nnu + 1, 0.0);
+    cum.assign((size_t)nnu + 1, 0.0);
     std::vector<int64_t> lo(ngas, 0), hi(ngas, 0);   // nu ascends (asserted by the callers of the product path; any order still works,
     for (int64_t i = 0; i < nnu; i++) {              // the two cursors just move both ways): lines in [nu - 2, nu + 2] by two cursors per gas
         double w = 0.19;
@@ -3811,6 +3811,10 @@ int cs_balanced_ranges(int64_t nnu, const double *nu, int ngas, const int64_t *n
         }
         cum[i + 1] = cum[i] + w;
     }
+}
+// nparts contiguous non-empty ranges of equal cost from the running cost sum; edges on multiples of 64 points where the grid allows
+static int cut_equal_cost(int64_t nnu, const std::vector<double> &cum, int nparts, int64_t *ranges)
+{
     std::vector<int64_t> edge(nparts + 1);
     const bool tiles = nnu >= (int64_t)64 * 4 * nparts;   // range edges on multiples of 64 points (the kernels' tile) where the grid allows
     for (int r = 0; r <= nparts; r++) {
@@ -3831,6 +3835,41 @@ int cs_balanced_ranges(int64_t nnu, const double *nu, int ngas, const int64_t *n
         ranges[2 * r + 1] = edge[r + 1];
     }
     return CS_OK;
+}
+
+int cs_balanced_ranges(int64_t nnu, const double *nu, int ngas, const int64_t *nlines, const double *const *line_nu, int nparts, int64_t *ranges)
+{
+    if (!nu || nnu < 1 || nparts < 1 || !ranges || ngas < 0 || (ngas > 0 && (!nlines || !line_nu))) return fail(CS_EINVAL, "bad arguments");
+    if (nparts > nnu) return fail(CS_EINVAL, "more parts (%d) than wavenumbers (%lld)", nparts, (long long)nnu);
+    std::vector<double> cum;
+    model_cost_sum(nnu, nu, ngas, nlines, line_nu, cum);
+    return cut_equal_cost(nnu, cum, nparts, ranges);
+}
+
+int cs_rebalance_ranges(int64_t nnu, const double *nu, int ngas, const int64_t *nlines, const double *const *line_nu, int nparts,
+                        const int64_t *prev_ranges, const double *prev_time, double fixed_time, int64_t *ranges)
+{
+    if (!nu || nnu < 1 || nparts < 1 || !ranges || !prev_ranges || !prev_time || ngas < 0 || (ngas > 0 && (!nlines || !line_nu)))
+        return fail(CS_EINVAL, "bad arguments");
+    if (nparts > nnu) return fail(CS_EINVAL, "more parts (%d) than wavenumbers (%lld)", nparts, (long long)nnu);
+    for (int r = 0; r < nparts; r++) {
+        const bool ok = prev_ranges[2 * r] == (r ? prev_ranges[2 * r - 1] : 0) && prev_ranges[2 * r + 1] > prev_ranges[2 * r] &&
+                        prev_time[r] > 0.0 && std::isfinite(prev_time[r]);
+        if (!ok || (r == nparts - 1 && prev_ranges[2 * r + 1] != nnu))
+            return fail(CS_EINVAL, "prev_ranges must be a partition of the grid into %d non-empty ranges with positive measured times", nparts);
+    }
+    if (!(fixed_time >= 0.0)) return fail(CS_EINVAL, "fixed_time must be >= 0");
+    std::vector<double> cum, cal((size_t)nnu + 1, 0.0);
+    model_cost_sum(nnu, nu, ngas, nlines, line_nu, cum);
+    // the model's density, rescaled part by part so that it reproduces what the part took beyond the share that does not move with the
+    // edges; a part the model under-rates gets denser and will shrink
+    for (int r = 0; r < nparts; r++) {
+        const int64_t a = prev_ranges[2 * r], b = prev_ranges[2 * r + 1];
+        const double t = std::max(prev_time[r] - fixed_time, 0.05 * prev_time[r]);
+        const double sc = t / std::max(cum[b] - cum[a], 1e-300);
+        for (int64_t i = a; i < b; i++) cal[i + 1] = cal[i] + (cum[i + 1] - cum[i]) * sc;
+    }
+    return cut_equal_cost(nnu, cal, nparts, ranges);
 }
 
 int cs_fluxes_discretized_multi(cs_ctx *const *ctxs, int nctx, int64_t nnu, const double *nu, int np, const double *P, double g, int nlobatto,
@@ -3866,8 +3905,17 @@ int cs_fluxes_discretized_multi(cs_ctx *const *ctxs, int nctx, int64_t nnu, cons
     MultiPlan &mp = ctxs[0]->mplan;
     std::vector<uint64_t> gens(ngas);
     for (int gi = 0; gi < ngas; gi++) gens[gi] = ctxs[0]->gas[gas_slots[gi]].generation;
+    bool calibrate = false;
     if (!(mp.nctx == nctx && (int64_t)mp.nu.size() == nnu && mp.gens == gens && memcmp(mp.nu.data(), nu, (size_t)nnu * sizeof(double)) == 0)) {
         if ((rc = cs_balanced_ranges(nnu, nu, ngas, nl_.data(), ln_.data(), nctx, ranges.data()))) return rc;
+        // a new plan: once, inside this call, the model's partition is re-cut from what its ranges are measured to take on THIS column
+        // (cs_rebalance_ranges) -- where every context has a device to itself, so that a range's time is its own (cs_set_tuning key 15 |
+        // 32 on the first context: also on shared devices, for tests)
+        calibrate = ngas > 0;
+        for (int i = 0; i < nctx && calibrate; i++)
+            for (int q = 0; q < i; q++)
+                if (ctxs[q]->device == ctxs[i]->device) calibrate = false;
+        if (ctxs[0]->tune[15] & 32) calibrate = ngas > 0;
         mp.nctx = nctx;
         mp.nu.assign(nu, nu + nnu);
         mp.gens = gens;
@@ -3875,8 +3923,10 @@ int cs_fluxes_discretized_multi(cs_ctx *const *ctxs, int nctx, int64_t nnu, cons
         mp.wt.resize(nnu);   // trapezoid weights of the WHOLE grid (util.jl:26-33): shards use slices, so their band fluxes simply add
         for (int64_t j = 0; j < nnu; j++) mp.wt[j] = ((j > 0 ? nu[j] - nu[j - 1] : 0.0) + (j + 1 < nnu ? nu[j + 1] - nu[j] : 0.0)) / 2;
     }
+  for (int pass = 0; pass < 2; pass++) {
     ranges = mp.ranges;
     const std::vector<double> &wt = mp.wt;
+    std::vector<double> run_ms(nctx, 0.0);
     const int K = (np - 1) * (nlobatto - 1) + 1, nl = np - 1;
     std::vector<int> rcs(nctx, CS_OK);
     std::vector<std::string> msgs(nctx);
@@ -3928,6 +3978,12 @@ int cs_fluxes_discretized_multi(cs_ctx *const *ctxs, int nctx, int64_t nnu, cons
         }
         if (!r) r = cs_column_run(ctx, nullptr);
         if (!r && hipStreamSynchronize(ctx->stream) != hipSuccess) r = fail(CS_EHIP, "hipStreamSynchronize failed");
+        if (!r && calibrate && pass == 0) {   // the range's own time: a second, warm evaluation (the first one loaded code objects)
+            const auto t0 = std::chrono::steady_clock::now();
+            r = cs_column_run(ctx, nullptr);
+            if (!r && hipStreamSynchronize(ctx->stream) != hipSuccess) r = fail(CS_EHIP, "hipStreamSynchronize failed");
+            run_ms[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        }
         {
             std::lock_guard<std::mutex> lk(turn_m);
             kernels_done[i] = 1;   // (also on failure: nobody is left waiting)
@@ -3941,12 +3997,23 @@ int cs_fluxes_discretized_multi(cs_ctx *const *ctxs, int nctx, int64_t nnu, cons
     worker_pool().run(nctx, work);
     for (int i = 0; i < nctx; i++)
         if (rcs[i]) return fail(rcs[i], "context %d (device %d): %s", i, ctxs[i]->device, msgs[i].c_str());
+    if (calibrate && pass == 0) {
+        calibrate = false;
+        std::vector<int64_t> re(2 * (size_t)nctx);
+        const double fixed = 0.3 * *std::min_element(run_ms.begin(), run_ms.end());   // (the launch chain of a step: does not move with the edges)
+        if (cs_rebalance_ranges(nnu, nu, ngas, nl_.data(), ln_.data(), nctx, mp.ranges.data(), run_ms.data(), fixed, re.data()) == CS_OK && re != mp.ranges) {
+            mp.ranges = re;
+            continue;   // the call's results come from the re-cut partition, like every later call's
+        }
+    }
     for (int l = 0; l < np; l++) {   // fixed-order host sum: bitwise repeatable (SURVEY 8e's deterministic alternative to an all-reduce)
         double u = 0.0, d = 0.0;
         for (int i = 0; i < nctx; i++) { u += Fpart[(size_t)i * 2 * np + l]; d += Fpart[(size_t)i * 2 * np + np + l]; }
         Fup[l] = u;
         Fdn[l] = d;
     }
+    return CS_OK;
+  }
     return CS_OK;
 }
 

@@ -146,7 +146,9 @@ int cs_set_merge(cs_ctx *ctx, int on);
  *          the near-line plane are added per 64-point tile in LDS instead of by read-modify-write passes over the [K][nnu] plane, and
  *          the last block adds the band-flux partials; fluxes.jl:270-277 does depth and flux of a wavenumber in one loop body) -- 0
  *          (default) where it pays: grids of up to 400 tiles (a nu-shard, a small column) and of 4096 tiles or more, 1 never, 2 always;
- *          | 4: the block partials are always added by k_freduce's own launch, | 8: the long-grid form with four waves per SIMD (A/B).
+ *          | 4: the block partials are always added by k_freduce's own launch, | 8: the long-grid form with four waves per SIMD (A/B);
+ *          | 32 (on the first context of a cs_fluxes_discretized_multi call): the partition is re-cut from measured times also when
+ *          contexts share a device (tests).
  * Applies to every later cs_column_setup / cs_column_run of the context. */
 int cs_set_tuning(cs_ctx *ctx, int key, int value);
 
@@ -264,6 +266,14 @@ int cs_fluxes_discretized_members(cs_ctx *ctx, int64_t nnu, const double *nu, in
  * (near-line pairs scale with the Doppler width); edges on multiples of 64 points where the grid is long enough; every range
  * non-empty.  line_nu[g][0 .. nlines[g]) = the sorted line positions of gas g. */
 int cs_balanced_ranges(int64_t nnu, const double *nu, int ngas, const int64_t *nlines, const double *const *line_nu, int nparts, int64_t *ranges);
+/* The same partition re-cut from MEASURED times (host only): prev_ranges = an earlier partition of this grid into nparts ranges,
+ * prev_time[r] = what range r took (any unit), fixed_time = the share of a step that does not move with the edges (launch chain; 0 if
+ * unknown: the correction then falls short and a second pass finishes it).  The cost model's density is rescaled range by range to
+ * reproduce the measured times, then cut into equal parts again -- the column's own behaviour instead of constants fitted to another
+ * column (BASELINE configs[2]).  cs_fluxes_discretized_multi does this once, inside its first call on a grid, when its contexts sit on
+ * different devices; bench.py does it across ranks before its timed region. */
+int cs_rebalance_ranges(int64_t nnu, const double *nu, int ngas, const int64_t *nlines, const double *const *line_nu, int nparts,
+                        const int64_t *prev_ranges, const double *prev_time, double fixed_time, int64_t *ranges);
 
 /*
  * Device-resident form of B3 for callers that keep the column in HBM (benchmarks, torch/RCCL plumbing, RCM loops):

@@ -83,3 +83,48 @@ def test_balanced_ranges_partition_properties():
     assert cs.balanced_ranges(np.linspace(1.0, 2.0, 10), [], 10) == [(i, i + 1) for i in range(10)]
     with pytest.raises(cs.ClearSkyHIPError):
         cs.balanced_ranges(np.linspace(1.0, 2.0, 10), [], 11)
+
+
+def test_rebalance_ranges_from_measured_times():
+    """cs_rebalance_ranges: a partition re-cut from what its ranges were measured to take (the column's own behaviour instead of the cost
+    model's constants, fitted to BASELINE configs[2]).  A synthetic 'true' cost that the model misses -- twice as expensive in the upper
+    half of the grid, plus a fixed share per range -- is balanced to a few per cent in two passes; the result is always a partition."""
+    import clearsky_jl_amd as cs
+    rng = np.random.default_rng(7)
+    nu = np.linspace(1.0, 2500.0, 40000)
+    tabs = [np.sort(rng.uniform(0.0, 2525.0, 30000)), np.sort(rng.uniform(500.0, 900.0, 8000))]
+    n = 8
+    truth = np.where(nu > 1250.0, 2.0, 1.0) * (1.0 + 0.5 * np.sin(nu / 200.0) ** 2)     # cost per point nobody told the model about
+    csum = np.concatenate([[0.0], np.cumsum(truth)])
+    fixed = 0.15 * csum[-1] / n
+
+    def measure(ranges):
+        return [fixed + csum[b] - csum[a] for a, b in ranges]
+
+    def check_partition(ranges):
+        assert ranges[0][0] == 0 and ranges[-1][1] == len(nu)
+        assert all(a < b for a, b in ranges) and all(ranges[i][1] == ranges[i + 1][0] for i in range(n - 1))
+        assert all(a % 64 == 0 for a, _ in ranges)
+
+    r0 = cs.balanced_ranges(nu, tabs, n)
+    t0 = measure(r0)
+    r1 = cs.rebalance_ranges(nu, tabs, r0, t0, fixed_time=0.3 * min(t0))
+    check_partition(r1)
+    t1 = measure(r1)
+    r2 = cs.rebalance_ranges(nu, tabs, r1, t1, fixed_time=0.3 * min(t1))
+    check_partition(r2)
+    t2 = measure(r2)
+    spread = lambda t: (max(t) - min(t)) / (sum(t) / len(t))
+    assert spread(t0) > 0.3                      # the model alone is far off on this column
+    assert spread(t1) < 0.5 * spread(t0) and spread(t2) < 0.05
+    assert max(t2) < 0.85 * max(t0)              # what an N-GPU step waits for: its slowest range
+    # equal measured times on the model's own partition: nothing to correct
+    cum_same = cs.rebalance_ranges(nu, tabs, r0, [1.0] * n, fixed_time=0.0)
+    assert cum_same == r0
+    # refusals: not a partition, non-positive times
+    bad = list(r0)
+    bad[3] = (bad[3][0] + 64, bad[3][1])
+    with pytest.raises(cs.ClearSkyHIPError):
+        cs.rebalance_ranges(nu, tabs, bad, t0)
+    with pytest.raises(cs.ClearSkyHIPError):
+        cs.rebalance_ranges(nu, tabs, r0, [0.0] + t0[1:])

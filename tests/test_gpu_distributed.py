@@ -140,3 +140,43 @@ def test_bench_rccl_path_single_rank():
         res[bool(flag)] = d
     assert res[True]["collective"].startswith("nccl") and res[False]["collective"] is None
     assert res[True]["olr_wm2"] == res[False]["olr_wm2"]
+
+
+def test_multi_context_partition_recut_from_measured_times(cs, O, lines):
+    """The product's N-GPU call re-cuts its partition once, inside the first call on a grid, from what the ranges were measured to take
+    (cs_rebalance_ranges; on the box's one card the times are those of contexts taking turns -- cs_set_tuning key 15 | 32 forces the
+    calibration there, which exercises the path: measure, re-cut, set the shards up again).  Results stay the oracle's; later calls keep
+    the re-cut partition and are bitwise repeatable."""
+    import workloads as W
+    nu = np.linspace(550.0, 800.0, 16000)
+    P = cs.pressuregrid(10.0, 1e5, 11)
+    T = W.earth_temperature(P)
+    gases = [cs.DirectGas(lines("H2O"), W.fC_h2o, nu), cs.DirectGas(lines("CO2"), 400e-6, nu)]
+    col = cs.Column(P, 9.8, T, 0.029, 0.0, 0.0, *gases, core=cs.Discretized(5, 2), ctx=cs.Context(0), _setup=False)
+    ref = O.fluxes_discretized(nu, P, 9.8, 2, col.Tn, col.mun, col.Tlev, [g.sl for g in col.gases], ["voigt"] * 2, [25.0] * 2, col.conc)
+    mc = cs.MultiContext([0, 0, 0])
+    mc.ctxs[0].set_tuning(15, 32)
+    F = cs.radiate(P, 9.8, T, 0.029, 0.0, 0.0, *gases, core=cs.Discretized(5, 2), ctx=mc)
+    assert np.max(np.abs(F.tau - ref["tau"]) / ref["tau"]) < 1e-11
+    assert np.max(np.abs(F.Fup - ref["Fup"])) < 1e-11 * ref["Fup"].max()
+    G = cs.radiate(P, 9.8, T, 0.029, 0.0, 0.0, *gases, core=cs.Discretized(5, 2), ctx=mc)
+    assert np.array_equal(F.Fup, G.Fup) and np.array_equal(F.tau, G.tau) and np.array_equal(F.Mup, G.Mup)
+    mc.close()
+
+
+def test_bench_emulated_shard_with_calibrated_partition():
+    """bench.py --emulate-shard r/N re-cuts the N-way partition from the N shards' measured times before its timed region (what every rank
+    of an N-GPU run does through one all-reduce of N doubles at setup time) and reports both partitions"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C2", "--steps", "5", "--warmup", "2", "--no-cpu",
+                          "--emulate-shard", "1/3"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    p = d["partition"]
+    assert p is not None and "error" not in p, p
+    assert len(p["model_ranges"]) == 3 and len(p["ranges"]) == 3 and len(p["model_shard_ms"]) == 3
+    assert p["ranges"][0][0] == 0 and p["ranges"][-1][1] == d["config"]["nnu"]
+    assert all(p["ranges"][i][1] == p["ranges"][i + 1][0] for i in range(2))
+    off = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C2", "--steps", "5", "--warmup", "2", "--no-cpu",
+                          "--emulate-shard", "1/3", "--no-calibrate"], env=env, capture_output=True, text=True, timeout=600)
+    assert off.returncode == 0 and json.loads([l for l in off.stdout.splitlines() if l.startswith("{")][0])["partition"] is None
