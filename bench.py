@@ -309,7 +309,7 @@ def main():
     # library loaded now (same build id) and on this exact workload; otherwise null -- never a stale number.
     traffic, traffic_note, traffic_step = None, "no PMC profile of this build/workload under profiles/", None
     try:
-        pm = json.load(open(os.path.join(_ROOT, "profiles", "pmc_traffic.json")))
+        pm = json.load(open(os.path.join(_ROOT, "profiles", "pmc_traffic.json" if args.config == "C3" else f"pmc_traffic_{args.config.lower()}.json")))
         default_wl = (args.nnu is None and args.lines is None and args.shape == "voigt" and N == 1 and interp_on and args.precision == "fp64"
                       and not args.emulate_shard and not args.nu_range and args.tune in ("", "2=0", "2=0,7=0") and not args.no_merge)
         if pm.get("source_sha16") != source_stamp():

@@ -702,6 +702,7 @@ struct Interp {
     const double *R = nullptr;     // the context's re-interpolation matrices (cs_ctx::reinterp); NULL: every piece on 64 nodes (cs_set_tuning key 11)
     int nsplit_levels = 1;    // cs_set_tuning key 6: interval sizes (largest first) whose node sums four waves share in k_cheb_nodes_mx
     bool small_mx = false;    // cs_set_tuning key 1: the matrix-core kernels on short grids too (their four-waves-per-item variants)
+    bool mxzones_one_thread = false;   // cs_set_tuning key 15 | 16: k_mxzones instead of k_mxzones16
     bool fuse_apply = false;  // the column's only interpolating group: k_voigt_edge_mx may carry the node sums to the grid itself
     double core4 = 0.0;       // the core takes the 4-term series where its radius is below core4 x the tile's span, else the 8-term one
                               // (0: always the 8-term one -- measured at C3 with 0.75 / 0.3 / 0: 2.61 / 2.55 / 2.52 ms)
@@ -717,6 +718,7 @@ static void interp_settings(const cs_ctx *ctx, Interp &itp)   // the cs_set_tuni
     itp.cascade = ctx->tune[12];
     itp.nodes_split = ctx->tune[13];
     itp.edge_phases = ctx->tune[14] ? 0 : 1;
+    itp.mxzones_one_thread = (ctx->tune[15] & 16) != 0;
 }
 
 // interval sizes worth using on this grid: an interval of width W leaves lines over (2 cut - 2.3 W) to interpolate
@@ -1174,9 +1176,18 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
                 ea.mu_min = G.mu_min; ea.cut = cut;
                 ea.core = (use_edge && itp.core) ? 1 : 0;
                 ea.core4 = itp.core4;
-                const unsigned nb_sep = use_sep ? (unsigned)(((int64_t)(itp.nItot - q0) * ngrp + 255) / 256) : 0u;
-                const unsigned nb_edge = use_edge ? (unsigned)(((int64_t)nt64 * ngrp + 255) / 256) : 0u;
-                CS_LAUNCH(k_mxzones, dim3(nb_sep + nb_edge), dim3(256), 0, s, nb_sep, sa, ea);
+                // sixteen lanes per item shorten the chain where the items are few (a nu-shard: 21 -> 8 us; the bench column 27 -> 9); from
+                // ~50 000 items on one thread per item has parallelism enough and sixteen times fewer threads (BASELINE configs[4]: 0.256 vs 0.276 ms)
+                const int64_t nitems = (use_sep ? (int64_t)(itp.nItot - q0) * ngrp : 0) + (use_edge ? (int64_t)nt64 * ngrp : 0);
+                if (itp.mxzones_one_thread || nitems > 50000) {   // (cs_set_tuning key 15 | 16: always)
+                    const unsigned nb_sep = use_sep ? (unsigned)(((int64_t)(itp.nItot - q0) * ngrp + 255) / 256) : 0u;
+                    const unsigned nb_edge = use_edge ? (unsigned)(((int64_t)nt64 * ngrp + 255) / 256) : 0u;
+                    CS_LAUNCH(k_mxzones, dim3(nb_sep + nb_edge), dim3(256), 0, s, nb_sep, sa, ea);
+                } else {                        // sixteen lanes per item
+                    const unsigned nb_sep = use_sep ? (unsigned)(((int64_t)(itp.nItot - q0) * ngrp + 15) / 16) : 0u;
+                    const unsigned nb_edge = use_edge ? (unsigned)(((int64_t)nt64 * ngrp + 15) / 16) : 0u;
+                    CS_LAUNCH(k_mxzones16, dim3(nb_sep + nb_edge), dim3(256), 0, s, nb_sep, sa, ea);
+                }
             }
             if (evg) (void)hipEventRecord(evg[0], s);
             const SepZone *sepz = use_sep ? itp.sep : nullptr;

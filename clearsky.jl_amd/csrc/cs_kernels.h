@@ -1672,6 +1672,153 @@ __global__ __launch_bounds__(256) void k_mxzones(unsigned nb_sep, SepArgs sa, Ed
     if (blockIdx.x < nb_sep) sepzones_body(blockIdx.x, sa);
     else edgezones_body(blockIdx.x - nb_sep, ea);
 }
+// The same two tables with SIXTEEN lanes per item, lane = state of the group (k_mxzones16): the bodies above are one thread per item --
+// sixteen zone records read one after the other and a 16 x 16 counting rank, ~3000 instructions in a chain -- and their launch sits at the
+// head of every step, where a nu-shard of a few hundred tiles has six blocks of it to run (21 us of 0.39 ms).  Here every lane reads its
+// own state's records, the group's bounds are 16-lane reductions, the rank of a state's series bound is sixteen shuffled comparisons,
+// and lane 0 stores: the same integers, a chain ten times shorter.
+template <class T, class Op> __device__ __forceinline__ T red16(T v, Op op)
+{
+#pragma unroll
+    for (int m = 8; m > 0; m >>= 1) v = op(v, __shfl_xor(v, m, 16));
+    return v;
+}
+__device__ __forceinline__ void sepzones_body16(unsigned bid, const SepArgs &a)
+{
+    const int item = (int)(bid * (blockDim.x >> 4) + (threadIdx.x >> 4)), kk = threadIdx.x & 15;
+    const int nq = a.nItot - a.q0;
+    if (item >= nq * a.ngrp) return;            // (uniform over the 16 lanes of an item)
+    const int g = item / nq, T = a.q0 + (item - g * nq);
+    const double vhi = a.nodes[(size_t)T * CS_NC], vlo = a.nodes[(size_t)T * CS_NC + CS_NC - 1];   // nodes run from the upper end down
+    const int k = g * 16 + kk;
+    const bool have = k < a.K;
+    IZone z = {};
+    if (have) z = a.iz[(size_t)k * a.nItot + T];
+    const auto imax = [](int x, int y) { return max(x, y); };
+    const auto imin = [](int x, int y) { return min(x, y); };
+    int lo[4], hi[4];
+    lo[0] = red16(have ? z.E0 : 0, imax); hi[0] = red16(have ? z.P0 : 0x7fffffff, imin);
+    lo[1] = red16(have ? z.P1 : 0, imax); hi[1] = red16(have ? z.Z0 : 0x7fffffff, imin);
+    lo[2] = red16(have ? z.Z1 : 0, imax); hi[2] = red16(have ? z.P2 : 0x7fffffff, imin);
+    lo[3] = red16(have ? z.P3 : 0, imax); hi[3] = red16(have ? z.E1 : 0x7fffffff, imin);
+    const int ns = min(16, a.K - g * 16);
+    const int E0 = __shfl(z.E0, ns - 1, 16), E1 = __shfl(z.E1, ns - 1, 16);      // (the last state's, as the one-thread body leaves them)
+    double R3 = 0.0;
+    if (have) {
+        const double amax = ((vhi + a.cut) / kC) * sqrt(2.0 * kRgas * a.Tk[k]) / sqrt(a.mu_min);
+        const double gb = a.gbound[k];
+        R3 = kSep3 * sqrt(gb * gb + 5.05 * amax * amax) * (1.0 + 1e-6);
+    }
+    R3 = red16(R3, [](double x, double y) { return fmax(x, y); });
+    // rank of this state's series bounds among the group's (ties: the lower state first), as in the one-thread body
+    const int s0 = have ? z.S0 : -0x7fffffff, s1 = have ? z.S1 : 0x7fffffff;
+    int c0 = 0, c1 = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const int t0 = __shfl(s0, j, 16), t1 = __shfl(s1, j, 16);
+        c0 += (t0 > s0 || (t0 == s0 && j < kk)) ? 1 : 0;
+        c1 += (t1 < s1 || (t1 == s1 && j < kk)) ? 1 : 0;
+    }
+    const int rk = min(max(a.min_states, 1), ns) - 1;
+    const int S0 = red16(c0 == rk ? s0 : -0x7fffffff - 1, imax);
+    int S1 = red16(c1 == rk ? s1 : -0x7fffffff - 1, imax);
+    S1 = max(S1, S0);
+    int sr[4];
+    {
+        const double sv[4] = {vlo - R3, vlo - R3, vhi + R3, vhi + R3};
+        search4(a.nul, sv, E0, E1, sr);          // (every lane of the item: same loads, no divergence)
+    }
+    if (kk != 0) return;
+    const int T0 = min(sr[1], S0), T1 = max(sr[3], S1);
+    SepZone o;
+    for (int p = 0; p < 4; p++) {
+        int pa = lo[p], pb = hi[p];
+        if (p < 2) pb = min(pb, S0); else pa = max(pa, S1);
+        if (pb - pa < 8) { pa = 0; pb = 0; }
+        o.a[p] = pa; o.b[p] = pb;
+        int pm = p < 2 ? min(max(T0, pa), pb) : min(max(T1, pa), pb);
+        if (p < 2 && pm - pa < 8) pm = pa;
+        if (p >= 2 && pb - pm < 8) pm = pb;
+        o.m[p] = pm;
+    }
+    a.out[(size_t)g * a.nItot + T] = o;
+}
+__device__ __forceinline__ void edgezones_body16(unsigned bid, const EdgeArgs &a)
+{
+    const int item = (int)(bid * (blockDim.x >> 4) + (threadIdx.x >> 4)), kk = threadIdx.x & 15;
+    if (item >= a.ntile * a.ngrp) return;
+    const int g = item / a.ntile, t = item - g * a.ntile;
+    const int64_t i0 = (int64_t)t * 64, i1 = (i0 + 63 < a.nnu ? i0 + 63 : a.nnu - 1);
+    const double vlo = a.nu[i0], vhi = a.nu[i1];
+    const WaveWin w = a.win[t];
+    const int k = g * 16 + kk;
+    const bool have = k < a.K;
+    int eL = w.W1, eR = w.W0, mL0 = w.W0, mL1 = w.W1, mR0 = w.W0, mR1 = w.W1;
+    double R = 0.0, R3 = 0.0, R8 = 0.0;
+    if (have) {
+        const Zone z = a.zones[(size_t)k * a.ntile + t];
+        int sa0 = z.M0, sa1 = z.M0, sb0 = z.M1, sb1 = z.M1;   // (as k_voigt_far)
+        if (a.iz) {
+            const IZone zi = a.iz[(size_t)k * a.nI + (t >> a.ishift)];
+            sa0 = min(max(zi.E0, w.W0), z.N0); sa1 = min(max(zi.Z0, sa0), z.N0);
+            sb0 = max(min(zi.Z1, w.W1), z.N1); sb1 = max(min(zi.E1, w.W1), sb0);
+        }
+        eL = min(eL, sa0); eR = max(eR, sb1);
+        mL0 = max(mL0, sa1); mL1 = min(mL1, z.N0);
+        mR0 = max(mR0, z.N1); mR1 = min(mR1, sb0);
+        const double amax = ((vhi + a.cut) / kC) * sqrt(2.0 * kRgas * a.Tk[k]) / sqrt(a.mu_min);
+        const double gb = a.gbound[k];
+        R = kSep4 * sqrt(gb * gb + 4.33 * amax * amax) * (1.0 + 1e-6);
+        R3 = kSep3 * sqrt(gb * gb + 5.05 * amax * amax) * (1.0 + 1e-6);
+        R8 = kSep8 * sqrt(gb * gb + 6.35 * amax * amax) * (1.0 + 1e-6);
+    }
+    const auto imax = [](int x, int y) { return max(x, y); };
+    const auto imin = [](int x, int y) { return min(x, y); };
+    const auto dmax = [](double x, double y) { return fmax(x, y); };
+    eL = red16(eL, imin); eR = red16(eR, imax);
+    mL0 = red16(mL0, imax); mL1 = red16(mL1, imin);
+    mR0 = red16(mR0, imax); mR1 = red16(mR1, imin);
+    R = red16(R, dmax); R3 = red16(R3, dmax); R8 = red16(R8, dmax);
+    int sr[4];
+    {
+        const double sv[4] = {vlo - R, vlo - R3, vhi + R, vhi + R3};
+        search4(a.nul, sv, w.W0, w.W1, sr);
+    }
+    if (kk != 0) return;
+    const int S0 = sr[0], S1 = max(sr[2], S0);            // the series holds in [W0, S0) and [S1, W1)
+    const int T0 = min(sr[1], S0), T1 = max(sr[3], S1);   // ... with three terms in [W0, T0) and [T1, W1)
+    EdgeZone e;
+    e.eL = max(min(eL, S0), w.W0);
+    e.eR = min(max(eR, S1), w.W1);
+    if (e.eL - w.W0 < 8) e.eL = w.W0;   // (too short to be worth a wave's trip)
+    if (w.W1 - e.eR < 8) e.eR = w.W1;
+    e.mL0 = mL0; e.mL1 = min(mL1, S0);
+    e.mR0 = max(mR0, S1); e.mR1 = mR1;
+    if (e.mL1 - e.mL0 < 8 || e.mL0 < e.eL) e.mL0 = e.mL1 = 0;
+    if (e.mR1 - e.mR0 < 8 || e.mR1 > e.eR) e.mR0 = e.mR1 = 0;
+    e.far3 = (e.eL <= T0 ? 1 : 0) | (e.eR >= T1 ? 2 : 0);
+    e.mL3 = min(max(T0, e.mL0), e.mL1);
+    if (e.mL3 - e.mL0 < 8) e.mL3 = e.mL0;
+    e.mR3 = min(max(T1, e.mR0), e.mR1);
+    if (e.mR1 - e.mR3 < 8) e.mR3 = e.mR1;
+    e.cL = e.mL1 > e.mL0 ? e.mL1 : mL0;
+    e.cR = e.mR1 > e.mR0 ? e.mR0 : mR1;
+    const bool core8 = !(R < a.core4 * (vhi - vlo));
+    const double Rc = core8 ? R8 : R;
+    const bool core_ok = a.core && a.iz && i0 + 63 < a.nnu && mL0 <= mL1 && mR0 <= mR1 && e.cL <= mL1 && e.cR >= mR0 && e.cR > e.cL &&
+                         Rc < (core8 ? 0.3 : 0.75) * (vhi - vlo);
+    if (!core_ok) e.cL = e.cR = 0;
+    else if (core8) e.far3 |= 4;
+    e.R = Rc;
+    e.pad0 = 0;
+    e.pad1 = 0.0;
+    a.out[item] = e;
+}
+__global__ __launch_bounds__(256) void k_mxzones16(unsigned nb_sep, SepArgs sa, EdgeArgs ea)
+{
+    if (blockIdx.x < nb_sep) sepzones_body16(blockIdx.x, sa);
+    else edgezones_body16(blockIdx.x - nb_sep, ea);
+}
 
 // (three waves per SIMD, with the 164 registers that allows: the 8-term step of the cores wants them -- left alone the allocator
 //  takes 148 + 32 accumulators, i.e. two waves: 0.44 vs 0.41 ms)

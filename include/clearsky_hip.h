@@ -147,6 +147,7 @@ int cs_set_merge(cs_ctx *ctx, int on);
  *          the last block adds the band-flux partials; fluxes.jl:270-277 does depth and flux of a wavenumber in one loop body) -- 0
  *          (default) where it pays: grids of up to 400 tiles (a nu-shard, a small column) and of 4096 tiles or more, 1 never, 2 always;
  *          | 4: the block partials are always added by k_freduce's own launch, | 8: the long-grid form with four waves per SIMD (A/B);
+ *          | 16: the matrix-core piece tables with one thread per (interval | tile, state group) (k_mxzones) instead of sixteen lanes (A/B);
  *          | 32 (on the first context of a cs_fluxes_discretized_multi call): the partition is re-cut from measured times also when
  *          contexts share a device (tests).
  * Applies to every later cs_column_setup / cs_column_run of the context. */

@@ -133,3 +133,21 @@ def test_long_grid_default_is_chunk_form(cs, lines):
     assert np.array_equal(a["tau"], b["tau"]) and np.array_equal(a["Mup"], b["Mup"]) and np.array_equal(a["Mdn"], b["Mdn"])
     assert np.max(np.abs(a["Fup"] - b["Fup"])) < 1e-14 * np.max(b["Fup"])
     a_ctx.close(); b_ctx.close()
+
+
+@pytest.mark.parametrize("nnu,np_", [(12500, 61), (9001, 22)])
+def test_piece_tables_sixteen_lanes_equal_one_thread(cs, lines, nnu, np_):
+    """k_mxzones16 (sixteen lanes per (interval | tile, state group): reductions and shuffled ranks) builds the same matrix-core piece
+    tables as the one-thread-per-item kernel (cs_set_tuning key 15 | 16): every output of the column bitwise equal, K not a multiple of 16"""
+    nu = np.linspace(500.0, 900.0, nnu)
+    P = cs.pressuregrid(1.0, 1e5, np_)
+    T = W.earth_temperature(P)
+    gases = (cs.DirectGas(W.lines("synthetic", "H2O"), W.fC_h2o, nu), cs.DirectGas(W.lines("synthetic", "CO2"), 400e-6, nu))
+    a_ctx, b_ctx = _ctx(cs, 0), _ctx(cs, 16)
+    for c_ in (a_ctx, b_ctx):
+        c_.set_matrix_cores(2)
+    _, a = _run(cs, a_ctx, P, T, gases, cs.Discretized(5, 2))
+    _, b = _run(cs, b_ctx, P, T, gases, cs.Discretized(5, 2))
+    for k in ("tau", "Mup", "Mdn", "Fup", "Fdn"):
+        assert np.array_equal(a[k], b[k]), k
+    a_ctx.close(); b_ctx.close()

@@ -12,7 +12,7 @@ import csv, glob, sys
 rows = []
 for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void csdev::", "")[:48], r.get("Queue_Id", "?"), r.get("Stream_Id", "?")))
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "").replace("csdev::", "")[:48], r.get("Queue_Id", "?"), r.get("Stream_Id", "?")))
 rows.sort()
 # the last complete step of the timed loop: find the last k_gas_setup before the final profile runs... print the 6th from the end occurrence
 idx = [i for i, r in enumerate(rows) if r[2].startswith("k_gas_setup")]
