@@ -289,7 +289,7 @@ def main():
     ns_ = cfg["core"].nstream
     rt_valu = (VALU_RT["down"] + VALU_RT["up"]) if ns_ == 5 else 2 * (VALU_RT["fixed"] + VALU_RT["per_stream"] * ns_)
     rt_lane_instr = float(col.nnu) * col.nl * rt_valu
-    flux_name = {0: "k_rt", 1: "k_flux_streams", 2: "k_flux_chunk"}[int(info.get("flux_form", 0))]
+    flux_name = {0: "k_rt", 1: "k_flux_streams", 2: "k_flux_chunk", 3: "k_flux_scan"}[int(info.get("flux_form", 0))]
     kern["k_rt"] = dict(bound="valu_issue", kernel=flux_name, ms_per_launch=t * 1e3, launches_per_step=1, lane_instructions_per_launch=rt_lane_instr,
                         valu_per_point_layer=rt_valu, achieved=rt_lane_instr / t if t > 0 else 0.0, peak=VALU_ISSUE_PEAK,
                         unit="fp64-rate lane-instructions/s", frac=rt_lane_instr / t / VALU_ISSUE_PEAK if t > 0 else 0.0,

@@ -239,6 +239,7 @@ struct Column {
     std::vector<double> h_Tk;
     DevBuf nu, wts, P, Pk, Tk, muk, Tlev, extra, S_toa, albedo;
     DevBuf hot, cold, sigma, sigma2, tau, Mup, Mdn, partial, F, stage, ranges;   // sigma2: the near-line plane (k_voigt_near on a side stream)
+    DevBuf fluxdbg;            // k_flux_scan: phase time stamps of block 0 (cs_set_tuning key 15 | 128; cs_column_work out[27..])
     DevBuf ticket;             // k_flux: blocks finished (the last one adds the block partials up)
     int flux_form_last = 0;      // which flux kernel the last run used (flux_form)
     bool sigma_partial = false;  // the last run finished the cross-sections on chip (k_flux): cs_column_sigma_fetch evaluates them again, in HBM
@@ -492,7 +493,7 @@ void launch_rt(int ns, const RtGeom &g, int B, hipStream_t s, const RtParams &p,
 }
 
 // which form of the flux kernel a step of the resident column uses: 0 = k_rt / k_rt_streams reading finished cross-sections from HBM,
-// 1 = k_flux_streams (short grids), 2 = k_flux_chunk (long grids)
+// 1 = k_flux_streams, 3 = k_flux_scan (short grids), 2 = k_flux_chunk (long grids)
 int flux_form(const cs_ctx *ctx, const Column &c, size_t *shmem, int *nblk, int *threads)
 {
     if ((ctx->tune[15] & 3) == 1 || !c.tab.empty() || c.gas.empty()) return 0;   // (baked tables are added between wings and CIA pairs: own pass)
@@ -501,10 +502,18 @@ int flux_form(const cs_ctx *ctx, const Column &c, size_t *shmem, int *nblk, int 
     const int np = c.np, ns = c.nstream, K = c.K;
     const size_t lim = 160 * 1024 - 4096;
     if (c.rtg.streams) {
-        const size_t sh = ((size_t)K * 64 + (size_t)(2 * np - 1) * 64 + (size_t)4 * ns * 64 + (size_t)2 * np + 64) * sizeof(double);
+        if (ctx->tune[15] & 64) {   // (the first short-grid form, one wave per stream and sweep: kept for A/B)
+            const size_t sh = ((size_t)K * 64 + (size_t)(2 * np - 1) * 64 + (size_t)4 * ns * 64 + (size_t)2 * np + 64) * sizeof(double);
+            if (sh > lim) return 0;
+            *shmem = sh; *nblk = c.rtg.nblk; *threads = 2 * ns * 64;
+            return 1;
+        }
+        // the sweeps as a scan over layer chunks: about six layers per wave, 4 .. 12 waves
+        const int nw = std::min(12, std::max(4, (c.nl + 5) / 6));
+        const size_t sh = ((size_t)K * 64 + (size_t)(2 * np - 1) * 64 + (size_t)2 * (ns + 1) * 64 + (size_t)2 * np) * sizeof(double);
         if (sh > lim) return 0;
-        *shmem = sh; *nblk = c.rtg.nblk; *threads = 2 * ns * 64;
-        return 1;
+        *shmem = sh; *nblk = c.rtg.nblk; *threads = nw * 64;
+        return 3;
     }
     // long grids: where k_rt runs one wave per tile for both sweeps (>= 4096 tiles) the chunked form saves the passes over the plane; in
     // between (the bench column at full size: 1563 tiles, two waves per tile) the separate kernels are as fast (profiles/r04_notes.md)
@@ -526,6 +535,11 @@ void launch_flux_ns(int form, size_t shmem, int nblk, int threads, hipStream_t s
         if constexpr (NS >= 2 && NS <= 8) {
             if (shmem > 65536) (void)hipFuncSetAttribute((const void *)k_flux_streams<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
             CS_LAUNCH((k_flux_streams<NS>), dim3(nblk), dim3(threads), shmem, s, p, nu, wts, nnu, sigma, muk, P, Tlev, S, alb, tau, Mup, Mdn, partial, f);
+        }
+    } else if (form == 3) {
+        if constexpr (NS >= 2 && NS <= 8) {
+            if (shmem > 65536) (void)hipFuncSetAttribute((const void *)k_flux_scan<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+            CS_LAUNCH((k_flux_scan<NS>), dim3(nblk), dim3(threads), shmem, s, p, nu, wts, nnu, sigma, muk, P, Tlev, S, alb, tau, Mup, Mdn, partial, f);
         }
     } else if (three_waves) {
         if (shmem > 65536) (void)hipFuncSetAttribute((const void *)k_flux_chunk3<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
@@ -1141,6 +1155,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
         unsigned nb_iz = 0;
         const IZone *iz = nullptr;
         int ishift = 0;
+        bool forked_here = false;   // ev_fork was recorded on the main stream after the zone launches: the near-line side stream can wait on it too
         bool use_edge = false;   // window ends of the per-point sum on the matrix cores (k_voigt_edge_mx; with the far wings interpolated only)
         bool fuse = false;       // ... which then also applies the interpolated wings (no k_cheb_apply launch for this group)
         ChebApply Afuse;
@@ -1195,6 +1210,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
             if (fork && fork->use_nodes && defer && !evg) {
                 (void)hipEventRecord(fork->ev_fork, s);
                 (void)hipStreamWaitEvent(fork->s2, fork->ev_fork, 0);
+                forked_here = true;
                 s = fork->s2;     // the two node kernels below run beside what follows them on the main stream
             }
 #define NODES_LAUNCH(M, L_, M4, L4, S4) do { if (nsplit4) CS_LAUNCH((k_cheb_nodes<M4, L4, S4>), gridn, dim3(256), 0, s, itp.nodes, G.L, hot, hot32, G.nu.as<double>(), itp.iz, \
@@ -1283,8 +1299,12 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
         const bool near_fork = !lor && fork && fork->use_near && fork->sigma2 && defer && !evg;
         double *zero2 = nullptr;   // (the far kernel can clear the plane itself: unused since k_voigt_sub adds to it beside k_voigt_far)
         if (near_fork) {   // zones, records and piece tables are written: the side stream may start
-            (void)hipEventRecord(fork->ev_fork3, s);
-            (void)hipStreamWaitEvent(fork->s3, fork->ev_fork3, 0);
+            if (forked_here) {   // (nothing was enqueued on the main stream since that record: one event serves both side streams)
+                (void)hipStreamWaitEvent(fork->s3, fork->ev_fork, 0);
+            } else {
+                (void)hipEventRecord(fork->ev_fork3, s);
+                (void)hipStreamWaitEvent(fork->s3, fork->ev_fork3, 0);
+            }
             if (!fork->zeroed) {
                 (void)hipMemsetAsync(fork->sigma2, 0, (size_t)kn * nnu * sizeof(double), fork->s3);
                 fork->zeroed = true;
@@ -2806,10 +2826,22 @@ static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e, bool *
                    use_fork ? &fk : nullptr);
         if (ev) { e += 6; HIPCHK(hipEventRecord(ev[e++], s)); }
     }
+    if (fuse) { fuse->apply = 0; fuse->ncia = 0; fuse->Kpad = cheb_kpad(K); }
+    // short grids with the node sums on their side stream: that stream has slack (it ends well before the per-point kernels), so the levels
+    // are folded into the smallest one THERE (k_cheb_cascade, exact to rounding) and the flux kernel carries one level to the grid instead
+    // of three -- one memory latency in its first phase instead of three (13 -> 6 us on a 1/8 shard of the bench column)
+    bool cascaded_aside = false;
+    if (fuse && apply.ngas == 1 && fk.pending && c.rtg.streams && !(ctx->tune[15] & (256 | 64)) && apply.nlev - apply.l0[0] >= 2) {
+        const double *Rc[CS_MAX_LEVEL];
+        for (int l = 0; l < CS_MAX_LEVEL; l++) Rc[l] = c.cheb.Rc[l].as<double>();
+        launch_apply_cascade(fk.s2, apply, Rc, c.cheb.itv, c.cheb.nI, 1, cheb_kpad(K), c.nnu, K, 0.0, nullptr, sig, 1, &fuse->A);
+        (void)hipEventRecord(fk.ev_join, fk.s2);   // (the main stream has not waited yet: it will wait for this later record)
+        fuse->apply = 1;
+        cascaded_aside = true;
+    }
     fork_join(&fk, s, true, false);   // the node sums; the near-line kernels may run on beside what follows (none of it touches their plane)
     // interpolated far wings of all gases: sigma += sum_level C (sum_gas F)  (one pass over C and sigma)
-    if (fuse) { fuse->apply = 0; fuse->ncia = 0; fuse->Kpad = cheb_kpad(K); }
-    if (apply.ngas > 0) {
+    if (apply.ngas > 0 && !cascaded_aside) {
         const double *Rc[CS_MAX_LEVEL];
         for (int l = 0; l < CS_MAX_LEVEL; l++) Rc[l] = c.cheb.Rc[l].as<double>();
         launch_apply_cascade(s, apply, Rc, c.cheb.itv, c.cheb.nI, ctx->tune[12], cheb_kpad(K), c.nnu, K, 0.0, nullptr, sig, 1,
@@ -2891,8 +2923,9 @@ static int run_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev)
         fuse.ticket = (fblk <= 512 && !(ctx->tune[15] & 4)) ? c.ticket.as<unsigned>() : nullptr;   // (| 4: k_freduce always, for A/B)
         fuse.gpartial = c.partial.as<double>() + (size_t)c.rtg.nblk * 2 * c.np;
         reduced = fuse.ticket != nullptr;
+        if ((ctx->tune[15] & 128) && c.fluxdbg.reserve(8 * sizeof(unsigned long long)) == hipSuccess) fuse.dbg = c.fluxdbg.as<unsigned long long>();
         // the chunked form always writes the layer optical depths (its upward sweep reads them back): into the caller's plane or scratch
-        double *dtau = (c.want_tau || form == 2) ? c.tau.as<double>() : nullptr;
+        double *dtau = (c.want_tau || form == 2) ? c.tau.as<double>() : nullptr;   // (forms 1 and 3 keep the optical depths in LDS)
 #define CS_FLUX_CASE(N) case N: launch_flux_ns<N>(form, fsh, fblk, fthr, s, c.rt, c.nu.as<double>(), c.wts.as<double>(), c.nnu, sig, c.muk.as<double>(), \
                                                   c.P.as<double>(), c.Tlev.as<double>(), dS, dA, dtau, dMu, dMd, c.partial.as<double>(), fuse, (ctx->tune[15] & 8) == 0); break;
         switch (c.nstream) {
@@ -3383,7 +3416,14 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
     out[24] = (int64_t)fl_nodes_useful;
     out[25] = (int64_t)fl_nodes_issued;
     out[26] = (int64_t)fl_apply;
-    for (int q = 27; q < 32; q++) out[q] = 0;
+    if (c.fluxdbg.p && (ctx->tune[15] & 128)) {   // k_flux_scan's phases in block 0, ns: cross-sections, depths + Planck, chunk pass, hand-over, second pass, band sum
+        unsigned long long st[8] = {};
+        (void)hipMemcpy(st, c.fluxdbg.p, sizeof st, hipMemcpyDeviceToHost);
+        for (int q = 0; q < 4; q++) out[27 + q] = (int64_t)(st[q + 1] - st[q]) * 10;   // (100 MHz clock)
+        out[31] = (int64_t)(st[7] - st[0]) * 10;   // block 0's first instruction to the last block's last word
+    } else {
+        for (int q = 27; q < 32; q++) out[q] = 0;
+    }
     out[0] = direct;
     out[1] = nodes;
     out[2] = c.cheb.nlev;

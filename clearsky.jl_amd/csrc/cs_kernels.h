@@ -3317,7 +3317,12 @@ struct FluxFuse {
     unsigned *ticket;          // NULL: k_freduce adds the block partials; else [1 + groups] counters, zero between launches
     double *gpartial;          // [groups][2 np] sums of the partials of 16 consecutive blocks
     double *F;                 // [2 np] band fluxes
+    unsigned long long *dbg;   // NULL, or [8] time stamps (100 MHz wall clock) of the phases of block 0 (measurement hook)
 };
+__device__ __forceinline__ void flux_stamp(const FluxFuse &f, int slot)
+{
+    if (f.dbg && blockIdx.x == 0 && threadIdx.x == 0) f.dbg[slot] = wall_clock64();
+}
 #define CS_FLUX_GROUP 16
 
 // tab[toff[b] + k*nb + c] = (1 - y) z0[c] + y z1[c]: the temperature half of the bilinear interpolation of ln k (BilinearInterpolator,
@@ -3511,6 +3516,7 @@ __device__ __forceinline__ void flux_last_block_reduce(const FluxFuse &f, const 
         f.F[e] = t;
     }
     if (threadIdx.x == 0) __hip_atomic_store(f.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (f.dbg && threadIdx.x == 0) f.dbg[7] = wall_clock64();   // (measurement hook: the last block's last word)
 }
 
 // K5 on short grids (a nu-shard, a small column: up to ~400 tiles): k_rt_streams with phase A in front -- one block = one 64-point
@@ -3650,6 +3656,190 @@ __global__ __launch_bounds__(2 * NS * 64) void k_flux_streams(RtParams p, const 
         else partial[(size_t)blockIdx.x * 2 * np + e] = red[e];
     }
     if (f.ticket) flux_last_block_reduce(f, partial, (int)gridDim.x, 2 * np);
+}
+
+// K5 on short grids, second form: the sweeps as a SCAN over layer chunks.  In k_flux_streams a wave walks all layers of one stream: 60
+// dependent steps of one exponential each, one barrier per layer -- 45 us that no amount of idle chip shortens.  But only the recurrence
+// I <- I e^(-tau m) + B_eff is sequential, and it is linear: a run of layers acts on the incoming intensity as I -> A I + B.  One block =
+// one tile, NW waves, wave w = a chunk of consecutive layers, all NS streams, both sweeps:
+//   phase A, 0  as k_flux_streams: cross-sections, then optical depths and Planck values of every layer into LDS;
+//   phase 1     every wave runs its chunk from zero incoming intensity -- NS independent chains per lane, no barrier -- and keeps the
+//               chunk's (A, B) per stream and sweep (and the stellar beam's attenuation) in registers;
+//   phase 2     the incoming intensities travel from chunk to chunk: NW steps of one fused multiply-add per stream, downward sweep in
+//               ascending chunk order, upward in descending (after the surface term, which needs the downward flux only with an albedo);
+//   phase 3     every wave runs its chunk again from its true incoming intensity and forms what radiate! returns at its levels.
+// Inside a chunk the operations and their order are discretized.jl:282-322's; across chunk boundaries the incoming intensity was
+// formed as A I + B instead of layer by layer: the same numbers to a few units in the last place (tests: 1e-13 against k_rt_streams).
+template <int NS>
+__global__ __launch_bounds__(768) void k_flux_scan(RtParams p, const double *__restrict__ nu, const double *__restrict__ wts, int64_t nnu,
+                                                    const double *__restrict__ sigma, const double *__restrict__ muk, const double *__restrict__ P,
+                                                    const double *__restrict__ Tlev, const double *__restrict__ S_toa,
+                                                    const double *__restrict__ albedo, double *__restrict__ tau, double *__restrict__ Mup,
+                                                    double *__restrict__ Mdn, double *__restrict__ partial, FluxFuse f)
+{
+    extern __shared__ double sh[];   // sig[K][64] | Blev[np][64] | tl[nl][64] | xin[2 sweeps][NS + 1][64] | red[2 np]
+    const int np = p.np, nl = np - 1, nlob = p.nlobatto, K = p.K;
+    double *sig = sh, *Blev = sig + (size_t)K * 64, *tl = Blev + (size_t)np * 64, *xin = tl + (size_t)nl * 64, *red = xin + (size_t)2 * (NS + 1) * 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int NW = (int)(blockDim.x >> 6);
+    const int64_t j = (int64_t)blockIdx.x * 64 + lane;
+    const bool live = j < nnu;
+    const int64_t jj = live ? j : nnu - 1;
+    flux_stamp(f, 0);
+    flux_sigma_tile(f, K, nnu, (int)blockIdx.x, sigma, nu, sig, wave, NW, lane);
+    __syncthreads();
+    flux_stamp(f, 1);
+    const double v = nu[jj];
+    const double w = live ? wts[jj] : 0.0;
+    const double fS = S_toa ? S_toa[jj] : 0.0;
+    const double fa = albedo ? albedo[jj] : 0.0;
+    const double c = p.cos_ts;
+    for (int i = wave; i < np; i += NW) {
+        Blev[(size_t)i * 64 + lane] = planck(v, Tlev[i]);
+        if (i < nl) {   // optical depth of layer i exactly as k_rt forms it (dDepth!, discretized.jl:136-177): beta at the layer's nodes, 1e-6 floor
+            const double dP = P[i + 1] - P[i];
+            const int kl = i * (nlob - 1);
+            auto sg = [&](int kk) { return sig[(size_t)kk * 64 + lane]; };
+            double ti = (dP * p.ws[0]) * (p.C * (sg(kl) / muk[kl]));
+            for (int n = 1; n < nlob - 1; n++) ti += (dP * p.ws[n]) * (p.C * (sg(kl + n) / muk[kl + n]));
+            ti += (dP * p.ws[nlob - 1]) * (p.C * (sg(kl + nlob - 1) / muk[kl + nlob - 1]));
+            const double t = ti > 1e-6 ? ti : 1e-6;
+            tl[(size_t)i * 64 + lane] = t;
+            if (tau && live) tau[(size_t)i * nnu + j] = t;
+        }
+    }
+    __syncthreads();
+    flux_stamp(f, 2);
+    // this wave's layers [l0, l1)
+    const int per = (nl + NW - 1) / NW;
+    const int l0 = min(wave * per, nl), l1 = min(l0 + per, nl);
+    // ---- phase 1: the chunk from zero incoming intensity
+    double Ad[NS], Bd[NS], Au[NS], Bu[NS], As = 1.0;
+#pragma unroll
+    for (int k = 0; k < NS; k++) { Ad[k] = 1.0; Bd[k] = 0.0; Au[k] = 1.0; Bu[k] = 0.0; }
+    for (int i = l0; i < l1; i++) {          // downward: layers ascending
+        const double t = tl[(size_t)i * 64 + lane], it = 1.0 / t;
+        const double B1 = Blev[(size_t)i * 64 + lane], B2 = Blev[(size_t)(i + 1) * 64 + lane];
+#pragma unroll
+        for (int k = 0; k < NS; k++) {
+            const double tr = exp_rt(-(t * p.m[k]));
+            const double Be = layerplanck_inv(B1, B2, it * p.im[k], tr);
+            Bd[k] = Bd[k] * tr + Be;
+            Ad[k] *= tr;
+        }
+        if (S_toa) As *= exp(-t / c);
+    }
+    for (int i = l1 - 1; i >= l0; i--) {     // upward: layers descending
+        const double t = tl[(size_t)i * 64 + lane], it = 1.0 / t;
+        const double Bhi = Blev[(size_t)(i + 1) * 64 + lane], Blo = Blev[(size_t)i * 64 + lane];
+#pragma unroll
+        for (int k = 0; k < NS; k++) {
+            const double tr = exp_rt(-(t * p.m[k]));
+            const double Be = layerplanck_inv(Bhi, Blo, it * p.im[k], tr);
+            Bu[k] = Bu[k] * tr + Be;
+            Au[k] *= tr;
+        }
+    }
+    flux_stamp(f, 3);
+    // ---- phase 2: incoming intensities from chunk to chunk.  xin[0][k] = what enters the current chunk going down, xin[1][k] going up;
+    // xin[0][NS] = the stellar beam entering the chunk
+    auto X = [&](int sweep, int k) { return xin + ((size_t)sweep * (NS + 1) + k) * 64 + lane; };
+    double Id[NS], Iu[NS], Ms_in = 0.0;
+    const bool serial = albedo != nullptr;   // (block-uniform) the surface term of the upward sweep needs the downward flux only with an albedo
+    if (wave == 0) {
+#pragma unroll
+        for (int k = 0; k < NS; k++) *X(0, k) = 0.0;
+        *X(0, NS) = c * fS;                  // M-[1] = c fS(nu), discretized.jl:299
+    }
+    auto surface = [&](double Md) {          // Lambertian reflection + Planck emission, discretized.jl:309-310
+        const double Is = Md * fa / kPi + Blev[(size_t)(np - 1) * 64 + lane];
+#pragma unroll
+        for (int k = 0; k < NS; k++) *X(1, k) = Is;
+        const double Mu = Is * kPi;
+        const double r = wave_sum(w * Mu);
+        if (lane == 0) red[np - 1] = r;
+        if (Mup && live) Mup[(size_t)(np - 1) * nnu + j] = Mu;
+    };
+    if (!serial && wave == NW - 1) surface(0.0);   // (no reflected part: both sweeps travel in the same steps below)
+    for (int s = 0; s < NW; s++) {
+        __syncthreads();
+        if (wave == s) {
+#pragma unroll
+            for (int k = 0; k < NS; k++) { Id[k] = *X(0, k); *X(0, k) = Id[k] * Ad[k] + Bd[k]; }
+            Ms_in = *X(0, NS);
+            *X(0, NS) = Ms_in * As;
+        }
+        if (!serial && wave == NW - 1 - s) {
+#pragma unroll
+            for (int k = 0; k < NS; k++) { Iu[k] = *X(1, k); *X(1, k) = Iu[k] * Au[k] + Bu[k]; }
+        }
+    }
+    if (serial) {
+        __syncthreads();
+        if (wave == NW - 1) {   // the downward flux at the surface is in xin[0]
+            double Md = 0.0;
+#pragma unroll
+            for (int k = 0; k < NS; k++) Md += p.W[k] * *X(0, k);
+            Md += *X(0, NS);
+            surface(Md);
+        }
+        for (int s = NW - 1; s >= 0; s--) {
+            __syncthreads();
+            if (wave == s) {
+#pragma unroll
+                for (int k = 0; k < NS; k++) { Iu[k] = *X(1, k); *X(1, k) = Iu[k] * Au[k] + Bu[k]; }
+            }
+        }
+    }
+    flux_stamp(f, 4);
+    // ---- phase 3: the chunk from its true incoming intensities; what radiate! returns at its levels
+    if (wave == 0) {   // level 0 of the downward flux
+        const double r = wave_sum(w * Ms_in);
+        if (lane == 0) red[np + 0] = r;
+        if (Mdn && live) Mdn[j] = Ms_in;
+    }
+    double Ms = Ms_in;
+    for (int i = l0; i < l1; i++) {
+        const double t = tl[(size_t)i * 64 + lane], it = 1.0 / t;
+        const double B1 = Blev[(size_t)i * 64 + lane], B2 = Blev[(size_t)(i + 1) * 64 + lane];
+        double Md = 0.0;
+#pragma unroll
+        for (int k = 0; k < NS; k++) {
+            const double tr = exp_rt(-(t * p.m[k]));
+            const double Be = layerplanck_inv(B1, B2, it * p.im[k], tr);
+            Id[k] = Id[k] * tr + Be;
+            Md += p.W[k] * Id[k];
+        }
+        if (S_toa) Ms *= exp(-t / c);
+        Md += Ms;
+        const double r = wave_sum(w * Md);
+        if (lane == 0) red[np + i + 1] = r;
+        if (Mdn && live) Mdn[(size_t)(i + 1) * nnu + j] = Md;
+    }
+    for (int i = l1 - 1; i >= l0; i--) {
+        const double t = tl[(size_t)i * 64 + lane], it = 1.0 / t;
+        const double Bhi = Blev[(size_t)(i + 1) * 64 + lane], Blo = Blev[(size_t)i * 64 + lane];
+        double Mu = 0.0;
+#pragma unroll
+        for (int k = 0; k < NS; k++) {
+            const double tr = exp_rt(-(t * p.m[k]));
+            const double Be = layerplanck_inv(Bhi, Blo, it * p.im[k], tr);
+            Iu[k] = Iu[k] * tr + Be;
+            Mu += p.W[k] * Iu[k];
+        }
+        const double r = wave_sum(w * Mu);
+        if (lane == 0) red[i] = r;
+        if (Mup && live) Mup[(size_t)i * nnu + j] = Mu;
+    }
+    __syncthreads();
+    flux_stamp(f, 5);
+    for (int e = threadIdx.x; e < 2 * np; e += blockDim.x) {
+        if (f.ticket) flux_store_dev(&partial[(size_t)blockIdx.x * 2 * np + e], red[e]);
+        else partial[(size_t)blockIdx.x * 2 * np + e] = red[e];
+    }
+    if (f.ticket) flux_last_block_reduce(f, partial, (int)gridDim.x, 2 * np);
+    flux_stamp(f, 6);
 }
 
 // K5 on long grids (thousands of tiles): one WAVE = one 64-point tile, both sweeps (k_rt<NS, false>'s arithmetic), four tiles per

@@ -148,6 +148,9 @@ int cs_set_merge(cs_ctx *ctx, int on);
  *          (default) where it pays: grids of up to 400 tiles (a nu-shard, a small column) and of 4096 tiles or more, 1 never, 2 always;
  *          | 4: the block partials are always added by k_freduce's own launch, | 8: the long-grid form with four waves per SIMD (A/B);
  *          | 16: the matrix-core piece tables with one thread per (interval | tile, state group) (k_mxzones) instead of sixteen lanes (A/B);
+ *          | 64: short grids with one wave per (sweep, stream) walking all layers (k_flux_streams) instead of the scan over layer chunks
+ *          (k_flux_scan) (A/B);
+ *          | 256: on short grids the interval levels are NOT folded into the smallest one on the node-sum side stream (A/B);
  *          | 32 (on the first context of a cs_fluxes_discretized_multi call): the partition is re-cut from measured times also when
  *          contexts share a device (tests).
  * Applies to every later cs_column_setup / cs_column_run of the context. */
@@ -320,7 +323,8 @@ int cs_column_sigma_fetch(cs_ctx *ctx, int64_t nnu, int K, double *sigma);
 int cs_column_counts(cs_ctx *ctx, int64_t *pair_evals, int64_t *lines_in_range);
 /* measurement hook, out[8]: out[0] = launch groups of the resident column (merged gases count once), out[1] = kernel launches of
  * the last cs_column_run, out[2] = lines of all groups, out[3] = cs_set_merge at setup time, out[4] = gases in the largest group,
- * out[5] = the flux kernel of the last run: 0 = k_rt / k_rt_streams on finished cross-sections, 1 = k_flux_streams, 2 = k_flux_chunk */
+ * out[5] = the flux kernel of the last run: 0 = k_rt / k_rt_streams on finished cross-sections, 1 = k_flux_streams, 2 = k_flux_chunk,
+ * 3 = k_flux_scan */
 int cs_column_info(cs_ctx *ctx, int64_t *out);
 /* line-shape evaluations the last cs_column_run actually issued for its Voigt gases (measurement hook): out[0] = per-point
  * evaluations of k_voigt_far/k_voigt_near (64 lanes x lines per wave), out[1] = node evaluations of k_cheb_nodes,
