@@ -501,8 +501,11 @@ int flux_form(const cs_ctx *ctx, const Column &c, size_t *shmem, int *nblk, int 
         if (cc.max_overlap > CS_CIA_ACT) return 0;
     const int np = c.np, ns = c.nstream, K = c.K;
     const size_t lim = 160 * 1024 - 4096;
-    if (c.rtg.streams) {
-        if (ctx->tune[15] & 64) {   // (the first short-grid form, one wave per stream and sweep: kept for A/B)
+    const int nt64_ = (int)((c.nnu + 63) / 64);
+    // the scan form: short grids (rt_geometry's `streams`), and -- key 15 = 2 -- every grid in k_rt's two-waves-per-tile regime (A/B)
+    const bool scan_ok = c.rtg.streams || ((ctx->tune[15] & 3) == 2 && c.rtg.ud && ns >= 2 && ns <= 8 && nt64_ >= 1);
+    if (scan_ok) {
+        if ((ctx->tune[15] & 64) && c.rtg.streams) {   // (the first short-grid form, one wave per stream and sweep: kept for A/B)
             const size_t sh = ((size_t)K * 64 + (size_t)(2 * np - 1) * 64 + (size_t)4 * ns * 64 + (size_t)2 * np + 64) * sizeof(double);
             if (sh > lim) return 0;
             *shmem = sh; *nblk = c.rtg.nblk; *threads = 2 * ns * 64;
@@ -512,7 +515,7 @@ int flux_form(const cs_ctx *ctx, const Column &c, size_t *shmem, int *nblk, int 
         const int nw = std::min(12, std::max(4, (c.nl + 5) / 6));
         const size_t sh = ((size_t)K * 64 + (size_t)(2 * np - 1) * 64 + (size_t)2 * (ns + 1) * 64 + (size_t)2 * np) * sizeof(double);
         if (sh > lim) return 0;
-        *shmem = sh; *nblk = c.rtg.nblk; *threads = nw * 64;
+        *shmem = sh; *nblk = nt64_; *threads = nw * 64;
         return 3;
     }
     // long grids: where k_rt runs one wave per tile for both sweeps (>= 4096 tiles) the chunked form saves the passes over the plane; in
@@ -2522,7 +2525,7 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
         HIPCHK(c.Mup.reserve((size_t)np * nnu * sizeof(double)));
         HIPCHK(c.Mdn.reserve((size_t)np * nnu * sizeof(double)));
     }
-    HIPCHK(c.partial.reserve(((size_t)c.rtg.nblk + 512 / CS_FLUX_GROUP) * 2 * np * sizeof(double)));   // + k_flux's group sums
+    HIPCHK(c.partial.reserve(((size_t)std::max<int64_t>(c.rtg.nblk, (nnu + 63) / 64) + 512 / CS_FLUX_GROUP) * 2 * np * sizeof(double)));   // (one block per tile at most) + k_flux's group sums
     HIPCHK(c.F.reserve((size_t)2 * np * sizeof(double)));
     HIPCHK(hipStreamSynchronize(s));
     c.ready = true;  // state upload below needs the sizes
@@ -2921,7 +2924,7 @@ static int run_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev)
         fuse.F = c.F.as<double>();
         // up to 512 blocks the last ones to finish add the block partials (two stages of 16 and <= 32 terms); longer grids keep k_freduce
         fuse.ticket = (fblk <= 512 && !(ctx->tune[15] & 4)) ? c.ticket.as<unsigned>() : nullptr;   // (| 4: k_freduce always, for A/B)
-        fuse.gpartial = c.partial.as<double>() + (size_t)c.rtg.nblk * 2 * c.np;
+        fuse.gpartial = c.partial.as<double>() + (size_t)std::max<int64_t>(c.rtg.nblk, (c.nnu + 63) / 64) * 2 * c.np;
         reduced = fuse.ticket != nullptr;
         if ((ctx->tune[15] & 128) && c.fluxdbg.reserve(8 * sizeof(unsigned long long)) == hipSuccess) fuse.dbg = c.fluxdbg.as<unsigned long long>();
         // the chunked form always writes the layer optical depths (its upward sweep reads them back): into the caller's plane or scratch

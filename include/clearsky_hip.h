@@ -340,8 +340,10 @@ int cs_column_info(cs_ctx *ctx, int64_t *out);
  * records of the last Voigt launch group; out[22], out[23] = flops of k_voigt_edge_mx: useful (2 x series terms for every (point,
  * line, state) with the point inside the cut-off and outside the core radius, real states only) and issued (2048 per matrix
  * instruction: masked columns, padded states and the fill of the last 4-line step included); out[24], out[25] = the same for
- * k_cheb_nodes_mx; out[26] = flops of the node-sum -> grid contraction (k_cheb_apply_mfma, or fused into k_voigt_edge_mx).  `out`
- * holds 32 values.
+ * k_cheb_nodes_mx; out[26] = flops of the node-sum -> grid contraction (k_cheb_apply_mfma, or inside k_voigt_edge_mx / k_flux_*); with
+ * cs_set_tuning key 15 | 128, out[27..30] = nanoseconds block 0 of k_flux_scan spent on cross-sections, optical depths + Planck values,
+ * first pass over its layer chunk, hand-over of the incoming intensities, and out[31] = from its first instruction to the last block's
+ * store of the band fluxes (100 MHz wall clock; 0 otherwise).  `out` holds 32 values.
  * cs_column_counts is the reference's count. */
 int cs_column_work(cs_ctx *ctx, int64_t *out);
 /* interval sizes (descending, <= 5, each 128..2048 points) cs_set_interp(on) would use for this grid and cut-off; returns
