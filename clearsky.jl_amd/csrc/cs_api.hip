@@ -502,8 +502,9 @@ int flux_form(const cs_ctx *ctx, const Column &c, size_t *shmem, int *nblk, int 
     const int np = c.np, ns = c.nstream, K = c.K;
     const size_t lim = 160 * 1024 - 4096;
     const int nt64_ = (int)((c.nnu + 63) / 64);
-    // the scan form: short grids (rt_geometry's `streams`), and -- key 15 = 2 -- every grid in k_rt's two-waves-per-tile regime (A/B)
-    const bool scan_ok = c.rtg.streams || ((ctx->tune[15] & 3) == 2 && c.rtg.ud && ns >= 2 && ns <= 8 && nt64_ >= 1);
+    // the scan form: short grids (rt_geometry's `streams`), and -- key 15 | 1024 -- every grid in k_rt's two-waves-per-tile regime (A/B: a
+    // tie at 782 tiles, 2.13 vs 1.98 ms at the bench column's 1563)
+    const bool scan_ok = c.rtg.streams || ((ctx->tune[15] & 1024) && c.rtg.ud && ns >= 2 && ns <= 8 && nt64_ >= 1);
     if (scan_ok) {
         if ((ctx->tune[15] & 64) && c.rtg.streams) {   // (the first short-grid form, one wave per stream and sweep: kept for A/B)
             const size_t sh = ((size_t)K * 64 + (size_t)(2 * np - 1) * 64 + (size_t)4 * ns * 64 + (size_t)2 * np + 64) * sizeof(double);
@@ -892,10 +893,35 @@ void launch_apply(hipStream_t s, const ChebApply &A, int Kpad, int64_t nnu, int 
 static bool cascade_pays(int nlevels_in_use) { return nlevels_in_use >= 4; }
 void launch_apply_cascade(hipStream_t s, ChebApply A, const double *const *Rc, const int *itv, const int *nI, int mode, int Kpad, int64_t nnu,
                           int kn, double base, const double *extra, double *sigma, int accumulate, ChebApply *carry = nullptr /* != NULL: the
-                          cascade only; *carry = what is still to be carried to the grid (k_flux does that) */)
+                          cascade only; *carry = what is still to be carried to the grid (k_flux does that) */, bool tree = false /* one launch for
+                          all levels (k_cheb_cascade_tree, A/B: BASELINE configs[4] 0.344 vs 0.331 ms -- the passes over F cost, not their boundaries) */)
 {
     const int l0 = A.l0[0];
     const bool on = A.ngas == 1 && A.nlev - l0 >= 2 && mode != 2 && (mode == 1 || cascade_pays(A.nlev - l0));
+    if (on && tree && A.nlev - l0 >= 2) {   // every level below an interval of the largest size in ONE launch (k_cheb_cascade_tree)
+        const int nst = cheb_kpad(kn) / 16;
+        CascTree ct;
+        memset(&ct, 0, sizeof ct);
+        ct.nlev = A.nlev; ct.l0 = l0;
+        bool pow2 = true;
+        for (int l = 0; l < A.nlev; l++) {
+            ct.ioff[l] = A.ioff[l]; ct.nI[l] = nI[l]; ct.Rc[l] = Rc[l];
+            if (l > l0) {
+                int ps = 0, cs_ = 0;
+                for (int r = itv[l - 1] / itv[l]; r > 1; r >>= 1) ps++;
+                for (int r = itv[l0] / itv[l]; r > 1; r >>= 1) cs_++;
+                pow2 = pow2 && (itv[l - 1] == (itv[l] << ps)) && (itv[l0] == (itv[l] << cs_));
+                ct.pshift[l] = ps; ct.cshift[l] = cs_;
+            }
+        }
+        if (pow2) {
+            CS_LAUNCH(k_cheb_cascade_tree, dim3((unsigned)nI[l0]), dim3(1024), 0, s, ct, const_cast<double *>(A.F[0]), Kpad, nst);
+            A.l0[0] = A.nlev - 1;
+            if (carry) { *carry = A; return; }
+            launch_apply(s, A, Kpad, nnu, kn, base, extra, sigma, accumulate);
+            return;
+        }
+    }
     if (on) {
         const int nst = cheb_kpad(kn) / 16;
         double *F = const_cast<double *>(A.F[0]);
@@ -2837,7 +2863,7 @@ static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e, bool *
     if (fuse && apply.ngas == 1 && fk.pending && c.rtg.streams && !(ctx->tune[15] & (256 | 64)) && apply.nlev - apply.l0[0] >= 2) {
         const double *Rc[CS_MAX_LEVEL];
         for (int l = 0; l < CS_MAX_LEVEL; l++) Rc[l] = c.cheb.Rc[l].as<double>();
-        launch_apply_cascade(fk.s2, apply, Rc, c.cheb.itv, c.cheb.nI, 1, cheb_kpad(K), c.nnu, K, 0.0, nullptr, sig, 1, &fuse->A);
+        launch_apply_cascade(fk.s2, apply, Rc, c.cheb.itv, c.cheb.nI, 1, cheb_kpad(K), c.nnu, K, 0.0, nullptr, sig, 1, &fuse->A, (ctx->tune[15] & 512) != 0);
         (void)hipEventRecord(fk.ev_join, fk.s2);   // (the main stream has not waited yet: it will wait for this later record)
         fuse->apply = 1;
         cascaded_aside = true;
@@ -2848,7 +2874,7 @@ static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e, bool *
         const double *Rc[CS_MAX_LEVEL];
         for (int l = 0; l < CS_MAX_LEVEL; l++) Rc[l] = c.cheb.Rc[l].as<double>();
         launch_apply_cascade(s, apply, Rc, c.cheb.itv, c.cheb.nI, ctx->tune[12], cheb_kpad(K), c.nnu, K, 0.0, nullptr, sig, 1,
-                             fuse ? &fuse->A : nullptr);
+                             fuse ? &fuse->A : nullptr, (ctx->tune[15] & 512) != 0);
         if (fuse) fuse->apply = 1;
     }
     for (auto &t : c.tab) {  // baked gases: sigma += fC * exp(Phi(T, ln P))

@@ -1307,6 +1307,53 @@ __global__ __launch_bounds__(256) void k_cheb_cascade(const double *__restrict__
         for (int r = 0; r < 4; r++) Fc[(size_t)(16 * st + 4 * r + lq) * Kpad] += acc[st][r];
 }
 
+// The whole cascade in ONE launch: a block = one interval of the largest size in use and everything below it -- its children level by
+// level, a barrier between levels (the block's waves share one L1, so a level's sums are visible to the next) -- instead of one launch per
+// level, each a full pass over F with a kernel boundary behind it (BASELINE configs[4], five levels: 4 x 0.08 ms).  Same products in the
+// same order per (interval, state group): the same F to the last bit.
+struct CascTree {
+    int nlev, l0;
+    int ioff[CS_MAX_LEVEL], nI[CS_MAX_LEVEL];
+    int cshift[CS_MAX_LEVEL];   // log2(size of level l0 / size of level l): children of top interval T0 at level l are [T0 << cshift, (T0 + 1) << cshift)
+    int pshift[CS_MAX_LEVEL];   // log2(size of level l - 1 / size of level l)
+    const double *Rc[CS_MAX_LEVEL];
+};
+__device__ __forceinline__ void cascade_item(const double *__restrict__ Rc, double *__restrict__ F, int ioff_p, int ioff_c, int pshift, int T, int sidx, int Kpad, int lane)
+{
+    const int lr = lane & 15, lq = lane >> 4;
+    const double *__restrict__ Fp = F + (size_t)(ioff_p + (T >> pshift)) * CS_NC * Kpad + (size_t)sidx * 16 + lr;
+    double *__restrict__ Fc = F + (size_t)(ioff_c + T) * CS_NC * Kpad + (size_t)sidx * 16 + lr;
+    const double *__restrict__ R = Rc + (size_t)T * CS_NC * CS_NC + lr;
+    typedef double v4 __attribute__((ext_vector_type(4)));
+    v4 acc[4];
+#pragma unroll
+    for (int st = 0; st < 4; st++) acc[st] = v4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int kk = 0; kk < CS_NC / 4; kk++) {
+        const int j = 4 * kk + lq;
+        const double b = Fp[(size_t)j * Kpad];
+#pragma unroll
+        for (int st = 0; st < 4; st++) acc[st] = __builtin_amdgcn_mfma_f64_16x16x4f64(R[(size_t)j * CS_NC + 16 * st], b, acc[st], 0, 0, 0);
+    }
+#pragma unroll
+    for (int st = 0; st < 4; st++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) Fc[(size_t)(16 * st + 4 * r + lq) * Kpad] += acc[st][r];
+}
+__global__ __launch_bounds__(1024) void k_cheb_cascade_tree(CascTree ct, double *__restrict__ F, int Kpad, int nst)
+{
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, nw = (int)(blockDim.x >> 6);
+    const int T0 = (int)blockIdx.x;
+    for (int l = ct.l0 + 1; l < ct.nlev; l++) {
+        const int first = T0 << ct.cshift[l], nch = 1 << ct.cshift[l];
+        for (int item = wv; item < nch * nst; item += nw) {
+            const int T = first + item / nst;
+            if (T < ct.nI[l]) cascade_item(ct.Rc[l], F, ct.ioff[l - 1], ct.ioff[l], ct.pshift[l], T, item % nst, Kpad, lane);
+        }
+        __syncthreads();
+    }
+}
+
 // The same contraction on the matrix cores: v_mfma_f64_16x16x4_f64 computes D(16 states x 16 nu) += A(16 states x 4 nodes) *
 // B(4 nodes x 16 nu).  Operand layout on gfx950 (tools/ubench/mfma_f64_layout.hip): lane l holds A[l%16][l/16], B[l/16][l%16] and,
 // in register r, D[4r + l/16][l%16] -- with states as the rows of D a store of one register is four 128-byte runs of consecutive

@@ -151,6 +151,8 @@ int cs_set_merge(cs_ctx *ctx, int on);
  *          | 64: short grids with one wave per (sweep, stream) walking all layers (k_flux_streams) instead of the scan over layer chunks
  *          (k_flux_scan) (A/B);
  *          | 256: on short grids the interval levels are NOT folded into the smallest one on the node-sum side stream (A/B);
+ *          | 512: the level cascade (key 12) as ONE launch for all levels (k_cheb_cascade_tree) instead of one per level (A/B: no faster);
+ *          | 1024: the scan form also on grids of 400 .. 4096 tiles (A/B: a tie at 782 tiles, slower at 1563);
  *          | 32 (on the first context of a cs_fluxes_discretized_multi call): the partition is re-cut from measured times also when
  *          contexts share a device (tests).
  * Applies to every later cs_column_setup / cs_column_run of the context. */

@@ -165,3 +165,25 @@ def test_piece_tables_sixteen_lanes_equal_one_thread(cs, lines, nnu, np_):
     for k in ("tau", "Mup", "Mdn", "Fup", "Fdn"):
         assert np.array_equal(a[k], b[k]), k
     a_ctx.close(); b_ctx.close()
+
+
+@pytest.mark.parametrize("key15", [1, 0])
+def test_cascade_tree_equals_level_by_level(cs, lines, key15):
+    """k_cheb_cascade_tree (every level below an interval of the largest size in one launch, a barrier between levels) against one
+    k_cheb_cascade launch per level (the default; the tree: cs_set_tuning key 15 | 512): the same products in the same order -- optical depths, fluxes bitwise
+    equal -- on a grid with five interval levels and a ragged end, with the separate apply kernel (key 15 = 1) and inside k_flux_chunk"""
+    nu = np.linspace(600.0, 1100.0, 300011)
+    assert cs.interp_plan(nu) == [2048, 1024, 512, 256, 128]
+    P = cs.pressuregrid(50.0, 1e5, 8)
+    T = W.earth_temperature(P)
+    gases = (cs.DirectGas(lines("CO2"), 400e-6, nu), cs.DirectGas(lines("H2O"), W.fC_h2o, nu))
+    res = []
+    for extra in (0, 512):
+        ctx = _ctx(cs, key15 | extra)
+        ctx.set_tuning(12, 1)
+        _, r = _run(cs, ctx, P, T, gases, cs.Discretized(5, 2))
+        res.append(r)
+        ctx.close()
+    assert res[0]["launches"] > res[1]["launches"]
+    for k in ("tau", "Mup", "Mdn", "Fup", "Fdn"):
+        assert np.array_equal(res[0][k], res[1][k]), k
