@@ -379,18 +379,26 @@ def main():
             ctx2.set_tuning(*map(int, kv.split("=")))
         d.ctx = ctx2
         d.slots = np.array([ctx2.slot_of(g_.sl) for g_ in d.gases], dtype=np.int32)
+        call_ms = []
         def timed(*bufs, reps=1):
             t1 = time.perf_counter()
             for _ in range(reps):
+                t2 = time.perf_counter()
                 Fq = _fluxes_discretized(d, *bufs)
+                call_ms.append(round((time.perf_counter() - t2) * 1e3, 3))
             return (time.perf_counter() - t1) * 1e3 / reps, Fq
+        import gc
+        gc.collect()
+        gc.disable()      # (a collection of the interpreter landing inside one of five 2 ms calls is not the library's time)
         first, _ = timed(None, None, None)
+        timed(None, None, None)
         rep_f, Fq = timed(None, None, None, reps=5)
         tau_h = np.zeros((d.nl, d.nnu), order="F"); Mu_h = np.zeros((d.np, d.nnu), order="F"); Md_h = np.zeros((d.np, d.nnu), order="F")
         timed(tau_h, Mu_h, Md_h)    # (changes want_tau/want_M: one more setup)
         rep_all, _ = timed(tau_h, Mu_h, Md_h, reps=3)
+        gc.enable()
         host_ptr = dict(first_call_ms=first, repeat_band_fluxes_ms=rep_f, repeat_with_tau_M_ms=rep_all,
-                        d2h_bytes_with_tau_M=int(tau_h.nbytes + Mu_h.nbytes + Md_h.nbytes), olr_wm2=float(Fq[0][0]))
+                        d2h_bytes_with_tau_M=int(tau_h.nbytes + Mu_h.nbytes + Md_h.nbytes), olr_wm2=float(Fq[0][0]), call_ms=call_ms)
         del tau_h, Mu_h, Md_h
         ctx2.close()
 

@@ -31,4 +31,4 @@ for n in (1, 2, 4, 8):
     out[n] = res
     print(n, res, flush=True)
     mc.close()
-json.dump(out, open("gpurun_out/r03_multi_overlap.json", "w"), indent=1)
+json.dump(out, open("gpurun_out/r04_multi_overlap.json", "w"), indent=1)

@@ -54,7 +54,7 @@ for f in glob.glob(out + "/stats/**/*kernel_stats.csv", recursive=True):
             best = (r["Name"].split("(")[0].replace("void ", "").replace("csdev::", ""), float(r["TotalDurationNs"]))
 traffic["dominant"] = best[0]
 # bytes per step: every kernel of the step once per launch group (the bench column has ONE merged group), the two near tiers separately
-step = [k for k in traffic["kernels"] if not k.startswith(("k_transpose", "k_cheb_setup", "k_devfn", "k_faddeeva", "k_fill", "k_table_log"))]
+step = [k for k in traffic["kernels"] if not k.startswith(("k_transpose", "k_cheb_setup", "k_cascade_setup", "k_devfn", "k_faddeeva", "k_fill", "k_table_log"))]
 traffic["bytes_per_step"] = sum((traffic["kernels"][k].get("FETCH_SIZE_KB", 0.0) + traffic["kernels"][k].get("WRITE_SIZE_KB", 0.0)) * 1024.0 for k in step)
 traffic["bytes_per_step_kernels"] = step
 json.dump(traffic, open(out + "/pmc_traffic.json", "w"), indent=1)
