@@ -268,7 +268,7 @@ class Context:
         check(lib().cs_set_merge(self._h, int(bool(on))))
 
     def set_tuning(self, key: int, value: int):
-        """A/B switches (cs_set_tuning), keys 0..13: where the interpolated wings are applied, matrix-core kernels on short grids,
+        """A/B switches (cs_set_tuning), keys 0..16: where the interpolated wings are applied, matrix-core kernels on short grids,
         side streams, interpolation margin, hipGraph replay, flux sweeps per stream, series radius rank, PHCO2 core and node counts,
         low-order far pieces, level cascade, split node kernel -- include/clearsky_hip.h describes each."""
         check(lib().cs_set_tuning(self._h, int(key), int(value)))

@@ -262,7 +262,7 @@ static void drop_graph(Column &c)
 }
 
 // workspace of the PHCO2 fast path (k_phco2): per-(state, line) chi factors and per-tile region windows
-constexpr int CS_NTUNE = 16;
+constexpr int CS_NTUNE = 17;
 // nu_lo .. grid_id: the grid of the call, set by the caller (ph_set_grid); cheb, piw, F: the interpolation levels of that grid for the
 // PHCO2 cut-off (k_phco2_nodes), rebuilt when the key (grid_id, nnu, cut) changes
 struct PhScratch {
@@ -313,7 +313,7 @@ struct cs_ctx {
     // PHCO2 node counts / 64-point intervals, [11] far pieces of the node sums on all 64 nodes, [12] level cascade, [13] k_cheb_nodes
     // with four waves per (interval, state), [14] cut-off edges of k_voigt_edge_mx without the sub-tile phases, [15] the flux kernel
     // finishes the cross-sections on chip (k_flux): 0 = where it pays, 1 = never, 2 = always
-    int tune[CS_NTUNE] = {0, 1, 2, 0, 0, 1, 0, 1, 7, 0, 0, 0, 0, 0, 0, 0};
+    int tune[CS_NTUNE] = {0, 1, 2, 0, 0, 1, 0, 1, 7, 0, 0, 0, 0, 0, 0, 0, 0};
     std::vector<std::shared_ptr<GasTable>> merged;   // merged tables (keyed by their members' (slot, generation)), least recently used first
     double far_s = 1e6;
     DevBuf reinterp;        // [64][32] then [64][16]: values at the 64 nodes of an interval from those at its 32 / 16 nodes (build_reinterp)
@@ -512,8 +512,9 @@ int flux_form(const cs_ctx *ctx, const Column &c, size_t *shmem, int *nblk, int 
             *shmem = sh; *nblk = c.rtg.nblk; *threads = 2 * ns * 64;
             return 1;
         }
-        // the sweeps as a scan over layer chunks: about six layers per wave, 4 .. 12 waves
-        const int nw = std::min(12, std::max(4, (c.nl + 5) / 6));
+        // the sweeps as a scan over layer chunks: five layers per wave where 12 waves reach (their transmissivities stay in registers,
+        // k_flux_scan<NS, 5>), whole waves per SIMD (4, 8 or 12: ten waves of six layers load two SIMDs with three waves and two with two)
+        const int nw = std::min(12, std::max(4, 4 * ((c.nl + 19) / 20)));
         const size_t sh = ((size_t)K * 64 + (size_t)(2 * np - 1) * 64 + (size_t)2 * (ns + 1) * 64 + (size_t)2 * np) * sizeof(double);
         if (sh > lim) return 0;
         *shmem = sh; *nblk = nt64_; *threads = nw * 64;
@@ -533,7 +534,7 @@ int flux_form(const cs_ctx *ctx, const Column &c, size_t *shmem, int *nblk, int 
 template <int NS>
 void launch_flux_ns(int form, size_t shmem, int nblk, int threads, hipStream_t s, const RtParams &p, const double *nu, const double *wts,
                            int64_t nnu, const double *sigma, const double *muk, const double *P, const double *Tlev, const double *S,
-                           const double *alb, double *tau, double *Mup, double *Mdn, double *partial, const FluxFuse &f, bool three_waves = true)
+                           const double *alb, double *tau, double *Mup, double *Mdn, double *partial, const FluxFuse &f, bool three_waves = true, bool scan_recompute = false)
 {
     if (form == 1) {
         if constexpr (NS >= 2 && NS <= 8) {
@@ -542,8 +543,20 @@ void launch_flux_ns(int form, size_t shmem, int nblk, int threads, hipStream_t s
         }
     } else if (form == 3) {
         if constexpr (NS >= 2 && NS <= 8) {
-            if (shmem > 65536) (void)hipFuncSetAttribute((const void *)k_flux_scan<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-            CS_LAUNCH((k_flux_scan<NS>), dim3(nblk), dim3(threads), shmem, s, p, nu, wts, nnu, sigma, muk, P, Tlev, S, alb, tau, Mup, Mdn, partial, f);
+            // a chunk of up to 5 layers (60 layers over 12 waves) keeps its transmissivities in registers between the sweeps and passes
+            const int nw = threads / 64, per = (p.np - 1 + nw - 1) / nw;
+            bool in_regs = false;
+            if constexpr (NS <= 6) {   // (seven streams and up: the 5 x NS values no longer fit beside the rest at three waves per SIMD)
+                if (per <= 5 && !scan_recompute) {
+                    if (shmem > 65536) (void)hipFuncSetAttribute((const void *)k_flux_scan<NS, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+                    CS_LAUNCH((k_flux_scan<NS, 5>), dim3(nblk), dim3(threads), shmem, s, p, nu, wts, nnu, sigma, muk, P, Tlev, S, alb, tau, Mup, Mdn, partial, f);
+                    in_regs = true;
+                }
+            }
+            if (!in_regs) {
+                if (shmem > 65536) (void)hipFuncSetAttribute((const void *)k_flux_scan<NS, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+                CS_LAUNCH((k_flux_scan<NS, 0>), dim3(nblk), dim3(threads), shmem, s, p, nu, wts, nnu, sigma, muk, P, Tlev, S, alb, tau, Mup, Mdn, partial, f);
+            }
         }
     } else if (three_waves) {
         if (shmem > 65536) (void)hipFuncSetAttribute((const void *)k_flux_chunk3<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
@@ -721,6 +734,7 @@ struct Interp {
     int nsplit_levels = 1;    // cs_set_tuning key 6: interval sizes (largest first) whose node sums four waves share in k_cheb_nodes_mx
     bool small_mx = false;    // cs_set_tuning key 1: the matrix-core kernels on short grids too (their four-waves-per-item variants)
     bool mxzones_one_thread = false;   // cs_set_tuning key 15 | 16: k_mxzones instead of k_mxzones16
+    int near_prio = 0;                 // cs_set_tuning key 16: issue priority for k_voigt_sub / k_voigt_near (0 = from 512 tiles on, 1 = never, 2 = always)
     bool fuse_apply = false;  // the column's only interpolating group: k_voigt_edge_mx may carry the node sums to the grid itself
     double core4 = 0.0;       // the core takes the 4-term series where its radius is below core4 x the tile's span, else the 8-term one
                               // (0: always the 8-term one -- measured at C3 with 0.75 / 0.3 / 0: 2.61 / 2.55 / 2.52 ms)
@@ -737,6 +751,7 @@ static void interp_settings(const cs_ctx *ctx, Interp &itp)   // the cs_set_tuni
     itp.nodes_split = ctx->tune[13];
     itp.edge_phases = ctx->tune[14] ? 0 : 1;
     itp.mxzones_one_thread = (ctx->tune[15] & 16) != 0;
+    itp.near_prio = ctx->tune[16];
 }
 
 // interval sizes worth using on this grid: an interval of width W leaves lines over (2 cut - 2.3 W) to interpolate
@@ -1173,6 +1188,8 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
     if (shape == SH_VOIGT || lor) {
         if (lor) hot32 = nullptr;           // (no fp32 variant of the Lorentz body)
         const int nt64 = (int)((nnu + 63) / 64);
+        // wave priority of the near-line stream's kernels (wave_prio): long grids only
+        const int near_prio = (itp.near_prio == 2 || (itp.near_prio == 0 && nt64 >= 512)) ? 3 : 0;
         ZoneArgs za;
         za.nu = dnu; za.nul = G.nu.as<double>(); za.Tk = Tk; za.gbound = gbound; za.win = win; za.zones = zones; za.nnu = nnu;
         za.lorentz = lor ? 1 : 0;
@@ -1340,7 +1357,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
             }
             if (use_edge && itp.core)
                 CS_LAUNCH(k_voigt_sub<CS_SUBW>, dim3((unsigned)nt64, (unsigned)((kn + 64 / CS_SUBW - 1) / (64 / CS_SUBW))), dim3(4096 / CS_SUBW), 0, fork->s3, dnu, nnu, G.L, hot,
-                          G.nu.as<double>(), zones, itp.edge, nt64, kn, cut, fork->sigma2, reinterpret_cast<unsigned *>(ranges));
+                          G.nu.as<double>(), zones, itp.edge, nt64, kn, cut, fork->sigma2, reinterpret_cast<unsigned *>(ranges), near_prio);
         }
         if (lor) {
             if (split == 1) CS_LOR_LAUNCH(1); else if (split == 2) CS_LOR_LAUNCH(2); else CS_LOR_LAUNCH(4);
@@ -1364,15 +1381,15 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
         if (evg) (void)hipEventRecord(evg[3], s);
         if (use_edge && itp.core && !near_fork)   // the window cores of the groups whose series radius is short: pairs inside it (the rest: k_voigt_edge_mx)
             CS_LAUNCH(k_voigt_sub<CS_SUBW>, dim3((unsigned)nt64, (unsigned)((kn + 64 / CS_SUBW - 1) / (64 / CS_SUBW))), dim3(4096 / CS_SUBW), 0, s, dnu, nnu, G.L, hot, G.nu.as<double>(), zones,
-                               itp.edge, nt64, kn, cut, sigma, reinterpret_cast<unsigned *>(ranges));
+                               itp.edge, nt64, kn, cut, sigma, reinterpret_cast<unsigned *>(ranges), near_prio);
         auto launch_near = [&](hipStream_t sn, double *out) {
             const int ngrpn = (nt64 + CS_NEAR_R - 1) / CS_NEAR_R;   // near kernels: one wave = CS_NEAR_R consecutive tiles ...
             // ... times nrep, one after the other, where the table is sparse against the grid (few tiles have candidates at all) and
             // the grid long enough to keep the chip full with an eighth of the waves
             const int nrep = (jhi - jlo < (int64_t)nt64 * 2 && (int64_t)ngrpn * kn >= 262144) ? 8 : 1;
             const dim3 gridq((unsigned)(((ngrpn + nrep - 1) / nrep + 3) / 4), kn);
-            CS_LAUNCH(k_voigt_near<0>, gridq, dim3(256), 0, sn, dnu, nnu, G.L, hot, cold, zones, nt64, ngrpn, nrep, cut, out, ranges);
-            CS_LAUNCH(k_voigt_near<1>, gridq, dim3(256), 0, sn, dnu, nnu, G.L, hot, cold, zones, nt64, ngrpn, nrep, cut, out, ranges);
+            CS_LAUNCH(k_voigt_near<0>, gridq, dim3(256), 0, sn, dnu, nnu, G.L, hot, cold, zones, nt64, ngrpn, nrep, cut, out, ranges, near_prio);
+            CS_LAUNCH(k_voigt_near<1>, gridq, dim3(256), 0, sn, dnu, nnu, G.L, hot, cold, zones, nt64, ngrpn, nrep, cut, out, ranges, near_prio);
         };
         if (near_fork) {   // the near kernels need the hand-off words of both k_voigt_far (main stream) and k_voigt_sub (theirs)
             (void)hipEventRecord(fork->ev_far3, s);
@@ -2952,11 +2969,11 @@ static int run_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev)
         fuse.ticket = (fblk <= 512 && !(ctx->tune[15] & 4)) ? c.ticket.as<unsigned>() : nullptr;   // (| 4: k_freduce always, for A/B)
         fuse.gpartial = c.partial.as<double>() + (size_t)std::max<int64_t>(c.rtg.nblk, (c.nnu + 63) / 64) * 2 * c.np;
         reduced = fuse.ticket != nullptr;
-        if ((ctx->tune[15] & 128) && c.fluxdbg.reserve(8 * sizeof(unsigned long long)) == hipSuccess) fuse.dbg = c.fluxdbg.as<unsigned long long>();
+        if ((ctx->tune[15] & 128) && c.fluxdbg.reserve((8 + 2 * (size_t)fblk + 32) * sizeof(unsigned long long)) == hipSuccess) fuse.dbg = c.fluxdbg.as<unsigned long long>();
         // the chunked form always writes the layer optical depths (its upward sweep reads them back): into the caller's plane or scratch
         double *dtau = (c.want_tau || form == 2) ? c.tau.as<double>() : nullptr;   // (forms 1 and 3 keep the optical depths in LDS)
 #define CS_FLUX_CASE(N) case N: launch_flux_ns<N>(form, fsh, fblk, fthr, s, c.rt, c.nu.as<double>(), c.wts.as<double>(), c.nnu, sig, c.muk.as<double>(), \
-                                                  c.P.as<double>(), c.Tlev.as<double>(), dS, dA, dtau, dMu, dMd, c.partial.as<double>(), fuse, (ctx->tune[15] & 8) == 0); break;
+                                                  c.P.as<double>(), c.Tlev.as<double>(), dS, dA, dtau, dMu, dMd, c.partial.as<double>(), fuse, (ctx->tune[15] & 8) == 0, (ctx->tune[15] & 2048) != 0); break;
         switch (c.nstream) {
             CS_FLUX_CASE(1) CS_FLUX_CASE(2) CS_FLUX_CASE(3) CS_FLUX_CASE(4) CS_FLUX_CASE(5) CS_FLUX_CASE(6) CS_FLUX_CASE(7) CS_FLUX_CASE(8)
             CS_FLUX_CASE(9) CS_FLUX_CASE(10) CS_FLUX_CASE(11) CS_FLUX_CASE(12) CS_FLUX_CASE(13) CS_FLUX_CASE(14) CS_FLUX_CASE(15) CS_FLUX_CASE(16)
@@ -3450,6 +3467,31 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
         (void)hipMemcpy(st, c.fluxdbg.p, sizeof st, hipMemcpyDeviceToHost);
         for (int q = 0; q < 4; q++) out[27 + q] = (int64_t)(st[q + 1] - st[q]) * 10;   // (100 MHz clock)
         out[31] = (int64_t)(st[7] - st[0]) * 10;   // block 0's first instruction to the last block's last word
+        if (getenv("CS_FLUX_DBG") && c.flux_form_last == 3) {   // every block's start and end (k_flux_scan), relative to the earliest start
+            const size_t nb = (size_t)(c.nnu + 63) / 64;
+            if (c.fluxdbg.bytes >= (8 + 2 * nb + 32) * sizeof(unsigned long long)) {
+                std::vector<unsigned long long> bs(2 * nb + 32);
+                (void)hipMemcpy(bs.data(), (const char *)c.fluxdbg.p + 8 * sizeof(unsigned long long), (2 * nb + 32) * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+                fprintf(stderr, "block 0 fine stamps [us from its start]: hand-over steps");
+                for (int q = 0; q < 12; q++) fprintf(stderr, " %.1f", (double)(bs[2 * nb + q] - st[0]) * 0.01);
+                fprintf(stderr, " | second pass down");
+                for (int q = 0; q < 5; q++) fprintf(stderr, " %.1f", (double)(bs[2 * nb + 16 + q] - st[0]) * 0.01);
+                fprintf(stderr, " up");
+                for (int q = 4; q >= 0; q--) fprintf(stderr, " %.1f", (double)(bs[2 * nb + 24 + q] - st[0]) * 0.01);
+                fprintf(stderr, "\n");
+                unsigned long long t0 = ~0ull;
+                for (size_t b = 0; b < nb; b++) t0 = std::min(t0, bs[2 * b]);
+                std::vector<double> st0(nb), en0(nb), du(nb);
+                for (size_t b = 0; b < nb; b++) { st0[b] = (double)(bs[2 * b] - t0) * 0.01; en0[b] = (double)(bs[2 * b + 1] - t0) * 0.01; du[b] = en0[b] - st0[b]; }
+                auto pct = [](std::vector<double> v, double q) { std::sort(v.begin(), v.end()); return v[(size_t)(q * (double)(v.size() - 1))]; };
+                fprintf(stderr, "block 0 stamps [us from its start]:");
+                for (int q = 1; q < 7; q++) fprintf(stderr, " %.1f", (double)(st[q] - st[0]) * 0.01);
+                fprintf(stderr, "\n");
+                fprintf(stderr, "flux blocks %zu [us]: start p50 %.1f p90 %.1f max %.1f | duration min %.1f p50 %.1f p90 %.1f max %.1f | end p50 %.1f p90 %.1f max %.1f | band fluxes stored %.1f\n",
+                        nb, pct(st0, 0.5), pct(st0, 0.9), pct(st0, 1.0), pct(du, 0.0), pct(du, 0.5), pct(du, 0.9), pct(du, 1.0), pct(en0, 0.5), pct(en0, 0.9), pct(en0, 1.0),
+                        (double)(st[7] - t0) * 0.01);
+            }
+        }
     } else {
         for (int q = 27; q < 32; q++) out[q] = 0;
     }

@@ -168,6 +168,20 @@ __device__ __forceinline__ double chi_phco2(double dn, double B1, double B2)
     return exp(-B1 * 27.0 - B2 * 90.0 - 0.0232 * (dn - 120.0));
 }
 
+// issue priority of a kernel's waves against the waves of the other kernels on the same SIMD (s_setprio).  A step is three streams of
+// kernels side by side; the stream that ends last on a long grid is the near-line one (k_voigt_sub, then k_voigt_near<0,1> once
+// k_voigt_far has handed over its ranges), whose waves are chains of dependent gathers that lose every issue slot to the streaming
+// kernels beside them.  With priority 3 for k_voigt_sub and k_voigt_near the bench column's step goes 2.00 -> 1.95 ms and its half
+// 1.16 -> 1.14; on a quarter it is a tie and on an eighth (196 tiles) a loss (0.378 -> 0.387): the host asks for it from 512 tiles on
+// (cs_set_tuning key 16).  Priorities for the other kernels (far, edge_mx, the node sums) changed nothing.
+__device__ __forceinline__ void wave_prio(int p)
+{
+    if (p == 1) __builtin_amdgcn_s_setprio(1);
+    else if (p == 2) __builtin_amdgcn_s_setprio(2);
+    else if (p == 3) __builtin_amdgcn_s_setprio(3);
+}
+
+
 // K2 (generic form): block = 256 consecutive wavenumbers x one node state; every lane walks the block's union
 // window of lines in ascending order (the order surf! sums in) with wave-uniform parameter loads.
 //   sigma[k][i] (nu-fastest) is overwritten when accumulate == 0, else added to (second and later gases).
@@ -2048,8 +2062,9 @@ template <int SW>
 __global__ __launch_bounds__(4096 / SW) void k_voigt_sub(const double *__restrict__ nu, int64_t nnu, int64_t L, const LineHot *__restrict__ hot,
                                                          const double *__restrict__ gnul, const Zone *__restrict__ zones,
                                                          const EdgeZone *__restrict__ edge, int ntile, int K, double cut,
-                                                         double *__restrict__ sigma, unsigned *__restrict__ rp)
+                                                         double *__restrict__ sigma, unsigned *__restrict__ rp, int prio)
 {
+    wave_prio(prio);
     constexpr int NSW = 64 / SW;     // states per wave = sub-tiles per tile = waves per block
     __shared__ unsigned fl_sh[NSW][2];
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -2686,8 +2701,9 @@ template <int TIER>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_voigt_near(const double *__restrict__ nu, int64_t nnu, int64_t L,
                                                      const LineHot *__restrict__ hot, const LineCold *__restrict__ cold,
                                                      const Zone *__restrict__ zones, int ntile, int ngrp, int nrep, double cut,
-                                                     double *__restrict__ sigma, const int2 *__restrict__ ranges)
+                                                     double *__restrict__ sigma, const int2 *__restrict__ ranges, int prio)
 {
+    wave_prio(prio);
     // nrep consecutive tiles per wave, one after the other: on a sparse table nearly every (tile, state) has no candidates, and a
     // wave that only reads its flag and exits still costs its launch -- 7.9e5 of them per kernel at C5, 0.3 ms whatever the gas
     __shared__ unsigned qidx_s[4][CS_NEAR_Q];
@@ -3370,6 +3386,16 @@ __device__ __forceinline__ void flux_stamp(const FluxFuse &f, int slot)
 {
     if (f.dbg && blockIdx.x == 0 && threadIdx.x == 0) f.dbg[slot] = wall_clock64();
 }
+// fine stamps of block 0's first thread behind the per-block ones (dbg[8 + 2 nblk + idx]): where inside a phase the time goes
+__device__ __forceinline__ void flux_stamp_fine(const FluxFuse &f, int idx)
+{
+    if (f.dbg && blockIdx.x == 0 && threadIdx.x == 0) f.dbg[8 + 2 * gridDim.x + idx] = wall_clock64();
+}
+// ... and every block's first and last instruction behind them: dbg[8 + 2 b], dbg[9 + 2 b] (start skew and tail of the launch)
+__device__ __forceinline__ void flux_stamp_block(const FluxFuse &f, int end)
+{
+    if (f.dbg && threadIdx.x == 0) f.dbg[8 + 2 * blockIdx.x + end] = wall_clock64();
+}
 #define CS_FLUX_GROUP 16
 
 // tab[toff[b] + k*nb + c] = (1 - y) z0[c] + y z1[c]: the temperature half of the bilinear interpolation of ln k (BilinearInterpolator,
@@ -3717,7 +3743,7 @@ __global__ __launch_bounds__(2 * NS * 64) void k_flux_streams(RtParams p, const 
 //   phase 3     every wave runs its chunk again from its true incoming intensity and forms what radiate! returns at its levels.
 // Inside a chunk the operations and their order are discretized.jl:282-322's; across chunk boundaries the incoming intensity was
 // formed as A I + B instead of layer by layer: the same numbers to a few units in the last place (tests: 1e-13 against k_rt_streams).
-template <int NS>
+template <int NS, int PER>
 __global__ __launch_bounds__(768) void k_flux_scan(RtParams p, const double *__restrict__ nu, const double *__restrict__ wts, int64_t nnu,
                                                     const double *__restrict__ sigma, const double *__restrict__ muk, const double *__restrict__ P,
                                                     const double *__restrict__ Tlev, const double *__restrict__ S_toa,
@@ -3734,6 +3760,7 @@ __global__ __launch_bounds__(768) void k_flux_scan(RtParams p, const double *__r
     const bool live = j < nnu;
     const int64_t jj = live ? j : nnu - 1;
     flux_stamp(f, 0);
+    flux_stamp_block(f, 0);
     flux_sigma_tile(f, K, nnu, (int)blockIdx.x, sigma, nu, sig, wave, NW, lane);
     __syncthreads();
     flux_stamp(f, 1);
@@ -3761,10 +3788,52 @@ __global__ __launch_bounds__(768) void k_flux_scan(RtParams p, const double *__r
     // this wave's layers [l0, l1)
     const int per = (nl + NW - 1) / NW;
     const int l0 = min(wave * per, nl), l1 = min(l0 + per, nl);
-    // ---- phase 1: the chunk from zero incoming intensity
+    // ---- phase 1: the chunk from zero incoming intensity.  PER > 0 (a chunk has at most PER layers): the transmissivities of the chunk
+    // -- one exponential per (layer, stream) -- stay in registers for the upward sweep and for phase 3, which would form the same
+    // numbers again (PER = 0: they do; same results either way)
     double Ad[NS], Bd[NS], Au[NS], Bu[NS], As = 1.0;
+    constexpr int PQ = PER > 0 ? PER : 1;
+    double trv[PQ][NS], itv[PQ], trs[PQ];
 #pragma unroll
     for (int k = 0; k < NS; k++) { Ad[k] = 1.0; Bd[k] = 0.0; Au[k] = 1.0; Bu[k] = 0.0; }
+    if constexpr (PER > 0) {
+#pragma unroll
+        for (int q = 0; q < PER; q++) {      // downward: layers ascending
+            const int i = l0 + q;
+            itv[q] = 0.0; trs[q] = 1.0;
+#pragma unroll
+            for (int k = 0; k < NS; k++) trv[q][k] = 1.0;
+            if (i < l1) {                    // (wave-uniform)
+                const double t = tl[(size_t)i * 64 + lane], it = 1.0 / t;
+                const double B1 = Blev[(size_t)i * 64 + lane], B2 = Blev[(size_t)(i + 1) * 64 + lane];
+                itv[q] = it;
+#pragma unroll
+                for (int k = 0; k < NS; k++) {
+                    const double tr = exp_rt(-(t * p.m[k]));
+                    const double Be = layerplanck_inv(B1, B2, it * p.im[k], tr);
+                    trv[q][k] = tr;
+                    Bd[k] = Bd[k] * tr + Be;
+                    Ad[k] *= tr;
+                }
+                if (S_toa) { trs[q] = exp(-t / c); As *= trs[q]; }
+            }
+        }
+#pragma unroll
+        for (int q = PER - 1; q >= 0; q--) { // upward: layers descending
+            const int i = l0 + q;
+            if (i < l1) {
+                const double it = itv[q];
+                const double Bhi = Blev[(size_t)(i + 1) * 64 + lane], Blo = Blev[(size_t)i * 64 + lane];
+#pragma unroll
+                for (int k = 0; k < NS; k++) {
+                    const double tr = trv[q][k];
+                    const double Be = layerplanck_inv(Bhi, Blo, it * p.im[k], tr);
+                    Bu[k] = Bu[k] * tr + Be;
+                    Au[k] *= tr;
+                }
+            }
+        }
+    } else {
     for (int i = l0; i < l1; i++) {          // downward: layers ascending
         const double t = tl[(size_t)i * 64 + lane], it = 1.0 / t;
         const double B1 = Blev[(size_t)i * 64 + lane], B2 = Blev[(size_t)(i + 1) * 64 + lane];
@@ -3787,6 +3856,7 @@ __global__ __launch_bounds__(768) void k_flux_scan(RtParams p, const double *__r
             Bu[k] = Bu[k] * tr + Be;
             Au[k] *= tr;
         }
+    }
     }
     flux_stamp(f, 3);
     // ---- phase 2: incoming intensities from chunk to chunk.  xin[0][k] = what enters the current chunk going down, xin[1][k] going up;
@@ -3811,6 +3881,7 @@ __global__ __launch_bounds__(768) void k_flux_scan(RtParams p, const double *__r
     if (!serial && wave == NW - 1) surface(0.0);   // (no reflected part: both sweeps travel in the same steps below)
     for (int s = 0; s < NW; s++) {
         __syncthreads();
+        flux_stamp_fine(f, s);
         if (wave == s) {
 #pragma unroll
             for (int k = 0; k < NS; k++) { Id[k] = *X(0, k); *X(0, k) = Id[k] * Ad[k] + Bd[k]; }
@@ -3847,6 +3918,50 @@ __global__ __launch_bounds__(768) void k_flux_scan(RtParams p, const double *__r
         if (Mdn && live) Mdn[j] = Ms_in;
     }
     double Ms = Ms_in;
+    if constexpr (PER > 0) {
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const int i = l0 + q;
+            if (i < l1) {
+                const double it = itv[q];
+                const double B1 = Blev[(size_t)i * 64 + lane], B2 = Blev[(size_t)(i + 1) * 64 + lane];
+                double Md = 0.0;
+#pragma unroll
+                for (int k = 0; k < NS; k++) {
+                    const double tr = trv[q][k];
+                    const double Be = layerplanck_inv(B1, B2, it * p.im[k], tr);
+                    Id[k] = Id[k] * tr + Be;
+                    Md += p.W[k] * Id[k];
+                }
+                if (S_toa) Ms *= trs[q];
+                Md += Ms;
+                const double r = wave_sum(w * Md);
+                if (lane == 0) red[np + i + 1] = r;
+                if (Mdn && live) Mdn[(size_t)(i + 1) * nnu + j] = Md;
+            }
+            flux_stamp_fine(f, 16 + q);
+        }
+#pragma unroll
+        for (int q = PER - 1; q >= 0; q--) {
+            const int i = l0 + q;
+            if (i < l1) {
+                const double it = itv[q];
+                const double Bhi = Blev[(size_t)(i + 1) * 64 + lane], Blo = Blev[(size_t)i * 64 + lane];
+                double Mu = 0.0;
+#pragma unroll
+                for (int k = 0; k < NS; k++) {
+                    const double tr = trv[q][k];
+                    const double Be = layerplanck_inv(Bhi, Blo, it * p.im[k], tr);
+                    Iu[k] = Iu[k] * tr + Be;
+                    Mu += p.W[k] * Iu[k];
+                }
+                const double r = wave_sum(w * Mu);
+                if (lane == 0) red[i] = r;
+                if (Mup && live) Mup[(size_t)i * nnu + j] = Mu;
+            }
+            flux_stamp_fine(f, 24 + q);
+        }
+    } else {
     for (int i = l0; i < l1; i++) {
         const double t = tl[(size_t)i * 64 + lane], it = 1.0 / t;
         const double B1 = Blev[(size_t)i * 64 + lane], B2 = Blev[(size_t)(i + 1) * 64 + lane];
@@ -3879,12 +3994,14 @@ __global__ __launch_bounds__(768) void k_flux_scan(RtParams p, const double *__r
         if (lane == 0) red[i] = r;
         if (Mup && live) Mup[(size_t)i * nnu + j] = Mu;
     }
+    }
     __syncthreads();
     flux_stamp(f, 5);
     for (int e = threadIdx.x; e < 2 * np; e += blockDim.x) {
         if (f.ticket) flux_store_dev(&partial[(size_t)blockIdx.x * 2 * np + e], red[e]);
         else partial[(size_t)blockIdx.x * 2 * np + e] = red[e];
     }
+    flux_stamp_block(f, 1);
     if (f.ticket) flux_last_block_reduce(f, partial, (int)gridDim.x, 2 * np);
     flux_stamp(f, 6);
 }

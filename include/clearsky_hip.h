@@ -153,8 +153,13 @@ int cs_set_merge(cs_ctx *ctx, int on);
  *          | 256: on short grids the interval levels are NOT folded into the smallest one on the node-sum side stream (A/B);
  *          | 512: the level cascade (key 12) as ONE launch for all levels (k_cheb_cascade_tree) instead of one per level (A/B: no faster);
  *          | 1024: the scan form also on grids of 400 .. 4096 tiles (A/B: a tie at 782 tiles, slower at 1563);
+ *          | 2048: k_flux_scan forms the transmissivities of a layer chunk again in its second sweep and second pass instead of
+ *          keeping them in registers (A/B; same results);
  *          | 32 (on the first context of a cs_fluxes_discretized_multi call): the partition is re-cut from measured times also when
- *          contexts share a device (tests).
+ *          contexts share a device (tests);
+ *   key 16: issue priority (s_setprio 3) for the waves of the near-line stream's kernels (k_voigt_sub, k_voigt_near), whose chains of
+ *          dependent gathers otherwise lose their issue slots to the streaming kernels on the other two streams -- 0 (default) on grids
+ *          of 512 tiles or more, 1 never, 2 always (bench column 2.00 -> 1.95 ms; an eighth of it 0.378 -> 0.387, hence the threshold).
  * Applies to every later cs_column_setup / cs_column_run of the context. */
 int cs_set_tuning(cs_ctx *ctx, int key, int value);
 

@@ -187,3 +187,37 @@ def test_cascade_tree_equals_level_by_level(cs, lines, key15):
     assert res[0]["launches"] > res[1]["launches"]
     for k in ("tau", "Mup", "Mdn", "Fup", "Fdn"):
         assert np.array_equal(res[0][k], res[1][k]), k
+
+
+@pytest.mark.parametrize("nlay,ns,fS,fa", [(60, 5, 0.4, 0.0), (40, 4, 0.0, 0.2), (23, 6, 0.0, 0.0), (75, 5, 0.0, 0.0)])
+def test_scan_transmissivities_in_registers_equal_recomputed(cs, lines, nlay, ns, fS, fa):
+    """k_flux_scan<NS, 5> keeps the chunk's exp(-tau m_k), 1/tau and the beam's attenuation in registers between the sweeps and passes;
+    k_flux_scan<NS, 0> (key 15 | 2048; and chunks of more than five layers: 75 layers over 12 waves) forms them again -- same
+    operations on the same operands: every output bitwise equal.  60 layers = 12 waves x 5, 40 = 8 x 5, 23 = 8 x 3 with a short tail"""
+    nu = np.linspace(600.0, 700.0, 5000)
+    P = cs.pressuregrid(5.0, 1e5, nlay + 1)
+    T = W.earth_temperature(P)
+    gases = (cs.DirectGas(lines("CO2"), 400e-6, nu),)
+    core = cs.Discretized(ns, 2)
+    col, a = _run(cs, _ctx(cs, 0), P, T, gases, core, fS, fa)
+    _, b = _run(cs, _ctx(cs, 2048), P, T, gases, core, fS, fa)
+    assert col.info()["flux_form"] == 3
+    for k in ("tau", "Mup", "Mdn", "Fup", "Fdn"):
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_wave_priority_changes_no_result(cs, lines):
+    """cs_set_tuning key 16: s_setprio for the near-line stream's kernels is scheduling only"""
+    nu = np.linspace(600.0, 760.0, 40000)
+    P = cs.pressuregrid(5.0, 1e5, 21)
+    T = W.earth_temperature(P)
+    gases = (cs.DirectGas(lines("H2O"), W.fC_h2o, nu), cs.DirectGas(lines("CO2"), 400e-6, nu))
+    core = cs.Discretized(5, 2)
+    res = []
+    for v in (1, 2, 0):
+        ctx = cs.Context(0)
+        ctx.set_tuning(16, v)
+        res.append(_run(cs, ctx, P, T, gases, core)[1])
+    for r in res[1:]:
+        for k in ("tau", "Mup", "Mdn", "Fup", "Fdn"):
+            assert np.array_equal(r[k], res[0][k]), k

@@ -17,6 +17,7 @@ for _ in range(5):
 col.sync()
 out = (C.c_int64 * 32)()
 cs.check(cs.lib().cs_column_work(ctx.handle, out))
+import os
 print(which, "flux form", col.info()["flux_form"], "block 0 [us]: sigma %.1f  depths+planck %.1f  pass1 %.1f  handover %.1f | block 0 start -> band fluxes stored %.1f" % tuple(out[27 + q] / 1e3 for q in range(5)))
 prof = col.profile(reps=5)
 print("   rt class (HIP events) %.1f us, reduce %.1f, apply %.1f" % (prof["rt"] * 1e3, prof["reduce"] * 1e3, prof["apply"] * 1e3))
