@@ -2877,17 +2877,25 @@ static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e, bool *
     // are folded into the smallest one THERE (k_cheb_cascade, exact to rounding) and the flux kernel carries one level to the grid instead
     // of three -- one memory latency in its first phase instead of three (13 -> 6 us on a 1/8 shard of the bench column)
     bool cascaded_aside = false;
-    if (fuse && apply.ngas == 1 && fk.pending && c.rtg.streams && !(ctx->tune[15] & (256 | 64)) && apply.nlev - apply.l0[0] >= 2) {
+    ChebApply carried;   // what a cascade on the side stream leaves to carry to the grid
+    const int nl_itp = apply.ngas == 1 ? apply.nlev - apply.l0[0] : 0;
+    const bool short_aside = fuse && c.rtg.streams && !(ctx->tune[15] & 64);
+    // long grids: where the cascade is in use anyway (four levels and up) it runs on the node-sum stream as well, beside the per-point
+    // kernels, instead of between them and the flux kernel (BASELINE configs[4]: four launches, 0.32 ms of the main stream)
+    const bool casc_on = nl_itp >= 2 && ctx->tune[12] != 2 && (ctx->tune[12] == 1 || cascade_pays(nl_itp));
+    if (apply.ngas == 1 && fk.pending && !(ctx->tune[15] & 256) && nl_itp >= 2 && (short_aside || casc_on)) {
         const double *Rc[CS_MAX_LEVEL];
         for (int l = 0; l < CS_MAX_LEVEL; l++) Rc[l] = c.cheb.Rc[l].as<double>();
-        launch_apply_cascade(fk.s2, apply, Rc, c.cheb.itv, c.cheb.nI, 1, cheb_kpad(K), c.nnu, K, 0.0, nullptr, sig, 1, &fuse->A, (ctx->tune[15] & 512) != 0);
+        launch_apply_cascade(fk.s2, apply, Rc, c.cheb.itv, c.cheb.nI, 1, cheb_kpad(K), c.nnu, K, 0.0, nullptr, sig, 1, &carried, (ctx->tune[15] & 512) != 0);
         (void)hipEventRecord(fk.ev_join, fk.s2);   // (the main stream has not waited yet: it will wait for this later record)
-        fuse->apply = 1;
         cascaded_aside = true;
     }
     fork_join(&fk, s, true, false);   // the node sums; the near-line kernels may run on beside what follows (none of it touches their plane)
     // interpolated far wings of all gases: sigma += sum_level C (sum_gas F)  (one pass over C and sigma)
-    if (apply.ngas > 0 && !cascaded_aside) {
+    if (apply.ngas > 0 && cascaded_aside) {
+        if (fuse) { fuse->A = carried; fuse->apply = 1; }
+        else launch_apply(s, carried, cheb_kpad(K), c.nnu, K, 0.0, nullptr, sig, 1);
+    } else if (apply.ngas > 0) {
         const double *Rc[CS_MAX_LEVEL];
         for (int l = 0; l < CS_MAX_LEVEL; l++) Rc[l] = c.cheb.Rc[l].as<double>();
         launch_apply_cascade(s, apply, Rc, c.cheb.itv, c.cheb.nI, ctx->tune[12], cheb_kpad(K), c.nnu, K, 0.0, nullptr, sig, 1,
