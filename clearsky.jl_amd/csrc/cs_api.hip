@@ -502,9 +502,11 @@ int flux_form(const cs_ctx *ctx, const Column &c, size_t *shmem, int *nblk, int 
     const int np = c.np, ns = c.nstream, K = c.K;
     const size_t lim = 160 * 1024 - 4096;
     const int nt64_ = (int)((c.nnu + 63) / 64);
-    // the scan form: short grids (rt_geometry's `streams`), and -- key 15 | 1024 -- every grid in k_rt's two-waves-per-tile regime (A/B: a
-    // tie at 782 tiles, 2.13 vs 1.98 ms at the bench column's 1563)
-    const bool scan_ok = c.rtg.streams || ((ctx->tune[15] & 1024) && c.rtg.ud && ns >= 2 && ns <= 8 && nt64_ >= 1);
+    // the scan form: grids of up to 1024 tiles -- with a chunk's transmissivities in registers it beats the separate kernels on a half
+    // (846 tiles: 1.10 -> 1.08 ms) and a quarter (407 tiles: 0.677 -> 0.610) of the bench column, not on the whole (1563 tiles: 1.94 ->
+    // 1.99) -- and, key 15 | 1024, every grid in k_rt's two-waves-per-tile regime (A/B)
+    // (key 15 = 2, `always`, keeps the chunked form on mid-size grids: tests)
+    const bool scan_ok = c.rtg.streams || (c.rtg.ud && ns >= 2 && ns <= 8 && nt64_ >= 1 && ((nt64_ <= 1024 && (ctx->tune[15] & 3) != 2) || (ctx->tune[15] & 1024)));
     if (scan_ok) {
         if ((ctx->tune[15] & 64) && c.rtg.streams) {   // (the first short-grid form, one wave per stream and sweep: kept for A/B)
             const size_t sh = ((size_t)K * 64 + (size_t)(2 * np - 1) * 64 + (size_t)4 * ns * 64 + (size_t)2 * np + 64) * sizeof(double);

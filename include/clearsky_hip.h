@@ -145,14 +145,14 @@ int cs_set_merge(cs_ctx *ctx, int on);
  *   key 15: the flux kernel finishes the cross-sections on chip (k_flux: the interpolated wings as a matrix product, the CIA pairs and
  *          the near-line plane are added per 64-point tile in LDS instead of by read-modify-write passes over the [K][nnu] plane, and
  *          the last block adds the band-flux partials; fluxes.jl:270-277 does depth and flux of a wavenumber in one loop body) -- 0
- *          (default) where it pays: grids of up to 400 tiles (a nu-shard, a small column) and of 4096 tiles or more, 1 never, 2 always;
+ *          (default) where it pays: grids of up to 1024 tiles (a nu-shard, a small column) and of 4096 tiles or more, 1 never, 2 always;
  *          | 4: the block partials are always added by k_freduce's own launch, | 8: the long-grid form with four waves per SIMD (A/B);
  *          | 16: the matrix-core piece tables with one thread per (interval | tile, state group) (k_mxzones) instead of sixteen lanes (A/B);
  *          | 64: short grids with one wave per (sweep, stream) walking all layers (k_flux_streams) instead of the scan over layer chunks
  *          (k_flux_scan) (A/B);
  *          | 256: on short grids the interval levels are NOT folded into the smallest one on the node-sum side stream (A/B);
  *          | 512: the level cascade (key 12) as ONE launch for all levels (k_cheb_cascade_tree) instead of one per level (A/B: no faster);
- *          | 1024: the scan form also on grids of 400 .. 4096 tiles (A/B: a tie at 782 tiles, slower at 1563);
+ *          | 1024: the scan form also on grids of 1024 .. 4096 tiles (A/B: slower at 1563 tiles);
  *          | 2048: k_flux_scan forms the transmissivities of a layer chunk again in its second sweep and second pass instead of
  *          keeping them in registers (A/B; same results);
  *          | 32 (on the first context of a cs_fluxes_discretized_multi call): the partition is re-cut from measured times also when

@@ -221,3 +221,21 @@ def test_wave_priority_changes_no_result(cs, lines):
     for r in res[1:]:
         for k in ("tau", "Mup", "Mdn", "Fup", "Fdn"):
             assert np.array_equal(r[k], res[0][k]), k
+
+
+def test_scan_form_up_to_1024_tiles(cs, lines):
+    """the scan form is the default up to 1024 tiles (a half of the bench column): 50 000 points = 782 tiles, k_freduce adds the block
+    partials there (more than 512 blocks); against the separate kernels at the scan form's tolerances"""
+    nu = np.linspace(560.0, 800.0, 50000)
+    P = cs.pressuregrid(5.0, 1e5, 31)
+    T = W.earth_temperature(P)
+    gases = (cs.DirectGas(lines("H2O"), W.fC_h2o, nu), cs.DirectGas(lines("CO2"), 400e-6, nu))
+    core = cs.Discretized(5, 2)
+    col, a = _run(cs, _ctx(cs, 0), P, T, gases, core, 0.2, 0.1)
+    _, b = _run(cs, _ctx(cs, 1), P, T, gases, core, 0.2, 0.1)
+    assert col.info()["flux_form"] == 3 and a["launches"] < b["launches"]
+    assert relerr(a["tau"], b["tau"]) < 5e-13
+    sm_ = max(b["Mup"].max(), b["Mdn"].max())
+    amp = source_rounding_bound(cs, nu, col.Tlev, b["tau"])
+    assert np.max(np.abs(a["Mup"] - b["Mup"])) < 1e-13 * sm_ + amp and np.max(np.abs(a["Mdn"] - b["Mdn"])) < 1e-13 * sm_ + amp
+    assert np.max(np.abs(a["Fup"] - b["Fup"])) < 1e-12 * np.max(b["Fup"])
