@@ -320,7 +320,8 @@ def main():
         elif pm.get("config") != args.config or not default_wl:
             traffic_note = "profiles/pmc_traffic.json was measured on another workload"
         else:
-            match = [k_ for k_ in pm["kernels"] if k_.split("<")[0] == dom]
+            dom_name = D.get("kernel", dom)   # (the flux class runs as k_rt, k_flux_scan or k_flux_chunk[3] depending on the grid)
+            match = [k_ for k_ in pm["kernels"] if k_.split("<")[0] == dom_name or (dom_name == "k_flux_chunk" and k_.startswith("k_flux_chunk"))]
             if match:
                 kk = pm["kernels"][match[0]]
                 traffic = (kk["FETCH_SIZE_KB"] + kk["WRITE_SIZE_KB"]) * 1024.0
@@ -345,7 +346,7 @@ def main():
     if "k_cheb_apply_mfma" in kern:
         tw_num += kern["k_cheb_apply_mfma"]["frac"] * prof["apply"]
         tw_den += prof["apply"]
-    roofline = dict(bound=D["bound"], kernel=dom, achieved=r_ach, peak=r_peak,
+    roofline = dict(bound=D["bound"], kernel=D.get("kernel", dom), achieved=r_ach, peak=r_peak,
                     unit=r_unit, frac=r_ach / r_peak if r_peak else None, traffic=traffic, traffic_note=traffic_note,
                     traffic_bytes_per_step=traffic_step, launches_per_step=D["launches_per_step"], avg_launch_ms=D["ms_per_launch"],
                     algorithmic_flops_per_launch=D.get("useful_flops_per_launch"), issued_flops_per_launch=D.get("issued_flops_per_launch"),
