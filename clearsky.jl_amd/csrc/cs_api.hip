@@ -1386,9 +1386,12 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
                                itp.edge, nt64, kn, cut, sigma, reinterpret_cast<unsigned *>(ranges), near_prio);
         auto launch_near = [&](hipStream_t sn, double *out) {
             const int ngrpn = (nt64 + CS_NEAR_R - 1) / CS_NEAR_R;   // near kernels: one wave = CS_NEAR_R consecutive tiles ...
-            // ... times nrep, one after the other, where the table is sparse against the grid (few tiles have candidates at all) and
-            // the grid long enough to keep the chip full with an eighth of the waves
-            const int nrep = (jhi - jlo < (int64_t)nt64 * 2 && (int64_t)ngrpn * kn >= 262144) ? 8 : 1;
+            // ... times nrep, one after the other: where the table is sparse against the grid (few tiles have candidates at all) and the
+            // grid long enough to keep the chip full with an eighth of the waves, and on every grid of half a million (tile, state) waves
+            // and more -- there the launch of the waves is what a near-line kernel costs first (BASELINE configs[4]: 7.9e5 waves per
+            // tier, step 7.06 -> 6.85 ms with eight tiles per wave; the bench column, 9.5e4 waves: a tie with two, a loss with four)
+            const int64_t nwaves_near = (int64_t)ngrpn * kn;
+            const int nrep = (nwaves_near >= 524288 || (jhi - jlo < (int64_t)nt64 * 2 && nwaves_near >= 262144)) ? 8 : 1;
             const dim3 gridq((unsigned)(((ngrpn + nrep - 1) / nrep + 3) / 4), kn);
             CS_LAUNCH(k_voigt_near<0>, gridq, dim3(256), 0, sn, dnu, nnu, G.L, hot, cold, zones, nt64, ngrpn, nrep, cut, out, ranges, near_prio);
             CS_LAUNCH(k_voigt_near<1>, gridq, dim3(256), 0, sn, dnu, nnu, G.L, hot, cold, zones, nt64, ngrpn, nrep, cut, out, ranges, near_prio);

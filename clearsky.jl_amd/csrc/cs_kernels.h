@@ -2704,8 +2704,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
                                                      double *__restrict__ sigma, const int2 *__restrict__ ranges, int prio)
 {
     wave_prio(prio);
-    // nrep consecutive tiles per wave, one after the other: on a sparse table nearly every (tile, state) has no candidates, and a
-    // wave that only reads its flag and exits still costs its launch -- 7.9e5 of them per kernel at C5, 0.3 ms whatever the gas
+    // nrep consecutive tiles per wave, one after the other: a wave that only reads its flag and exits still costs its launch -- 7.9e5 of
+    // them per kernel at BASELINE configs[4], 0.2 ms each for flags and ranges alone (measured with the kernel cut short), whatever the
+    // gas.  Eight tiles per wave there: near-line kernels 1.27 -> 1.06 ms
     __shared__ unsigned qidx_s[4][CS_NEAR_Q];
     __shared__ double qres_s[4][CS_NEAR_Q];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -2716,8 +2717,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     // two planes of packed words: tier 0 ranges, then tier 1 ranges, [gridDim.y][nnu] each; behind them the per-(tile, node) flags
     const unsigned *__restrict__ fl = reinterpret_cast<const unsigned *>(ranges) + 2 * (size_t)gridDim.y * nnu + ((size_t)TIER * gridDim.y + k) * ntile;
     const unsigned *__restrict__ rp = reinterpret_cast<const unsigned *>(ranges) + (size_t)TIER * gridDim.y * nnu + (size_t)k * nnu;
+    // (the flags of the wave's tiles -- nrep <= 8 -- are requested together: one round trip, not one per tile)
+    unsigned livemask = 0u;
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+        if (q < nrep && grp0 + q < ngrp && fl[grp0 + q] != 0u) livemask |= 1u << q;
+    livemask = __builtin_amdgcn_readfirstlane(livemask);
     for (int grp = grp0; grp < min(grp0 + nrep, ngrp); grp++) {
-        if (fl[grp] == 0u) continue;   // (wave-uniform: CS_NEAR_R = 1, group = tile)
+        if (!((livemask >> (grp - grp0)) & 1u)) continue;   // (wave-uniform: CS_NEAR_R = 1, group = tile)
         const int tile0 = grp * CS_NEAR_R;
         int lo[CS_NEAR_R], hi[CS_NEAR_R];
         double acc[CS_NEAR_R];
