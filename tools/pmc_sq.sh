@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ counters per kernel of one step (tools/pmc_sq.sh [bench.py args, e.g. --config C5]), kernels in serial order (serial: --tune 2=0,7=0 "$@"), two passes of four counters; summaries -> gpurun_out/pmc_sq_<n>.csv
+# SQ counters per kernel of one step (tools/pmc_sq.sh [bench.py args, e.g. --config C5]), kernels in serial order (--tune 2=0,7=0), two passes of four counters; summaries -> gpurun_out/pmc_sq_<n>.csv
 root=${GRAFT_REPO_ROOT:-$PWD}
 out=$root/gpurun_out/pmc_sq
 rm -rf $out; mkdir -p $out
