@@ -277,9 +277,11 @@ def main():
     kern["k_voigt_sub"] = valu_entry("sub", work.get("sub_evals", 0) * VALU_PER_LINE["near_zone"], dict(lane_line_evals=work.get("sub_evals", 0)))
     p0, p1 = work.get("near_pairs_tier0", 0), work.get("near_pairs_tier1", 0)
     kern["k_voigt_near"] = valu_entry("near", p0 * (VALU_NEAR["tier0_eval"] + VALU_NEAR["per_candidate"]) + p1 * (VALU_NEAR["tier1_eval"] + VALU_NEAR["per_candidate"]),
-                                      dict(pairs_tier0=p0, pairs_tier1=p1, valu_per_pair=VALU_NEAR, launches_per_step=2 * ngrp,
-                                           note="k_voigt_near<0> (100 <= x^2+y^2 < 1e3: continued fraction) + <1> (< 100: trapezoid + pole); (nu, line, "
-                                                "state) pairs counted on the host from the device's per-(state, line) records; both tiers in one time"))
+                                      dict(pairs_tier0=p0, pairs_tier1=p1, valu_per_pair=VALU_NEAR,
+                                           launches_per_step=(2 if nt64 * K >= 524288 else 1) * ngrp,
+                                           note="tier 0 (100 <= x^2+y^2 < 1e3: continued fraction) + tier 1 (< 100: trapezoid + pole): k_voigt_near_both, one "
+                                                "launch, or k_voigt_near<0> + <1> on grids of half a million (tile, state) waves and more; (nu, line, state) "
+                                                "pairs counted on the host from the device's per-(state, line) records; both tiers in one time"))
     # HBM-bound kernels: algorithmic bytes = what must cross HBM once
     setup_bytes = (58.0 * lines_total + 48.0 * K * lines_total + 32.0 * K * nt64 + 48.0 * K * work["intervals"]) / ngrp
     t = sec("prep")

@@ -736,6 +736,7 @@ struct Interp {
     int nsplit_levels = 1;    // cs_set_tuning key 6: interval sizes (largest first) whose node sums four waves share in k_cheb_nodes_mx
     bool small_mx = false;    // cs_set_tuning key 1: the matrix-core kernels on short grids too (their four-waves-per-item variants)
     bool mxzones_one_thread = false;   // cs_set_tuning key 15 | 16: k_mxzones instead of k_mxzones16
+    bool near_both = true;             // both tiers of the near-line pairs in one launch where a wave takes one tile (cs_set_tuning key 16 | 4: off)
     int near_prio = 0;                 // cs_set_tuning key 16: issue priority for k_voigt_sub / k_voigt_near (0 = from 512 tiles on, 1 = never, 2 = always)
     bool fuse_apply = false;  // the column's only interpolating group: k_voigt_edge_mx may carry the node sums to the grid itself
     double core4 = 0.0;       // the core takes the 4-term series where its radius is below core4 x the tile's span, else the 8-term one
@@ -753,7 +754,8 @@ static void interp_settings(const cs_ctx *ctx, Interp &itp)   // the cs_set_tuni
     itp.nodes_split = ctx->tune[13];
     itp.edge_phases = ctx->tune[14] ? 0 : 1;
     itp.mxzones_one_thread = (ctx->tune[15] & 16) != 0;
-    itp.near_prio = ctx->tune[16];
+    itp.near_prio = ctx->tune[16] & 3;
+    itp.near_both = (ctx->tune[16] & 4) == 0;
 }
 
 // interval sizes worth using on this grid: an interval of width W leaves lines over (2 cut - 2.3 W) to interpolate
@@ -1393,6 +1395,10 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
             const int64_t nwaves_near = (int64_t)ngrpn * kn;
             const int nrep = (nwaves_near >= 524288 || (jhi - jlo < (int64_t)nt64 * 2 && nwaves_near >= 262144)) ? 8 : 1;
             const dim3 gridq((unsigned)(((ngrpn + nrep - 1) / nrep + 3) / 4), kn);
+            if (nrep == 1 && itp.near_both) {   // both tiers in one launch (one tile per wave; cs_set_tuning key 16 | 4: two launches, A/B)
+                CS_LAUNCH(k_voigt_near_both, gridq, dim3(256), 0, sn, dnu, nnu, G.L, hot, cold, zones, nt64, cut, out, ranges, near_prio);
+                return;
+            }
             CS_LAUNCH(k_voigt_near<0>, gridq, dim3(256), 0, sn, dnu, nnu, G.L, hot, cold, zones, nt64, ngrpn, nrep, cut, out, ranges, near_prio);
             CS_LAUNCH(k_voigt_near<1>, gridq, dim3(256), 0, sn, dnu, nnu, G.L, hot, cold, zones, nt64, ngrpn, nrep, cut, out, ranges, near_prio);
         };

@@ -160,6 +160,8 @@ int cs_set_merge(cs_ctx *ctx, int on);
  *   key 16: issue priority (s_setprio 3) for the waves of the near-line stream's kernels (k_voigt_sub, k_voigt_near), whose chains of
  *          dependent gathers otherwise lose their issue slots to the streaming kernels on the other two streams -- 0 (default) on grids
  *          of 512 tiles or more, 1 never, 2 always (bench column 2.00 -> 1.95 ms; an eighth of it 0.378 -> 0.387, hence the threshold).
+ *          | 4: the two tiers of the near-line pairs in two launches (k_voigt_near<0>, <1>) also where a wave takes one tile, instead of
+ *          one (k_voigt_near_both) (A/B; same results).
  * Applies to every later cs_column_setup / cs_column_run of the context. */
 int cs_set_tuning(cs_ctx *ctx, int key, int value);
 

@@ -239,3 +239,21 @@ def test_scan_form_up_to_1024_tiles(cs, lines):
     amp = source_rounding_bound(cs, nu, col.Tlev, b["tau"])
     assert np.max(np.abs(a["Mup"] - b["Mup"])) < 1e-13 * sm_ + amp and np.max(np.abs(a["Mdn"] - b["Mdn"])) < 1e-13 * sm_ + amp
     assert np.max(np.abs(a["Fup"] - b["Fup"])) < 1e-12 * np.max(b["Fup"])
+
+
+def test_near_tiers_in_one_launch_equal_two(cs, lines):
+    """k_voigt_near_both (default where a wave takes one tile) against k_voigt_near<0> + <1> (cs_set_tuning key 16 | 4): (sigma + tier 0)
+    + tier 1 either way -- every output bitwise equal, one launch fewer"""
+    nu = np.linspace(600.0, 760.0, 20011)
+    P = cs.pressuregrid(1.0, 1e5, 25)
+    T = W.earth_temperature(P)
+    gases = (cs.DirectGas(lines("H2O"), W.fC_h2o, nu), cs.DirectGas(lines("CO2"), 400e-6, nu))
+    core = cs.Discretized(5, 2)
+    res = []
+    for v in (0, 4):
+        ctx = cs.Context(0)
+        ctx.set_tuning(16, v)
+        res.append(_run(cs, ctx, P, T, gases, core)[1])
+    assert res[0]["launches"] == res[1]["launches"] - 1
+    for k in ("tau", "Mup", "Mdn", "Fup", "Fdn"):
+        assert np.array_equal(res[0][k], res[1][k]), k
