@@ -69,6 +69,7 @@ def main():
                     "(rehearsal of the RCCL path on a one-GPU box)")
     ap.add_argument("--nu-range", default=None, help="a:b -- time only the wavenumbers [a, b) of the grid, with the global trapezoid weights (rehearsal of one shard)")
     ap.add_argument("--no-calibrate", action="store_true", help="N > 1: keep the cost model's partition instead of re-cutting it from the shards' measured times")
+    ap.add_argument("--no-emulated-shards", action="store_true", help="skip the emulated_shards block (shards 0, 3, 7 of 8 and 1 of 4 timed after the headline)")
     ap.add_argument("--cpu-stride", type=int, default=0, help="cpu_baseline evaluates every n-th wavenumber (0 = size the sample for ~15 s)")
     args = ap.parse_args()
 
@@ -152,36 +153,83 @@ def main():
     # path's only per-step collective stays the band-flux all-reduce).  --emulate-shard r/N measures all N shards on the one GPU for that.
     partition = None
     n_parts = N if not args.emulate_shard else int(args.emulate_shard.split("/")[1])
-    if n_parts > 1 and not args.no_calibrate:
+    lines_pos = [a.sl.nu for a in cfg["absorbers"] if isinstance(a, cs.DirectGas)]
+    if n_parts > 1 and not args.no_calibrate and args.emulate_shard:
         try:
             base = W.balanced_ranges(nu, cfg["absorbers"], n_parts)
-            if args.emulate_shard:
-                # every shard through the SAME context, one after the other (a second context's streams would share hardware queues with
-                # this one's and lose their overlap: measured +12 %), the resident column being replaced each time
-                me = int(args.emulate_shard.split("/")[0])
-                times = []
-                for r_i in range(n_parts):
-                    tmp = make_column(base[r_i])
-                    times.append(shard_ms(tmp))
-                    del tmp
-                col = make_column(base[me])
-                col.sync()
-            else:
-                me = rank
-                tv = torch.zeros(n_parts, dtype=torch.float64, device=(f"cuda:{dev}" if args.dist_backend == "nccl" else "cpu"))
-                tv[rank] = shard_ms(col)
-                dist.all_reduce(tv)
-                times = [float(x) for x in tv.cpu()]
-            lines_pos = [a.sl.nu for a in cfg["absorbers"] if isinstance(a, cs.DirectGas)]
+            # every shard through the SAME context, one after the other (a second context's streams would share hardware queues with
+            # this one's and lose their overlap: measured +12 %), the resident column being replaced each time
+            me = int(args.emulate_shard.split("/")[0])
+            times = []
+            for r_i in range(n_parts):
+                tmp = make_column(base[r_i])
+                times.append(shard_ms(tmp))
+                del tmp
             recut = cs.rebalance_ranges(nu, lines_pos, base, times, fixed_time=0.3 * min(times))
             partition = dict(model_ranges=base, model_shard_ms=times, ranges=recut, calibrated=recut != base)
-            if recut[me] != base[me]:
-                col = make_column(recut[me])
-                col.sync()
-        except Exception as exc:     # (a failed calibration keeps the model's partition: the step itself does not depend on it)
-            partition = dict(calibrated=False, error=repr(exc))
-            col = make_column(ranges[rank])
+            col = make_column(recut[me])
             col.sync()
+        except Exception as exc:     # (one process: a failed calibration keeps the model's partition, the step itself does not depend on it)
+            partition = dict(calibrated=False, error=repr(exc))
+            col = make_column(ranges[0])
+            col.sync()
+    elif n_parts > 1 and not args.no_calibrate:
+        # N ranks.  Every decision here is COLLECTIVE: each rank reaches the same all-reduces in the same order whatever happened to it
+        # locally, and the re-cut partition is adopted only if EVERY rank measured its shard and set its new one up -- otherwise every rank
+        # keeps the model's range.  (A rank falling back on its own would leave ranges that do not tile the grid -- wavenumbers counted
+        # twice or not at all under a healthy-looking JSON line -- or pair its band-flux all-reduce with the others' calibration one.)
+        cdev = f"cuda:{dev}" if args.dist_backend == "nccl" else "cpu"
+        base = ranges
+        tv = torch.zeros(n_parts + 1, dtype=torch.float64, device=cdev)     # [times of the N shards..., number of ranks that failed]
+        err = None
+        try:
+            if os.environ.get("CS_BENCH_FAIL_CALIBRATION") == f"measure:{rank}":
+                raise RuntimeError("injected calibration failure (test)")
+            tv[rank] = shard_ms(col)
+        except Exception as exc:
+            err = repr(exc)
+            tv[n_parts] = 1.0
+        dist.all_reduce(tv)
+        times = [float(x) for x in tv[:n_parts].cpu()]
+        adopted = False
+        if float(tv[n_parts].item()) == 0.0:
+            recut = cs.rebalance_ranges(nu, lines_pos, base, times, fixed_time=0.3 * min(times))      # (same inputs on every rank: same cut)
+            ok = torch.ones(1, dtype=torch.float64, device=cdev)
+            new_col = None
+            try:
+                if os.environ.get("CS_BENCH_FAIL_CALIBRATION") == f"setup:{rank}":
+                    raise RuntimeError("injected set-up failure (test)")
+                if recut[rank] != base[rank]:
+                    new_col = make_column(recut[rank])     # (replaces this context's resident column)
+                    new_col.sync()
+            except Exception as exc:
+                err = repr(exc)
+                ok[0] = 0.0
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok.item()) == 1.0:
+                adopted = True
+                ranges = recut
+                if new_col is not None:
+                    col = new_col
+            else:       # somebody could not set its new shard up: everybody back to the model's range
+                del new_col
+                col = make_column(base[rank])
+                col.sync()
+        partition = dict(model_ranges=base, model_shard_ms=times, ranges=ranges, calibrated=adopted and ranges != base)
+        if not adopted:
+            partition["error"] = err or "another rank failed to calibrate: every rank keeps the model's partition"
+    if use_dist and N > 1:
+        # what each rank ACTUALLY runs, gathered: the ranges must tile [0, nnu) exactly once
+        mine = torch.tensor([col.j0, col.j1], dtype=torch.int64, device=(f"cuda:{dev}" if args.dist_backend == "nccl" else "cpu"))
+        allr = [torch.zeros_like(mine) for _ in range(N)]
+        dist.all_gather(allr, mine)
+        by_rank = [[int(x[0]), int(x[1])] for x in allr]
+        tiles = by_rank[0][0] == 0 and by_rank[-1][1] == len(nu) and all(by_rank[i][1] == by_rank[i + 1][0] for i in range(N - 1))
+        if partition is None:
+            partition = dict(calibrated=False)
+        partition["ranges_by_rank"] = by_rank
+        if not tiles:
+            raise SystemExit(f"rank {rank}: the ranks' wavenumber ranges {by_rank} do not tile [0, {len(nu)})")
     # one explicit torch stream carries the kernels, the D2D copy of the band fluxes and the collective, so they are
     # ordered by the stream (torch's default stream has handle 0, which the C ABI reads as "use the context's stream")
     tstream = torch.cuda.Stream(device=dev)
@@ -190,9 +238,10 @@ def main():
     assert stream != 0
     F = torch.zeros(2 * col.np, dtype=torch.float64, device=f"cuda:{dev}")
 
+    col.set_flux_dst(F.data_ptr())      # the flux kernel's last blocks write the band fluxes where the collective reduces them in place
+
     def step():
         col.run(stream)
-        col.flux_to(F.data_ptr(), stream)
         if use_dist:
             if args.dist_backend == "nccl":
                 dist.all_reduce(F)   # RCCL over xGMI: 2*np doubles, the only collective of the path
@@ -401,6 +450,8 @@ def main():
         rep_all, _ = timed(tau_h, Mu_h, Md_h, reps=3)
         gc.enable()
         host_ptr = dict(first_call_ms=first, repeat_band_fluxes_ms=rep_f, repeat_with_tau_M_ms=rep_all,
+                        radiate_bands_ms=rep_f, radiate_full_ms=rep_all,    # radiate!(F, HIPDiscretized(fluxpack=:bands | :full), ...): what heating! pays per step
+
                         d2h_bytes_with_tau_M=int(tau_h.nbytes + Mu_h.nbytes + Md_h.nbytes), olr_wm2=float(Fq[0][0]), call_ms=call_ms)
         del tau_h, Mu_h, Md_h
         ctx2.close()
@@ -460,6 +511,45 @@ def main():
                                "over max F+ (F-[1] = 0 at the top of the atmosphere), F+ also element-wise relative"))
             del tau_g, Mu_g, Md_g, sig_g, sig_c
 
+    # The same column cut for 8 and 4 GPUs, one shard at a time on THIS card after the headline (the driver's scaling run needs an
+    # 8-GPU node; this block puts the per-shard step under the driver's clock on a 1-GPU box too): shards 0, 3, 7 of 8 and 1 of 4 of the
+    # partition re-cut from measured times, each timed like the headline (same stream, same step, fence on both sides).  A PROJECTION of
+    # strong-scaling efficiency before the all-reduce, (headline ms / n) / shard ms -- not a measurement on n GPUs.
+    emu = None
+    if (rank == 0 and N == 1 and not args.emulate_shard and not args.nu_range and not args.no_emulated_shards and args.config == "C3"
+            and args.nnu is None):
+        emu = dict(note="one shard at a time on one GPU, after the headline, same context and stream; projected_efficiency = "
+                        "(headline ms_per_step / n) / shard ms_per_step, before the band-flux all-reduce", shards=[])
+        try:
+            cuts = {}
+            for n_ in (8, 4):
+                base_ = W.balanced_ranges(nu, cfg["absorbers"], n_)
+                times_ = []
+                for r_i in range(n_):
+                    tmp = make_column(base_[r_i])
+                    times_.append(shard_ms(tmp, reps=8, batches=3))
+                    del tmp
+                cuts[n_] = cs.rebalance_ranges(nu, lines_pos, base_, times_, fixed_time=0.3 * min(times_))
+            for r_, n_ in ((0, 8), (3, 8), (7, 8), (1, 4)):
+                col = make_column(cuts[n_][r_])
+                col.set_flux_dst(F.data_ptr())
+                col.sync()
+                for _ in range(args.warmup):
+                    step()
+                fence()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                fence()
+                sm = (time.perf_counter() - t1) / args.steps * 1e3
+                emu["shards"].append(dict(shard=f"{r_}/{n_}", nu_range=list(cuts[n_][r_]), ms_per_step=sm, launches_per_step=int(col.info()["launches"]),
+                                          projected_efficiency=ms / n_ / sm))
+            e8 = [x["projected_efficiency"] for x in emu["shards"] if x["shard"].endswith("/8")]
+            emu["projected_efficiency_8gpu"] = min(e8)
+            emu["projected_efficiency_4gpu"] = [x["projected_efficiency"] for x in emu["shards"] if x["shard"].endswith("/4")][0]
+        except Exception as exc:
+            emu["error"] = repr(exc)
+
     if rank == 0:
         out = dict(metric="spectral-points/s (nu x layers), whole-column LBL flux evaluation", value=value,
                    unit="spectral-points/s", n_gpus=N, steps=args.steps, warmup=args.warmup, ms_per_step=ms,
@@ -471,7 +561,7 @@ def main():
                                nnu=len(nu), layers=nl, lines=lines_total, parallelism=f"nu-shard x{N}"),
                    collective=(f"{args.dist_backend} all_reduce of {2 * col.np} doubles per step" if use_dist else None),
                    olr_wm2=olr, setup_ms=setup_ms, launches_per_step=int(info["launches"]), launch_groups=int(info["groups"]), host_pointer_ms=host_ptr, kernel_source_sha16=source_stamp(),
-                   partition=partition, roofline=roofline, cpu_baseline=cpu)
+                   partition=partition, emulated_shards=emu, roofline=roofline, cpu_baseline=cpu)
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

@@ -8,7 +8,7 @@ from . import constants
 from ._lib import ClearSkyHIPError, build_native, lib, check, dptr, as_f64, SHAPES, LIB_PATH, SIGNATURES, HEADER
 from .hitran import MOLPARAM, TMIN, TMAX, ISOINDEX, MolParam, SpectralLines, readpar
 from .cia import CIATables, cia, readcia
-from .core import (interp_plan, phco2_plan, MultiContext, balanced_ranges, rebalance_ranges, CIA, AcceleratedAbsorber, Sigma, update_, checkpressures, pressurelimits, temperaturelimits, shape_points, AtmosphericDomain, AtmosphericProfile, Column, Gas, reconcentrate, Context, DirectGas, Discretized, FluxPack, GrayGas, UnifiedAbsorber,
+from .core import (interp_plan, phco2_plan, MultiContext, balanced_ranges, rebalance_ranges, CIA, AcceleratedAbsorber, Sigma, update_, checkpressures, pressurelimits, temperaturelimits, shape_points, AtmosphericDomain, AtmosphericProfile, Column, Gas, reconcentrate, Context, DirectGas, Discretized, HIPDiscretized, FluxPack, GrayGas, SemiGrayGas, UnifiedAbsorber, hipfluxes, hipnetfluxes, opacityerror,
                    PHCO2, PHCO2_, chebygrid, default_context, doppler, doppler_, dtaudP, faddeeva, device_function, fluxes, formprofile,
                    lobattoevaluations, lobattonodes, logrange, lorentz, lorentz_, monochromaticfluxes,
                    monochromaticfluxes_, netfluxes, nodepressures, nodevalues, opticaldepth, ozonelayer, planck,

@@ -73,6 +73,7 @@ SIGNATURES = {
     "cs_column_profile": (C.c_int, [_vp, _vp, C.c_int, _dp]),
     "cs_column_flux_ptr": (C.c_int, [_vp, C.POINTER(_vp)]),
     "cs_column_flux_to": (C.c_int, [_vp, _vp, _vp]),
+    "cs_column_set_flux_dst": (C.c_int, [_vp, _vp]),
     "cs_column_fetch": (C.c_int, [_vp, C.c_int64, C.c_int, _dp, _dp, _dp, _dp, _dp]),
     "cs_column_sigma_fetch": (C.c_int, [_vp, C.c_int64, C.c_int, _dp]),
     "cs_column_counts": (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

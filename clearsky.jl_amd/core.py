@@ -576,6 +576,26 @@ class GrayGas(AbstractGas):
         return self.sigma
 
 
+class SemiGrayGas(AbstractGas):
+    """gases.jl:366-386: sigma [cm^2/molecule] at the wavenumbers up to nu_cut, zero beyond -- g(i, ...) = (nu[i] <= nu_cut) ? sigma : 0.
+    In a column it travels as a per-wavenumber vector added at every node state (the C ABI's sigma_extra)."""
+
+    def __init__(self, sigma, nu, nucut):
+        self.name = self.formula = "SemiGray"
+        self.mu = float("nan")
+        self.nu = np.array(nu, dtype=float)
+        self.nucut = float(nucut)
+        self.sigma = float(sigma)
+
+    def __call__(self, *a):
+        if len(a) == 2:        # U(T, P): every wavenumber
+            return self.vector(self.nu)
+        return self.sigma if self.nu[int(a[0])] <= self.nucut else 0.0
+
+    def vector(self, nu):
+        return np.where(np.asarray(nu, float) <= self.nucut, self.sigma, 0.0)
+
+
 class AtmosphericDomain:
     """gases.jl:26-61: Chebyshev-extrema grids in T and ln P over which cross-sections are baked."""
 
@@ -679,6 +699,25 @@ class _GasView(Gas):
 
 def reconcentrate(g: Gas, fC):
     return g.reconcentrate(fC)
+
+
+def opacityerror(g: Gas, i: int, N: int = 50, shape=None):
+    """opacityerror(Π, Ω, sl, ν, C, shape=voigt, N=50) (gases.jl:152-175) for the table of wavenumber index i (0-based) of a baked Gas
+    -- Π = that wavenumber's OpacityTable, Ω = g.Omega, sl = g.sl, ν = g.nu[i], C = the concentration the gas was baked with.
+    Returns (T, P, aerr, rerr) on the reference's N x N grid (T linear over [Tmin, Tmax], P logarithmic over [Pmin, Pmax]):
+    interpolated minus exact cross-section and that over the exact one.  The N*N exact values come from ONE cs_shape_points call
+    (the scalar-wavenumber `shape(ν, sl, T, P, C(T,P)*P)` at N*N states), the interpolated ones from cs_table_eval."""
+    Om = g.Omega
+    T = np.linspace(Om.Tmin, Om.Tmax, N)
+    P = 10.0 ** np.linspace(math.log10(Om.Pmin), math.log10(Om.Pmax), N)
+    TT, PP = np.meshgrid(T, P, indexing="ij")
+    Pp = np.array([g.fC(t, p) * p for t, p in zip(TT.ravel(), PP.ravel())])
+    sex = shape_points(g.sl, shape or g.shape, [g.nu[int(i)]], TT.ravel(), PP.ravel(), Pp, g.dnu_cut, g.ctx)[:, 0].reshape(N, N)
+    sop = np.array([[g.rawsigma(t, p, int(i)) for p in P] for t in T])
+    aerr = sop - sex
+    with np.errstate(divide="ignore", invalid="ignore"):
+        rerr = aerr / sex
+    return T, P, aerr, rerr
 
 
 class UnifiedAbsorber:
@@ -896,13 +935,21 @@ def unifyabsorbers(absorbers):
 
 
 class Discretized:
-    """core/shared.jl:55-66"""
+    """core/shared.jl:55-66 -- and julia/ClearSkyHIP.jl's HIPDiscretized, whose extra field it carries: `fluxpack` says what
+    radiate_ (radiate!, fluxes.jl:357-383) brings back.  "full": tau, M+, M- and the band fluxes, as the reference fills its FluxPack;
+    "bands": Fup, Fdn, Fnet only -- all heating! reads (radiative_convective.jl:109-144) -- tau, M+, M- stay in HBM (NULL across the
+    ABI: no 146 MB copy per call at 1e5 x 60) and keep whatever the FluxPack held."""
 
-    def __init__(self, nstream: int = 5, nlobatto: int = 2):
-        self.nstream, self.nlobatto = int(nstream), int(nlobatto)
+    def __init__(self, nstream: int = 5, nlobatto: int = 2, fluxpack: str = "full"):
+        if fluxpack not in ("full", "bands"):
+            raise ValueError(f"fluxpack must be 'full' or 'bands', not {fluxpack!r}")
+        self.nstream, self.nlobatto, self.fluxpack = int(nstream), int(nlobatto), fluxpack
 
     def __repr__(self):
-        return f"Discretized(nstream={self.nstream}, nlobatto={self.nlobatto})"
+        return f"Discretized(nstream={self.nstream}, nlobatto={self.nlobatto}" + (", fluxpack='bands')" if self.fluxpack == "bands" else ")")
+
+
+HIPDiscretized = Discretized     # the name of the core type in julia/ClearSkyHIP.jl
 
 
 class FluxPack:
@@ -996,7 +1043,7 @@ class Column:
                 assert p_ <= g_.Omega.Pmax, f"Pressure {p_} Pa too low, domain minimum is {g_.Omega.Pmax}"
         self.sigma_gray = float(sum(g_.sigma for g_ in U.gas if isinstance(g_, GrayGas)))
         for g_ in U.gas:
-            if not isinstance(g_, (DirectGas, GrayGas, Gas)):
+            if not isinstance(g_, (DirectGas, GrayGas, SemiGrayGas, Gas)):
                 raise TypeError(f"unsupported gas type {type(g_).__name__} for the HIP Discretized core")
         self.slots = np.array(self.ctx.slots_of([g_.sl for g_ in self.gases]), dtype=np.int32)
         self.shapes = np.array([SHAPES[g_.shape] for g_ in self.gases], dtype=np.int32)
@@ -1032,8 +1079,11 @@ class Column:
             for k in range(self.K):
                 self.cia_P1[ci, k] = self.Pk[k] * x.g1.concentration(self.Tk[k], self.Pk[k])   # cia…jl:378-382
                 self.cia_P2[ci, k] = self.Pk[k] * x.g2.concentration(self.Tk[k], self.Pk[k])
-        if self.U.fun:
+        semi = [g_ for g_ in self.U.gas if isinstance(g_, SemiGrayGas)]
+        if self.U.fun or semi:
             ex = np.zeros((self.K, self.nnu))
+            for g_ in semi:                      # (nu[i] <= nu_cut) ? sigma : 0 at every node state, gases.jl:386
+                ex += g_.vector(self.nu)[None, :]
             for k in range(self.K):
                 for f in self.U.fun:
                     try:
@@ -1062,6 +1112,8 @@ class Column:
             check(lib().cs_column_set_accel(self.ctx.handle, self.accel.slot))
         self._set = True
         self.ctx._resident = self      # a context holds ONE resident column
+        if getattr(self, "_flux_dst", 0):
+            check(lib().cs_column_set_flux_dst(self.ctx.handle, C.c_void_p(self._flux_dst)))
 
     def _set_cia(self):
         if not self.U.cia:
@@ -1177,6 +1229,13 @@ class Column:
         """Async copy of [Fup; Fdn] (2*np doubles) into caller-owned device memory (e.g. a torch tensor's data_ptr())."""
         self._require_resident("flux_to")
         check(lib().cs_column_flux_to(self.ctx.handle, C.c_void_p(device_ptr), C.c_void_p(stream) if stream else None))
+
+    def set_flux_dst(self, device_ptr: int):
+        """From now on the column writes [Fup; Fdn] straight into caller-owned device memory (cs_column_set_flux_dst): the buffer a
+        collective reduces in place -- no copy per step.  0 / None: back to the column's own."""
+        self._flux_dst = int(device_ptr or 0)      # (re-applied whenever the column is set up again: _setup)
+        self._ensure_resident()
+        check(lib().cs_column_set_flux_dst(self.ctx.handle, C.c_void_p(self._flux_dst) if self._flux_dst else None))
 
     def counts(self):
         self._require_resident("counts")
@@ -1322,11 +1381,19 @@ def netfluxes(P, g, T, mu, fS, fa, *absorbers, **kw):
     return Fup - Fdn
 
 
+# julia/ClearSkyHIP.jl's names for the two (there `fluxes` itself cannot dispatch on its `core` keyword and stays the reference's
+# host-integrating body; here `fluxes` already is the band-fluxes-only call)
+hipfluxes, hipnetfluxes = fluxes, netfluxes
+
+
 def radiate_(F: FluxPack, core: Discretized, P, g, T, mu, fS, fa, *absorbers, theta_s=0.841, ctx=None):
     """radiate!(F, core, P, g, T, mu, fS, fa, absorbers...) fluxes.jl:357-383"""
     U, nu, nnu = unifyabsorbers(absorbers)
     assert F.size == (len(P), nnu), "size of FluxPack does not match number of pressure or wavenumber coordinates"
-    Fup, Fdn = _b3(P, g, T, mu, fS, fa, (U,), core, theta_s, ctx, F.tau, F.Mup, F.Mdn)
+    if getattr(core, "fluxpack", "full") == "bands":     # F+, F-, Fnet from the device's intF!; tau, M+, M- neither copied nor touched
+        Fup, Fdn = _b3(P, g, T, mu, fS, fa, (U,), core, theta_s, ctx, None, None, None)
+    else:
+        Fup, Fdn = _b3(P, g, T, mu, fS, fa, (U,), core, theta_s, ctx, F.tau, F.Mup, F.Mdn)
     F.Fup[:] = Fup
     F.Fdn[:] = Fdn
     F.Fnet[:] = Fup - Fdn

@@ -118,6 +118,8 @@ struct GasTable {
 
 struct TableDev {
     bool present = false;
+    uint64_t generation = 0;   // bumped whenever the slot is (re)filled (cs_bake, cs_table_upload) or cleared: a resident column's weights
+                               // W [nT * nP][K] belong to one generation's (T, P) grid
     int64_t nnu = 0;
     int nT = 0, nP = 0;
     std::vector<double> T, lnP, nu;
@@ -126,12 +128,15 @@ struct TableDev {
 
 struct ColTab {
     int slot = 0;
+    uint64_t generation = 0;   // of the table slot the weights were formed for
     DevBuf W, conc;  // [M][K], [K]
 };
 
 // AcceleratedAbsorber (absorbers.jl:114-203): ln sigma on pressure knots, per wavenumber
 struct AccelDev {
     bool present = false;
+    uint64_t generation = 0;   // bumped whenever the KNOTS of the slot change (cs_accel_upload; cs_accel_store with other knots) or it is
+                               // cleared: a resident column's knot cells belong to one generation (new VALUES on the same knots keep it)
     int64_t nnu = 0;
     int nk = 0;
     std::vector<double> lnP, nu;   // knots (ascending), wavenumbers
@@ -139,6 +144,7 @@ struct AccelDev {
 };
 struct ColAccel {
     int slot = -1;                 // -1: none
+    uint64_t generation = 0;       // of the accelerated-absorber slot the cells were formed for
     DevBuf cell, x, xa, xb;        // per node: knot interval and the three abscissae of the LinearInterpolator formula
 };
 
@@ -206,6 +212,8 @@ struct ColGas {
 struct RtGeom { bool ud, streams; int tiles, nblk, threads; size_t shmem; };   // streams: k_rt_streams (one wave per stream and sweep)
 
 struct Column {
+    double *F_dst = nullptr;   // cs_column_set_flux_dst: caller-owned device memory the band fluxes [2 np] are written to (NULL: the column's own F)
+    double *flux_out() { return F_dst ? F_dst : F.as<double>(); }
     bool ready = false;
     int64_t nnu = 0;
     int np = 0, nl = 0, nlob = 0, K = 0, nstream = 0, ngas = 0, ntile = 0;
@@ -262,7 +270,7 @@ static void drop_graph(Column &c)
 }
 
 // workspace of the PHCO2 fast path (k_phco2): per-(state, line) chi factors and per-tile region windows
-constexpr int CS_NTUNE = 17;
+constexpr int CS_NTUNE = 24;
 // nu_lo .. grid_id: the grid of the call, set by the caller (ph_set_grid); cheb, piw, F: the interpolation levels of that grid for the
 // PHCO2 cut-off (k_phco2_nodes), rebuilt when the key (grid_id, nnu, cut) changes
 struct PhScratch {
@@ -313,7 +321,8 @@ struct cs_ctx {
     // PHCO2 node counts / 64-point intervals, [11] far pieces of the node sums on all 64 nodes, [12] level cascade, [13] k_cheb_nodes
     // with four waves per (interval, state), [14] cut-off edges of k_voigt_edge_mx without the sub-tile phases, [15] the flux kernel
     // finishes the cross-sections on chip (k_flux): 0 = where it pays, 1 = never, 2 = always
-    int tune[CS_NTUNE] = {0, 1, 2, 0, 0, 1, 0, 1, 7, 0, 0, 0, 0, 0, 0, 0, 0};
+    bool gfx950 = false;    // cs_create: the device reports gcnArchName gfx950 (the in-kernel band sum of k_flux_* is used only then)
+    int tune[CS_NTUNE] = {0, 1, 2, 0, 0, 1, 0, 1, 7, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     std::vector<std::shared_ptr<GasTable>> merged;   // merged tables (keyed by their members' (slot, generation)), least recently used first
     double far_s = 1e6;
     DevBuf reinterp;        // [64][32] then [64][16]: values at the 64 nodes of an interval from those at its 32 / 16 nodes (build_reinterp)
@@ -739,6 +748,9 @@ struct Interp {
     bool near_both = true;             // both tiers of the near-line pairs in one launch where a wave takes one tile (cs_set_tuning key 16 | 4: off)
     int near_prio = 0;                 // cs_set_tuning key 16: issue priority for k_voigt_sub / k_voigt_near (0 = from 512 tiles on, 1 = never, 2 = always)
     bool fuse_apply = false;  // the column's only interpolating group: k_voigt_edge_mx may carry the node sums to the grid itself
+    int mx_sub = 0;           // cs_set_tuning key 17: short grids, matrix-core items cut along the node / point axis (k_*_mx_sub): 0 = by item count,
+                              // 1 / 2 = one / two 16-column sub-tiles per block, 3 = never (four waves per whole item, as before round 5)
+    int mx_sub_items = 0;     // cs_set_tuning key 18: ... on grids with fewer (tile | interval, group) items than this (0: 2048)
     double core4 = 0.0;       // the core takes the 4-term series where its radius is below core4 x the tile's span, else the 8-term one
                               // (0: always the 8-term one -- measured at C3 with 0.75 / 0.3 / 0: 2.61 / 2.55 / 2.52 ms)
 };
@@ -756,6 +768,8 @@ static void interp_settings(const cs_ctx *ctx, Interp &itp)   // the cs_set_tuni
     itp.mxzones_one_thread = (ctx->tune[15] & 16) != 0;
     itp.near_prio = ctx->tune[16] & 3;
     itp.near_both = (ctx->tune[16] & 4) == 0;
+    itp.mx_sub = ctx->tune[17];
+    itp.mx_sub_items = ctx->tune[18] > 0 ? ctx->tune[18] : 2048;
 }
 
 // interval sizes worth using on this grid: an interval of width W leaves lines over (2 cut - 2.3 W) to interpolate
@@ -1134,6 +1148,15 @@ constexpr int CS_EDGE_DENS = 4;
 // blocks to fill the chip -- on a short grid (a nu-shard) the one-state-per-wave vector kernel has the shorter critical path
 // (1/8 of C3: 0.17 vs 0.25 ms)
 static bool mx_big(int nblocks, int kn, int min_blocks) { return (int64_t)nblocks * ((kn + 15) / 16) >= min_blocks; }
+// short grids: 16-column sub-tiles per block of k_cheb_nodes_mx_sub / k_voigt_edge_mx_sub (1, 2), or 0 = whole items (the long-grid kernels)
+// -- enough blocks to deal out ~8 per CU as they finish (cs_set_tuning keys 17, 18)
+static int mx_sub_tiles(int mode, int max_items, int64_t items)
+{
+    if (mode == 3) return 0;
+    if (mode == 1 || mode == 2) return mode;
+    if (items >= max_items) return 0;
+    return items * 2 >= 2048 ? 2 : 1;
+}
 // `small`: cs_set_tuning key 1 -- short grids too, through the variants that share one (interval | tile, group) between the four
 // waves of a block (k_cheb_nodes_mx with every level split, k_voigt_edge_mx<4>)
 static bool sep_in_use(bool have_sep, bool always, int nblocks_intervals, int kn, bool lor, bool mixed, bool small = false)
@@ -1288,6 +1311,12 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
                 for (int l = 0; l < itp.nlev; l++) { mf.ioff[l] = itp.ioff[l]; mf.nfar[l] = itp.nfar[l] > 0 ? itp.nfar[l] : CS_NC; }
                 mf.ioff[itp.nlev] = itp.nItot;
                 mf.R = itp.R;
+                const int nsub = mx_sub_tiles(itp.mx_sub, itp.mx_sub_items, (int64_t)nq * ngrp);
+                if (nsplit == nq && nsub == 1)
+                    CS_LAUNCH(k_cheb_nodes_mx_sub<1>, dim3((unsigned)(nq * ngrp * 4)), dim3(256), 0, s, itp.nodes, G.L, hot, itp.sep, itp.nItot, q0, kn, itp.Kpad, ngrp, itp.F, itp.iz);
+                else if (nsplit == nq && nsub == 2)
+                    CS_LAUNCH(k_cheb_nodes_mx_sub<2>, dim3((unsigned)(nq * ngrp * 2)), dim3(256), 0, s, itp.nodes, G.L, hot, itp.sep, itp.nItot, q0, kn, itp.Kpad, ngrp, itp.F, itp.iz);
+                else
                 CS_LAUNCH(k_cheb_nodes_mx, dim3(nblk_mx), dim3(256), 0, s, itp.nodes, G.L, hot, itp.sep, itp.nItot, q0, nsplit, kn,
                                    itp.Kpad, ngrp, itp.F, itp.iz, mf);
             }
@@ -1414,7 +1443,14 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
         if (use_edge)
         {
             if (fuse) fork_join(fork, s);   // (it reads F)
-            if (mx_big(nt64, kn, 1024))
+            const int esub = fuse ? 0 : mx_sub_tiles(itp.mx_sub, itp.mx_sub_items, (int64_t)nt64 * ((kn + 15) / 16));
+            if (esub == 1)
+                CS_LAUNCH(k_voigt_edge_mx_sub<1>, dim3((unsigned)nt64 * 4u, (unsigned)((kn + 15) / 16)), dim3(256), 0, s, dnu, nnu, G.L, hot, win,
+                          itp.edge, nt64, kn, cut, sigma, G.nu.as<double>());
+            else if (esub == 2)
+                CS_LAUNCH(k_voigt_edge_mx_sub<2>, dim3((unsigned)nt64 * 2u, (unsigned)((kn + 15) / 16)), dim3(256), 0, s, dnu, nnu, G.L, hot, win,
+                          itp.edge, nt64, kn, cut, sigma, G.nu.as<double>());
+            else if (mx_big(nt64, kn, 1024))
                 CS_LAUNCH(k_voigt_edge_mx<1>, dim3((unsigned)((nt64 + 3) / 4), (unsigned)((kn + 15) / 16)), dim3(256), 0, s, dnu, nnu, G.L, hot, win,
                           itp.edge, nt64, kn, cut, sigma, fuse ? 1 : 0, Afuse, itp.Kpad, G.nu.as<double>(), itp.edge_phases);
             else   // short grid: four waves per (tile, group)
@@ -1566,6 +1602,11 @@ int cs_create(int device, cs_ctx **out)
     HIPCHK(hipSetDevice(device));
     cs_ctx *c = new cs_ctx();
     c->device = device;
+    {   // the code object is built for gfx950 only; k_flux_*'s in-kernel band sum (flux_last_block_reduce) additionally relies on a
+        // property of that architecture -- see its comment -- so it is switched on by the device's name, not assumed
+        hipDeviceProp_t prop;
+        c->gfx950 = hipGetDeviceProperties(&prop, device) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+    }
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking);
@@ -2004,6 +2045,7 @@ int cs_bake(cs_ctx *ctx, int gas_slot, int table_slot, int shape, double dnu_cut
     tb.lnP.resize(nP);
     for (int j = 0; j < nP; j++) tb.lnP[j] = std::log(P[j]);
     tb.nu.assign(nu, nu + nnu);
+    tb.generation = next_generation();
     tb.present = true;
     return CS_OK;
 }
@@ -2115,6 +2157,7 @@ int cs_column_set_tables(cs_ctx *ctx, int ntab, const int *table_slots, const do
         if (tb.nnu != c.nnu || !std::equal(tb.nu.begin(), tb.nu.end(), c.h_nu.begin()))
             return fail(CS_EINVAL, "gases must have identical wavenumber vectors");
         c.tab[t].slot = sl;
+        c.tab[t].generation = tb.generation;
     }
     int rc = upload_tables(ctx, conc_tab);
     if (rc) c.tab.clear();
@@ -2324,11 +2367,13 @@ int cs_accel_store(cs_ctx *ctx, int accel_slot)
     CS_LAUNCH(k_accel_store, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, c.sigma.as<double>(), ad.L.as<double>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s));
+    std::vector<double> lnP(c.K);
+    for (int k = 0; k < c.K; k++) lnP[k] = std::log(c.h_Pk[k]);
+    if (!ad.present || ad.nnu != c.nnu || ad.nk != c.K || ad.lnP != lnP || ad.nu != c.h_nu) ad.generation = next_generation();   // other knots or grid (new values on the same ones: update!, absorbers.jl:173-200)
     ad.nnu = c.nnu;
     ad.nk = c.K;
     ad.nu = c.h_nu;
-    ad.lnP.resize(c.K);
-    for (int k = 0; k < c.K; k++) ad.lnP[k] = std::log(c.h_Pk[k]);
+    ad.lnP = lnP;
     ad.present = true;
     return CS_OK;
 }
@@ -2403,6 +2448,7 @@ int cs_column_set_accel(cs_ctx *ctx, int accel_slot)
         return rc;
     HIPCHK(hipStreamSynchronize(s));
     c.accel.slot = accel_slot;
+    c.accel.generation = ad.generation;
     return CS_OK;
 }
 
@@ -2415,6 +2461,7 @@ int cs_column_setup(cs_ctx *ctx, int64_t nnu, const double *nu, const double *wt
     if (!ctx) return fail(CS_EINVAL, "ctx is NULL");
     Column &c = ctx->col;
     c.ready = false;
+    c.F_dst = nullptr;      // (a destination for the band fluxes belongs to the column it was set for)
     drop_graph(c);
     if (np < 2) return fail(CS_EINVAL, "need at least two pressure levels");
     if (nlobatto < 2 || nlobatto > CS_MAX_LOBATTO) return fail(CS_EINVAL, "nlobatto must be in [2,%d]", CS_MAX_LOBATTO);
@@ -2955,6 +3002,13 @@ static int column_current(cs_ctx *ctx)
             c.ready = false;
             return fail(CS_ESTATE, "gas slot %d was re-uploaded or cleared after cs_column_setup", ug.slot);
         }
+    // the same for the opacity tables and the accelerated absorber the column names by slot: its weights [nT * nP][K] / knot cells were
+    // formed for the (T, P) grid / knots the slot held at cs_column_set_tables / cs_column_set_accel
+    for (auto &ct : c.tab)
+        if (!ctx->tab[ct.slot].present || ctx->tab[ct.slot].generation != ct.generation)
+            return fail(CS_ESTATE, "opacity-table slot %d was baked, uploaded or cleared after cs_column_set_tables: call it again", ct.slot);
+    if (c.accel.slot >= 0 && (!ctx->accel[c.accel.slot].present || ctx->accel[c.accel.slot].generation != c.accel.generation))
+        return fail(CS_ESTATE, "accelerated-absorber slot %d got other knots (or was cleared) after cs_column_set_accel: call it again", c.accel.slot);
     return CS_OK;
 }
 
@@ -2983,9 +3037,9 @@ static int run_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev)
     bool reduced = false;
     if (form) {
         fuse.sigma2 = near_live ? c.sigma2.as<double>() : nullptr;
-        fuse.F = c.F.as<double>();
+        fuse.F = c.flux_out();
         // up to 512 blocks the last ones to finish add the block partials (two stages of 16 and <= 32 terms); longer grids keep k_freduce
-        fuse.ticket = (fblk <= 512 && !(ctx->tune[15] & 4)) ? c.ticket.as<unsigned>() : nullptr;   // (| 4: k_freduce always, for A/B)
+        fuse.ticket = (fblk <= 512 && !(ctx->tune[15] & 4) && ctx->gfx950) ? c.ticket.as<unsigned>() : nullptr;   // (| 4: k_freduce always, for A/B)
         fuse.gpartial = c.partial.as<double>() + (size_t)std::max<int64_t>(c.rtg.nblk, (c.nnu + 63) / 64) * 2 * c.np;
         reduced = fuse.ticket != nullptr;
         if ((ctx->tune[15] & 128) && c.fluxdbg.reserve((8 + 2 * (size_t)fblk + 32) * sizeof(unsigned long long)) == hipSuccess) fuse.dbg = c.fluxdbg.as<unsigned long long>();
@@ -3005,7 +3059,7 @@ static int run_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev)
     }
     if (ev) HIPCHK(hipEventRecord(ev[e++], s));
     if (!reduced)
-        CS_LAUNCH(k_freduce, dim3(2 * c.np), dim3(256), 0, s, c.partial.as<double>(), form ? fblk : c.rtg.nblk, 2 * c.np, c.F.as<double>());
+        CS_LAUNCH(k_freduce, dim3(2 * c.np), dim3(256), 0, s, c.partial.as<double>(), form ? fblk : c.rtg.nblk, 2 * c.np, c.flux_out());
     if (ev) HIPCHK(hipEventRecord(ev[e++], s));
     c.launches = g_nlaunch;
     HIPCHK(hipGetLastError());
@@ -3028,8 +3082,10 @@ int cs_column_run(cs_ctx *ctx, void *stream)
     Column &c = ctx->col;
     if (!ctx->tune[4]) return run_impl(ctx, s, nullptr);
     if (c.graph_exec) {
-        for (auto &ug : c.ugas)
-            if (!ctx->gas[ug.slot].present || ctx->gas[ug.slot].generation != ug.generation) { drop_graph(c); return run_impl(ctx, s, nullptr); }
+        {   // (a replayed graph carries the kernel arguments of the slots' old contents: gas tables, opacity tables, knots)
+            const int rc0 = column_current(ctx);
+            if (rc0) { drop_graph(c); return rc0; }
+        }
         HIPCHK(hipGraphLaunch(c.graph_exec, s));
         // the replayed kernels wrote the near-line plane again and ran on THIS stream: what cs_column_sigma_fetch / cs_column_fetch /
         // cs_column_info read must say so, as after an eager run
@@ -3101,7 +3157,7 @@ int cs_column_sync(cs_ctx *ctx)
 int cs_column_flux_ptr(cs_ctx *ctx, double **dF)
 {
     if (!ctx || !ctx->col.ready || !dF) return fail(CS_ESTATE, "no resident column");
-    *dF = ctx->col.F.as<double>();
+    *dF = ctx->col.flux_out();
     return CS_OK;
 }
 
@@ -3109,7 +3165,16 @@ int cs_column_flux_to(cs_ctx *ctx, double *dst_device, void *stream)
 {
     if (!ctx || !ctx->col.ready || !dst_device) return fail(CS_ESTATE, "no resident column");
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-    HIPCHK(hipMemcpyAsync(dst_device, ctx->col.F.p, (size_t)2 * ctx->col.np * sizeof(double), hipMemcpyDeviceToDevice, s));
+    if (dst_device != ctx->col.flux_out())   // (the kernels write there already: cs_column_set_flux_dst)
+        HIPCHK(hipMemcpyAsync(dst_device, ctx->col.flux_out(), (size_t)2 * ctx->col.np * sizeof(double), hipMemcpyDeviceToDevice, s));
+    return CS_OK;
+}
+
+int cs_column_set_flux_dst(cs_ctx *ctx, double *dst_device)
+{
+    if (!ctx || !ctx->col.ready) return fail(CS_ESTATE, "no resident column");
+    if (ctx->col.F_dst != dst_device) drop_graph(ctx->col);   // (a captured step carries the old pointer)
+    ctx->col.F_dst = dst_device;
     return CS_OK;
 }
 
@@ -3144,8 +3209,8 @@ int cs_column_fetch(cs_ctx *ctx, int64_t nnu, int np, double *tau, double *Mup, 
     if ((Mup || Mdn) && !c.want_M) return fail(CS_ESTATE, "column was set up without want_M");
     if (Mup && (rc = fetch_transposed(ctx, c.Mup.as<double>(), c.np, c.nnu, Mup))) return rc;
     if (Mdn && (rc = fetch_transposed(ctx, c.Mdn.as<double>(), c.np, c.nnu, Mdn))) return rc;
-    if (Fup) HIPCHK(hipMemcpyAsync(Fup, c.F.as<double>(), c.np * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (Fdn) HIPCHK(hipMemcpyAsync(Fdn, c.F.as<double>() + c.np, c.np * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (Fup) HIPCHK(hipMemcpyAsync(Fup, c.flux_out(), c.np * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (Fdn) HIPCHK(hipMemcpyAsync(Fdn, c.flux_out() + c.np, c.np * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return CS_OK;
 }
@@ -3358,8 +3423,24 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
                     };
                     // the cut-off edges, cut where the next sub-tile comes into reach (k_voigt_edge_mx's phases: one wave per (tile, group) only)
                     const bool phased = !ctx->tune[14] && mx_big(nt64, K, 1024);
+                    // short grids: blocks of esub 16-point sub-tiles, each with the part of an end its own points can reach (k_voigt_edge_mx_sub)
+                    const int esub = ctx->tune[0] ? 0 : mx_sub_tiles(ctx->tune[17], ctx->tune[18] > 0 ? ctx->tune[18] : 2048, (int64_t)nt64 * ((K + 15) / 16));
                     auto end_piece = [&](int ja, int jb, int nt, bool left) {
                         if (jb <= ja) return;
+                        if (esub > 0) {
+                            const double issued0 = fl_edge_issued;
+                            piece(ja, jb, nt, 1);              // (for the useful flops)
+                            fl_edge_issued = issued0;
+                            const int nn = 16 * esub;
+                            for (int sg = 0; sg < 4 / esub; sg++) {
+                                const double vfirst = vv[std::min<int64_t>((int64_t)t * 64 + sg * nn, c.nnu - 1)], vlast = vv[std::min<int64_t>((int64_t)t * 64 + sg * nn + nn - 1, c.nnu - 1)];
+                                const double tolc = 1e-9 * (std::fabs(vfirst) + g.cut + 1.0);
+                                const int n = left ? jb - (int)(std::lower_bound(nl + ja, nl + jb, vfirst - g.cut - tolc) - nl)
+                                                   : (int)(std::upper_bound(nl + ja, nl + jb, vlast + g.cut + tolc) - nl) - ja;
+                                fl_edge_issued += 2.0 * nt * nn * 16.0 * ((n + 3) / 4 * 4);
+                            }
+                            return;
+                        }
                         if (!phased || jb - ja < 48) { piece(ja, jb, nt, 1); return; }
                         const double issued0 = fl_edge_issued;
                         piece(ja, jb, nt, 1);              // (for the useful flops)
@@ -3645,6 +3726,7 @@ int cs_table_upload(cs_ctx *ctx, int table_slot, int64_t nnu, const double *nu, 
     tb.lnP.resize(nP);
     for (int j = 0; j < nP; j++) tb.lnP[j] = std::log(P[j]);
     tb.nu.assign(nu, nu + nnu);
+    tb.generation = next_generation();
     tb.present = true;
     return CS_OK;
 }
@@ -3662,14 +3744,19 @@ int cs_accel_upload(cs_ctx *ctx, int accel_slot, int64_t nnu, const double *nu, 
     AccelDev &ad = ctx->accel[accel_slot];
     const bool resident_here = ctx->col.ready && ctx->col.accel.slot == accel_slot;
     if (resident_here && (ad.nk != nk || ad.nnu != nnu)) ctx->col.ready = false;   // (its knot cells belong to the old knots)
+    std::vector<double> lnP(nk);
+    for (int k = 0; k < nk; k++) lnP[k] = std::log(P_knots[k]);
+    // other knots (or another grid) than the slot held: a resident column's knot cells are stale (column_current refuses them until
+    // cs_column_set_accel forms new ones); the same knots with new values -- what update! leaves -- keep the generation
+    const bool same_knots = ad.present && ad.nk == nk && ad.nnu == nnu && ad.lnP == lnP && std::equal(ad.nu.begin(), ad.nu.end(), nu);
     ad.present = false;
     if ((rc = upload(ad.L, lnsigma, (size_t)nk * nnu, ctx->stream))) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (!same_knots) ad.generation = next_generation();
     ad.nnu = nnu;
     ad.nk = nk;
     ad.nu.assign(nu, nu + nnu);
-    ad.lnP.resize(nk);
-    for (int k = 0; k < nk; k++) ad.lnP[k] = std::log(P_knots[k]);
+    ad.lnP = lnP;
     ad.present = true;
     return CS_OK;
 }

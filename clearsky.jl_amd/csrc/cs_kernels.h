@@ -15,6 +15,10 @@
 #include <rocprim/warp/warp_scan.hpp>
 #include "cs_faddeeva.h"
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "cs_kernels.h is written for gfx950 (CDNA4: 64-wide waves, v_mfma_f64_16x16x4_f64, 160 KB of LDS per CU, 8 XCDs) -- build with --offload-arch=gfx950"
+#endif
+
 namespace csdev {
 
 // src/constants.jl:1-26, verbatim (k is the CODATA-2014 value on purpose)
@@ -1146,6 +1150,69 @@ __global__ __launch_bounds__(256) void k_cheb_nodes_mx(const double *__restrict_
     }
 }
 
+// Short grids (a nu-shard of a multi-GPU run: a few hundred (interval, group) items for 256 CUs).  With one block per item every CU holds
+// two or three blocks of unequal length for the whole launch and the longest CU is the kernel (1/8 of the bench column: 103 us for
+// work that takes 43 at the full grid's efficiency).  Here an item is cut along its NODE axis: one block = the item's lines for NSUB of
+// the four 16-node sub-tiles (its four waves share the lines as above), so a launch has 4 / NSUB times more blocks, each a 4 / NSUB
+// times shorter chain, dealt out as blocks finish -- and every block still owns its own entries of F (no second adder: the sums stay
+// bitwise repeatable).  The price is the per-line coefficient arithmetic once per block instead of once per item (~25 of a step's
+// vector instructions); the matrix instructions are the same ones.
+template <int NSUB>
+__global__ __launch_bounds__(256) void k_cheb_nodes_mx_sub(const double *__restrict__ nodes, int64_t L, const LineHot *__restrict__ hot,
+                                                           const SepZone *__restrict__ sep, int nItot, int q0, int K, int Kpad, int ngrp,
+                                                           double *__restrict__ F, const IZone *__restrict__ iz)
+{
+    constexpr int NB = 4 / NSUB, NN = 16 * NSUB, PITCH = NN + 1;   // blocks per item, nodes per block, LDS row pitch (odd: rows on different banks)
+    __shared__ double part[4][16][PITCH];
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int item = (int)blockIdx.x / NB, sg = (int)blockIdx.x % NB;
+    const int T = q0 + item / ngrp;
+    const int g = (item % ngrp + T) % ngrp;   // (rotated as in k_cheb_nodes_mx)
+    const SepZone z = sep[(size_t)g * nItot + T];
+    if (!(z.b[0] > z.a[0] || z.b[1] > z.a[1] || z.b[2] > z.a[2] || z.b[3] > z.a[3])) return;   // (block-uniform)
+    const int lr = lane & 15, lq = lane >> 4;
+    {
+        const int kk = min(g * 16 + lr, K - 1);
+        const LineHot *__restrict__ hk = hot + (size_t)kk * L;
+        const int S0k = iz[(size_t)kk * nItot + T].S0, S1k = iz[(size_t)kk * nItot + T].S1;
+        double vn[NSUB];
+        v4f64_sep acc[NSUB];
+#pragma unroll
+        for (int st = 0; st < NSUB; st++) {
+            vn[st] = nodes[(size_t)T * CS_NC + (sg * NSUB + st) * 16 + lr];
+            acc[st] = v4f64_sep{0.0, 0.0, 0.0, 0.0};
+        }
+        auto quarter = [&](int pa, int pb, bool asc, int &ja, int &jb) {   // this wave's run of [pa, pb): multiples of 4 lines
+            const int run = ((pb - pa + 15) >> 4) << 2;
+            ja = asc ? pa + wv * run : max(pb - (wv + 1) * run, pa);
+            jb = asc ? min(ja + run, pb) : pb - wv * run;
+        };
+        for (int pp = 0; pp < 4; pp++) {
+            const int p = pp < 2 ? pp : 5 - pp;          // 0, 1, 3, 2
+            const bool asc = pp < 2;
+            if (z.b[p] <= z.a[p]) continue;
+            int ja, jb;
+            if (asc) {
+                if (z.m[p] > z.a[p]) { quarter(z.a[p], z.m[p], true, ja, jb); sep_run<3, 0, NSUB, 0, NSUB>(acc, vn, hk, ja, jb, true, lq, 0.0, 0.0, -0x7fffffff, S0k); }
+                if (z.b[p] > z.m[p]) { quarter(z.m[p], z.b[p], true, ja, jb); sep_run<4, 0, NSUB, 0, NSUB>(acc, vn, hk, ja, jb, true, lq, 0.0, 0.0, -0x7fffffff, S0k); }
+            } else {
+                if (z.b[p] > z.m[p]) { quarter(z.m[p], z.b[p], false, ja, jb); sep_run<3, 0, NSUB, 0, NSUB>(acc, vn, hk, ja, jb, false, lq, 0.0, 0.0, S1k); }
+                if (z.m[p] > z.a[p]) { quarter(z.a[p], z.m[p], false, ja, jb); sep_run<4, 0, NSUB, 0, NSUB>(acc, vn, hk, ja, jb, false, lq, 0.0, 0.0, S1k); }
+            }
+        }
+#pragma unroll
+        for (int st = 0; st < NSUB; st++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) part[wv][4 * r + lq][st * 16 + lr] = acc[st][r];   // D[state 4r + lq][node 16 st + lr]
+    }
+    __syncthreads();
+    // 16 states x NN nodes of F, state fastest (its layout): thread = (node, state), the four partial sums in wave order
+    for (int idx = threadIdx.x; idx < 16 * NN; idx += 256) {
+        const int ks = idx & 15, n = idx >> 4, k = g * 16 + ks;
+        if (k < K) F[((size_t)T * CS_NC + sg * NN + n) * Kpad + k] += ((part[0][ks][n] + part[1][ks][n]) + part[2][ks][n]) + part[3][ks][n];
+    }
+}
+
 // sigma[k][i] (+)= sum over levels of  C_l[T_l][:, i] . F[T_l][:, k]  -- the interpolation as a small matrix product.
 // One wave = one 64-point tile x 16 states: a column of C is loaded once and used for 16 states whose F values arrive as
 // wave-uniform scalar operands.
@@ -2046,6 +2113,100 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const int ks = 4 * wv + s4, k = g * 16 + ks;
         if (k >= K || i >= nnu) break;
         sigma[(size_t)k * nnu + i] += ((part[0][ks][lane] + part[1][ks][lane]) + part[2][ks][lane]) + part[3][ks][lane];
+    }
+}
+
+// Short grids, as k_cheb_nodes_mx_sub: a (tile, group) item is cut along its POINT axis -- one block = the item's pieces for NSUB of the
+// tile's four 16-point sub-tiles, its four waves sharing the lines -- 4 / NSUB times more, shorter blocks, each owning its own entries
+// of sigma.  A block then sees only the part of a cut-off edge its own points can reach (the lines of the left end from the first one
+// within the cut-off of the block's first point on, of the right end up to the last one within that of its last point): what the
+// phases of k_voigt_edge_mx<1> do for whole tiles falls out of the split.
+template <int NSUB>
+__global__ __launch_bounds__(256) void k_voigt_edge_mx_sub(const double *__restrict__ nu, int64_t nnu, int64_t L, const LineHot *__restrict__ hot,
+                                                           const WaveWin *__restrict__ win, const EdgeZone *__restrict__ edge, int ntile, int K,
+                                                           double cut, double *__restrict__ sigma, const double *__restrict__ gnul)
+{
+    constexpr int NB = 4 / NSUB, NN = 16 * NSUB, PITCH = NN + 2;
+    __shared__ double part[4][16][PITCH];
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int tile = (int)blockIdx.x / NB, sg = (int)blockIdx.x % NB, g = blockIdx.y;
+    const WaveWin w = win[tile];
+    const EdgeZone e = edge[(size_t)g * ntile + tile];
+    if (e.eL <= w.W0 && e.eR >= w.W1 && e.mL1 <= e.mL0 && e.mR1 <= e.mR0 && e.cR <= e.cL) return;   // (block-uniform)
+    const int lr = lane & 15, lq = lane >> 4;
+    {
+        const int kk = min(g * 16 + lr, K - 1);
+        const LineHot *__restrict__ hk = hot + (size_t)kk * L;
+        double vn[NSUB];
+        v4f64_sep acc[NSUB];
+#pragma unroll
+        for (int st = 0; st < NSUB; st++) {
+            const int64_t i = (int64_t)tile * 64 + (sg * NSUB + st) * 16 + lr;
+            vn[st] = nu[i < nnu ? i : nnu - 1];
+            acc[st] = v4f64_sep{0.0, 0.0, 0.0, 0.0};
+        }
+        // the block's first and last point (wave-uniform)
+        const double vfirst = __shfl(vn[0], 0), vlast = __shfl(vn[NSUB - 1], 15);
+        const double tolc = 1e-9 * (fabs(vfirst) + cut + 1.0);
+        // left end [W0, eL): from the first line with nul >= vfirst - cut on; right end [eR, W1): up to the last line with nul <= vlast + cut
+        // (one vector load per 64 lines and a ballot, as the phases of k_voigt_edge_mx)
+        int pL = w.W0, pR = w.W1;
+        if (e.eL > w.W0) {
+            const int p0 = w.W0, p1 = e.eL;
+            const double a0 = vfirst - cut - tolc;
+            pL = p1;
+            for (int base = p0; base < p1; base += 64) {
+                const int j = base + lane;
+                const double x = gnul[j < p1 ? j : p1 - 1];
+                const uint64_t m0 = __builtin_amdgcn_ballot_w64(j < p1 && x >= a0);
+                if (m0 != 0) { pL = base + __builtin_ctzll(m0); break; }
+            }
+        }
+        if (w.W1 > e.eR) {
+            const int p0 = e.eR, p1 = w.W1;
+            const double b0 = vlast + cut + tolc;
+            pR = p1;
+            for (int base = p0; base < p1; base += 64) {
+                const int j = base + lane;
+                const double x = gnul[j < p1 ? j : p1 - 1];
+                const uint64_t m0 = __builtin_amdgcn_ballot_w64(j < p1 && x > b0);
+                if (m0 != 0) { pR = base + __builtin_ctzll(m0); break; }
+            }
+        }
+        // this wave's run of the piece [pa, pb): one of four runs of a multiple of 4 lines, wave 0 at the far end
+        auto run = [&](int pa, int pb, bool asc, int &ja, int &jb) {
+            const int len = ((max(pb - pa, 0) + 15) >> 4) << 2;
+            ja = asc ? min(pa + wv * len, pb) : max(pb - (wv + 1) * len, pa);
+            jb = asc ? min(ja + len, pb) : max(pb - wv * len, pa);
+        };
+        int ja, jb;
+        run(pL, e.eL, true, ja, jb);
+        if (e.far3 & 1) sep_run<3, 1, NSUB, 0, NSUB>(acc, vn, hk, ja, jb, true, lq, cut); else sep_run<4, 1, NSUB, 0, NSUB>(acc, vn, hk, ja, jb, true, lq, cut);
+        if (e.mL1 > e.mL0) {
+            run(e.mL0, e.mL3, true, ja, jb); sep_run<3, 1, NSUB, 0, NSUB>(acc, vn, hk, ja, jb, true, lq, cut);
+            run(e.mL3, e.mL1, true, ja, jb); sep_run<4, 1, NSUB, 0, NSUB>(acc, vn, hk, ja, jb, true, lq, cut);
+        }
+        run(e.eR, pR, false, ja, jb);
+        if (e.far3 & 2) sep_run<3, 1, NSUB, 0, NSUB>(acc, vn, hk, ja, jb, false, lq, cut); else sep_run<4, 1, NSUB, 0, NSUB>(acc, vn, hk, ja, jb, false, lq, cut);
+        if (e.mR1 > e.mR0) {
+            run(e.mR3, e.mR1, false, ja, jb); sep_run<3, 1, NSUB, 0, NSUB>(acc, vn, hk, ja, jb, false, lq, cut);
+            run(e.mR0, e.mR3, false, ja, jb); sep_run<4, 1, NSUB, 0, NSUB>(acc, vn, hk, ja, jb, false, lq, cut);
+        }
+        if (e.cR > e.cL) {   // the core: pairs at least R apart
+            run(e.cL, e.cR, true, ja, jb);
+            if (e.far3 & 4) sep_run<8, 2, NSUB, 0, NSUB>(acc, vn, hk, ja, jb, true, lq, cut, e.R); else sep_run<4, 2, NSUB, 0, NSUB>(acc, vn, hk, ja, jb, true, lq, cut, e.R);
+        }
+#pragma unroll
+        for (int st = 0; st < NSUB; st++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) part[wv][4 * r + lq][st * 16 + lr] = acc[st][r];   // D[state 4r + lq][point 16 st + lr]
+    }
+    __syncthreads();
+    // 16 states x NN points of sigma, point fastest: the four partial sums in wave order
+    for (int idx = threadIdx.x; idx < 16 * NN; idx += 256) {
+        const int n = idx % NN, ks = idx / NN, k = g * 16 + ks;
+        const int64_t i = (int64_t)tile * 64 + sg * NN + n;
+        if (k < K && i < nnu) sigma[(size_t)k * nnu + i] += ((part[0][ks][n] + part[1][ks][n]) + part[2][ks][n]) + part[3][ks][n];
     }
 }
 
@@ -3596,6 +3757,24 @@ __device__ __forceinline__ void flux_sigma_tile(const FluxFuse &f, int K, int64_
 //  invalidate the whole L2 of the block's XCD -- measured: +40 us on a 157-block grid -- so the partials and group sums travel as
 //  device-scope relaxed atomic stores and loads instead (write-through / L2-bypassing accesses to just those words), ordered by
 //  waiting for the stores before the ticket and by the ticket's own device-scope atomicity.)
+// The band-flux partials of k_flux_* cross from the blocks that form them to the last block(s) to finish, which add them -- in other
+// workgroups, usually on other XCDs (eight L2s, not coherent with each other).  The textbook hand-over is release / acquire at agent
+// scope around the ticket; on this part an agent-scope release is a write-back of the XCD's whole L2 (measured: +40 us on a 157-block
+// grid, profiles/r04_notes.md), for a few hundred doubles.  What is used instead, and what it rests on:
+//   * the partials are written and read with AGENT-scope relaxed ATOMIC stores / loads.  On gfx942 / gfx950 these are global_store /
+//     global_load with sc1 set: the store writes through the XCD's L2 to memory, the load misses L2 on purpose -- each access is
+//     coherent at the agent by itself, no cache maintenance needed (AMDGPU backend memory model, "gfx942" column: atomic store /
+//     load monotonic, agent scope);
+//   * s_waitcnt vmcnt(0) after the stores: a write-through store is counted in vmcnt until it has been acknowledged by the memory
+//     side, so when the wait returns this thread's partials are visible at the agent; the workgroup barrier behind it extends that to
+//     every thread of the block BEFORE thread 0 takes the ticket.  The ticket is an agent-scope atomic RMW (performed at memory on
+//     this part): a block that draws the last number therefore finds every other block's partials already there;
+//   * the compiler must not move the partial stores below, or the partial loads above, the ticket: the workgroup-scope release /
+//     acquire fences around it say so in the language of the memory model (no L2 action at that scope), beside the barriers.
+// Formally the ticket would have to be release / acquire at AGENT scope for the hand-over to be a happens-before edge of the HIP
+// memory model; the relaxed form is correct for the hardware named in the #error above, which is why the host hands out a ticket only
+// on a device that reports gfx950 (cs_create; otherwise k_freduce, a second launch, adds the partials) -- tests/test_gpu_flux_fused.py
+// compares the two bit for bit.
 __device__ __forceinline__ void flux_store_dev(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double flux_load_dev(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void flux_last_block_reduce(const FluxFuse &f, const double *__restrict__ partial, int nblk, int n2)
@@ -3604,9 +3783,11 @@ __device__ __forceinline__ void flux_last_block_reduce(const FluxFuse &f, const 
     const int grp = (int)blockIdx.x / CS_FLUX_GROUP, ngrp = (nblk + CS_FLUX_GROUP - 1) / CS_FLUX_GROUP;
     const int b0 = grp * CS_FLUX_GROUP, nb = min(CS_FLUX_GROUP, nblk - b0);
     __builtin_amdgcn_s_waitcnt(0);      // this thread's partials (device-scope stores) have left before the block takes its ticket
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (threadIdx.x == 0) last = (__hip_atomic_fetch_add(f.ticket + 1 + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nb - 1u) ? 1u : 0u;
     __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     if (!last) return;
     for (int e = threadIdx.x; e < n2; e += blockDim.x) {
         double v[CS_FLUX_GROUP];
@@ -3618,12 +3799,14 @@ __device__ __forceinline__ void flux_last_block_reduce(const FluxFuse &f, const 
         flux_store_dev(&f.gpartial[(size_t)grp * n2 + e], t);
     }
     __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (threadIdx.x == 0) {
         __hip_atomic_store(f.ticket + 1 + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch (stream order)
         last = (__hip_atomic_fetch_add(f.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)ngrp - 1u) ? 1u : 0u;
     }
     __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     if (!last) return;
     for (int e = threadIdx.x; e < n2; e += blockDim.x) {
         double t = 0.0;

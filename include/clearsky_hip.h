@@ -327,6 +327,10 @@ int cs_column_profile(cs_ctx *ctx, void *stream, int reps, double *ms);
 int cs_column_flux_ptr(cs_ctx *ctx, double **dF);
 /* asynchronously copy the [2*np] band fluxes (Fup then Fdn) into caller-owned DEVICE memory on `stream` */
 int cs_column_flux_to(cs_ctx *ctx, double *dst_device, void *stream);
+/* from now on the resident column WRITES its [2*np] band fluxes into caller-owned device memory (a buffer a collective reduces in place,
+ * a tensor of the host framework) instead of its own -- no copy per step; NULL: back to its own.  Holds until the next cs_column_setup.
+ * cs_column_flux_ptr / cs_column_fetch / cs_column_flux_to read from wherever the fluxes are. */
+int cs_column_set_flux_dst(cs_ctx *ctx, double *dst_device);
 int cs_column_fetch(cs_ctx *ctx, int64_t nnu, int np, double *tau, double *Mup, double *Mdn, double *Fup, double *Fdn);
 int cs_column_sigma_fetch(cs_ctx *ctx, int64_t nnu, int K, double *sigma);
 int cs_column_counts(cs_ctx *ctx, int64_t *pair_evals, int64_t *lines_in_range);

@@ -16,6 +16,7 @@
 #       - `HIPGas`      baked on the device, tables resident in HBM               -> cs_bake
 #       - `Gas`         the reference's own baked object [gases.jl:205-249]       -> cs_table_upload of its knot values
 #       - `GrayGas`     [gases.jl:342-360]                                        -> sigma_gray
+#       - `SemiGrayGas` [gases.jl:366-386]                                        -> a per-ν vector in sigma_extra
 #       - `CIATables`   paired with any of the gases above by formula [cia...jl:431-465] -> cs_cia_begin / cs_cia_band
 #       - functions σ(ν,T,P) [absorbers.jl:24,71]                                 -> evaluated here, sigma_extra
 #       - `AcceleratedAbsorber` [absorbers.jl:114-203], what `RCM` holds and `heating!` passes -> cs_accel_upload, or
@@ -27,10 +28,10 @@
 module ClearSkyHIP
 
 using ClearSky
-using ClearSky: AbstractNumericalCore, AbstractGas, AbstractAbsorber, SpectralLines, Gas, GrayGas, CIATables, CIA,
+using ClearSky: AbstractNumericalCore, AbstractGas, AbstractAbsorber, SpectralLines, Gas, GrayGas, SemiGrayGas, CIATables, CIA,
                 UnifiedAbsorber, AcceleratedAbsorber, AtmosphericDomain, MOLPARAM, formprofiles, lobattoevaluations,
                 lobattonodes, checkstreams, checkazimuth, checkpressures, getwavenumbers, cia, TMIN, TMAX
-import ClearSky: monochromaticfluxes!, update!, concentration, rawσ, reconcentrate
+import ClearSky: monochromaticfluxes!, radiate!, update!, concentration, rawσ, reconcentrate
 
 const LIB = get(ENV, "CLEARSKY_HIP_LIB", joinpath(@__DIR__, "..", "clearsky.jl_amd", "csrc", "libclearsky_hip.so"))
 const CHEB_LD = 16
@@ -339,6 +340,20 @@ end
 (g::HIPGas)(i::Int, T, P) = concentration(g, T, P)*rawσ(g, i, T, P)
 (g::HIPGas)(T, P) = concentration(g, T, P)*rawσ(g, T, P)
 
+# opacityerror [gases.jl:152-175] for the table of wavenumber index i of a device-baked gas: Π = that wavenumber's table, Ω = g.Ω,
+# sl = g.sl, ν = g.ν[i], C = the concentration the tables were baked with.  Same N × N grid and the same four results; the N² exact
+# values are ONE cs_shape_points call (the scalar-ν shape at N² states), the interpolated ones cs_table_eval.
+function ClearSky.opacityerror(g::HIPGas, i::Int, N::Int=50)
+    T = collect(LinRange(g.Ω.Tmin, g.Ω.Tmax, N))
+    P = 10 .^ collect(LinRange(log10(g.Ω.Pmin), log10(g.Ω.Pmax), N))
+    Ts = Float64[T[a] for a in 1:N, b in 1:N][:]; Ps = Float64[P[b] for a in 1:N, b in 1:N][:]
+    Pp = Float64[g.fCbake(Ts[k], Ps[k])*Ps[k] for k in 1:N*N]
+    σex = reshape(hipshapepoints(g.shape, Float64[g.ν[i]], g.sl, Ts, Ps, Pp, g.Δνcut), N, N)
+    σop = Float64[rawσ(g, i, T[a], P[b]) for a in 1:N, b in 1:N]
+    aerr = σop .- σex
+    return T, P, aerr, aerr./σex
+end
+
 # reconcentrate [gases.jl:292-320]: same tables (same key), new concentration function
 function reconcentrate(g::HIPGas, fC)
     f = fC isa Real ? ((T,P)->float(fC)) : fC
@@ -437,8 +452,9 @@ function members(ctx::Context, U::UnifiedAbsorber, Tk::Vector{Float64}, Pk::Vect
     direct = [g for g in U.gas if g isa DirectGas]
     baked  = [g for g in U.gas if g isa Union{HIPGas,Gas}]
     gray   = [g for g in U.gas if g isa GrayGas]
-    length(direct) + length(baked) + length(gray) == length(U.gas) ||
-        error("HIPDiscretized takes DirectGas, HIPGas, Gas and GrayGas members (got $(map(typeof, U.gas)))")
+    semi   = [g for g in U.gas if g isa SemiGrayGas]      # (ν[i] ≤ νcut) ? σ : 0 [gases.jl:366-386]: a per-ν vector at every node state
+    length(direct) + length(baked) + length(gray) + length(semi) == length(U.gas) ||
+        error("HIPDiscretized takes DirectGas, HIPGas, Gas, GrayGas and SemiGrayGas members (got $(map(typeof, U.gas)))")
     tables = [g.sl for g in direct]
     slots  = Cint[slot!(ctx, g.sl; keep=tables) for g in direct]
     shapes = Cint[SHAPES[g.shape] for g in direct]
@@ -453,7 +469,8 @@ function members(ctx::Context, U::UnifiedAbsorber, Tk::Vector{Float64}, Pk::Vect
     P₁ = Float64[Pk[k]*concentration(U.cia[c].g₁, Tk[k], Pk[k]) for c in 1:length(U.cia), k in 1:K]   # cia...jl:378-382
     P₂ = Float64[Pk[k]*concentration(U.cia[c].g₂, Tk[k], Pk[k]) for c in 1:length(U.cia), k in 1:K]
     σgray = isempty(gray) ? 0.0 : Float64(sum(g.σ for g in gray))
-    extra = isempty(U.fun) ? nothing : Float64[ClearSky.σchain(U.fun, ν[j], Tk[k], Pk[k]) for j in 1:length(ν), k in 1:K]
+    extra = (isempty(U.fun) && isempty(semi)) ? nothing :
+        Float64[ClearSky.σchain(U.fun, ν[j], Tk[k], Pk[k]) + sum(Float64[g(j) for g in semi]) for j in 1:length(ν), k in 1:K]
     Members(slots, shapes, cuts, conc, tslots, conctab, cslots, cflags, P₁, P₂, σgray, extra)
 end
 
@@ -528,7 +545,7 @@ end
 # role in the cross-sections) + cs_accel_store -- instead of nν × nk scalar Σ calls.  The knots stay in HBM for the flux calls that
 # follow, and are copied back into A.ϕ so that the reference's own Σ(A, i, ·, P) and A(P) keep working.  Absorbers made only of
 # reference members keep the reference's method.
-const HIPCapable = UnifiedAbsorber{<:Tuple{Vararg{Union{DirectGas,HIPGas,Gas,GrayGas}}}}
+const HIPCapable = UnifiedAbsorber{<:Tuple{Vararg{Union{DirectGas,HIPGas,Gas,GrayGas,SemiGrayGas}}}}
 function update!(A::AcceleratedAbsorber{V,Q}, T::AbstractVector)::Nothing where {V,Q<:HIPCapable}
     any(g -> g isa HIPLineGas, A.U.gas) || return invoke(update!, Tuple{AcceleratedAbsorber,AbstractVector}, A, T)
     @assert length(T) == length(A.P)
@@ -572,12 +589,21 @@ end
 struct HIPDiscretized <: AbstractNumericalCore
     nstream::Int64
     nlobatto::Int64
-    ngpu::Int64     # devices 0 .. ngpu-1 of this node share the wavenumber grid (cs_fluxes_discretized_multi); 1: one device
+    ngpu::Int64         # devices 0 .. ngpu-1 of this node share the wavenumber grid (cs_fluxes_discretized_multi); 1: one device
+    fluxpack::Symbol    # what radiate! brings back: :full = τ, M⁺, M⁻ and the band fluxes, as the reference fills its FluxPack
+                        # [fluxes.jl:357-383]; :bands = F⁺, F⁻, Fnet only -- all heating! reads [radiative_convective.jl:109-144] --
+                        # τ, M⁺, M⁻ stay in HBM (C_NULL across the ABI: no 146 MB copy per call at 1e5 × 60, no host ∫F!)
 end
-HIPDiscretized(; nstream::Int=5, nlobatto::Int=2, ngpu::Int=1) = HIPDiscretized(nstream, nlobatto, ngpu)
+function HIPDiscretized(; nstream::Int=5, nlobatto::Int=2, ngpu::Int=1, fluxpack::Symbol=:full)
+    fluxpack in (:full, :bands) || error("fluxpack must be :full or :bands, not :$fluxpack")
+    HIPDiscretized(nstream, nlobatto, ngpu, fluxpack)
+end
 
-function monochromaticfluxes!(M⁺::AbstractMatrix, M⁻::AbstractMatrix, τ::AbstractMatrix, core::HIPDiscretized,
-                              P::AbstractVector{<:Real}, g::Real, T, μ, 𝒻S, 𝒻a, absorbers...; θₛ::Real=0.841)::Nothing
+# One whole-column evaluation through the C ABI.  F⁺, F⁻ [np] always come back -- ∫F! [shared.jl:125-137] runs on the device, in
+# the same trapezoid order; M⁺, M⁻ [np, nν] and τ [np-1, nν] are filled when given and skipped (C_NULL) when `nothing`.
+function hipcolumn!(F⁺::Vector{Float64}, F⁻::Vector{Float64}, M⁺::Union{Nothing,AbstractMatrix}, M⁻::Union{Nothing,AbstractMatrix},
+                    τ::Union{Nothing,AbstractMatrix}, core::HIPDiscretized, P::AbstractVector{<:Real}, g::Real, T, μ, 𝒻S, 𝒻a,
+                    absorbers...; θₛ::Real=0.841)::Nothing
     𝒜, ν, nν = ClearSky.unifyabsorbers(absorbers)      # a UnifiedAbsorber (method above for HIP members) or an AcceleratedAbsorber
     𝒻T, 𝒻μ = formprofiles(P, T, μ)
     nstream, nlobatto = core.nstream, core.nlobatto
@@ -589,6 +615,7 @@ function monochromaticfluxes!(M⁺::AbstractMatrix, M⁻::AbstractMatrix, τ::Ab
     hipcheckpressures(𝒜, P[end], P[1])                  # fluxes.jl:265
     checkstreams(nstream); checkazimuth(θₛ)
     np = length(P)
+    @assert length(F⁺) == length(F⁻) == np
     Pv = collect(Float64, P)
     Pk, Tk = nodestates(Pv, Tn, nlobatto)
     ctxs = [context(d) for d in 0:core.ngpu-1]          # one context per device
@@ -611,27 +638,30 @@ function monochromaticfluxes!(M⁺::AbstractMatrix, M⁻::AbstractMatrix, τ::Ab
         end
     end
     Stoa = Float64[𝒻S(x) for x in ν]; alb = Float64[𝒻a(x) for x in ν]
-    F⁺ = Vector{Float64}(undef, np); F⁻ = similar(F⁺)
-    dense(A) = (A isa Matrix{Float64}) ? A : Matrix{Float64}(undef, size(A))
+    # caller's arrays are written in place when they are dense Float64 matrices (FluxPack's are); anything else goes through a copy
+    dense(A) = A === nothing ? nothing : ((A isa Matrix{Float64}) ? A : Matrix{Float64}(undef, size(A)))
     Mu, Md, Ta = dense(M⁺), dense(M⁻), dense(τ)
     handles = Ptr{Cvoid}[c.handle for c in ctxs]
     ngas, ntab, ncia = length(m.slots), length(m.tslots), length(m.cslots)
     extra = m.extra
     GC.@preserve ν Pv Tn μn Tlev m extra Stoa alb Mu Md Ta F⁺ F⁻ handles begin
+        pτ = Ta === nothing ? C_NULL : pointer(Ta)      # C_NULL: the output stays in HBM (include/clearsky_hip.h: "nullable")
+        p⁺ = Mu === nothing ? C_NULL : pointer(Mu)
+        p⁻ = Md === nothing ? C_NULL : pointer(Md)
         if core.ngpu > 1      # ν cut into ngpu cost-balanced ranges, one per device; band fluxes added on the host in device order
             check(ccall((:cs_fluxes_discretized_multi, LIB), Cint,
                 (Ptr{Ptr{Cvoid}}, Cint, Int64, Ptr{Float64}, Cint, Ptr{Float64}, Float64, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
                  Cint, Ptr{Cint}, Ptr{Cint}, Ptr{Float64}, Ptr{Float64}, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
                  Float64, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
                 handles, core.ngpu, nν, ν, np, Pv, Float64(g), nlobatto, Tn, μn, Tlev, ngas, m.slots, m.shapes, m.cuts, m.conc,
-                m.σgray, extra === nothing ? C_NULL : pointer(extra), Stoa, alb, Float64(θₛ), nstream, Ta, Mu, Md, F⁺, F⁻))
+                m.σgray, extra === nothing ? C_NULL : pointer(extra), Stoa, alb, Float64(θₛ), nstream, pτ, p⁺, p⁻, F⁺, F⁻))
         elseif ntab == 0 && ncia == 0 && accel < 0
             check(ccall((:cs_fluxes_discretized, LIB), Cint,
                 (Ptr{Cvoid}, Int64, Ptr{Float64}, Cint, Ptr{Float64}, Float64, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
                  Cint, Ptr{Cint}, Ptr{Cint}, Ptr{Float64}, Ptr{Float64}, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
                  Float64, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
                 ctx.handle, nν, ν, np, Pv, Float64(g), nlobatto, Tn, μn, Tlev, ngas, m.slots, m.shapes, m.cuts, m.conc,
-                m.σgray, extra === nothing ? C_NULL : pointer(extra), Stoa, alb, Float64(θₛ), nstream, Ta, Mu, Md, F⁺, F⁻))
+                m.σgray, extra === nothing ? C_NULL : pointer(extra), Stoa, alb, Float64(θₛ), nstream, pτ, p⁺, p⁻, F⁺, F⁻))
         else                  # baked gases, CIA pairs or an accelerated absorber among the members
             check(ccall((:cs_fluxes_discretized_members, LIB), Cint,
                 (Ptr{Cvoid}, Int64, Ptr{Float64}, Cint, Ptr{Float64}, Float64, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
@@ -644,11 +674,59 @@ function monochromaticfluxes!(M⁺::AbstractMatrix, M⁻::AbstractMatrix, τ::Ab
                 ntab, m.tslots, m.conctab,
                 ncia, m.cslots, m.cflags, m.P₁, m.P₂,
                 accel, m.σgray, extra === nothing ? C_NULL : pointer(extra), Stoa, alb,
-                Float64(θₛ), nstream, Ta, Mu, Md, F⁺, F⁻))
+                Float64(θₛ), nstream, pτ, p⁺, p⁻, F⁺, F⁻))
         end
     end
-    Mu === M⁺ || copyto!(M⁺, Mu); Md === M⁻ || copyto!(M⁻, Md); Ta === τ || copyto!(τ, Ta)
+    (Mu === nothing || Mu === M⁺) || copyto!(M⁺, Mu)
+    (Md === nothing || Md === M⁻) || copyto!(M⁻, Md)
+    (Ta === nothing || Ta === τ) || copyto!(τ, Ta)
     nothing
+end
+
+# the reference's in-place entry point [fluxes.jl:238-249]: M⁺, M⁻, τ are the outputs, so all three cross PCIe; the band fluxes the
+# device formed on the way have no place in this signature (the callers that want them dispatch to the radiate! method below)
+function monochromaticfluxes!(M⁺::AbstractMatrix, M⁻::AbstractMatrix, τ::AbstractMatrix, core::HIPDiscretized,
+                              P::AbstractVector{<:Real}, g::Real, T, μ, 𝒻S, 𝒻a, absorbers...; θₛ::Real=0.841)::Nothing
+    np = length(P)
+    hipcolumn!(Vector{Float64}(undef, np), Vector{Float64}(undef, np), M⁺, M⁻, τ, core, P, g, T, μ, 𝒻S, 𝒻a, absorbers...; θₛ=θₛ)
+end
+
+# radiate!(F, core, P, g, T, μ, 𝒻S, 𝒻a, absorbers...) [fluxes.jl:357-383] takes `core` positionally, so this method is what
+# `heating!` [radiative_convective.jl:113], `step!`, `jacobian!` and `radiate` reach with an RCM built on `core=HIPDiscretized(...)`.
+# Same checks as the reference's body; F.F⁺, F.F⁻ come from the device's ∫F! instead of the serial strided host trapz over
+# 2·np rows of nν [shared.jl:125-137, util.jl:26-33], and with `fluxpack=:bands` τ, M⁺, M⁻ are neither copied nor touched
+# (they keep whatever the FluxPack held: zeros from its constructor).
+function radiate!(F::ClearSky.FluxPack, core::HIPDiscretized, P::AbstractVector{<:Real}, g::Real, T, μ, 𝒻S, 𝒻a,
+                           absorbers...; θₛ::Real=0.841)::Nothing
+    𝒜, ν, nν = ClearSky.unifyabsorbers(absorbers)
+    np = length(P)
+    @assert size(F) == (np, nν) "size of FluxPack does not match number of pressure or wavenumber coordinates"
+    F⁺ = F.F⁺ isa Vector{Float64} ? F.F⁺ : Vector{Float64}(undef, np)
+    F⁻ = F.F⁻ isa Vector{Float64} ? F.F⁻ : Vector{Float64}(undef, np)
+    if core.fluxpack == :bands
+        hipcolumn!(F⁺, F⁻, nothing, nothing, nothing, core, P, g, T, μ, 𝒻S, 𝒻a, 𝒜; θₛ=θₛ)
+    else
+        hipcolumn!(F⁺, F⁻, F.M⁺, F.M⁻, F.τ, core, P, g, T, μ, 𝒻S, 𝒻a, 𝒜; θₛ=θₛ)
+    end
+    F⁺ === F.F⁺ || copyto!(F.F⁺, F⁺)
+    F⁻ === F.F⁻ || copyto!(F.F⁻, F⁻)
+    @. F.Fnet = F.F⁺ - F.F⁻
+    return nothing
+end
+
+# fluxes / netfluxes [fluxes.jl:311-352] take `core` as a KEYWORD, which Julia does not dispatch on, so the reference's bodies
+# always allocate M⁺, M⁻, τ [np, nν] and integrate on the host.  These two return the same F⁺, F⁻ [W/m²] from the device's ∫F!
+# without any of the three leaving HBM.
+function hipfluxes(P::AbstractVector{<:Real}, g::Real, T, μ, 𝒻S, 𝒻a, absorbers...; core::HIPDiscretized=HIPDiscretized(),
+                   θₛ::Real=0.841)
+    np = length(P)
+    F⁺ = Vector{Float64}(undef, np); F⁻ = Vector{Float64}(undef, np)
+    hipcolumn!(F⁺, F⁻, nothing, nothing, nothing, core, P, g, T, μ, 𝒻S, 𝒻a, absorbers...; θₛ=θₛ)
+    return F⁺, F⁻
+end
+function hipnetfluxes(P::AbstractVector{<:Real}, g::Real, T, μ, 𝒻S, 𝒻a, absorbers...; kwargs...)
+    F⁺, F⁻ = hipfluxes(P, g, T, μ, 𝒻S, 𝒻a, absorbers...; kwargs...)
+    return F⁺ .- F⁻
 end
 
 # jacobian! [radiative_convective.jl:154-171] as ONE device batch: the band fluxes of B temperature profiles on the column of the
@@ -690,6 +768,7 @@ function batchfluxes(core::HIPDiscretized, P::AbstractVector{<:Real}, Ts::Abstra
     return F⁺, F⁻
 end
 
-export HIPDiscretized, DirectGas, HIPGas, HIPCIA, hipvoigt!, hiplorentz!, hipdoppler!, hipPHCO2!, hipbake!, hipshapepoints, batchfluxes
+export HIPDiscretized, DirectGas, HIPGas, HIPCIA, hipvoigt!, hiplorentz!, hipdoppler!, hipPHCO2!, hipbake!, hipshapepoints, batchfluxes,
+       hipfluxes, hipnetfluxes
 
 end # module

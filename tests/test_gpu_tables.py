@@ -114,3 +114,71 @@ def test_table_domain_errors(cs, baked, ctx):
     assert a[0][0] < b[0][0]                                                   # more CO2, less OLR; same tables
     with pytest.raises(AssertionError):
         g.reconcentrate(1.5)
+
+
+def test_refilled_slot_of_a_resident_column_is_refused(cs, lines, ctx):
+    """a table slot baked or uploaded again (another (T, P) grid), or an accelerated-absorber slot given other knots, while a
+    resident column still holds weights / knot cells formed for the old contents: cs_column_run must refuse (CS_ESTATE) instead of
+    reading W [nT * nP][K] sized for the old grid; cs_column_set_tables / cs_column_set_accel make the column current again."""
+    import ctypes as C
+    nu = np.linspace(660.0, 680.0, 193)
+    Om = cs.AtmosphericDomain((180.0, 320.0), 5, (10.0, 1e5), 6)
+    g = cs.Gas(lines("CO2"), 400e-6, nu, Om, ctx=ctx, keep_host_tables=True)
+    P = cs.pressuregrid(20.0, 9e4, 7)
+    T = np.linspace(200.0, 290.0, 7)
+    col = cs.Column(P, 9.8, T, 0.029, 0.0, 0.0, g, core=cs.Discretized(5, 2), ctx=ctx)
+    col.run()
+    F0 = col.fetch()
+    # the reference's own table object handed over into the SAME slot with a larger grid (cs_table_upload, B2)
+    Om2 = cs.AtmosphericDomain((180.0, 320.0), 7, (10.0, 1e5), 9)
+    g2 = cs.Gas(lines("CO2"), 400e-6, nu, Om2, ctx=ctx, keep_host_tables=True)
+    dp = lambda a: np.ascontiguousarray(a, dtype=float).ctypes.data_as(C.POINTER(C.c_double))
+    lns = np.ascontiguousarray(np.transpose(g2.lnsigma, (2, 1, 0)))       # [nP][nT][nnu]: nu fastest, then T, then P
+    cs.check(cs.lib().cs_table_upload(ctx.handle, g.slot, len(nu), dp(nu), Om2.nT, dp(Om2.T), Om2.nP, dp(Om2.P), dp(lns)))
+    with pytest.raises(cs.ClearSkyHIPError) as ei:
+        col.run()
+    assert ei.value.code == -6 and "table slot" in str(ei.value)
+    slots = np.array([g.slot], dtype=np.int32)
+    conc = np.full(col.K, 400e-6)
+    cs.check(cs.lib().cs_column_set_tables(ctx.handle, 1, slots.ctypes.data_as(C.POINTER(C.c_int)), dp(conc)))
+    col.run()
+    F1 = col.fetch()
+    col2 = cs.Column(P, 9.8, T, 0.029, 0.0, 0.0, g2, core=cs.Discretized(5, 2), ctx=ctx)     # the finer table in its own slot: same numbers
+    col2.run()
+    F2 = col2.fetch()
+    assert np.array_equal(F1[0], F2[0]) and np.array_equal(F1[1], F2[1])
+    assert relerr(F1[0], F0[0]) < 0.05 and not np.array_equal(F1[0], F0[0])
+
+
+def test_other_knots_under_a_resident_accelerated_column_are_refused(cs, lines):
+    import ctypes as C
+    c = cs.Context(0)
+    try:
+        nu = np.linspace(660.0, 680.0, 193)
+        gas = cs.DirectGas(lines("CO2"), 400e-6, nu)
+        Pk = cs.pressuregrid(20.0, 9e4, 9)
+        Tk = np.linspace(200.0, 290.0, 9)
+        A = cs.AcceleratedAbsorber(Tk, Pk, gas, ctx=c)
+        P = cs.pressuregrid(30.0, 8e4, 6)
+        T = np.linspace(205.0, 285.0, 6)
+        col = cs.Column(P, 9.8, T, 0.029, 0.0, 0.0, A, core=cs.Discretized(5, 2), ctx=c)
+        col.run()
+        F0 = col.fetch()
+        dp = lambda a: np.ascontiguousarray(a, dtype=float).ctypes.data_as(C.POINTER(C.c_double))
+        L = np.zeros((len(Pk), len(nu)))
+        cs.check(cs.lib().cs_accel_fetch(c.handle, A.slot, len(nu), len(Pk), dp(L)))
+        # the same knots with new values (what update! leaves): still current
+        cs.check(cs.lib().cs_accel_upload(c.handle, A.slot, len(nu), dp(nu), len(Pk), dp(Pk), dp(L)))
+        col.run()
+        assert np.array_equal(col.fetch()[0], F0[0])
+        # the same number of knots at OTHER pressures: the column's knot cells are stale
+        Pk2 = Pk * 1.1
+        cs.check(cs.lib().cs_accel_upload(c.handle, A.slot, len(nu), dp(nu), len(Pk2), dp(Pk2), dp(L)))
+        with pytest.raises(cs.ClearSkyHIPError) as ei:
+            col.run()
+        assert ei.value.code == -6 and "knots" in str(ei.value)
+        cs.check(cs.lib().cs_column_set_accel(c.handle, A.slot))
+        col.run()
+        assert not np.array_equal(col.fetch()[0], F0[0])
+    finally:
+        c.close()

@@ -156,9 +156,29 @@ def test_julia_binding_has_no_commented_out_b2():
     body = src[:src.index("end # module")]
     for needle in ("function monochromaticfluxes!(", "function update!(A::AcceleratedAbsorber", "function ClearSky.UnifiedAbsorber(",
                    "struct HIPGas", "struct HIPCIA", "function tableslot!(ctx::Context, g::Gas", "function accelslot!(",
-                   "hipcheckpressures(𝒜, P[end], P[1])"):
+                   "hipcheckpressures(𝒜, P[end], P[1])", "g isa SemiGrayGas", "function ClearSky.opacityerror(g::HIPGas"):
         assert needle in body, needle
     assert src[src.index("end # module"):].strip() == "end # module", "nothing but the module may follow (the B2 addendum used to be a comment)"
+
+
+def test_julia_binding_gives_the_caller_the_device_band_fluxes():
+    """Round 5: radiate! dispatches on the core (fluxes.jl:357-383 takes it positionally) and fills F.F+, F.F-, F.Fnet from
+    the ABI's Fup / Fdn instead of the host's serial intF!; fluxpack = :bands passes C_NULL for tau, M+, M- (no 146 MB copy per call);
+    hipfluxes / hipnetfluxes stand in for fluxes / netfluxes, whose `core` keyword cannot dispatch."""
+    src = open(JL).read()
+    for needle in ("import ClearSky: monochromaticfluxes!, radiate!", "fluxpack::Symbol", "function hipcolumn!(F⁺::Vector{Float64}, F⁻::Vector{Float64}",
+                   "function radiate!(F::ClearSky.FluxPack, core::HIPDiscretized", "if core.fluxpack == :bands",
+                   "hipcolumn!(F⁺, F⁻, nothing, nothing, nothing, core, P, g, T, μ, 𝒻S, 𝒻a, 𝒜; θₛ=θₛ)", "@. F.Fnet = F.F⁺ - F.F⁻",
+                   "function hipfluxes(", "function hipnetfluxes(", "pτ = Ta === nothing ? C_NULL : pointer(Ta)", "hipfluxes, hipnetfluxes"):
+        assert needle in src, needle
+    # all three flux entry points are called with the nullable output pointers (tau, M+, M-) and the band-flux vectors, in the header's order
+    calls = [c for c in re.findall(r"ccall\(\(:cs_fluxes_discretized\w*, LIB\).*?\)\)\n", src, flags=re.S)]
+    assert len(calls) == 3
+    for c in calls:
+        assert re.search(r"nstream, pτ, p⁺, p⁻, F⁺, F⁻\)\)\n$", c), c[-120:]
+    # monochromaticfluxes! keeps the reference's contract (fills M+, M-, tau in place) on top of the same call
+    body = src[src.index("function monochromaticfluxes!("):src.index("function radiate!(")]
+    assert "hipcolumn!(Vector{Float64}(undef, np), Vector{Float64}(undef, np), M⁺, M⁻, τ, core" in body
 
 
 _CT = {C.c_int: "int", C.c_int64: "int64", C.c_double: "double", C.c_char_p: "char*", C.c_void_p: "void*", None: "void",
