@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--precision", default="fp64", help="fp64 (headline) | mixed (fp32 far wings, BASELINE configs[4])")
     ap.add_argument("--no-interp", action="store_true", help="evaluate every (nu, line) pair (no far-wing interpolation)")
     ap.add_argument("--interp-first-level", type=int, default=-1, help="tuning: first interval level every gas uses (-1 = by line density)")
+    ap.add_argument("--interp-size-min", type=int, default=128, help="tuning: smallest interval size of the far-wing interpolation (64 = one tile)")
     ap.add_argument("--no-matrix-nodes", action="store_true", help="tuning: no far-line sums on the matrix cores (same as --matrix-cores 0)")
     ap.add_argument("--matrix-cores", type=int, default=1, help="tuning: far-line sums on the matrix cores: 1 where the grid is long enough (default), 2 always, 0 never")
     ap.add_argument("--no-merge", action="store_true", help="tuning: one launch set per gas instead of one merged line table per column")
@@ -121,7 +122,7 @@ def main():
     ctx = cs.Context(dev)
     ctx.set_precision(args.precision, args.far_s)
     ctx.set_interp(not args.no_interp)
-    ctx.set_interp_plan(first_level=args.interp_first_level)
+    ctx.set_interp_plan(first_level=args.interp_first_level, size_min=args.interp_size_min)
     ctx.set_matrix_cores(0 if args.no_matrix_nodes else args.matrix_cores)
     ctx.set_merge(not args.no_merge)
     for kv in filter(None, args.tune.split(",")):
@@ -424,7 +425,7 @@ def main():
         ctx2 = cs.Context(dev)      # a context of its own: first call = full setup, later calls re-use the resident column
         ctx2.set_precision(args.precision, args.far_s)      # ... with every setting of the run beside it
         ctx2.set_interp(not args.no_interp)
-        ctx2.set_interp_plan(first_level=args.interp_first_level)
+        ctx2.set_interp_plan(first_level=args.interp_first_level, size_min=args.interp_size_min)
         ctx2.set_matrix_cores(0 if args.no_matrix_nodes else args.matrix_cores)
         ctx2.set_merge(not args.no_merge)
         for kv in filter(None, args.tune.split(",")):

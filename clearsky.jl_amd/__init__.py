@@ -5,7 +5,7 @@ integrals (reference src/absorption/line_shapes.jl, src/core/discretized.jl, src
 The directory name is not a Python identifier; import it as `clearsky_jl_amd` through the shim at the repo root.
 """
 from . import constants
-from ._lib import ClearSkyHIPError, build_native, lib, check, dptr, as_f64, SHAPES, LIB_PATH, SIGNATURES, HEADER
+from ._lib import ClearSkyHIPError, build_native, lib, check, dptr, as_f64, SHAPES, LIB_PATH, SIGNATURES, HEADER, HEADER_DEV
 from .hitran import MOLPARAM, TMIN, TMAX, ISOINDEX, MolParam, SpectralLines, readpar
 from .cia import CIATables, cia, readcia
 from .core import (interp_plan, phco2_plan, MultiContext, balanced_ranges, rebalance_ranges, CIA, AcceleratedAbsorber, Sigma, update_, checkpressures, pressurelimits, temperaturelimits, shape_points, AtmosphericDomain, AtmosphericProfile, Column, Gas, reconcentrate, Context, DirectGas, Discretized, HIPDiscretized, FluxPack, GrayGas, SemiGrayGas, UnifiedAbsorber, hipfluxes, hipnetfluxes, opacityerror,

@@ -11,7 +11,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libclearsky_hip.so")
-HEADER = os.path.join(os.path.dirname(_HERE), "include", "clearsky_hip.h")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "clearsky_hip.h")            # the product surface
+HEADER_DEV = os.path.join(os.path.dirname(_HERE), "include", "clearsky_hip_dev.h")    # measurement / tuning / test hooks of the same library
 
 CS_MAX_GAS = 16
 CS_MAX_TABLE = 16
@@ -24,7 +25,7 @@ _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
 _vp = C.c_void_p
 
-# name -> (restype, argtypes); must list every symbol the header declares
+# name -> (restype, argtypes); must list every symbol the two headers declare
 SIGNATURES = {
     "cs_version": (C.c_int, []),
     "cs_build_id": (C.c_char_p, []),
@@ -115,13 +116,14 @@ def source_id() -> str:
         if f.endswith((".hip", ".h")):
             h.update(open(os.path.join(CSRC, f), "rb").read())
     h.update(open(HEADER, "rb").read())
+    h.update(open(HEADER_DEV, "rb").read())
     return h.hexdigest()[:16]
 
 
 def build_native(force: bool = False, verbose: bool = False) -> str:
     """Compile csrc/*.hip for gfx950 into csrc/libclearsky_hip.so with hipcc (cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, "cs_api.hip")]
-    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [HEADER]
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [HEADER, HEADER_DEV]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

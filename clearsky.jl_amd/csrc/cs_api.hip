@@ -22,6 +22,7 @@
 #include <unistd.h>
 
 #include "../../include/clearsky_hip.h"
+#include "../../include/clearsky_hip_dev.h"
 #include "cs_kernels.h"
 
 using namespace csdev;
@@ -502,7 +503,7 @@ void launch_rt(int ns, const RtGeom &g, int B, hipStream_t s, const RtParams &p,
 }
 
 // which form of the flux kernel a step of the resident column uses: 0 = k_rt / k_rt_streams reading finished cross-sections from HBM,
-// 1 = k_flux_streams, 3 = k_flux_scan (short grids), 2 = k_flux_chunk (long grids)
+// 3 = k_flux_scan (short grids), 2 = k_flux_chunk (long grids)
 int flux_form(const cs_ctx *ctx, const Column &c, size_t *shmem, int *nblk, int *threads)
 {
     if ((ctx->tune[15] & 3) == 1 || !c.tab.empty() || c.gas.empty()) return 0;   // (baked tables are added between wings and CIA pairs: own pass)
@@ -517,12 +518,6 @@ int flux_form(const cs_ctx *ctx, const Column &c, size_t *shmem, int *nblk, int 
     // (key 15 = 2, `always`, keeps the chunked form on mid-size grids: tests)
     const bool scan_ok = c.rtg.streams || (c.rtg.ud && ns >= 2 && ns <= 8 && nt64_ >= 1 && ((nt64_ <= 1024 && (ctx->tune[15] & 3) != 2) || (ctx->tune[15] & 1024)));
     if (scan_ok) {
-        if ((ctx->tune[15] & 64) && c.rtg.streams) {   // (the first short-grid form, one wave per stream and sweep: kept for A/B)
-            const size_t sh = ((size_t)K * 64 + (size_t)(2 * np - 1) * 64 + (size_t)4 * ns * 64 + (size_t)2 * np + 64) * sizeof(double);
-            if (sh > lim) return 0;
-            *shmem = sh; *nblk = c.rtg.nblk; *threads = 2 * ns * 64;
-            return 1;
-        }
         // the sweeps as a scan over layer chunks: five layers per wave where 12 waves reach (their transmissivities stay in registers,
         // k_flux_scan<NS, 5>), whole waves per SIMD (4, 8 or 12: ten waves of six layers load two SIMDs with three waves and two with two)
         const int nw = std::min(12, std::max(4, 4 * ((c.nl + 19) / 20)));
@@ -547,12 +542,7 @@ void launch_flux_ns(int form, size_t shmem, int nblk, int threads, hipStream_t s
                            int64_t nnu, const double *sigma, const double *muk, const double *P, const double *Tlev, const double *S,
                            const double *alb, double *tau, double *Mup, double *Mdn, double *partial, const FluxFuse &f, bool three_waves = true, bool scan_recompute = false)
 {
-    if (form == 1) {
-        if constexpr (NS >= 2 && NS <= 8) {
-            if (shmem > 65536) (void)hipFuncSetAttribute((const void *)k_flux_streams<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-            CS_LAUNCH((k_flux_streams<NS>), dim3(nblk), dim3(threads), shmem, s, p, nu, wts, nnu, sigma, muk, P, Tlev, S, alb, tau, Mup, Mdn, partial, f);
-        }
-    } else if (form == 3) {
+    if (form == 3) {
         if constexpr (NS >= 2 && NS <= 8) {
             // a chunk of up to 5 layers (60 layers over 12 waves) keeps its transmissivities in registers between the sweeps and passes
             const int nw = threads / 64, per = (p.np - 1 + nw - 1) / nw;
@@ -745,12 +735,11 @@ struct Interp {
     int nsplit_levels = 1;    // cs_set_tuning key 6: interval sizes (largest first) whose node sums four waves share in k_cheb_nodes_mx
     bool small_mx = false;    // cs_set_tuning key 1: the matrix-core kernels on short grids too (their four-waves-per-item variants)
     bool mxzones_one_thread = false;   // cs_set_tuning key 15 | 16: k_mxzones instead of k_mxzones16
+    int mxzones_merge = 0;             // cs_set_tuning key 21: the piece tables as blocks of k_gas_setup's launch (k_gas_setup_mx) -- 0 = on grids below 1024 tiles, 1 = never, 2 = always
     bool near_both = true;             // both tiers of the near-line pairs in one launch where a wave takes one tile (cs_set_tuning key 16 | 4: off)
     int near_prio = 0;                 // cs_set_tuning key 16: issue priority for k_voigt_sub / k_voigt_near (0 = from 512 tiles on, 1 = never, 2 = always)
     bool fuse_apply = false;  // the column's only interpolating group: k_voigt_edge_mx may carry the node sums to the grid itself
-    int mx_sub = 0;           // cs_set_tuning key 17: short grids, matrix-core items cut along the node / point axis (k_*_mx_sub): 0 = by item count,
-                              // 1 / 2 = one / two 16-column sub-tiles per block, 3 = never (four waves per whole item, as before round 5)
-    int mx_sub_items = 0;     // cs_set_tuning key 18: ... on grids with fewer (tile | interval, group) items than this (0: 2048)
+    bool near_memset = false; // cs_set_tuning key 19: the near-line plane cleared by a memset in front of k_voigt_sub (1) instead of written by it (0, default)
     double core4 = 0.0;       // the core takes the 4-term series where its radius is below core4 x the tile's span, else the 8-term one
                               // (0: always the 8-term one -- measured at C3 with 0.75 / 0.3 / 0: 2.61 / 2.55 / 2.52 ms)
 };
@@ -768,8 +757,8 @@ static void interp_settings(const cs_ctx *ctx, Interp &itp)   // the cs_set_tuni
     itp.mxzones_one_thread = (ctx->tune[15] & 16) != 0;
     itp.near_prio = ctx->tune[16] & 3;
     itp.near_both = (ctx->tune[16] & 4) == 0;
-    itp.mx_sub = ctx->tune[17];
-    itp.mx_sub_items = ctx->tune[18] > 0 ? ctx->tune[18] : 2048;
+    itp.near_memset = ctx->tune[19] != 0;
+    itp.mxzones_merge = ctx->tune[21];
 }
 
 // interval sizes worth using on this grid: an interval of width W leaves lines over (2 cut - 2.3 W) to interpolate
@@ -778,7 +767,7 @@ int choose_levels(double nu_lo, double nu_hi, int64_t nnu, double cut, int *itv,
     int n = 0;
     if (nnu < 128) return 0;
     const double dnu = (nu_hi - nu_lo) / (double)(nnu - 1);
-    for (int sz = 8192; sz >= 128 && n < CS_MAX_LEVEL; sz >>= 1)
+    for (int sz = 8192; sz >= 64 && n < CS_MAX_LEVEL; sz >>= 1)
         if (sz <= szmax && sz >= szmin && 2.3 * sz * dnu <= 1.5 * cut && sz / 2 <= nnu &&
             sz * dnu > 1e-8 * std::fabs(nu_hi))   // (nodes 1e-3 of an interval apart must stay distinct doubles)
             itv[n++] = sz;
@@ -926,35 +915,10 @@ void launch_apply(hipStream_t s, const ChebApply &A, int Kpad, int64_t nnu, int 
 static bool cascade_pays(int nlevels_in_use) { return nlevels_in_use >= 4; }
 void launch_apply_cascade(hipStream_t s, ChebApply A, const double *const *Rc, const int *itv, const int *nI, int mode, int Kpad, int64_t nnu,
                           int kn, double base, const double *extra, double *sigma, int accumulate, ChebApply *carry = nullptr /* != NULL: the
-                          cascade only; *carry = what is still to be carried to the grid (k_flux does that) */, bool tree = false /* one launch for
-                          all levels (k_cheb_cascade_tree, A/B: BASELINE configs[4] 0.344 vs 0.331 ms -- the passes over F cost, not their boundaries) */)
+                          cascade only; *carry = what is still to be carried to the grid (k_flux does that) */)
 {
     const int l0 = A.l0[0];
     const bool on = A.ngas == 1 && A.nlev - l0 >= 2 && mode != 2 && (mode == 1 || cascade_pays(A.nlev - l0));
-    if (on && tree && A.nlev - l0 >= 2) {   // every level below an interval of the largest size in ONE launch (k_cheb_cascade_tree)
-        const int nst = cheb_kpad(kn) / 16;
-        CascTree ct;
-        memset(&ct, 0, sizeof ct);
-        ct.nlev = A.nlev; ct.l0 = l0;
-        bool pow2 = true;
-        for (int l = 0; l < A.nlev; l++) {
-            ct.ioff[l] = A.ioff[l]; ct.nI[l] = nI[l]; ct.Rc[l] = Rc[l];
-            if (l > l0) {
-                int ps = 0, cs_ = 0;
-                for (int r = itv[l - 1] / itv[l]; r > 1; r >>= 1) ps++;
-                for (int r = itv[l0] / itv[l]; r > 1; r >>= 1) cs_++;
-                pow2 = pow2 && (itv[l - 1] == (itv[l] << ps)) && (itv[l0] == (itv[l] << cs_));
-                ct.pshift[l] = ps; ct.cshift[l] = cs_;
-            }
-        }
-        if (pow2) {
-            CS_LAUNCH(k_cheb_cascade_tree, dim3((unsigned)nI[l0]), dim3(1024), 0, s, ct, const_cast<double *>(A.F[0]), Kpad, nst);
-            A.l0[0] = A.nlev - 1;
-            if (carry) { *carry = A; return; }
-            launch_apply(s, A, Kpad, nnu, kn, base, extra, sigma, accumulate);
-            return;
-        }
-    }
     if (on) {
         const int nst = cheb_kpad(kn) / 16;
         double *F = const_cast<double *>(A.F[0]);
@@ -973,16 +937,6 @@ void launch_apply(hipStream_t s, const ChebApply &A, int Kpad, int64_t nnu, int 
                   int accumulate, bool varnc)
 {
     const int nt64 = (int)((nnu + 63) / 64);
-#ifdef CS_APPLY_VALU   // the vector-unit version (kept for A/B builds)
-    const int nsg = (kn + CS_KPAD - 1) / CS_KPAD;
-    if ((int64_t)nt64 * nsg <= 1200) {   // small grid: four waves per (tile, state group), 16 nodes each (0.076 -> 0.040 ms at 784; a tie at 1564, slower beyond)
-        CS_LAUNCH(k_cheb_apply_split, dim3((unsigned)(nt64 * nsg)), dim3(256), 0, s, A, Kpad, nnu, nt64, kn, base, extra, sigma,
-                           accumulate);
-        return;
-    }
-    CS_LAUNCH(k_cheb_apply, dim3((unsigned)(((nt64 + 3) / 4 + 7) / 8 * 8) * (unsigned)nsg), dim3(256), 0, s, A,
-                       Kpad, nnu, nt64, kn, base, extra, sigma, accumulate);
-#else
     const int kp = cheb_kpad(kn);                // sub-tiles actually in use (Kpad is the row pitch of F)
     const int nst = kp / 16;
     const unsigned tb8 = (unsigned)(((nt64 + 3) / 4 + 7) / 8 * 8);
@@ -999,7 +953,6 @@ void launch_apply(hipStream_t s, const ChebApply &A, int Kpad, int64_t nnu, int 
         if (big) CS_LAUNCH((k_cheb_apply_mfma<CS_APPLY_NSUB, false>), gridb, dim3(256), 0, s, A, Kpad, nnu, nt64, kn, base, extra, sigma, accumulate);
         else CS_LAUNCH((k_cheb_apply_mfma<1, false>), grids, dim3(256), 0, s, A, Kpad, nnu, nt64, kn, base, extra, sigma, accumulate);
     }
-#endif
 }
 
 // PHCO2 fast path preconditions + workspace.  Returns false -> generic kernel.
@@ -1148,15 +1101,6 @@ constexpr int CS_EDGE_DENS = 4;
 // blocks to fill the chip -- on a short grid (a nu-shard) the one-state-per-wave vector kernel has the shorter critical path
 // (1/8 of C3: 0.17 vs 0.25 ms)
 static bool mx_big(int nblocks, int kn, int min_blocks) { return (int64_t)nblocks * ((kn + 15) / 16) >= min_blocks; }
-// short grids: 16-column sub-tiles per block of k_cheb_nodes_mx_sub / k_voigt_edge_mx_sub (1, 2), or 0 = whole items (the long-grid kernels)
-// -- enough blocks to deal out ~8 per CU as they finish (cs_set_tuning keys 17, 18)
-static int mx_sub_tiles(int mode, int max_items, int64_t items)
-{
-    if (mode == 3) return 0;
-    if (mode == 1 || mode == 2) return mode;
-    if (items >= max_items) return 0;
-    return items * 2 >= 2048 ? 2 : 1;
-}
 // `small`: cs_set_tuning key 1 -- short grids too, through the variants that share one (interval | tile, group) between the four
 // waves of a block (k_cheb_nodes_mx with every level split, k_voigt_edge_mx<4>)
 static bool sep_in_use(bool have_sep, bool always, int nblocks_intervals, int kn, bool lor, bool mixed, bool small = false)
@@ -1240,7 +1184,43 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
             for (int l = 0; l < itp.nlev; l++) { P.itv[l] = itp.itv[l]; P.nI[l] = itp.nI[l]; P.ioff[l] = itp.ioff[l]; P.iwin[l] = itp.iwin[l]; }
             nb_iz = (unsigned)(((int64_t)(itp.nItot - itp.ioff[itp.l0]) * kn + 255) / 256);
         }
-        CS_LAUNCH(k_gas_setup, dim3(nb_prep + nb_zones + nb_iz), dim3(256), 0, s, nb_prep, nb_zones, pa, za, P, itp.iz);
+        // what the matrix cores take of the interpolated sets and of the window ends: piece tables per (interval | tile, state group).  They
+        // need the zones -- which their sixteen-lanes-per-item form computes itself, as blocks of the SAME launch (k_gas_setup_mx); the
+        // one-thread-per-item form (from ~50 000 items on: BASELINE configs[4]) reads them, a launch of its own behind k_gas_setup
+        const int q0s = itp.nlev > 0 ? itp.ioff[itp.l0] : 0, ngrp_s = (kn + 15) / 16;
+        const bool use_sep_s = itp.nlev > 0 && sep_in_use(itp.sep != nullptr, itp.sep_always, itp.nItot - q0s, kn, lor, hot32 != nullptr, itp.small_mx);
+        if (itp.nlev > 0) use_edge = edge_in_use(itp.edge != nullptr, itp.sep_always, nt64, kn, lor, hot32 != nullptr, jhi - jlo, itp.small_mx);
+        SepArgs sa;
+        EdgeArgs ea;
+        memset(&sa, 0, sizeof sa);
+        memset(&ea, 0, sizeof ea);
+        bool mx_one_thread = false, mx_merged = false;
+        if (use_sep_s || use_edge) {
+            sa.nodes = itp.nodes; sa.nul = G.nu.as<double>(); sa.gbound = gbound; sa.Tk = Tk; sa.iz = itp.iz; sa.out = itp.sep;
+            sa.nItot = itp.nItot; sa.q0 = q0s; sa.K = kn; sa.ngrp = ngrp_s; sa.mu_min = G.mu_min; sa.cut = cut; sa.min_states = itp.mx_min_states;
+            ea.nu = dnu; ea.nul = G.nu.as<double>(); ea.gbound = gbound; ea.Tk = Tk; ea.win = win; ea.zones = zones;
+            ea.iz = itp.iz + itp.ioff[itp.nlev - 1]; ea.out = itp.edge; ea.nnu = nnu; ea.ntile = nt64; ea.K = kn; ea.ngrp = ngrp_s;
+            ea.nI = itp.nItot; ea.ishift = 0;
+            for (int r = itp.itv[itp.nlev - 1] / 64; r > 1; r >>= 1) ea.ishift++;
+            ea.mu_min = G.mu_min; ea.cut = cut;
+            ea.core = (use_edge && itp.core) ? 1 : 0;
+            ea.core4 = itp.core4;
+            // sixteen lanes per item shorten the chain where the items are few (a nu-shard: 21 -> 8 us; the bench column 27 -> 9); from
+            // ~50 000 items on one thread per item has parallelism enough and sixteen times fewer threads (BASELINE configs[4]: 0.256 vs 0.276 ms)
+            const int64_t nitems = (use_sep_s ? (int64_t)(itp.nItot - q0s) * ngrp_s : 0) + (use_edge ? (int64_t)nt64 * ngrp_s : 0);
+            mx_one_thread = itp.mxzones_one_thread || nitems > 50000;   // (cs_set_tuning key 15 | 16: always)
+            // merged on short grids, where the head of the step is a chain of launch tails (1/8 of the bench column: 0.347 -> 0.340 ms);
+            // at full size the second set of searches beside 300 MB of record stores costs more than the launch it saves (1.900 -> 1.908)
+            // (cs_set_tuning key 21: 1 = never, 2 = always, A/B)
+            mx_merged = !mx_one_thread && itp.mxzones_merge != 1 && (itp.mxzones_merge == 2 || nt64 < 1024);
+        }
+        if (mx_merged) {
+            const unsigned nb_sep = use_sep_s ? (unsigned)(((int64_t)(itp.nItot - q0s) * ngrp_s + 15) / 16) : 0u;
+            const unsigned nb_edge = use_edge ? (unsigned)(((int64_t)nt64 * ngrp_s + 15) / 16) : 0u;
+            CS_LAUNCH(k_gas_setup_mx, dim3(nb_prep + nb_zones + nb_iz + nb_sep + nb_edge), dim3(256), 0, s, nb_prep, nb_zones, nb_iz, nb_sep, pa, za, P, itp.iz, sa, ea);
+        } else {
+            CS_LAUNCH(k_gas_setup, dim3(nb_prep + nb_zones + nb_iz), dim3(256), 0, s, nb_prep, nb_zones, pa, za, P, itp.iz);
+        }
         if (evg && itp.nlev == 0) (void)hipEventRecord(evg[0], s);
         if (itp.nlev > 0) {   // sigma = base + extra + interpolated far wings; the per-point kernels add the rest
             const int q0 = itp.ioff[itp.l0];
@@ -1249,25 +1229,10 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
             // short grids: four waves per (interval, state) (cs_set_tuning key 13: 0 = below 16384 waves, 1 = always, 2 = never)
             const bool nsplit4 = itp.nodes_split == 1 || (itp.nodes_split == 0 && (int64_t)(itp.nItot - q0) * kn < 16384);
             const dim3 gridn(nsplit4 ? (unsigned)kn * (unsigned)(itp.nItot - q0) : (unsigned)((kn + 3) / 4) * (unsigned)(itp.nItot - q0));
-            const int ngrp = (kn + 15) / 16;
-            const bool use_sep = sep_in_use(itp.sep != nullptr, itp.sep_always, itp.nItot - q0, kn, lor, hot32 != nullptr, itp.small_mx);
-            use_edge = edge_in_use(itp.edge != nullptr, itp.sep_always, nt64, kn, lor, hot32 != nullptr, jhi - jlo, itp.small_mx);
-            if (use_sep || use_edge) {   // what the matrix cores take of the interpolated sets and of the window ends (needs the zones of k_gas_setup)
-                SepArgs sa;
-                sa.nodes = itp.nodes; sa.nul = G.nu.as<double>(); sa.gbound = gbound; sa.Tk = Tk; sa.iz = itp.iz; sa.out = itp.sep;
-                sa.nItot = itp.nItot; sa.q0 = q0; sa.K = kn; sa.ngrp = ngrp; sa.mu_min = G.mu_min; sa.cut = cut; sa.min_states = itp.mx_min_states;
-                EdgeArgs ea;
-                ea.nu = dnu; ea.nul = G.nu.as<double>(); ea.gbound = gbound; ea.Tk = Tk; ea.win = win; ea.zones = zones;
-                ea.iz = itp.iz + itp.ioff[itp.nlev - 1]; ea.out = itp.edge; ea.nnu = nnu; ea.ntile = nt64; ea.K = kn; ea.ngrp = ngrp;
-                ea.nI = itp.nItot; ea.ishift = 0;
-                for (int r = itp.itv[itp.nlev - 1] / 64; r > 1; r >>= 1) ea.ishift++;
-                ea.mu_min = G.mu_min; ea.cut = cut;
-                ea.core = (use_edge && itp.core) ? 1 : 0;
-                ea.core4 = itp.core4;
-                // sixteen lanes per item shorten the chain where the items are few (a nu-shard: 21 -> 8 us; the bench column 27 -> 9); from
-                // ~50 000 items on one thread per item has parallelism enough and sixteen times fewer threads (BASELINE configs[4]: 0.256 vs 0.276 ms)
-                const int64_t nitems = (use_sep ? (int64_t)(itp.nItot - q0) * ngrp : 0) + (use_edge ? (int64_t)nt64 * ngrp : 0);
-                if (itp.mxzones_one_thread || nitems > 50000) {   // (cs_set_tuning key 15 | 16: always)
+            const int ngrp = ngrp_s;
+            const bool use_sep = use_sep_s;
+            if ((use_sep || use_edge) && !mx_merged) {
+                if (mx_one_thread) {
                     const unsigned nb_sep = use_sep ? (unsigned)(((int64_t)(itp.nItot - q0) * ngrp + 255) / 256) : 0u;
                     const unsigned nb_edge = use_edge ? (unsigned)(((int64_t)nt64 * ngrp + 255) / 256) : 0u;
                     CS_LAUNCH(k_mxzones, dim3(nb_sep + nb_edge), dim3(256), 0, s, nb_sep, sa, ea);
@@ -1311,12 +1276,6 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
                 for (int l = 0; l < itp.nlev; l++) { mf.ioff[l] = itp.ioff[l]; mf.nfar[l] = itp.nfar[l] > 0 ? itp.nfar[l] : CS_NC; }
                 mf.ioff[itp.nlev] = itp.nItot;
                 mf.R = itp.R;
-                const int nsub = mx_sub_tiles(itp.mx_sub, itp.mx_sub_items, (int64_t)nq * ngrp);
-                if (nsplit == nq && nsub == 1)
-                    CS_LAUNCH(k_cheb_nodes_mx_sub<1>, dim3((unsigned)(nq * ngrp * 4)), dim3(256), 0, s, itp.nodes, G.L, hot, itp.sep, itp.nItot, q0, kn, itp.Kpad, ngrp, itp.F, itp.iz);
-                else if (nsplit == nq && nsub == 2)
-                    CS_LAUNCH(k_cheb_nodes_mx_sub<2>, dim3((unsigned)(nq * ngrp * 2)), dim3(256), 0, s, itp.nodes, G.L, hot, itp.sep, itp.nItot, q0, kn, itp.Kpad, ngrp, itp.F, itp.iz);
-                else
                 CS_LAUNCH(k_cheb_nodes_mx, dim3(nblk_mx), dim3(256), 0, s, itp.nodes, G.L, hot, itp.sep, itp.nItot, q0, nsplit, kn,
                                    itp.Kpad, ngrp, itp.F, itp.iz, mf);
             }
@@ -1384,13 +1343,15 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
                 (void)hipEventRecord(fork->ev_fork3, s);
                 (void)hipStreamWaitEvent(fork->s3, fork->ev_fork3, 0);
             }
-            if (!fork->zeroed) {
-                (void)hipMemsetAsync(fork->sigma2, 0, (size_t)kn * nnu * sizeof(double), fork->s3);
-                fork->zeroed = true;
-            }
-            if (use_edge && itp.core)
+            // the plane's first writer of the step defines all of it: k_voigt_sub where it runs (sums where a tile has a core, zeros
+            // elsewhere: cs_set_tuning key 19 = 1 keeps the memset for A/B), else a memset
+            const bool sub_here = use_edge && itp.core;
+            const bool sub_assigns = sub_here && !fork->zeroed && !itp.near_memset;
+            if (!fork->zeroed && !sub_assigns) (void)hipMemsetAsync(fork->sigma2, 0, (size_t)kn * nnu * sizeof(double), fork->s3);
+            fork->zeroed = true;
+            if (sub_here)
                 CS_LAUNCH(k_voigt_sub<CS_SUBW>, dim3((unsigned)nt64, (unsigned)((kn + 64 / CS_SUBW - 1) / (64 / CS_SUBW))), dim3(4096 / CS_SUBW), 0, fork->s3, dnu, nnu, G.L, hot,
-                          G.nu.as<double>(), zones, itp.edge, nt64, kn, cut, fork->sigma2, reinterpret_cast<unsigned *>(ranges), near_prio);
+                          G.nu.as<double>(), zones, itp.edge, nt64, kn, cut, fork->sigma2, reinterpret_cast<unsigned *>(ranges), near_prio, sub_assigns ? 1 : 0);
         }
         if (lor) {
             if (split == 1) CS_LOR_LAUNCH(1); else if (split == 2) CS_LOR_LAUNCH(2); else CS_LOR_LAUNCH(4);
@@ -1414,7 +1375,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
         if (evg) (void)hipEventRecord(evg[3], s);
         if (use_edge && itp.core && !near_fork)   // the window cores of the groups whose series radius is short: pairs inside it (the rest: k_voigt_edge_mx)
             CS_LAUNCH(k_voigt_sub<CS_SUBW>, dim3((unsigned)nt64, (unsigned)((kn + 64 / CS_SUBW - 1) / (64 / CS_SUBW))), dim3(4096 / CS_SUBW), 0, s, dnu, nnu, G.L, hot, G.nu.as<double>(), zones,
-                               itp.edge, nt64, kn, cut, sigma, reinterpret_cast<unsigned *>(ranges), near_prio);
+                               itp.edge, nt64, kn, cut, sigma, reinterpret_cast<unsigned *>(ranges), near_prio, 0);
         auto launch_near = [&](hipStream_t sn, double *out) {
             const int ngrpn = (nt64 + CS_NEAR_R - 1) / CS_NEAR_R;   // near kernels: one wave = CS_NEAR_R consecutive tiles ...
             // ... times nrep, one after the other: where the table is sparse against the grid (few tiles have candidates at all) and the
@@ -1443,14 +1404,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
         if (use_edge)
         {
             if (fuse) fork_join(fork, s);   // (it reads F)
-            const int esub = fuse ? 0 : mx_sub_tiles(itp.mx_sub, itp.mx_sub_items, (int64_t)nt64 * ((kn + 15) / 16));
-            if (esub == 1)
-                CS_LAUNCH(k_voigt_edge_mx_sub<1>, dim3((unsigned)nt64 * 4u, (unsigned)((kn + 15) / 16)), dim3(256), 0, s, dnu, nnu, G.L, hot, win,
-                          itp.edge, nt64, kn, cut, sigma, G.nu.as<double>());
-            else if (esub == 2)
-                CS_LAUNCH(k_voigt_edge_mx_sub<2>, dim3((unsigned)nt64 * 2u, (unsigned)((kn + 15) / 16)), dim3(256), 0, s, dnu, nnu, G.L, hot, win,
-                          itp.edge, nt64, kn, cut, sigma, G.nu.as<double>());
-            else if (mx_big(nt64, kn, 1024))
+            if (mx_big(nt64, kn, 1024))
                 CS_LAUNCH(k_voigt_edge_mx<1>, dim3((unsigned)((nt64 + 3) / 4), (unsigned)((kn + 15) / 16)), dim3(256), 0, s, dnu, nnu, G.L, hot, win,
                           itp.edge, nt64, kn, cut, sigma, fuse ? 1 : 0, Afuse, itp.Kpad, G.nu.as<double>(), itp.edge_phases);
             else   // short grid: four waves per (tile, group)
@@ -1810,7 +1764,7 @@ int cs_set_interp(cs_ctx *ctx, int on)
 int cs_set_interp_plan(cs_ctx *ctx, int first_level, int size_min, int size_max)
 {
     if (!ctx) return fail(CS_EINVAL, "ctx is NULL");
-    if (size_min < 128 || size_max > 2048 || size_min > size_max) return fail(CS_EINVAL, "interval sizes must satisfy 128 <= size_min <= size_max <= 2048");
+    if (size_min < 64 || size_max > 2048 || size_min > size_max) return fail(CS_EINVAL, "interval sizes must satisfy 64 <= size_min <= size_max <= 2048");
     if (first_level < -1 || first_level > CS_MAX_LEVEL) return fail(CS_EINVAL, "first_level must be -1 (automatic) or 0..%d", CS_MAX_LEVEL);
     ctx->itp_first = first_level;
     ctx->itp_min = size_min;
@@ -2063,19 +2017,11 @@ int cs_table_clear(cs_ctx *ctx, int table_slot)
 #endif
 static int launch_table_eval(hipStream_t s, const double *Z, int M, int64_t nnu, const double *W, int K, const double *conc, double *sigma)
 {
-#ifdef CS_TABLE_VALU   // the vector-unit version (kept for A/B builds)
-    const int ntile = (int)((nnu + 255) / 256);
-    if ((size_t)M * CS_TAB_KC * sizeof(double) > 65536)
-        HIPCHK(hipFuncSetAttribute((const void *)k_table_eval, hipFuncAttributeMaxDynamicSharedMemorySize, M * CS_TAB_KC * (int)sizeof(double)));
-    CS_LAUNCH(k_table_eval, dim3((unsigned)ntile, (unsigned)((K + CS_TAB_KC - 1) / CS_TAB_KC)), dim3(256),
-                       (size_t)M * CS_TAB_KC * sizeof(double), s, Z, M, nnu, W, K, conc, sigma);
-#else
     const int nt64 = (int)((nnu + 63) / 64);
     const int nst = (K + 15) / 16, nsg = (nst + CS_TABLE_NSUB - 1) / CS_TABLE_NSUB;
     const int64_t nblk = (int64_t)((nt64 + 3) / 4) * nsg;
     if (nblk > 0x7fffffffLL) return fail(CS_EINVAL, "too many (tile, state) blocks for the opacity-table kernel");
     CS_LAUNCH(k_table_eval_mfma<CS_TABLE_NSUB>, dim3((unsigned)nblk), dim3(256), 0, s, Z, M, nnu, nt64, W, K, conc, sigma);
-#endif
     return CS_OK;
 }
 
@@ -2937,14 +2883,14 @@ static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e, bool *
     bool cascaded_aside = false;
     ChebApply carried;   // what a cascade on the side stream leaves to carry to the grid
     const int nl_itp = apply.ngas == 1 ? apply.nlev - apply.l0[0] : 0;
-    const bool short_aside = fuse && c.rtg.streams && !(ctx->tune[15] & 64);
+    const bool short_aside = fuse && c.rtg.streams;
     // long grids: where the cascade is in use anyway (four levels and up) it runs on the node-sum stream as well, beside the per-point
     // kernels, instead of between them and the flux kernel (BASELINE configs[4]: four launches, 0.32 ms of the main stream)
     const bool casc_on = nl_itp >= 2 && ctx->tune[12] != 2 && (ctx->tune[12] == 1 || cascade_pays(nl_itp));
     if (apply.ngas == 1 && fk.pending && !(ctx->tune[15] & 256) && nl_itp >= 2 && (short_aside || casc_on)) {
         const double *Rc[CS_MAX_LEVEL];
         for (int l = 0; l < CS_MAX_LEVEL; l++) Rc[l] = c.cheb.Rc[l].as<double>();
-        launch_apply_cascade(fk.s2, apply, Rc, c.cheb.itv, c.cheb.nI, 1, cheb_kpad(K), c.nnu, K, 0.0, nullptr, sig, 1, &carried, (ctx->tune[15] & 512) != 0);
+        launch_apply_cascade(fk.s2, apply, Rc, c.cheb.itv, c.cheb.nI, 1, cheb_kpad(K), c.nnu, K, 0.0, nullptr, sig, 1, &carried);
         (void)hipEventRecord(fk.ev_join, fk.s2);   // (the main stream has not waited yet: it will wait for this later record)
         cascaded_aside = true;
     }
@@ -2957,7 +2903,7 @@ static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e, bool *
         const double *Rc[CS_MAX_LEVEL];
         for (int l = 0; l < CS_MAX_LEVEL; l++) Rc[l] = c.cheb.Rc[l].as<double>();
         launch_apply_cascade(s, apply, Rc, c.cheb.itv, c.cheb.nI, ctx->tune[12], cheb_kpad(K), c.nnu, K, 0.0, nullptr, sig, 1,
-                             fuse ? &fuse->A : nullptr, (ctx->tune[15] & 512) != 0);
+                             fuse ? &fuse->A : nullptr);
         if (fuse) fuse->apply = 1;
     }
     for (auto &t : c.tab) {  // baked gases: sigma += fC * exp(Phi(T, ln P))
@@ -3423,24 +3369,8 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
                     };
                     // the cut-off edges, cut where the next sub-tile comes into reach (k_voigt_edge_mx's phases: one wave per (tile, group) only)
                     const bool phased = !ctx->tune[14] && mx_big(nt64, K, 1024);
-                    // short grids: blocks of esub 16-point sub-tiles, each with the part of an end its own points can reach (k_voigt_edge_mx_sub)
-                    const int esub = ctx->tune[0] ? 0 : mx_sub_tiles(ctx->tune[17], ctx->tune[18] > 0 ? ctx->tune[18] : 2048, (int64_t)nt64 * ((K + 15) / 16));
                     auto end_piece = [&](int ja, int jb, int nt, bool left) {
                         if (jb <= ja) return;
-                        if (esub > 0) {
-                            const double issued0 = fl_edge_issued;
-                            piece(ja, jb, nt, 1);              // (for the useful flops)
-                            fl_edge_issued = issued0;
-                            const int nn = 16 * esub;
-                            for (int sg = 0; sg < 4 / esub; sg++) {
-                                const double vfirst = vv[std::min<int64_t>((int64_t)t * 64 + sg * nn, c.nnu - 1)], vlast = vv[std::min<int64_t>((int64_t)t * 64 + sg * nn + nn - 1, c.nnu - 1)];
-                                const double tolc = 1e-9 * (std::fabs(vfirst) + g.cut + 1.0);
-                                const int n = left ? jb - (int)(std::lower_bound(nl + ja, nl + jb, vfirst - g.cut - tolc) - nl)
-                                                   : (int)(std::upper_bound(nl + ja, nl + jb, vlast + g.cut + tolc) - nl) - ja;
-                                fl_edge_issued += 2.0 * nt * nn * 16.0 * ((n + 3) / 4 * 4);
-                            }
-                            return;
-                        }
                         if (!phased || jb - ja < 48) { piece(ja, jb, nt, 1); return; }
                         const double issued0 = fl_edge_issued;
                         piece(ja, jb, nt, 1);              // (for the useful flops)

@@ -295,17 +295,13 @@ struct ZoneArgs {
     double mu_min, mu_max, cut, far_s;
     double margin;           // an interval's interpolated set stays max(dA, margin x its half-width) away from it (kChebMargin)
 };
-__device__ __forceinline__ void zones_body(unsigned bid, const ZoneArgs &a)
+// the zones of (state k, tile t)
+__device__ __forceinline__ Zone zone_compute(const ZoneArgs &a, int k, int t)
 {
     const double *__restrict__ nu = a.nu, *__restrict__ nul = a.nul, *__restrict__ Tk = a.Tk, *__restrict__ gbound = a.gbound;
     const WaveWin *__restrict__ win = a.win;
-    Zone *__restrict__ zones = a.zones;
     const int64_t nnu = a.nnu;
-    const int ntile = a.ntile, K = a.K;
     const double mu_min = a.mu_min, mu_max = a.mu_max, cut = a.cut, far_s = a.far_s;
-    const int idx = bid * blockDim.x + threadIdx.x;
-    if (idx >= ntile * K) return;
-    const int k = idx / ntile, t = idx - k * ntile;
     const int64_t i0 = (int64_t)t * 64, i1 = (i0 + 63 < nnu ? i0 + 63 : nnu - 1);
     const double vlo = nu[i0], vhi = nu[i1];
     const WaveWin w = win[t];
@@ -321,8 +317,7 @@ __device__ __forceinline__ void zones_body(unsigned bid, const ZoneArgs &a)
         z.M0 = z.Q0 = min(lo, w.E1);
         z.M1 = z.Q1 = max(lo, w.E0);
         z.pad1 = z.pad2 = 0;
-        zones[idx] = z;
-        return;
+        return z;
     }
     // largest Doppler width any line of the window can have at this temperature (alphadoppler, line_shapes.jl:144)
     const double vth = sqrt(2.0 * kRgas * Tk[k]);
@@ -359,7 +354,14 @@ __device__ __forceinline__ void zones_body(unsigned bid, const ZoneArgs &a)
         z.Q0 = w.W0; z.Q1 = w.W1;
     }
     z.pad1 = z.pad2 = 0;
-    zones[idx] = z;
+    return z;
+}
+__device__ __forceinline__ void zones_body(unsigned bid, const ZoneArgs &a)
+{
+    const int idx = bid * blockDim.x + threadIdx.x;
+    if (idx >= a.ntile * a.K) return;
+    const int k = idx / a.ntile, t = idx - k * a.ntile;
+    a.zones[idx] = zone_compute(a, k, t);
 }
 
 // constants of the series kept in VGPRs for the whole kernel (gfx950 VALU instructions take one constant-bus operand:
@@ -610,29 +612,22 @@ __device__ __forceinline__ bool izone_frame(const IzParams &P, int l, int T, con
     dZ = fmax(dA, margin * h);
     return true;
 }
-__device__ __forceinline__ void izones_body(unsigned bid, const IzParams &P, const ZoneArgs &a, IZone *__restrict__ iz)
+// the zones of (state k, interval q of the concatenated list; q >= ioff[l0])
+__device__ __forceinline__ IZone izone_compute(const IzParams &P, const ZoneArgs &a, int k, int q)
 {
     const double *__restrict__ nu = a.nu, *__restrict__ nul = a.nul, *__restrict__ Tk = a.Tk, *__restrict__ gbound = a.gbound;
     const int64_t nnu = a.nnu;
-    const int K = a.K;
     const double mu_min = a.mu_min, mu_max = a.mu_max, cut = a.cut, far_s = a.far_s;
-    // zones of all levels live in one array [K][nItot]; level l starts at ioff[l]
-    const int idx0 = bid * blockDim.x + threadIdx.x;
-    const int q0 = P.ioff[P.l0], nq = P.nItot - q0;
-    if (idx0 >= nq * K) return;
-    const int k = idx0 / nq, q = q0 + (idx0 - k * nq);
     int l = P.l0;
     while (l + 1 < P.nlev && q >= P.ioff[l + 1]) l++;
     const int T = q - P.ioff[l];
-    const size_t idx = (size_t)k * P.nItot + q;
     const double vth = sqrt(2.0 * kRgas * Tk[k]);
     double vlo, vhi, dA, dZ;
     IZone z;
     if (!izone_frame(P, l, T, nu, nnu, vth, mu_min, cut, vlo, vhi, dA, dZ, z.E0, z.E1, a.lorentz, a.margin)) {
         z.Z0 = z.Z1 = z.Q0 = z.M0 = z.M1 = z.Q1 = z.P0 = z.P1 = z.P2 = z.P3 = z.S0 = z.S1 = z.E0;
         z.pad0 = z.pad1 = 0;
-        iz[idx] = z;
-        return;
+        return z;
     }
     const double dAA = dA * sqrt(far_s * 1e-4);
     const double vmin = vlo - cut;
@@ -687,7 +682,16 @@ __device__ __forceinline__ void izones_body(unsigned bid, const IzParams &P, con
         if (qZ0 > qE0) { z.P0 = min(max(qE0, z.E0), z.Z0); z.P1 = min(max(qZ0, z.P0), z.Z0); }
         if (qE1 > qZ1) { z.P2 = min(max(qZ1, z.Z1), z.E1); z.P3 = min(max(qE1, z.P2), z.E1); }
     }
-    iz[idx] = z;
+    return z;
+}
+__device__ __forceinline__ void izones_body(unsigned bid, const IzParams &P, const ZoneArgs &a, IZone *__restrict__ iz)
+{
+    // zones of all levels live in one array [K][nItot]; level l starts at ioff[l]
+    const int idx0 = bid * blockDim.x + threadIdx.x;
+    const int q0 = P.ioff[P.l0], nq = P.nItot - q0;
+    if (idx0 >= nq * a.K) return;
+    const int k = idx0 / nq, q = q0 + (idx0 - k * nq);
+    iz[(size_t)k * P.nItot + q] = izone_compute(P, a, k, q);
 }
 
 // K1 and the zone bounds of one gas in ONE launch: the three jobs are independent of each other (the first nb_zones blocks find the
@@ -1059,7 +1063,10 @@ __device__ __forceinline__ void mx_far_pieces(v4f64_sep (&acc)[4], const SepZone
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
 }
-__global__ __launch_bounds__(256) void k_cheb_nodes_mx(const double *__restrict__ nodes, int64_t L, const LineHot *__restrict__ hot,
+// (waves_per_eu: left alone the allocator puts the 32 accumulator registers into AGPRs but carries them around the loop's back edge in VGPRs
+//  -- 32 v_accvgpr_write + 32 v_accvgpr_read per 4-line step, 64 of the step's 144 vector instructions, round 5's reading of the ISA; with
+//  the register budget of three waves per SIMD it keeps them in VGPRs, as k_voigt_edge_mx has had since round 3)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_cheb_nodes_mx(const double *__restrict__ nodes, int64_t L, const LineHot *__restrict__ hot,
                                                        const SepZone *__restrict__ sep, int nItot, int q0, int nsplit, int K, int Kpad,
                                                        int ngrp, double *__restrict__ F, const IZone *__restrict__ iz, MxFar far)
 {
@@ -1150,69 +1157,6 @@ __global__ __launch_bounds__(256) void k_cheb_nodes_mx(const double *__restrict_
     }
 }
 
-// Short grids (a nu-shard of a multi-GPU run: a few hundred (interval, group) items for 256 CUs).  With one block per item every CU holds
-// two or three blocks of unequal length for the whole launch and the longest CU is the kernel (1/8 of the bench column: 103 us for
-// work that takes 43 at the full grid's efficiency).  Here an item is cut along its NODE axis: one block = the item's lines for NSUB of
-// the four 16-node sub-tiles (its four waves share the lines as above), so a launch has 4 / NSUB times more blocks, each a 4 / NSUB
-// times shorter chain, dealt out as blocks finish -- and every block still owns its own entries of F (no second adder: the sums stay
-// bitwise repeatable).  The price is the per-line coefficient arithmetic once per block instead of once per item (~25 of a step's
-// vector instructions); the matrix instructions are the same ones.
-template <int NSUB>
-__global__ __launch_bounds__(256) void k_cheb_nodes_mx_sub(const double *__restrict__ nodes, int64_t L, const LineHot *__restrict__ hot,
-                                                           const SepZone *__restrict__ sep, int nItot, int q0, int K, int Kpad, int ngrp,
-                                                           double *__restrict__ F, const IZone *__restrict__ iz)
-{
-    constexpr int NB = 4 / NSUB, NN = 16 * NSUB, PITCH = NN + 1;   // blocks per item, nodes per block, LDS row pitch (odd: rows on different banks)
-    __shared__ double part[4][16][PITCH];
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int item = (int)blockIdx.x / NB, sg = (int)blockIdx.x % NB;
-    const int T = q0 + item / ngrp;
-    const int g = (item % ngrp + T) % ngrp;   // (rotated as in k_cheb_nodes_mx)
-    const SepZone z = sep[(size_t)g * nItot + T];
-    if (!(z.b[0] > z.a[0] || z.b[1] > z.a[1] || z.b[2] > z.a[2] || z.b[3] > z.a[3])) return;   // (block-uniform)
-    const int lr = lane & 15, lq = lane >> 4;
-    {
-        const int kk = min(g * 16 + lr, K - 1);
-        const LineHot *__restrict__ hk = hot + (size_t)kk * L;
-        const int S0k = iz[(size_t)kk * nItot + T].S0, S1k = iz[(size_t)kk * nItot + T].S1;
-        double vn[NSUB];
-        v4f64_sep acc[NSUB];
-#pragma unroll
-        for (int st = 0; st < NSUB; st++) {
-            vn[st] = nodes[(size_t)T * CS_NC + (sg * NSUB + st) * 16 + lr];
-            acc[st] = v4f64_sep{0.0, 0.0, 0.0, 0.0};
-        }
-        auto quarter = [&](int pa, int pb, bool asc, int &ja, int &jb) {   // this wave's run of [pa, pb): multiples of 4 lines
-            const int run = ((pb - pa + 15) >> 4) << 2;
-            ja = asc ? pa + wv * run : max(pb - (wv + 1) * run, pa);
-            jb = asc ? min(ja + run, pb) : pb - wv * run;
-        };
-        for (int pp = 0; pp < 4; pp++) {
-            const int p = pp < 2 ? pp : 5 - pp;          // 0, 1, 3, 2
-            const bool asc = pp < 2;
-            if (z.b[p] <= z.a[p]) continue;
-            int ja, jb;
-            if (asc) {
-                if (z.m[p] > z.a[p]) { quarter(z.a[p], z.m[p], true, ja, jb); sep_run<3, 0, NSUB, 0, NSUB>(acc, vn, hk, ja, jb, true, lq, 0.0, 0.0, -0x7fffffff, S0k); }
-                if (z.b[p] > z.m[p]) { quarter(z.m[p], z.b[p], true, ja, jb); sep_run<4, 0, NSUB, 0, NSUB>(acc, vn, hk, ja, jb, true, lq, 0.0, 0.0, -0x7fffffff, S0k); }
-            } else {
-                if (z.b[p] > z.m[p]) { quarter(z.m[p], z.b[p], false, ja, jb); sep_run<3, 0, NSUB, 0, NSUB>(acc, vn, hk, ja, jb, false, lq, 0.0, 0.0, S1k); }
-                if (z.m[p] > z.a[p]) { quarter(z.a[p], z.m[p], false, ja, jb); sep_run<4, 0, NSUB, 0, NSUB>(acc, vn, hk, ja, jb, false, lq, 0.0, 0.0, S1k); }
-            }
-        }
-#pragma unroll
-        for (int st = 0; st < NSUB; st++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) part[wv][4 * r + lq][st * 16 + lr] = acc[st][r];   // D[state 4r + lq][node 16 st + lr]
-    }
-    __syncthreads();
-    // 16 states x NN nodes of F, state fastest (its layout): thread = (node, state), the four partial sums in wave order
-    for (int idx = threadIdx.x; idx < 16 * NN; idx += 256) {
-        const int ks = idx & 15, n = idx >> 4, k = g * 16 + ks;
-        if (k < K) F[((size_t)T * CS_NC + sg * NN + n) * Kpad + k] += ((part[0][ks][n] + part[1][ks][n]) + part[2][ks][n]) + part[3][ks][n];
-    }
-}
-
 // sigma[k][i] (+)= sum over levels of  C_l[T_l][:, i] . F[T_l][:, k]  -- the interpolation as a small matrix product.
 // One wave = one 64-point tile x 16 states: a column of C is loaded once and used for 16 states whose F values arrive as
 // wave-uniform scalar operands.
@@ -1226,101 +1170,6 @@ struct ChebApply {
     const double *F[16];       // node sums of up to CS_MAX_GAS gases: C is read once for all of them
     int l0[16];                // first level each gas uses
 };
-__global__ __launch_bounds__(256) void k_cheb_apply(ChebApply A, int Kpad, int64_t nnu, int ntile,
-                                                     int K, double base, const double *__restrict__ extra,
-                                                     double *__restrict__ sigma, int accumulate)
-{
-    // 1-D grid.  Workgroups are dealt round-robin over the 8 XCDs (private L2 each): all state groups of a tile block go to
-    // the same XCD, back to back, so its column block of C is fetched from HBM once.  Grid = 8 * ceil(ntb/8) * nsg blocks.
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int nsg = (K + CS_KPAD - 1) / CS_KPAD;
-    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-    const int tile = ((q / nsg) * 8 + xcd) * 4 + wv;
-    if (tile >= ntile) return;
-    const int k0 = (q % nsg) * CS_KPAD;
-    double acc[CS_KPAD];
-#pragma unroll
-    for (int q = 0; q < CS_KPAD; q++) acc[q] = 0.0;
-    for (int g = 0; g < A.ngas; g++) {   // gas outermost: the column block of C comes from L2 again, sigma is touched once
-        const double *__restrict__ Fg = A.F[g];
-        for (int l = A.l0[g]; l < A.nlev; l++) {
-            const int sh = A.shift[l];
-            const int T = tile >> sh, sub = tile & ((1 << sh) - 1);
-            const size_t itv = (size_t)64 << sh;
-            const int nc = A.nc[l];
-            const double *__restrict__ Cp = A.Cm[l] + (size_t)T * nc * itv + (size_t)sub * 64 + lane;
-            const double *__restrict__ Fp = Fg + ((size_t)A.noff[l] + (size_t)T * nc) * Kpad + k0;
-#pragma unroll 4   // (2 is 10 % faster on the bench workload but 20-40 % slower on nu-shards and on five levels x four gases)
-            for (int m = 0; m < nc; m++) {
-                const double cv = Cp[(size_t)m * itv];
-                const double *__restrict__ fr = Fp + (size_t)m * Kpad;
-#pragma unroll
-                for (int q = 0; q < CS_KPAD; q++) acc[q] = __builtin_fma(cv, fr[q], acc[q]);
-            }
-        }
-    }
-    const int64_t i = (int64_t)tile * 64 + lane;
-    if (i >= nnu) return;
-#pragma unroll
-    for (int q = 0; q < CS_KPAD; q++) {
-        if (k0 + q < K) {
-            const size_t o = (size_t)(k0 + q) * nnu + i;
-            const double prev = accumulate ? sigma[o] : (base + (extra ? extra[o] : 0.0));
-            sigma[o] = prev + acc[q];
-        }
-    }
-}
-
-// The same for small grids (a nu-shard): the four waves of a block share ONE tile x 16 states and take 16 of the 64 nodes
-// each, then add their partial sums through LDS in wave order -- a few hundred tiles would otherwise mean a few hundred
-// waves, each a serial chain of levels x gases x 64 loads.
-__global__ __launch_bounds__(256) void k_cheb_apply_split(ChebApply A, int Kpad, int64_t nnu, int ntile, int K, double base,
-                                                           const double *__restrict__ extra, double *__restrict__ sigma,
-                                                           int accumulate)
-{
-    __shared__ double part[3][CS_KPAD][64];
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int nsg = (K + CS_KPAD - 1) / CS_KPAD;
-    const int tile = (int)(blockIdx.x / nsg);
-    const int k0 = (int)(blockIdx.x % nsg) * CS_KPAD;
-    double acc[CS_KPAD];
-#pragma unroll
-    for (int q = 0; q < CS_KPAD; q++) acc[q] = 0.0;
-    for (int g = 0; g < A.ngas; g++) {
-        const double *__restrict__ Fg = A.F[g];
-        for (int l = A.l0[g]; l < A.nlev; l++) {
-            const int sh = A.shift[l];
-            const int T = tile >> sh, sub = tile & ((1 << sh) - 1);
-            const size_t itv = (size_t)64 << sh;
-            const int nc = A.nc[l], nq = nc >> 2;   // (a quarter of the level's nodes per wave)
-            const double *__restrict__ Cp = A.Cm[l] + (size_t)T * nc * itv + (size_t)sub * 64 + lane;
-            const double *__restrict__ Fp = Fg + ((size_t)A.noff[l] + (size_t)T * nc) * Kpad + k0;
-#pragma unroll 4
-            for (int m = nq * wv; m < nq * wv + nq; m++) {
-                const double cv = Cp[(size_t)m * itv];
-                const double *__restrict__ fr = Fp + (size_t)m * Kpad;
-#pragma unroll
-                for (int q = 0; q < CS_KPAD; q++) acc[q] = __builtin_fma(cv, fr[q], acc[q]);
-            }
-        }
-    }
-    if (wv > 0) {
-#pragma unroll
-        for (int q = 0; q < CS_KPAD; q++) part[wv - 1][q][lane] = acc[q];
-    }
-    __syncthreads();
-    if (wv > 0) return;
-    const int64_t i = (int64_t)tile * 64 + lane;
-    if (i >= nnu) return;
-#pragma unroll
-    for (int q = 0; q < CS_KPAD; q++) {
-        if (k0 + q < K) {
-            const size_t o = (size_t)(k0 + q) * nnu + i;
-            const double prev = accumulate ? sigma[o] : (base + (extra ? extra[o] : 0.0));
-            sigma[o] = prev + (((acc[q] + part[0][q][lane]) + part[1][q][lane]) + part[2][q][lane]);
-        }
-    }
-}
 
 // ---- cascade: the node sums of a level carried to the nodes of the next smaller one ----------------------------------------------
 // The interpolant of an interval is a polynomial of degree 63; its values at the 64 nodes of a child interval define the same
@@ -1360,7 +1209,7 @@ __global__ __launch_bounds__(256) void k_cascade_setup(const double *__restrict_
 }
 // one wave = one child interval x 16 states: D(16 child nodes x 16 states) += A(16 child nodes x 4 parent nodes) B(4 parent nodes x
 // 16 states), operands as in k_cheb_apply_mfma -- both loads and the read-modify-write of F are 128-byte runs (F is state-fastest)
-__global__ __launch_bounds__(256) void k_cheb_cascade(const double *__restrict__ Rc, double *__restrict__ F, int ioff_p, int ioff_c, int pshift,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_cheb_cascade(const double *__restrict__ Rc, double *__restrict__ F, int ioff_p, int ioff_c, int pshift,
                                                       int nIc, int Kpad, int nst)
 {
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -1386,53 +1235,6 @@ __global__ __launch_bounds__(256) void k_cheb_cascade(const double *__restrict__
     for (int st = 0; st < 4; st++)
 #pragma unroll
         for (int r = 0; r < 4; r++) Fc[(size_t)(16 * st + 4 * r + lq) * Kpad] += acc[st][r];
-}
-
-// The whole cascade in ONE launch: a block = one interval of the largest size in use and everything below it -- its children level by
-// level, a barrier between levels (the block's waves share one L1, so a level's sums are visible to the next) -- instead of one launch per
-// level, each a full pass over F with a kernel boundary behind it (BASELINE configs[4], five levels: 4 x 0.08 ms).  Same products in the
-// same order per (interval, state group): the same F to the last bit.
-struct CascTree {
-    int nlev, l0;
-    int ioff[CS_MAX_LEVEL], nI[CS_MAX_LEVEL];
-    int cshift[CS_MAX_LEVEL];   // log2(size of level l0 / size of level l): children of top interval T0 at level l are [T0 << cshift, (T0 + 1) << cshift)
-    int pshift[CS_MAX_LEVEL];   // log2(size of level l - 1 / size of level l)
-    const double *Rc[CS_MAX_LEVEL];
-};
-__device__ __forceinline__ void cascade_item(const double *__restrict__ Rc, double *__restrict__ F, int ioff_p, int ioff_c, int pshift, int T, int sidx, int Kpad, int lane)
-{
-    const int lr = lane & 15, lq = lane >> 4;
-    const double *__restrict__ Fp = F + (size_t)(ioff_p + (T >> pshift)) * CS_NC * Kpad + (size_t)sidx * 16 + lr;
-    double *__restrict__ Fc = F + (size_t)(ioff_c + T) * CS_NC * Kpad + (size_t)sidx * 16 + lr;
-    const double *__restrict__ R = Rc + (size_t)T * CS_NC * CS_NC + lr;
-    typedef double v4 __attribute__((ext_vector_type(4)));
-    v4 acc[4];
-#pragma unroll
-    for (int st = 0; st < 4; st++) acc[st] = v4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-    for (int kk = 0; kk < CS_NC / 4; kk++) {
-        const int j = 4 * kk + lq;
-        const double b = Fp[(size_t)j * Kpad];
-#pragma unroll
-        for (int st = 0; st < 4; st++) acc[st] = __builtin_amdgcn_mfma_f64_16x16x4f64(R[(size_t)j * CS_NC + 16 * st], b, acc[st], 0, 0, 0);
-    }
-#pragma unroll
-    for (int st = 0; st < 4; st++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) Fc[(size_t)(16 * st + 4 * r + lq) * Kpad] += acc[st][r];
-}
-__global__ __launch_bounds__(1024) void k_cheb_cascade_tree(CascTree ct, double *__restrict__ F, int Kpad, int nst)
-{
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, nw = (int)(blockDim.x >> 6);
-    const int T0 = (int)blockIdx.x;
-    for (int l = ct.l0 + 1; l < ct.nlev; l++) {
-        const int first = T0 << ct.cshift[l], nch = 1 << ct.cshift[l];
-        for (int item = wv; item < nch * nst; item += nw) {
-            const int T = first + item / nst;
-            if (T < ct.nI[l]) cascade_item(ct.Rc[l], F, ct.ioff[l - 1], ct.ioff[l], ct.pshift[l], T, item % nst, Kpad, lane);
-        }
-        __syncthreads();
-    }
 }
 
 // The same contraction on the matrix cores: v_mfma_f64_16x16x4_f64 computes D(16 states x 16 nu) += A(16 states x 4 nodes) *
@@ -1811,7 +1613,11 @@ template <class T, class Op> __device__ __forceinline__ T red16(T v, Op op)
     for (int m = 8; m > 0; m >>= 1) v = op(v, __shfl_xor(v, m, 16));
     return v;
 }
-__device__ __forceinline__ void sepzones_body16(unsigned bid, const SepArgs &a)
+// RC: the per-state zones are computed here (izone_compute / zone_compute: the searches of k_gas_setup's zone blocks again, every lane its
+// own state's) instead of read -- then the piece tables need nothing k_gas_setup writes and are blocks of ITS launch (k_gas_setup_mx):
+// one launch and one dependent kernel boundary less at the head of every step (14 + 3 us on a 1/8 shard of the bench column)
+template <bool RC>
+__device__ __forceinline__ void sepzones_body16(unsigned bid, const SepArgs &a, const IzParams *ip = nullptr, const ZoneArgs *za = nullptr)
 {
     const int item = (int)(bid * (blockDim.x >> 4) + (threadIdx.x >> 4)), kk = threadIdx.x & 15;
     const int nq = a.nItot - a.q0;
@@ -1821,7 +1627,7 @@ __device__ __forceinline__ void sepzones_body16(unsigned bid, const SepArgs &a)
     const int k = g * 16 + kk;
     const bool have = k < a.K;
     IZone z = {};
-    if (have) z = a.iz[(size_t)k * a.nItot + T];
+    if (have) z = RC ? izone_compute(*ip, *za, k, T) : a.iz[(size_t)k * a.nItot + T];
     const auto imax = [](int x, int y) { return max(x, y); };
     const auto imin = [](int x, int y) { return min(x, y); };
     int lo[4], hi[4];
@@ -1871,7 +1677,8 @@ __device__ __forceinline__ void sepzones_body16(unsigned bid, const SepArgs &a)
     }
     a.out[(size_t)g * a.nItot + T] = o;
 }
-__device__ __forceinline__ void edgezones_body16(unsigned bid, const EdgeArgs &a)
+template <bool RC>
+__device__ __forceinline__ void edgezones_body16(unsigned bid, const EdgeArgs &a, const IzParams *ip = nullptr, const ZoneArgs *za = nullptr)
 {
     const int item = (int)(bid * (blockDim.x >> 4) + (threadIdx.x >> 4)), kk = threadIdx.x & 15;
     if (item >= a.ntile * a.ngrp) return;
@@ -1884,10 +1691,10 @@ __device__ __forceinline__ void edgezones_body16(unsigned bid, const EdgeArgs &a
     int eL = w.W1, eR = w.W0, mL0 = w.W0, mL1 = w.W1, mR0 = w.W0, mR1 = w.W1;
     double R = 0.0, R3 = 0.0, R8 = 0.0;
     if (have) {
-        const Zone z = a.zones[(size_t)k * a.ntile + t];
+        const Zone z = RC ? zone_compute(*za, k, t) : a.zones[(size_t)k * a.ntile + t];
         int sa0 = z.M0, sa1 = z.M0, sb0 = z.M1, sb1 = z.M1;   // (as k_voigt_far)
         if (a.iz) {
-            const IZone zi = a.iz[(size_t)k * a.nI + (t >> a.ishift)];
+            const IZone zi = RC ? izone_compute(*ip, *za, k, ip->ioff[ip->nlev - 1] + (t >> a.ishift)) : a.iz[(size_t)k * a.nI + (t >> a.ishift)];
             sa0 = min(max(zi.E0, w.W0), z.N0); sa1 = min(max(zi.Z0, sa0), z.N0);
             sb0 = max(min(zi.Z1, w.W1), z.N1); sb1 = max(min(zi.E1, w.W1), sb0);
         }
@@ -1944,8 +1751,26 @@ __device__ __forceinline__ void edgezones_body16(unsigned bid, const EdgeArgs &a
 }
 __global__ __launch_bounds__(256) void k_mxzones16(unsigned nb_sep, SepArgs sa, EdgeArgs ea)
 {
-    if (blockIdx.x < nb_sep) sepzones_body16(blockIdx.x, sa);
-    else edgezones_body16(blockIdx.x - nb_sep, ea);
+    if (blockIdx.x < nb_sep) sepzones_body16<false>(blockIdx.x, sa);
+    else edgezones_body16<false>(blockIdx.x - nb_sep, ea);
+}
+// k_gas_setup and k_mxzones16 in ONE launch: zone blocks, interval-zone blocks, the piece tables of the matrix-core kernels (which
+// compute the zones they need themselves), record blocks
+__global__ __launch_bounds__(256) void k_gas_setup_mx(unsigned nb_prep, unsigned nb_zones, unsigned nb_iz, unsigned nb_sep, PrepArgs pa, ZoneArgs za, IzParams ip,
+                                                      IZone *__restrict__ iz, SepArgs sa, EdgeArgs ea)
+{
+    unsigned b = blockIdx.x;
+    if (b < nb_zones) { zones_body(b, za); return; }
+    b -= nb_zones;
+    if (b < nb_iz) { izones_body(b, ip, za, iz); return; }
+    b -= nb_iz;
+    const unsigned nb_mx = gridDim.x - nb_zones - nb_iz - nb_prep;
+    if (b < nb_mx) {
+        if (b < nb_sep) sepzones_body16<true>(b, sa, &ip, &za);
+        else edgezones_body16<true>(b - nb_sep, ea, &ip, &za);
+        return;
+    }
+    prep_body(b - nb_mx, pa);
 }
 
 // (three waves per SIMD, with the 164 registers that allows: the 8-term step of the cores wants them -- left alone the allocator
@@ -2116,100 +1941,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
 }
 
-// Short grids, as k_cheb_nodes_mx_sub: a (tile, group) item is cut along its POINT axis -- one block = the item's pieces for NSUB of the
-// tile's four 16-point sub-tiles, its four waves sharing the lines -- 4 / NSUB times more, shorter blocks, each owning its own entries
-// of sigma.  A block then sees only the part of a cut-off edge its own points can reach (the lines of the left end from the first one
-// within the cut-off of the block's first point on, of the right end up to the last one within that of its last point): what the
-// phases of k_voigt_edge_mx<1> do for whole tiles falls out of the split.
-template <int NSUB>
-__global__ __launch_bounds__(256) void k_voigt_edge_mx_sub(const double *__restrict__ nu, int64_t nnu, int64_t L, const LineHot *__restrict__ hot,
-                                                           const WaveWin *__restrict__ win, const EdgeZone *__restrict__ edge, int ntile, int K,
-                                                           double cut, double *__restrict__ sigma, const double *__restrict__ gnul)
-{
-    constexpr int NB = 4 / NSUB, NN = 16 * NSUB, PITCH = NN + 2;
-    __shared__ double part[4][16][PITCH];
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int tile = (int)blockIdx.x / NB, sg = (int)blockIdx.x % NB, g = blockIdx.y;
-    const WaveWin w = win[tile];
-    const EdgeZone e = edge[(size_t)g * ntile + tile];
-    if (e.eL <= w.W0 && e.eR >= w.W1 && e.mL1 <= e.mL0 && e.mR1 <= e.mR0 && e.cR <= e.cL) return;   // (block-uniform)
-    const int lr = lane & 15, lq = lane >> 4;
-    {
-        const int kk = min(g * 16 + lr, K - 1);
-        const LineHot *__restrict__ hk = hot + (size_t)kk * L;
-        double vn[NSUB];
-        v4f64_sep acc[NSUB];
-#pragma unroll
-        for (int st = 0; st < NSUB; st++) {
-            const int64_t i = (int64_t)tile * 64 + (sg * NSUB + st) * 16 + lr;
-            vn[st] = nu[i < nnu ? i : nnu - 1];
-            acc[st] = v4f64_sep{0.0, 0.0, 0.0, 0.0};
-        }
-        // the block's first and last point (wave-uniform)
-        const double vfirst = __shfl(vn[0], 0), vlast = __shfl(vn[NSUB - 1], 15);
-        const double tolc = 1e-9 * (fabs(vfirst) + cut + 1.0);
-        // left end [W0, eL): from the first line with nul >= vfirst - cut on; right end [eR, W1): up to the last line with nul <= vlast + cut
-        // (one vector load per 64 lines and a ballot, as the phases of k_voigt_edge_mx)
-        int pL = w.W0, pR = w.W1;
-        if (e.eL > w.W0) {
-            const int p0 = w.W0, p1 = e.eL;
-            const double a0 = vfirst - cut - tolc;
-            pL = p1;
-            for (int base = p0; base < p1; base += 64) {
-                const int j = base + lane;
-                const double x = gnul[j < p1 ? j : p1 - 1];
-                const uint64_t m0 = __builtin_amdgcn_ballot_w64(j < p1 && x >= a0);
-                if (m0 != 0) { pL = base + __builtin_ctzll(m0); break; }
-            }
-        }
-        if (w.W1 > e.eR) {
-            const int p0 = e.eR, p1 = w.W1;
-            const double b0 = vlast + cut + tolc;
-            pR = p1;
-            for (int base = p0; base < p1; base += 64) {
-                const int j = base + lane;
-                const double x = gnul[j < p1 ? j : p1 - 1];
-                const uint64_t m0 = __builtin_amdgcn_ballot_w64(j < p1 && x > b0);
-                if (m0 != 0) { pR = base + __builtin_ctzll(m0); break; }
-            }
-        }
-        // this wave's run of the piece [pa, pb): one of four runs of a multiple of 4 lines, wave 0 at the far end
-        auto run = [&](int pa, int pb, bool asc, int &ja, int &jb) {
-            const int len = ((max(pb - pa, 0) + 15) >> 4) << 2;
-            ja = asc ? min(pa + wv * len, pb) : max(pb - (wv + 1) * len, pa);
-            jb = asc ? min(ja + len, pb) : max(pb - wv * len, pa);
-        };
-        int ja, jb;
-        run(pL, e.eL, true, ja, jb);
-        if (e.far3 & 1) sep_run<3, 1, NSUB, 0, NSUB>(acc, vn, hk, ja, jb, true, lq, cut); else sep_run<4, 1, NSUB, 0, NSUB>(acc, vn, hk, ja, jb, true, lq, cut);
-        if (e.mL1 > e.mL0) {
-            run(e.mL0, e.mL3, true, ja, jb); sep_run<3, 1, NSUB, 0, NSUB>(acc, vn, hk, ja, jb, true, lq, cut);
-            run(e.mL3, e.mL1, true, ja, jb); sep_run<4, 1, NSUB, 0, NSUB>(acc, vn, hk, ja, jb, true, lq, cut);
-        }
-        run(e.eR, pR, false, ja, jb);
-        if (e.far3 & 2) sep_run<3, 1, NSUB, 0, NSUB>(acc, vn, hk, ja, jb, false, lq, cut); else sep_run<4, 1, NSUB, 0, NSUB>(acc, vn, hk, ja, jb, false, lq, cut);
-        if (e.mR1 > e.mR0) {
-            run(e.mR3, e.mR1, false, ja, jb); sep_run<3, 1, NSUB, 0, NSUB>(acc, vn, hk, ja, jb, false, lq, cut);
-            run(e.mR0, e.mR3, false, ja, jb); sep_run<4, 1, NSUB, 0, NSUB>(acc, vn, hk, ja, jb, false, lq, cut);
-        }
-        if (e.cR > e.cL) {   // the core: pairs at least R apart
-            run(e.cL, e.cR, true, ja, jb);
-            if (e.far3 & 4) sep_run<8, 2, NSUB, 0, NSUB>(acc, vn, hk, ja, jb, true, lq, cut, e.R); else sep_run<4, 2, NSUB, 0, NSUB>(acc, vn, hk, ja, jb, true, lq, cut, e.R);
-        }
-#pragma unroll
-        for (int st = 0; st < NSUB; st++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) part[wv][4 * r + lq][st * 16 + lr] = acc[st][r];   // D[state 4r + lq][point 16 st + lr]
-    }
-    __syncthreads();
-    // 16 states x NN points of sigma, point fastest: the four partial sums in wave order
-    for (int idx = threadIdx.x; idx < 16 * NN; idx += 256) {
-        const int n = idx % NN, ks = idx / NN, k = g * 16 + ks;
-        const int64_t i = (int64_t)tile * 64 + sg * NN + n;
-        if (k < K && i < nnu) sigma[(size_t)k * nnu + i] += ((part[0][ks][n] + part[1][ks][n]) + part[2][ks][n]) + part[3][ks][n];
-    }
-}
-
 // K2f: the core of the window on 16-point sub-tiles.  The tile-wide near-zone pass of k_voigt_far runs its 37 instructions for every
 // line within the TILE's reach on all 64 lanes, of which the few within 100 Doppler widths of the line need them.  Here one wave =
 // one sub-tile of 16 points x 4 states (lane = 16 s + point; the record of (state, line) through a vector load, 16 lanes per
@@ -2223,18 +1954,28 @@ template <int SW>
 __global__ __launch_bounds__(4096 / SW) void k_voigt_sub(const double *__restrict__ nu, int64_t nnu, int64_t L, const LineHot *__restrict__ hot,
                                                          const double *__restrict__ gnul, const Zone *__restrict__ zones,
                                                          const EdgeZone *__restrict__ edge, int ntile, int K, double cut,
-                                                         double *__restrict__ sigma, unsigned *__restrict__ rp, int prio)
+                                                         double *__restrict__ sigma, unsigned *__restrict__ rp, int prio, int assign)
 {
+    // assign != 0: `sigma` is the near-line plane of the step (its first writer on the side stream): every (state, point) of it is
+    // WRITTEN here -- the sum where the tile has a core, a zero where it has not (and for the points of a ragged last tile) -- instead
+    // of a memset of the whole plane in front of this kernel (49 MB at 0.7 TB/s = 72 us at the head of the near-line stream of the bench
+    // column, 24 us on a 1/8 shard: profiles/r04_trace_c3.txt); assign == 0: added to the cross-sections where non-zero, as before
     wave_prio(prio);
     constexpr int NSW = 64 / SW;     // states per wave = sub-tiles per tile = waves per block
     __shared__ unsigned fl_sh[NSW][2];
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int tile = blockIdx.x, kq = blockIdx.y;   // states NSW kq .. NSW kq + NSW - 1 (all in one group of 16)
     const EdgeZone e = edge[(size_t)((kq * NSW) >> 4) * ntile + tile];
-    if (e.cR <= e.cL) return;   // (block-uniform)
     const int s4 = lane / SW, pt = lane % SW;
     const int k = NSW * kq + s4;
     const bool kin = k < K;
+    if (e.cR <= e.cL) {   // (block-uniform) no core here: nothing to sum
+        if (assign && kin) {
+            const int64_t i0 = (int64_t)tile * 64 + wv * SW + pt;
+            if (i0 < nnu) sigma[(size_t)k * nnu + i0] = 0.0;
+        }
+        return;
+    }
     const LineHot *__restrict__ hk = hot + (size_t)(kin ? k : K - 1) * L;
     const int64_t i = (int64_t)tile * 64 + wv * SW + pt;   // (a core exists on complete tiles only)
     const double v = nu[i];
@@ -2305,7 +2046,8 @@ __global__ __launch_bounds__(4096 / SW) void k_voigt_sub(const double *__restric
     const size_t plane = (size_t)K * nnu;
     if (kin) {
         const size_t o = (size_t)k * nnu + i;
-        if (acc != 0.0) sigma[o] += acc;
+        if (assign) sigma[o] = acc;
+        else if (acc != 0.0) sigma[o] += acc;
         rp[o] = r0;            // (always written: whether the tile has candidates at all is known after the block's OR)
         rp[plane + o] = r1;
     }
@@ -3410,33 +3152,6 @@ __global__ __launch_bounds__(256) void k_table_log(double *__restrict__ Z, int M
 // with the 2-D Chebyshev interpolant written as a contraction against the Lagrange-basis weights W = a(T_k) (x) b(ln P_k).
 // Block = 256 wavenumbers x 16 node states; the 16 weight columns are staged in LDS and read as broadcasts.
 #define CS_TAB_KC 16
-__global__ __launch_bounds__(256) void k_table_eval(const double *__restrict__ Z, int M, int64_t nnu, const double *__restrict__ W,
-                                                     int K, const double *__restrict__ conc, double *__restrict__ sigma)
-{
-    extern __shared__ double wsh[];  // [M][CS_TAB_KC]
-    const int k0 = blockIdx.y * CS_TAB_KC;
-    for (int e = threadIdx.x; e < M * CS_TAB_KC; e += 256) {
-        const int m = e / CS_TAB_KC, kk = e - m * CS_TAB_KC;
-        wsh[e] = (k0 + kk < K) ? W[(size_t)m * K + k0 + kk] : 0.0;
-    }
-    __syncthreads();
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t ii = i < nnu ? i : nnu - 1;
-    double acc[CS_TAB_KC];
-#pragma unroll
-    for (int kk = 0; kk < CS_TAB_KC; kk++) acc[kk] = 0.0;
-    for (int m = 0; m < M; m++) {
-        const double z = Z[(size_t)m * nnu + ii];
-        const double *w = wsh + m * CS_TAB_KC;
-#pragma unroll
-        for (int kk = 0; kk < CS_TAB_KC; kk++) acc[kk] = __builtin_fma(z, w[kk], acc[kk]);
-    }
-    if (i < nnu) {
-#pragma unroll
-        for (int kk = 0; kk < CS_TAB_KC; kk++)
-            if (k0 + kk < K) sigma[(size_t)(k0 + kk) * nnu + i] += conc[k0 + kk] * exp(acc[kk]);
-    }
-}
 
 // The same on the matrix cores (the contraction over the nT*nP table nodes is the dense part of Mode T): D(16 states x 16 nu) +=
 // A(16 states x 4 table nodes) * B(4 table nodes x 16 nu) with v_mfma_f64_16x16x4, operands as in k_cheb_apply_mfma.  One wave =
@@ -3821,145 +3536,6 @@ __device__ __forceinline__ void flux_last_block_reduce(const FluxFuse &f, const 
     }
     if (threadIdx.x == 0) __hip_atomic_store(f.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (f.dbg && threadIdx.x == 0) f.dbg[7] = wall_clock64();   // (measurement hook: the last block's last word)
-}
-
-// K5 on short grids (a nu-shard, a small column: up to ~400 tiles): k_rt_streams with phase A in front -- one block = one 64-point
-// tile, 2 NS waves.  Phase A: every wave takes (state group, half tile) items of the interpolation product and states of the CIA /
-// near-line sums -> sig[K][64] in LDS.  Phase 0 and 1 are k_rt_streams' (same operations in the same order: same rounding).
-template <int NS>
-__global__ __launch_bounds__(2 * NS * 64) void k_flux_streams(RtParams p, const double *__restrict__ nu, const double *__restrict__ wts,
-                                                              int64_t nnu, const double *__restrict__ sigma, const double *__restrict__ muk,
-                                                              const double *__restrict__ P, const double *__restrict__ Tlev,
-                                                              const double *__restrict__ S_toa, const double *__restrict__ albedo,
-                                                              double *__restrict__ tau, double *__restrict__ Mup, double *__restrict__ Mdn,
-                                                              double *__restrict__ partial, FluxFuse f)
-{
-    extern __shared__ double sh[];   // sig[K][64] | Blev[np][64] | tl[nl][64] | xch[2 buffers][2 roles][NS][64] | red[2 np] | msurf[64]
-    const int np = p.np, nl = np - 1, nlob = p.nlobatto, K = p.K;
-    double *sig = sh, *Blev = sig + (size_t)K * 64, *tl = Blev + (size_t)np * 64, *xch = tl + (size_t)nl * 64, *red = xch + (size_t)2 * 2 * NS * 64,
-           *msurf = red + 2 * np;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const bool up = wave >= NS;
-    const int k = up ? wave - NS : wave;
-    const int64_t j = (int64_t)blockIdx.x * 64 + lane;
-    const bool live = j < nnu;
-    const int64_t jj = live ? j : nnu - 1;
-    flux_sigma_tile(f, K, nnu, (int)blockIdx.x, sigma, nu, sig, wave, 2 * NS, lane);
-    __syncthreads();
-    const double v = nu[jj];
-    const double w = live ? wts[jj] : 0.0;
-    const double fS = S_toa ? S_toa[jj] : 0.0;
-    const double fa = albedo ? albedo[jj] : 0.0;
-    const double c = p.cos_ts;
-    for (int i = wave; i < np; i += 2 * NS) {
-        Blev[(size_t)i * 64 + lane] = planck(v, Tlev[i]);
-        if (i < nl) {   // optical depth of layer i exactly as k_rt forms it (dDepth!, discretized.jl:136-177): beta at the layer's nodes, 1e-6 floor
-            const double dP = P[i + 1] - P[i];
-            const int kl = i * (nlob - 1);
-            auto sg = [&](int kk) { return sig[(size_t)kk * 64 + lane]; };
-            double ti = (dP * p.ws[0]) * (p.C * (sg(kl) / muk[kl]));
-            for (int n = 1; n < nlob - 1; n++) ti += (dP * p.ws[n]) * (p.C * (sg(kl + n) / muk[kl + n]));
-            ti += (dP * p.ws[nlob - 1]) * (p.C * (sg(kl + nlob - 1) / muk[kl + nlob - 1]));
-            const double t = ti > 1e-6 ? ti : 1e-6;
-            tl[(size_t)i * 64 + lane] = t;
-            if (tau && live) tau[(size_t)i * nnu + j] = t;
-        }
-    }
-    __syncthreads();
-    const bool serial = albedo != nullptr;           // (block-uniform) the upward sweep waits for the surface downward flux
-    const double mk = p.m[k], imk = p.im[k], Wk = p.W[k];
-    auto slot = [&](int buf, int role, int kk) { return xch + (((size_t)buf * 2 + role) * NS + kk) * 64 + lane; };
-    double I = 0.0, Ms = c * fS;
-    if (!up && k == 0) {   // level 0: M-[1] = c fS(nu), discretized.jl:299
-        const double r = wave_sum(w * Ms);
-        if (lane == 0) red[np + 0] = r;
-        if (Mdn && live) Mdn[j] = Ms;
-    }
-    double Iu = 0.0;
-    if (up && !serial) {   // surface: Planck emission only (no reflected part without an albedo), discretized.jl:309-310
-        Iu = Blev[(size_t)(np - 1) * 64 + lane];
-        if (k == 0) {
-            const double Mu = Iu * kPi;
-            const double r = wave_sum(w * Mu);
-            if (lane == 0) red[np - 1] = r;
-            if (Mup && live) Mup[(size_t)(np - 1) * nnu + j] = Mu;
-        }
-    }
-    for (int s = 0; s < nl; s++) {
-        const int buf = s & 1;
-        if (!up) {
-            const double t = tl[(size_t)s * 64 + lane];
-            const double tr = exp_rt(-(t * mk));
-            const double Be = layerplanck_inv(Blev[(size_t)s * 64 + lane], Blev[(size_t)(s + 1) * 64 + lane], (1.0 / t) * imk, tr);
-            I = I * tr + Be;
-            *slot(buf, 0, k) = Wk * I;
-            if (k == 0 && S_toa) Ms *= exp(-t / c);
-        } else if (!serial) {
-            const int i = nl - 1 - s;
-            const double t = tl[(size_t)i * 64 + lane];
-            const double tr = exp_rt(-(t * mk));
-            const double Be = layerplanck_inv(Blev[(size_t)(i + 1) * 64 + lane], Blev[(size_t)i * 64 + lane], (1.0 / t) * imk, tr);
-            Iu = Iu * tr + Be;
-            *slot(buf, 1, k) = Wk * Iu;
-        }
-        __syncthreads();
-        if (k == 0 && (!up || !serial)) {   // the role's sum over the streams, in stream order
-            const int role = up ? 1 : 0;
-            double M = 0.0;
-#pragma unroll
-            for (int kk = 0; kk < NS; kk++) M += *slot(buf, role, kk);
-            if (!up) {
-                M += Ms;
-                const double r = wave_sum(w * M);
-                if (lane == 0) red[np + s + 1] = r;
-                if (Mdn && live) Mdn[(size_t)(s + 1) * nnu + j] = M;
-                if (serial && s == nl - 1) msurf[lane] = M;
-            } else {
-                const int i = nl - 1 - s;
-                const double r = wave_sum(w * M);
-                if (lane == 0) red[i] = r;
-                if (Mup && live) Mup[(size_t)i * nnu + j] = M;
-            }
-        }
-    }
-    if (serial) {   // ---- upward sweep after the downward one: Lambertian reflection + Planck emission at the surface
-        __syncthreads();
-        if (up) {
-            Iu = msurf[lane] * fa / kPi + Blev[(size_t)(np - 1) * 64 + lane];
-            if (k == 0) {
-                const double Mu = Iu * kPi;
-                const double r = wave_sum(w * Mu);
-                if (lane == 0) red[np - 1] = r;
-                if (Mup && live) Mup[(size_t)(np - 1) * nnu + j] = Mu;
-            }
-        }
-        for (int s = 0; s < nl; s++) {
-            const int buf = s & 1, i = nl - 1 - s;
-            if (up) {
-                const double t = tl[(size_t)i * 64 + lane];
-                const double tr = exp_rt(-(t * mk));
-                const double Be = layerplanck_inv(Blev[(size_t)(i + 1) * 64 + lane], Blev[(size_t)i * 64 + lane], (1.0 / t) * imk, tr);
-                Iu = Iu * tr + Be;
-                *slot(buf, 1, k) = Wk * Iu;
-            }
-            __syncthreads();
-            if (up && k == 0) {
-                double M = 0.0;
-#pragma unroll
-                for (int kk = 0; kk < NS; kk++) M += *slot(buf, 1, kk);
-                const double r = wave_sum(w * M);
-                if (lane == 0) red[i] = r;
-                if (Mup && live) Mup[(size_t)i * nnu + j] = M;
-            }
-        }
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < 2 * np; e += blockDim.x) {
-        if (f.ticket) flux_store_dev(&partial[(size_t)blockIdx.x * 2 * np + e], red[e]);
-        else partial[(size_t)blockIdx.x * 2 * np + e] = red[e];
-    }
-    if (f.ticket) flux_last_block_reduce(f, partial, (int)gridDim.x, 2 * np);
 }
 
 // K5 on short grids, second form: the sweeps as a SCAN over layer chunks.  In k_flux_streams a wave walks all layers of one stream: 60

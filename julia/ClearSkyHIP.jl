@@ -160,8 +160,6 @@ function slotfrompar!(ctx::Context, filename::String, M::Integer; νmin::Real=0,
     return slot, L[]
 end
 
-# far-line sums on the matrix cores: 1 where the grid is long enough (default), 2 always, 0 never
-matrixcores!(ctx::Context, on::Integer=1) = check(ccall((:cs_set_matrix_cores, LIB), Cint, (Ptr{Cvoid}, Cint), ctx.handle, on))
 # fp32 far wings (BASELINE configs[4]): mode 1 with the x² threshold far_s ≥ 1e6; mode 0 = fp64 everywhere
 precision!(ctx::Context, mode::Integer=0, far_s::Real=1e6) =
     check(ccall((:cs_set_precision, LIB), Cint, (Ptr{Cvoid}, Cint, Cdouble), ctx.handle, mode, far_s))

@@ -33,11 +33,11 @@ def _ctx(cs, key15):
     return c
 
 
-@pytest.mark.parametrize("key15", [0, 64])
 @pytest.mark.parametrize("nnu,nlob,ns,fS,fa", [(6000, 2, 5, 0.0, 0.0), (6001, 3, 4, 0.3, 0.2), (2500, 4, 8, 0.0, 0.15), (20000, 2, 5, 0.0, 0.0), (4100, 2, 2, 0.7, 0.0)])
-def test_short_grid_forms_vs_separate_kernels(cs, O, lines, nnu, nlob, ns, fS, fa, key15):
-    """short grids -- k_flux_scan (default: sweeps as a scan over layer chunks) and k_flux_streams (key 15 | 64: one wave per stream and
-    sweep): line-by-line H2O + CO2, with and without stellar beam / albedo, ragged last tile, 13 layers over 4 waves"""
+def test_short_grid_forms_vs_separate_kernels(cs, O, lines, nnu, nlob, ns, fS, fa, key15=0):
+    """short grids -- k_flux_scan (sweeps as a scan over layer chunks): line-by-line H2O + CO2, with and without stellar beam / albedo,
+    ragged last tile, 13 layers over 4 waves.  (The first short-grid form, k_flux_streams -- one wave per stream and sweep, bitwise the
+    separate kernels -- lost its A/B in round 4 and was removed in round 5.)"""
     nu = np.linspace(580.0, 780.0, nnu)
     P = cs.pressuregrid(5.0, 1e5, 14)
     T = W.earth_temperature(P)
@@ -165,28 +165,6 @@ def test_piece_tables_sixteen_lanes_equal_one_thread(cs, lines, nnu, np_):
     for k in ("tau", "Mup", "Mdn", "Fup", "Fdn"):
         assert np.array_equal(a[k], b[k]), k
     a_ctx.close(); b_ctx.close()
-
-
-@pytest.mark.parametrize("key15", [1, 0])
-def test_cascade_tree_equals_level_by_level(cs, lines, key15):
-    """k_cheb_cascade_tree (every level below an interval of the largest size in one launch, a barrier between levels) against one
-    k_cheb_cascade launch per level (the default; the tree: cs_set_tuning key 15 | 512): the same products in the same order -- optical depths, fluxes bitwise
-    equal -- on a grid with five interval levels and a ragged end, with the separate apply kernel (key 15 = 1) and inside k_flux_chunk"""
-    nu = np.linspace(600.0, 1100.0, 300011)
-    assert cs.interp_plan(nu) == [2048, 1024, 512, 256, 128]
-    P = cs.pressuregrid(50.0, 1e5, 8)
-    T = W.earth_temperature(P)
-    gases = (cs.DirectGas(lines("CO2"), 400e-6, nu), cs.DirectGas(lines("H2O"), W.fC_h2o, nu))
-    res = []
-    for extra in (0, 512):
-        ctx = _ctx(cs, key15 | extra)
-        ctx.set_tuning(12, 1)
-        _, r = _run(cs, ctx, P, T, gases, cs.Discretized(5, 2))
-        res.append(r)
-        ctx.close()
-    assert res[0]["launches"] > res[1]["launches"]
-    for k in ("tau", "Mup", "Mdn", "Fup", "Fdn"):
-        assert np.array_equal(res[0][k], res[1][k]), k
 
 
 @pytest.mark.parametrize("nlay,ns,fS,fa", [(60, 5, 0.4, 0.0), (40, 4, 0.0, 0.2), (23, 6, 0.0, 0.0), (75, 5, 0.0, 0.0)])

@@ -131,31 +131,41 @@ def test_opacityerror_vs_definition(cs, lines, ctx):
 def test_band_fluxes_written_into_caller_memory(cs, lines, ctx):
     """cs_column_set_flux_dst: the flux kernel's last blocks (or k_freduce) write [Fup; Fdn] straight into caller-owned device memory --
     the tensor a collective reduces in place -- bitwise what the column's own buffer gets, for every later run until the column is set up
-    again; fetch / flux_to follow the destination."""
-    import torch
+    again; fetch / flux_to follow the destination.  The "caller-owned" memory here is the band-flux buffer of a column on ANOTHER context
+    (2 np doubles the library itself allocated: no second HIP runtime in the process), read back through that column's fetch."""
     nu, P, T, gas = _small_column(cs, lines)
     col = cs.Column(P, 9.8, T, 0.029, 1e-4, 0.2, gas, core=cs.Discretized(5, 2), ctx=ctx)
     col.run()
     F0 = np.concatenate(col.fetch())
-    dst = torch.full((2 * col.np,), -1.0, dtype=torch.float64, device="cuda:0")
-    col.set_flux_dst(dst.data_ptr())
-    col.run()
-    col.sync()
-    assert np.array_equal(dst.cpu().numpy(), F0)
-    assert np.array_equal(np.concatenate(col.fetch()), F0) and col.flux_ptr() == dst.data_ptr()
-    other = torch.zeros(2 * col.np, dtype=torch.float64, device="cuda:0")
-    col.flux_to(other.data_ptr())
-    col.sync()
-    assert np.array_equal(other.cpu().numpy(), F0)
-    # new temperatures on the resident column: the destination holds
-    col.update(T + 2.0)
-    dst.fill_(-1.0)
-    col.run()
-    col.sync()
-    F1 = dst.cpu().numpy()
-    assert np.all(F1 != -1.0) and not np.array_equal(F1, F0)
-    col.set_flux_dst(0)
-    dst.fill_(-1.0)
-    col.run()
-    col.sync()
-    assert np.all(dst.cpu().numpy() == -1.0) and np.array_equal(np.concatenate(col.fetch()), F1)
+    other_ctx = cs.Context(0)
+    try:
+        col2 = cs.Column(P, 9.8, T + 5.0, 0.029, 1e-4, 0.2, gas, core=cs.Discretized(5, 2), ctx=other_ctx)
+        col2.run()
+        F2 = np.concatenate(col2.fetch())
+        assert not np.array_equal(F2, F0)
+        dst = col2.flux_ptr()                       # device memory this column does not own
+        col.set_flux_dst(dst)
+        col.run()
+        col.sync()
+        assert np.array_equal(np.concatenate(col2.fetch()), F0)           # ... now holds this column's band fluxes
+        assert np.array_equal(np.concatenate(col.fetch()), F0) and col.flux_ptr() == dst
+        # new temperatures on the resident column: the destination holds
+        col.update(T + 2.0)
+        col.run()
+        col.sync()
+        F1 = np.concatenate(col2.fetch())
+        assert not np.array_equal(F1, F0) and np.array_equal(np.concatenate(col.fetch()), F1)
+        # back to the column's own buffer: the foreign one is left alone, flux_to copies on request
+        col.set_flux_dst(0)
+        col2.run()
+        col2.sync()
+        assert np.array_equal(np.concatenate(col2.fetch()), F2)
+        col.run()
+        col.sync()
+        assert np.array_equal(np.concatenate(col2.fetch()), F2) and np.array_equal(np.concatenate(col.fetch()), F1)
+        col.flux_to(dst)
+        col.sync()
+        assert np.array_equal(np.concatenate(col2.fetch()), F1)
+    finally:
+        col.set_flux_dst(0)
+        other_ctx.close()

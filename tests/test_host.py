@@ -11,8 +11,9 @@ from conftest import HITRAN, ROOT
 
 
 def test_library_exports_every_declared_symbol(cs):
-    """The shared library loads and exports every cs_* function include/clearsky_hip.h declares."""
-    hdr = open(os.path.join(ROOT, "include", "clearsky_hip.h")).read()
+    """The shared library loads and exports every cs_* function include/clearsky_hip.h (product) and include/clearsky_hip_dev.h
+    (measurement / tuning / test hooks) declare."""
+    hdr = open(os.path.join(ROOT, "include", "clearsky_hip.h")).read() + open(os.path.join(ROOT, "include", "clearsky_hip_dev.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     declared = set(re.findall(r"\b(cs_[a-z_0-9]+)\s*\(", hdr))
     assert len(declared) >= 20

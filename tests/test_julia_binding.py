@@ -37,8 +37,12 @@ def _canon_c(decl: str) -> str:
     return base + "*" * depth
 
 
-def header_prototypes():
-    src = open(HEADER).read()
+HEADER_DEV = os.path.join(ROOT, "include", "clearsky_hip_dev.h")
+
+
+def header_prototypes(dev=False):
+    """prototypes of the product header; dev=True: of the product AND the laboratory header (clearsky_hip_dev.h: same library)"""
+    src = open(HEADER).read() + (open(HEADER_DEV).read() if dev else "")
     src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
     src = re.sub(r"//[^\n]*", " ", src)
     protos = {}
@@ -119,8 +123,14 @@ def _check_calls(calls, protos, where):
 
 def test_header_parses_every_symbol():
     from clearsky_jl_amd import SIGNATURES
-    protos = header_prototypes()
+    protos = header_prototypes(dev=True)
     assert set(protos) == set(SIGNATURES), (sorted(set(protos) ^ set(SIGNATURES)))
+    # product and laboratory are separate headers (round 5): nothing is declared twice, and the lab symbols are the lab's
+    pub = header_prototypes()
+    lab = set(protos) - set(pub)
+    assert lab == {"cs_set_tuning", "cs_set_interp_plan", "cs_set_matrix_cores", "cs_set_merge", "cs_column_profile", "cs_column_counts",
+                   "cs_column_info", "cs_column_work", "cs_interp_plan", "cs_phco2_plan", "cs_faddeeva_batch", "cs_devfn_batch"}, sorted(lab)
+    assert len(pub) <= 48, len(pub)
     assert protos["cs_fluxes_discretized"][1][:4] == ["void*", "int64", "double*", "int"]
     assert protos["cs_balanced_ranges"][1][4] == "double**"
     assert protos["cs_fluxes_discretized_multi"][1][0] == "void**"
@@ -188,7 +198,7 @@ _CT = {C.c_int: "int", C.c_int64: "int64", C.c_double: "double", C.c_char_p: "ch
 
 def test_ctypes_signatures_match_header():
     from clearsky_jl_amd import SIGNATURES
-    protos = header_prototypes()
+    protos = header_prototypes(dev=True)
     for name, (res, args) in SIGNATURES.items():
         cret, cargs = protos[name]
         assert _CT[res] == cret, f"{name}: returns {cret} in the header, ctypes says {_CT[res]}"

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """The drop-in entry point with the whole FluxPack copied back (tau, M+, M-: 146 MB at C3), through n contexts on ONE device:
 cs_fluxes_discretized_multi cuts the grid into n ranges, one host thread per context -- the device-to-host copies of one range run
-beside the kernels of the others.  Prints ms per call (repeat calls on an unchanged grid) for n = 1, 2, 4, 8."""
+beside the kernels of the others.  Prints ms per call (repeat calls on an unchanged grid) for n = 1, 2, 4, 8:
+tools/multi_overlap.py <output.json> [config]"""
 import json
 import sys
 import time
@@ -13,7 +14,7 @@ import clearsky_jl_amd as cs
 import workloads as W
 from clearsky_jl_amd.core import _fluxes_discretized
 
-cfg = W.config(sys.argv[1] if len(sys.argv) > 1 else "C3")
+cfg = W.config(sys.argv[2] if len(sys.argv) > 2 else "C3")
 out = {}
 for n in (1, 2, 4, 8):
     mc = cs.MultiContext([0] * n) if n > 1 else cs.Context(0)
@@ -31,4 +32,4 @@ for n in (1, 2, 4, 8):
     out[n] = res
     print(n, res, flush=True)
     mc.close()
-json.dump(out, open("gpurun_out/r04_multi_overlap.json", "w"), indent=1)
+json.dump(out, open(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/multi_overlap.json", "w"), indent=1)
