@@ -58,7 +58,6 @@ def main():
     ap.add_argument("--precision", default="fp64", help="fp64 (headline) | mixed (fp32 far wings, BASELINE configs[4])")
     ap.add_argument("--no-interp", action="store_true", help="evaluate every (nu, line) pair (no far-wing interpolation)")
     ap.add_argument("--interp-first-level", type=int, default=-1, help="tuning: first interval level every gas uses (-1 = by line density)")
-    ap.add_argument("--interp-size-min", type=int, default=128, help="tuning: smallest interval size of the far-wing interpolation (64 = one tile)")
     ap.add_argument("--no-matrix-nodes", action="store_true", help="tuning: no far-line sums on the matrix cores (same as --matrix-cores 0)")
     ap.add_argument("--matrix-cores", type=int, default=1, help="tuning: far-line sums on the matrix cores: 1 where the grid is long enough (default), 2 always, 0 never")
     ap.add_argument("--no-merge", action="store_true", help="tuning: one launch set per gas instead of one merged line table per column")
@@ -122,7 +121,7 @@ def main():
     ctx = cs.Context(dev)
     ctx.set_precision(args.precision, args.far_s)
     ctx.set_interp(not args.no_interp)
-    ctx.set_interp_plan(first_level=args.interp_first_level, size_min=args.interp_size_min)
+    ctx.set_interp_plan(first_level=args.interp_first_level)
     ctx.set_matrix_cores(0 if args.no_matrix_nodes else args.matrix_cores)
     ctx.set_merge(not args.no_merge)
     for kv in filter(None, args.tune.split(",")):
@@ -289,13 +288,19 @@ def main():
     nt64 = (col.nnu + 63) // 64
     sec = lambda name: prof.get(name, 0.0) * 1e-3 / ngrp      # seconds per launch of a class
 
-    def mfma_entry(name, useful, issued, note):
+    def mfma_entry(name, useful, issued, note, alg_bytes=None, requested=None):
         t = sec(name)
-        return dict(bound="mfma", ms_per_launch=t * 1e3, launches_per_step=ngrp, useful_flops_per_launch=useful / ngrp,
-                    issued_flops_per_launch=issued / ngrp, achieved=(useful / ngrp / t / 1e12) if t > 0 else 0.0,
-                    achieved_issued=(issued / ngrp / t / 1e12) if t > 0 else 0.0, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=(useful / ngrp / t / 1e12 / FP64_MFMA_PEAK_TFLOPS) if t > 0 else 0.0,
-                    frac_issued=(issued / ngrp / t / 1e12 / FP64_MFMA_PEAK_TFLOPS) if t > 0 else 0.0, note=note)
+        d = dict(bound="mfma", ms_per_launch=t * 1e3, launches_per_step=ngrp, useful_flops_per_launch=useful / ngrp,
+                 issued_flops_per_launch=issued / ngrp, achieved=(useful / ngrp / t / 1e12) if t > 0 else 0.0,
+                 achieved_issued=(issued / ngrp / t / 1e12) if t > 0 else 0.0, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                 frac=(useful / ngrp / t / 1e12 / FP64_MFMA_PEAK_TFLOPS) if t > 0 else 0.0,
+                 frac_issued=(issued / ngrp / t / 1e12 / FP64_MFMA_PEAK_TFLOPS) if t > 0 else 0.0, note=note)
+        if alg_bytes is not None:
+            # what must cross HBM once: every per-(state, line) record in range (32 B) + the read-modify-write of the plane the kernel adds to;
+            # requested: the records of every piece as the waves ask for them (neighbouring tiles / intervals share lines: L2 traffic)
+            d.update(algorithmic_bytes_per_launch=alg_bytes / ngrp, requested_record_bytes_per_launch=(requested or 0) / ngrp,
+                     hbm_frac_of_algorithmic_bytes=(alg_bytes / ngrp / t / 1e9 / HBM_PEAK_GBS) if t > 0 else 0.0)
+        return d
 
     def valu_entry(name, lane_instr, extra):
         t = sec(name)
@@ -309,10 +314,14 @@ def main():
     # matrix-core kernels: USEFUL flops = 2 x series terms per (point | node, line, state) with the point inside the cut-off and outside
     # the core radius and the state a real one (cs_column_work counts them on the host from the zone tables and the grid); ISSUED = 2048
     # per matrix instruction, i.e. masked columns, padded states and the fill of the last 4-line step included
+    rec_unique = 32.0 * K * cnt["lines_in_range"]          # every per-(state, line) record some window of this grid can reach, once
     kern["k_voigt_edge_mx"] = mfma_entry("far_mx", work["edge_mx_flops_useful"], work["edge_mx_flops_issued"],
-                                         "window ends, pieces between interpolated sets and near zone, window cores beyond the series radius")
+                                         "window ends, pieces between interpolated sets and near zone, window cores beyond the series radius",
+                                         alg_bytes=rec_unique + 16.0 * K * col.nnu, requested=work.get("edge_mx_record_bytes_requested"))
     kern["k_cheb_nodes_mx"] = mfma_entry("nodes_mx", work["nodes_mx_flops_useful"], work["nodes_mx_flops_issued"],
-                                         "node sums of the interpolated far wings, 3- / 4-term series in 1/dnu^2")
+                                         "node sums of the interpolated far wings, 3- / 4-term series in 1/dnu^2",
+                                         alg_bytes=rec_unique + 16.0 * 64 * max(work["intervals"], 0) * (16 * ((K + 15) // 16)),
+                                         requested=work.get("nodes_mx_record_bytes_requested"))
     if prof.get("apply", 0.0) > 0 and not col.baked and not col.U.cia:
         t = prof["apply"] * 1e-3
         kern["k_cheb_apply_mfma"] = dict(bound="mfma", ms_per_launch=t * 1e3, launches_per_step=1, useful_flops_per_launch=work["apply_flops"],
@@ -323,12 +332,17 @@ def main():
     # (hipcc -S, gfx950; all 64 lanes of a wave count, also those the cut-off predicate masks), against the fp64-rate issue peak
     db, nb = work.get("direct_by_body", {}), work.get("node_by_body", {})
     kern["k_voigt_far"] = valu_entry("far", sum(db.get(b_, 0) * VALU_PER_LINE[b_] for b_ in db), dict(lines_x_lanes_by_body=db))
+    line_kernel = {0: "k_voigt_far", 1: f"k_linesum<{args.shape}>", 2: "k_phco2"}[int(info.get("line_kernel", 0))]
+    kern["k_voigt_far"]["kernel"] = line_kernel       # (the class "far" is whatever summed the per-point far lines: Doppler and PHCO2 have their own kernels)
+    if line_kernel != "k_voigt_far":
+        kern["k_voigt_far"].update(frac=None, lane_instructions_per_launch=None, achieved=None,
+                                   note="the instruction accounting above is k_voigt_far's: not applicable to this kernel, only its time is reported")
     kern["k_cheb_nodes"] = valu_entry("nodes", sum(nb.get(b_, 0) * VALU_PER_LINE[b_] for b_ in nb), dict(lines_x_nodes_by_body=nb))
     kern["k_voigt_sub"] = valu_entry("sub", work.get("sub_evals", 0) * VALU_PER_LINE["near_zone"], dict(lane_line_evals=work.get("sub_evals", 0)))
     p0, p1 = work.get("near_pairs_tier0", 0), work.get("near_pairs_tier1", 0)
     kern["k_voigt_near"] = valu_entry("near", p0 * (VALU_NEAR["tier0_eval"] + VALU_NEAR["per_candidate"]) + p1 * (VALU_NEAR["tier1_eval"] + VALU_NEAR["per_candidate"]),
                                       dict(pairs_tier0=p0, pairs_tier1=p1, valu_per_pair=VALU_NEAR,
-                                           launches_per_step=(2 if nt64 * K >= 524288 else 1) * ngrp,
+                                           launches_per_step=int(info.get("near_launches", ngrp)),     # (counted by the library where it launches them)
                                            note="tier 0 (100 <= x^2+y^2 < 1e3: continued fraction) + tier 1 (< 100: trapezoid + pole): k_voigt_near_both, one "
                                                 "launch, or k_voigt_near<0> + <1> on grids of half a million (tile, state) waves and more; (nu, line, state) "
                                                 "pairs counted on the host from the device's per-(state, line) records; both tiers in one time"))
@@ -344,7 +358,7 @@ def main():
     ns_ = cfg["core"].nstream
     rt_valu = (VALU_RT["down"] + VALU_RT["up"]) if ns_ == 5 else 2 * (VALU_RT["fixed"] + VALU_RT["per_stream"] * ns_)
     rt_lane_instr = float(col.nnu) * col.nl * rt_valu
-    flux_name = {0: "k_rt", 1: "k_flux_streams", 2: "k_flux_chunk", 3: "k_flux_scan"}[int(info.get("flux_form", 0))]
+    flux_name = {0: "k_rt", 2: "k_flux_chunk", 3: "k_flux_scan"}[int(info.get("flux_form", 0))]
     kern["k_rt"] = dict(bound="valu_issue", kernel=flux_name, ms_per_launch=t * 1e3, launches_per_step=1, lane_instructions_per_launch=rt_lane_instr,
                         valu_per_point_layer=rt_valu, achieved=rt_lane_instr / t if t > 0 else 0.0, peak=VALU_ISSUE_PEAK,
                         unit="fp64-rate lane-instructions/s", frac=rt_lane_instr / t / VALU_ISSUE_PEAK if t > 0 else 0.0,
@@ -425,7 +439,7 @@ def main():
         ctx2 = cs.Context(dev)      # a context of its own: first call = full setup, later calls re-use the resident column
         ctx2.set_precision(args.precision, args.far_s)      # ... with every setting of the run beside it
         ctx2.set_interp(not args.no_interp)
-        ctx2.set_interp_plan(first_level=args.interp_first_level, size_min=args.interp_size_min)
+        ctx2.set_interp_plan(first_level=args.interp_first_level)
         ctx2.set_matrix_cores(0 if args.no_matrix_nodes else args.matrix_cores)
         ctx2.set_merge(not args.no_merge)
         for kv in filter(None, args.tune.split(",")):

@@ -1248,19 +1248,21 @@ class Column:
         self._require_resident("info")
         out = (C.c_int64 * 8)()
         check(lib().cs_column_info(self.ctx.handle, out))
-        return dict(groups=out[0], launches=out[1], lines=out[2], merge=out[3], max_members=out[4], flux_form=out[5])
+        return dict(groups=out[0], launches=out[1], lines=out[2], merge=out[3], max_members=out[4], flux_form=out[5], near_launches=out[6],
+                    line_kernel=out[7])
 
     def work(self):
         """Evaluations the last run issued for its Voigt gases: per-point, at interpolation nodes; levels in use."""
         self._require_resident("work")
-        out = (C.c_int64 * 32)()
+        out = (C.c_int64 * 40)()
         check(lib().cs_column_work(self.ctx.handle, out))
         return dict(direct_evals=out[0], node_evals=out[1], levels=out[2], intervals=out[3],
                     direct_by_body=dict(zip(("t2", "t2_cut", "t3", "t3_cut", "t4_cut", "near_zone"), [out[4 + q] for q in range(6)])),
                     node_by_body=dict(zip(("t2", "t3", "t4"), [out[10 + q] for q in range(3)])), node_evals_matrix=out[13],
                     direct_evals_matrix=out[14], matrix_evals_3term=out[15], sub_evals=out[16], core_tile_states=out[17], matrix_evals_8term=out[18], node_evals_matrix_3term=out[19],
                     near_pairs_tier0=out[20], near_pairs_tier1=out[21], edge_mx_flops_useful=out[22], edge_mx_flops_issued=out[23],
-                    nodes_mx_flops_useful=out[24], nodes_mx_flops_issued=out[25], apply_flops=out[26])
+                    nodes_mx_flops_useful=out[24], nodes_mx_flops_issued=out[25], apply_flops=out[26],
+                    edge_mx_record_bytes_requested=out[32], nodes_mx_record_bytes_requested=out[33])
 
     def fetch(self, tau=None, Mup=None, Mdn=None):
         """Copy results to host.  Returns (Fup, Fdn); fills the optional Fortran-order matrices in place."""

@@ -43,6 +43,8 @@ int fail(int code, const char *fmt, ...)
 }
 
 thread_local int g_nlaunch = 0;   // kernel launches since the last reset (cs_column_run reports its count)
+thread_local int g_near_launches = 0, g_line_kernel = 0;   // of the step being enqueued: near-line launches (all groups), and what summed the per-point
+                                                           // far lines of its last group: 0 = k_voigt_far, 1 = k_linesum<shape>, 2 = k_phco2
 #define CS_LAUNCH(...) do { g_nlaunch++; hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 
 #define HIPCHK(expr)                                                                                   \
@@ -251,6 +253,7 @@ struct Column {
     DevBuf fluxdbg;            // k_flux_scan: phase time stamps of block 0 (cs_set_tuning key 15 | 128; cs_column_work out[27..])
     DevBuf ticket;             // k_flux: blocks finished (the last one adds the block partials up)
     int flux_form_last = 0;      // which flux kernel the last run used (flux_form)
+    int near_launches_last = 0, line_kernel_last = 0;   // cs_column_info out[6], out[7]
     bool sigma_partial = false;  // the last run finished the cross-sections on chip (k_flux): cs_column_sigma_fetch evaluates them again, in HBM
     ChebGrid cheb;             // interpolation levels of the nu grid (nlev = 0: off)
     DevBuf chebF;              // node sums F [nItot][64][Kpad], summed over the column's gases (k_cheb_nodes accumulates)
@@ -735,6 +738,7 @@ struct Interp {
     int nsplit_levels = 1;    // cs_set_tuning key 6: interval sizes (largest first) whose node sums four waves share in k_cheb_nodes_mx
     bool small_mx = false;    // cs_set_tuning key 1: the matrix-core kernels on short grids too (their four-waves-per-item variants)
     bool mxzones_one_thread = false;   // cs_set_tuning key 15 | 16: k_mxzones instead of k_mxzones16
+    int far_split = 0;                 // cs_set_tuning key 22: waves per tile of k_voigt_far (1, 2, 4; 0 = by grid size)
     int mxzones_merge = 0;             // cs_set_tuning key 21: the piece tables as blocks of k_gas_setup's launch (k_gas_setup_mx) -- 0 = on grids below 1024 tiles, 1 = never, 2 = always
     bool near_both = true;             // both tiers of the near-line pairs in one launch where a wave takes one tile (cs_set_tuning key 16 | 4: off)
     int near_prio = 0;                 // cs_set_tuning key 16: issue priority for k_voigt_sub / k_voigt_near (0 = from 512 tiles on, 1 = never, 2 = always)
@@ -759,6 +763,7 @@ static void interp_settings(const cs_ctx *ctx, Interp &itp)   // the cs_set_tuni
     itp.near_both = (ctx->tune[16] & 4) == 0;
     itp.near_memset = ctx->tune[19] != 0;
     itp.mxzones_merge = ctx->tune[21];
+    itp.far_split = ctx->tune[22];
 }
 
 // interval sizes worth using on this grid: an interval of width W leaves lines over (2 cut - 2.3 W) to interpolate
@@ -767,7 +772,7 @@ int choose_levels(double nu_lo, double nu_hi, int64_t nnu, double cut, int *itv,
     int n = 0;
     if (nnu < 128) return 0;
     const double dnu = (nu_hi - nu_lo) / (double)(nnu - 1);
-    for (int sz = 8192; sz >= 64 && n < CS_MAX_LEVEL; sz >>= 1)
+    for (int sz = 8192; sz >= 128 && n < CS_MAX_LEVEL; sz >>= 1)
         if (sz <= szmax && sz >= szmin && 2.3 * sz * dnu <= 1.5 * cut && sz / 2 <= nnu &&
             sz * dnu > 1e-8 * std::fabs(nu_hi))   // (nodes 1e-3 of an interval apart must stay distinct doubles)
             itv[n++] = sz;
@@ -1321,10 +1326,12 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
             (void)hipEventRecord(evg[2], s);
         }
         const int nblk = (nt64 + 3) / 4;
+        g_line_kernel = 0;
 
         // waves per tile: enough waves to fill 256 CUs x 32 wave slots about 4 times over
         const int64_t nwave = (int64_t)nt64 * kn;
-        const int split = nwave >= 16384 ? 1 : (nwave >= 4096 ? 2 : 4);   // (re-tuned with the far wings interpolated: waves are 3x shorter)
+        int split = nwave >= 16384 ? 1 : (nwave >= 4096 ? 2 : 4);   // (re-tuned with the far wings interpolated: waves are 3x shorter)
+        if (itp.far_split == 1 || itp.far_split == 2 || itp.far_split == 4) split = itp.far_split;   // (cs_set_tuning key 22, A/B)
         const int nblk_s = (nt64 * split + 3) / 4;
         // 8 x (blocks of the longest XCD stretch): XCD-aware tile mapping (tile_block); xtiles is a multiple of 4 tiles
         const dim3 grid_s((unsigned)(8 * (xtiles * split / 4)), kn);
@@ -1387,8 +1394,10 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
             const dim3 gridq((unsigned)(((ngrpn + nrep - 1) / nrep + 3) / 4), kn);
             if (nrep == 1 && itp.near_both) {   // both tiers in one launch (one tile per wave; cs_set_tuning key 16 | 4: two launches, A/B)
                 CS_LAUNCH(k_voigt_near_both, gridq, dim3(256), 0, sn, dnu, nnu, G.L, hot, cold, zones, nt64, cut, out, ranges, near_prio);
+                g_near_launches += 1;
                 return;
             }
+            g_near_launches += 2;
             CS_LAUNCH(k_voigt_near<0>, gridq, dim3(256), 0, sn, dnu, nnu, G.L, hot, cold, zones, nt64, ngrpn, nrep, cut, out, ranges, near_prio);
             CS_LAUNCH(k_voigt_near<1>, gridq, dim3(256), 0, sn, dnu, nnu, G.L, hot, cold, zones, nt64, ngrpn, nrep, cut, out, ranges, near_prio);
         };
@@ -1490,6 +1499,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
             piw = ph->piw.as<PhIWin>();
             fine = pg.fine;
         } else if (evg) { (void)hipEventRecord(evg[1], s); (void)hipEventRecord(evg[2], s); }
+        g_line_kernel = 2;
         CS_LAUNCH(k_phco2, dim3((unsigned)((nt64 + 3) / 4), kn), dim3(256), 0, s, dnu, nnu, G.L, hot, cold, ph->fac.as<double>(), ph->nu_c,
                            ph->win.as<PhWin>(), zones, nt64, cut, Tk, kn, base, extra, sigma, accumulate, piw, fine, inner ? 1 : 0);
         if (evg) (void)hipEventRecord(evg[3], s);
@@ -1509,6 +1519,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
             CS_LAUNCH(k_gas_setup, dim3(nb_prep), dim3(256), 0, s, nb_prep, 0u, pa, za, P, (IZone *)nullptr);
         }
         if (evg) { (void)hipEventRecord(evg[0], s); (void)hipEventRecord(evg[1], s); (void)hipEventRecord(evg[2], s); }
+        g_line_kernel = 1;
         launch_linesum_shape(shape, dim3(ntile256, kn), s, dnu, nnu, G.L, hot, cold, J0, J1, cut, Tk, base, extra, sigma,
                              accumulate);
         if (evg) { (void)hipEventRecord(evg[3], s); (void)hipEventRecord(evg[4], s); (void)hipEventRecord(evg[5], s); }
@@ -1764,7 +1775,7 @@ int cs_set_interp(cs_ctx *ctx, int on)
 int cs_set_interp_plan(cs_ctx *ctx, int first_level, int size_min, int size_max)
 {
     if (!ctx) return fail(CS_EINVAL, "ctx is NULL");
-    if (size_min < 64 || size_max > 2048 || size_min > size_max) return fail(CS_EINVAL, "interval sizes must satisfy 64 <= size_min <= size_max <= 2048");
+    if (size_min < 128 || size_max > 2048 || size_min > size_max) return fail(CS_EINVAL, "interval sizes must satisfy 128 <= size_min <= size_max <= 2048");
     if (first_level < -1 || first_level > CS_MAX_LEVEL) return fail(CS_EINVAL, "first_level must be -1 (automatic) or 0..%d", CS_MAX_LEVEL);
     ctx->itp_first = first_level;
     ctx->itp_min = size_min;
@@ -2965,6 +2976,8 @@ static int run_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev)
     double *sig = c.sigma.as<double>();
     int e = 0, rc;
     g_nlaunch = 0;
+    g_near_launches = 0;
+    g_line_kernel = 0;
     c.last_stream = s;
     if (ev) HIPCHK(hipEventRecord(ev[e++], s));
     bool near_live = false;
@@ -3008,6 +3021,8 @@ static int run_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev)
         CS_LAUNCH(k_freduce, dim3(2 * c.np), dim3(256), 0, s, c.partial.as<double>(), form ? fblk : c.rtg.nblk, 2 * c.np, c.flux_out());
     if (ev) HIPCHK(hipEventRecord(ev[e++], s));
     c.launches = g_nlaunch;
+    c.near_launches_last = g_near_launches;
+    c.line_kernel_last = g_line_kernel;
     HIPCHK(hipGetLastError());
     return CS_OK;
 }
@@ -3214,6 +3229,8 @@ int cs_column_info(cs_ctx *ctx, int64_t *out)
     for (auto &g : c.gas) { out[2] += g.tab->L; out[4] = std::max<int64_t>(out[4], (int64_t)g.mem.size()); }
     out[3] = c.merge;
     out[5] = c.flux_form_last;
+    out[6] = c.near_launches_last;
+    out[7] = c.line_kernel_last;
     return CS_OK;
 }
 
@@ -3251,6 +3268,8 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
     // flops of the two matrix-core kernels: issued = every matrix instruction's 2048; useful = 2 x terms per (column, line, state) with
     // the column inside the cut-off, outside the core radius, and the state a real one (a group's tail rows are padding)
     double fl_edge_useful = 0.0, fl_edge_issued = 0.0, fl_nodes_useful = 0.0, fl_nodes_issued = 0.0, fl_apply = 0.0;
+    int64_t rec_edge = 0, rec_nodes = 0;   // (state, line) records the two matrix-core kernels REQUEST: lines of every piece x 16 states (neighbouring tiles and
+                                           // intervals ask for the same record again: the unique ones are K x lines in range)
     int64_t near0 = 0, near1 = 0;
     int64_t body[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // per-point lines by body: 2-term, 2-term+cut-off, 3-term, 3-term+cut-off, 4-term+cut-off,
                                                      // near-zone pass; node lines: 2-, 3-, 4-term
@@ -3332,6 +3351,7 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
                             if (z.b[p] <= z.a[p]) continue;
                             const int n3 = p < 2 ? z.m[p] - z.a[p] : z.b[p] - z.m[p], n4 = (z.b[p] - z.a[p]) - n3;
                             (void)ns;   // (useful flops: per state, above -- a state takes part only beyond its own series radius)
+                            rec_nodes += 16 * (int64_t)(n3 + n4);
                             fl_nodes_issued += 2.0 * far_nodes(q, p) * 16 * (3.0 * ((n3 + 3) / 4 * 4) + 4.0 * ((n4 + 3) / 4 * 4));
                         }
                     }
@@ -3357,6 +3377,7 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
                     const double *v0 = vv + (size_t)t * 64, *v1 = vv + std::min<int64_t>((int64_t)t * 64 + 64, c.nnu);
                     auto piece = [&](int ja, int jb, int nt, int mask) {   // mask 0: every point counts; 1: |dnu| <= cut; 2: also |dnu| >= R
                         if (jb <= ja) return;
+                        rec_edge += 16 * (int64_t)(jb - ja);
                         fl_edge_issued += 2.0 * nt * 64.0 * 16.0 * ((jb - ja + 3) / 4 * 4);
                         double cols = 0.0;
                         for (int j = ja; j < jb; j++) {
@@ -3525,6 +3546,9 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
     } else {
         for (int q = 27; q < 32; q++) out[q] = 0;
     }
+    out[32] = rec_edge * (int64_t)sizeof(LineHot);
+    out[33] = rec_nodes * (int64_t)sizeof(LineHot);
+    for (int q = 34; q < 40; q++) out[q] = 0;
     out[0] = direct;
     out[1] = nodes;
     out[2] = c.cheb.nlev;

@@ -100,8 +100,9 @@ int cs_column_counts(cs_ctx *ctx, int64_t *pair_evals, int64_t *lines_in_range);
 
 /* measurement hook, out[8]: out[0] = launch groups of the resident column (merged gases count once), out[1] = kernel launches of
  * the last cs_column_run, out[2] = lines of all groups, out[3] = cs_set_merge at setup time, out[4] = gases in the largest group,
- * out[5] = the flux kernel of the last run: 0 = k_rt / k_rt_streams on finished cross-sections, 1 = k_flux_streams, 2 = k_flux_chunk,
- * 3 = k_flux_scan */
+ * out[5] = the flux kernel of the last run: 0 = k_rt / k_rt_streams on finished cross-sections, 2 = k_flux_chunk, 3 = k_flux_scan;
+ * out[6] = near-line launches of the last run, all groups (k_voigt_near_both: 1 per group; k_voigt_near<0> + <1>: 2); out[7] = what
+ * summed the per-point far lines of its last group: 0 = k_voigt_far, 1 = k_linesum<shape> (Doppler; PHCO2 without its fast path), 2 = k_phco2 */
 int cs_column_info(cs_ctx *ctx, int64_t *out);
 
 /* line-shape evaluations the last cs_column_run actually issued for its Voigt gases (measurement hook): out[0] = per-point
@@ -121,7 +122,9 @@ int cs_column_info(cs_ctx *ctx, int64_t *out);
  * k_cheb_nodes_mx; out[26] = flops of the node-sum -> grid contraction (k_cheb_apply_mfma, or inside k_voigt_edge_mx / k_flux_*); with
  * cs_set_tuning key 15 | 128, out[27..30] = nanoseconds block 0 of k_flux_scan spent on cross-sections, optical depths + Planck values,
  * first pass over its layer chunk, hand-over of the incoming intensities, and out[31] = from its first instruction to the last block's
- * store of the band fluxes (100 MHz wall clock; 0 otherwise).  `out` holds 32 values.
+ * store of the band fluxes (100 MHz wall clock; 0 otherwise); out[32], out[33] = bytes of per-(state, line) records k_voigt_edge_mx and
+ * k_cheb_nodes_mx REQUEST per launch (lines of every piece x 16 states x 32 B: neighbouring tiles / intervals ask for the same record again --
+ * the unique ones are K x lines in range x 32 B).  `out` holds 40 values.
  * cs_column_counts is the reference's count. */
 int cs_column_work(cs_ctx *ctx, int64_t *out);
 

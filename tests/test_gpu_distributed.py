@@ -180,3 +180,27 @@ def test_bench_emulated_shard_with_calibrated_partition():
     off = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C2", "--steps", "5", "--warmup", "2", "--no-cpu",
                           "--emulate-shard", "1/3", "--no-calibrate"], env=env, capture_output=True, text=True, timeout=600)
     assert off.returncode == 0 and json.loads([l for l in off.stdout.splitlines() if l.startswith("{")][0])["partition"] is None
+
+
+@pytest.mark.parametrize("fail", [None, "measure:1", "setup:0"])
+def test_bench_calibration_is_collective(fail):
+    """the N-rank partition calibration of bench.py.  Every rank reaches the same all-reduces whatever happened to it locally,
+    and the re-cut partition is adopted only if EVERY rank measured its shard and set its new one up; a rank that fails (injected:
+    CS_BENCH_FAIL_CALIBRATION=measure:<rank> | setup:<rank>) sends every rank back to the model's ranges -- no hang, no mixed partition.
+    Rank 0 gathers the ranges the ranks actually run and refuses a result whose ranges do not tile the grid."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    if fail:
+        env["CS_BENCH_FAIL_CALIBRATION"] = fail
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--config", "C2",
+                          "--steps", "3", "--warmup", "1", "--no-cpu"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    p = d["partition"]
+    by_rank = p["ranges_by_rank"]
+    assert len(by_rank) == 2 and by_rank[0][0] == 0 and by_rank[0][1] == by_rank[1][0] and by_rank[1][1] == d["config"]["nnu"]
+    assert [list(r) for r in p["ranges"]] == by_rank
+    if fail:
+        assert p["calibrated"] is False and "error" in p and [list(r) for r in p["model_ranges"]] == by_rank
+    else:
+        assert "error" not in p and len(p["model_shard_ms"]) == 2 and all(t > 0 for t in p["model_shard_ms"])
+    assert d["olr_wm2"] > 0
