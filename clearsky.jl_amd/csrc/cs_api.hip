@@ -1508,6 +1508,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
             launch_gas(s, SH_VOIGT, G, jrange0, jrange1, kn, Tk, Pk, Ppk, scale, mstride, lrt, qrefq, hot, cold, dnu, nnu, ntile256, J0, J1,
                        ph->win3.as<WaveWin>(), per, ph->zones3.as<Zone>(), ranges, gbound, 3.0, 0.0, nullptr, sigma, 1, nullptr, nullptr, far_s,
                        Interp(), nullptr, nullptr, nullptr, true);
+            g_line_kernel = 2;   // (the group's far lines were k_phco2's; the inner pass only took the pairs within 3 cm^-1)
         }
         if (evg) { (void)hipEventRecord(evg[4], s); (void)hipEventRecord(evg[5], s); }
     } else {

@@ -74,10 +74,7 @@ int cs_set_merge(cs_ctx *ctx, int on);
  *          (default) where it pays: grids of up to 1024 tiles (a nu-shard, a small column) and of 4096 tiles or more, 1 never, 2 always;
  *          | 4: the block partials are always added by k_freduce's own launch, | 8: the long-grid form with four waves per SIMD (A/B);
  *          | 16: the matrix-core piece tables with one thread per (interval | tile, state group) (k_mxzones) instead of sixteen lanes (A/B);
- *          | 64: short grids with one wave per (sweep, stream) walking all layers (k_flux_streams) instead of the scan over layer chunks
- *          (k_flux_scan) (A/B);
  *          | 256: on short grids the interval levels are NOT folded into the smallest one on the node-sum side stream (A/B);
- *          | 512: the level cascade (key 12) as ONE launch for all levels (k_cheb_cascade_tree) instead of one per level (A/B: no faster);
  *          | 1024: the scan form also on grids of 1024 .. 4096 tiles (A/B: slower at 1563 tiles);
  *          | 2048: k_flux_scan forms the transmissivities of a layer chunk again in its second sweep and second pass instead of
  *          keeping them in registers (A/B; same results);
@@ -88,6 +85,12 @@ int cs_set_merge(cs_ctx *ctx, int on);
  *          of 512 tiles or more, 1 never, 2 always (bench column 2.00 -> 1.95 ms; an eighth of it 0.378 -> 0.387, hence the threshold).
  *          | 4: the two tiers of the near-line pairs in two launches (k_voigt_near<0>, <1>) also where a wave takes one tile, instead of
  *          one (k_voigt_near_both) (A/B; same results).
+ *   key 19: the near-line plane of a step is cleared by a memset in front of its first kernel (1) instead of written by that kernel,
+ *          k_voigt_sub (0, default: one launch and 8 B per (state, point) of writes less) (A/B; same results);
+ *   key 21: the piece tables of the matrix-core kernels as blocks of k_gas_setup's launch, computing the zones they need themselves
+ *          (k_gas_setup_mx) -- 0 (default) on grids below 1024 tiles, 1 never (k_mxzones16 as its own launch), 2 always (A/B; same tables);
+ *   key 22: waves per 64-point tile of k_voigt_far: 1, 2 or 4 (0, default: by the number of (tile, state) waves) (A/B).
+ *   (keys 17, 18, 20 are unused.)
  * Applies to every later cs_column_setup / cs_column_run of the context. */
 int cs_set_tuning(cs_ctx *ctx, int key, int value);
 

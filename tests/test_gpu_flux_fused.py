@@ -235,3 +235,31 @@ def test_near_tiers_in_one_launch_equal_two(cs, lines):
     assert res[0]["launches"] == res[1]["launches"] - 1
     for k in ("tau", "Mup", "Mdn", "Fup", "Fdn"):
         assert np.array_equal(res[0][k], res[1][k]), k
+
+
+def test_in_kernel_band_sum_vs_freduce(cs, lines):
+    """The last-block band sum of k_flux_scan (agent-scope relaxed atomics + a ticket, on gfx950 only: DESIGN.md section 4) against the same
+    kernel with its block partials added by k_freduce's own launch (cs_set_tuning key 15 | 4): everything per wavenumber bitwise equal, the
+    band fluxes equal to rounding of the different association (two stages of 16 and <= 32 terms against one fixed-order sum), and each
+    form repeatable bit for bit over many runs (a partial arriving late would show as a changed last digit)."""
+    nu = np.linspace(580.0, 780.0, 12000)         # 188 tiles: several groups of 16 blocks, a partial last group
+    P = cs.pressuregrid(5.0, 1e5, 21)
+    T = W.earth_temperature(P)
+    gases = (cs.DirectGas(lines("H2O"), W.fC_h2o, nu), cs.DirectGas(lines("CO2"), 400e-6, nu))
+    core = cs.Discretized(5, 2)
+    res = {}
+    for key in (0, 4):
+        ctx = _ctx(cs, key)
+        col, r = _run(cs, ctx, P, T, gases, core, 0.3, 0.1)
+        assert col.info()["flux_form"] == 3
+        for _ in range(20):
+            col.run()
+            F = col.fetch()
+            assert np.array_equal(F[0], r["Fup"]) and np.array_equal(F[1], r["Fdn"])
+        res[key] = r
+        ctx.close()
+    assert res[0]["launches"] == res[4]["launches"] - 1
+    for k in ("tau", "Mup", "Mdn"):
+        assert np.array_equal(res[0][k], res[4][k]), k
+    fm = np.max(res[4]["Fup"])
+    assert np.max(np.abs(res[0]["Fup"] - res[4]["Fup"])) < 1e-13 * fm and np.max(np.abs(res[0]["Fdn"] - res[4]["Fdn"])) < 1e-13 * fm

@@ -4,8 +4,8 @@ root=${GRAFT_REPO_ROOT:-$PWD}
 out=$root/gpurun_out/pmc_sq
 rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU --output-format csv -d $out/a -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu --tune 2=0,7=0 "$@" > $out/a.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $out/b -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu --tune 2=0,7=0 "$@" > $out/b.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU --output-format csv -d $out/a -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu --no-emulated-shards --tune 2=0,7=0 "$@" > $out/a.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $out/b -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu --no-emulated-shards --tune 2=0,7=0 "$@" > $out/b.log 2>&1
 cd $root
 python3 - <<'PY'
 import csv, glob, collections, json

@@ -13,10 +13,10 @@ cd /tmp && export TMPDIR=/tmp
 # (--tune 2=0,7=0: kernels one after the other on one stream, as in the HIP-event profile bench.py's roofline is built from; with the side
 #  streams of the default step a kernel's trace duration includes the time it shares the chip with the kernels beside it -- that trace
 #  is kept too, as stats_concurrent)
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $root/bench.py --steps 10 --warmup 2 --no-cpu --tune 2=0,7=0 "$@" > $out/stats.log 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_concurrent -- python3 $root/bench.py --steps 10 --warmup 2 --no-cpu "$@" > $out/stats_concurrent.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu "$@" > $out/fetch.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu "$@" > $out/write.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $root/bench.py --steps 10 --warmup 2 --no-cpu --no-emulated-shards --tune 2=0,7=0 "$@" > $out/stats.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_concurrent -- python3 $root/bench.py --steps 10 --warmup 2 --no-cpu --no-emulated-shards "$@" > $out/stats_concurrent.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu --no-emulated-shards "$@" > $out/fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu --no-emulated-shards "$@" > $out/write.log 2>&1
 cd $root
 python3 - "$out" "$tag" "$@" <<'PY'
 import csv, glob, json, sys, collections

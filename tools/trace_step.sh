@@ -5,7 +5,7 @@ root=${GRAFT_REPO_ROOT:-$PWD}
 out=$root/gpurun_out/trace_$tag
 rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $out -- python3 $root/bench.py --steps 6 --warmup 2 --no-cpu "$@" > $out/log.txt 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $out -- python3 $root/bench.py --steps 6 --warmup 2 --no-cpu --no-emulated-shards --no-calibrate "$@" > $out/log.txt 2>&1
 cd $root
 python3 - "$out" > gpurun_out/trace_$tag.txt <<'PY'
 import csv, glob, sys
