@@ -120,12 +120,22 @@ def source_id() -> str:
     return h.hexdigest()[:16]
 
 
+def built_id():
+    """cs_build_id() of the library file in the tree (None if it is missing or does not load).  Asked of a child process, so that a
+    library about to be rebuilt is never mapped into this one."""
+    if not os.path.exists(LIB_PATH):
+        return None
+    import sys
+    code = f"import ctypes; L = ctypes.CDLL({LIB_PATH!r}); L.cs_build_id.restype = ctypes.c_char_p; print(L.cs_build_id().decode())"
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    return out.stdout.strip() if out.returncode == 0 else None
+
+
 def build_native(force: bool = False, verbose: bool = False) -> str:
     """Compile csrc/*.hip for gfx950 into csrc/libclearsky_hip.so with hipcc (cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, "cs_api.hip")]
-    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [HEADER, HEADER_DEV]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
-        return LIB_PATH
+    if not force and os.path.exists(LIB_PATH) and built_id() == source_id():
+        return LIB_PATH      # the binary says which sources it was compiled from (cs_build_id): file dates are not consulted
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", f'-DCS_BUILD_ID="{source_id()}"', "-o", LIB_PATH] + srcs
     if verbose:

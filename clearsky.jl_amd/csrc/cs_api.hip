@@ -181,6 +181,9 @@ struct ChebGrid {
     DevBuf nodes;               // [nItot][64]
     DevBuf Cm[CS_MAX_LEVEL];    // [nI][64][itv]
     DevBuf Rc[CS_MAX_LEVEL];    // level l >= 1: [nI][64][64], the parent's node values carried to the nodes of an interval (k_cheb_cascade)
+    DevBuf tnodes, tC;          // per 64-point tile: 16 Chebyshev nodes [tiles][16] and the matrix that carries values at them to the tile's points
+                                // [tiles][16][64] (k_voigt_edge_mx: the window-end lines inside the cut-off of every point of the tile)
+    bool tile_nodes_ok = false; // 16 nodes carry such lines to rounding on this grid (far_node_count of their distance; cheb_build)
 };
 // per gas on that grid: windows per level, zones [K][nItot], node sums F [nItot][64][Kpad]
 struct GasInterp { int nlev = 0, l0 = 0; int nfar[CS_MAX_LEVEL] = {}; DevBuf iwin[CS_MAX_LEVEL], iz, F, sep, edge; };   // nfar: nodes for a level's far pieces (far_node_count)   // levels l0 .. nlev-1 of the grid are in use; sep: SepZone [K/16][nItot]
@@ -738,6 +741,7 @@ struct Interp {
     int nsplit_levels = 1;    // cs_set_tuning key 6: interval sizes (largest first) whose node sums four waves share in k_cheb_nodes_mx
     bool small_mx = false;    // cs_set_tuning key 1: the matrix-core kernels on short grids too (their four-waves-per-item variants)
     bool mxzones_one_thread = false;   // cs_set_tuning key 15 | 16: k_mxzones instead of k_mxzones16
+    const double *tnodes = nullptr, *tC = nullptr;   // ChebGrid::tnodes, tC where the grid allows (tile_nodes_ok) and cs_set_tuning key 23 = 0
     int far_split = 0;                 // cs_set_tuning key 22: waves per tile of k_voigt_far (1, 2, 4; 0 = by grid size)
     int mxzones_merge = 0;             // cs_set_tuning key 21: the piece tables as blocks of k_gas_setup's launch (k_gas_setup_mx) -- 0 = on grids below 1024 tiles, 1 = never, 2 = always
     bool near_both = true;             // both tiers of the near-line pairs in one launch where a wave takes one tile (cs_set_tuning key 16 | 4: off)
@@ -764,6 +768,7 @@ static void interp_settings(const cs_ctx *ctx, Interp &itp)   // the cs_set_tuni
     itp.near_memset = ctx->tune[19] != 0;
     itp.mxzones_merge = ctx->tune[21];
     itp.far_split = ctx->tune[22];
+    if (ctx->tune[23]) itp.tnodes = itp.tC = nullptr;     // (cs_set_tuning key 23 = 1: every window-end line at the points, A/B)
 }
 
 // interval sizes worth using on this grid: an interval of width W leaves lines over (2 cut - 2.3 W) to interpolate
@@ -785,12 +790,22 @@ int choose_levels(const double *nu, int64_t nnu, double cut, int *itv, int szmin
 
 // the grid part: nodes [nItot][64] and interpolation matrices [nI][64][itv] per level
 int cheb_build_range(ChebGrid &g, double nu_lo, double nu_hi, const double *dnu, int64_t nnu, double cut, int szmin, int szmax, hipStream_t s);
+int far_node_count(double dist, double h);
 int cheb_build(const cs_ctx *ctx, ChebGrid &g, const double *h_nu, const double *dnu, int64_t nnu, double cut, hipStream_t s)
 {
     const int rc = cheb_build_range(g, h_nu[0], h_nu[nnu - 1], dnu, nnu, cut, ctx->itp_min, ctx->itp_max, s);
     for (int l = 0; l < g.nlev; l++) {
         g.span[l] = 0.0;
         for (int64_t i0 = 0; i0 < nnu; i0 += g.itv[l]) g.span[l] = std::max(g.span[l], h_nu[std::min<int64_t>(i0 + g.itv[l] - 1, nnu - 1)] - h_nu[i0]);
+    }
+    // the window-end lines inside the cut-off of every point of a tile are at least cut-off - (smallest interval) - (tile) from it:
+    // 16 nodes of the tile carry their sum to rounding where far_node_count says so (23 cm^-1 from a 1.6 cm^-1 tile: by far)
+    g.tile_nodes_ok = false;
+    if (g.nlev > 0) {
+        double tspan = 0.0;
+        for (int64_t i0 = 0; i0 < nnu; i0 += 64) tspan = std::max(tspan, h_nu[std::min<int64_t>(i0 + 63, nnu - 1)] - h_nu[i0]);
+        const double dist = cut - g.span[g.nlev - 1] - tspan;
+        g.tile_nodes_ok = tspan > 0.0 && dist > 0.0 && far_node_count(dist, 0.5 * tspan) == 16;
     }
     return rc;
 }
@@ -824,6 +839,13 @@ int cheb_build_range(ChebGrid &g, double nu_lo, double nu_hi, const double *dnu,
         for (int r = g.itv[l - 1] / g.itv[l]; r > 1; r >>= 1) pshift++;
         HIPCHK(g.Rc[l].reserve((size_t)g.nI[l] * CS_NC * CS_NC * sizeof(double)));
         CS_LAUNCH(k_cascade_setup, dim3(g.nI[l]), dim3(256), 0, s, g.nodes.as<double>(), g.ioff[l - 1], g.ioff[l], pshift, g.Rc[l].as<double>());
+        HIPCHK(hipGetLastError());
+    }
+    {   // the tiles as intervals of their own with 16 nodes (k_voigt_edge_mx's node path)
+        const int nt64 = (int)((nnu + 63) / 64);
+        HIPCHK(g.tnodes.reserve((size_t)nt64 * 16 * sizeof(double)));
+        HIPCHK(g.tC.reserve((size_t)nt64 * 16 * 64 * sizeof(double)));
+        CS_LAUNCH(k_cheb_setup, dim3(nt64), dim3(256), 0, s, dnu, nnu, 64, nt64, 16, g.tnodes.as<double>(), g.tC.as<double>());
         HIPCHK(hipGetLastError());
     }
     return CS_OK;
@@ -901,6 +923,7 @@ Interp interp_view(const ChebGrid &g, const GasInterp &gi, int K, IZone *iz_over
     v.F = gi.F.as<double>();
     v.sep = gi.sep.as<SepZone>();
     v.edge = gi.edge.as<EdgeZone>();
+    if (g.tile_nodes_ok) { v.tnodes = g.tnodes.as<double>(); v.tC = g.tC.as<double>(); }
     for (int l = 0; l < gi.nlev; l++) {
         v.itv[l] = g.itv[l]; v.nI[l] = g.nI[l]; v.ioff[l] = g.ioff[l];
         v.nfar[l] = gi.nfar[l];
@@ -1415,10 +1438,12 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
             if (fuse) fork_join(fork, s);   // (it reads F)
             if (mx_big(nt64, kn, 1024))
                 CS_LAUNCH(k_voigt_edge_mx<1>, dim3((unsigned)((nt64 + 3) / 4), (unsigned)((kn + 15) / 16)), dim3(256), 0, s, dnu, nnu, G.L, hot, win,
-                          itp.edge, nt64, kn, cut, sigma, fuse ? 1 : 0, Afuse, itp.Kpad, G.nu.as<double>(), itp.edge_phases);
+                          itp.edge, nt64, kn, cut, sigma, fuse ? 1 : 0, Afuse, itp.Kpad, G.nu.as<double>(), itp.edge_phases,
+                          itp.edge_phases ? itp.tnodes : nullptr, itp.tC);
             else   // short grid: four waves per (tile, group)
                 CS_LAUNCH(k_voigt_edge_mx<4>, dim3((unsigned)nt64, (unsigned)((kn + 15) / 16)), dim3(256), 0, s, dnu, nnu, G.L, hot, win,
-                          itp.edge, nt64, kn, cut, sigma, fuse ? 1 : 0, Afuse, itp.Kpad, G.nu.as<double>(), itp.edge_phases);
+                          itp.edge, nt64, kn, cut, sigma, fuse ? 1 : 0, Afuse, itp.Kpad, G.nu.as<double>(), itp.edge_phases,
+                          (const double *)nullptr, (const double *)nullptr);
         }
         if (evg) (void)hipEventRecord(evg[5], s);
         if (!lor && !near_fork) launch_near(s, sigma);
@@ -3391,6 +3416,7 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
                     };
                     // the cut-off edges, cut where the next sub-tile comes into reach (k_voigt_edge_mx's phases: one wave per (tile, group) only)
                     const bool phased = !ctx->tune[14] && mx_big(nt64, K, 1024);
+                    bool tile_carry = false;
                     auto end_piece = [&](int ja, int jb, int nt, bool left) {
                         if (jb <= ja) return;
                         if (!phased || jb - ja < 48) { piece(ja, jb, nt, 1); return; }
@@ -3399,7 +3425,18 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
                         fl_edge_issued = issued0;
                         const double tolc = 1e-9 * (std::fabs(v0[0]) + g.cut + 1.0);
                         int cutp[5];
+                        // the lines inside the cut-off of every point of the tile: on 16 nodes of the tile (one sub-tile per step) + the carry
+                        // to the points, 16 matrix instructions per (tile, group) that has any
+                        const bool tnodes_on = c.cheb.tile_nodes_ok && !ctx->tune[23];
                         if (left) {
+                            if (tnodes_on) {
+                                const int j3 = (int)(std::lower_bound(nl + ja, nl + jb, *(v1 - 1) - g.cut + tolc) - nl);
+                                if (jb - j3 >= 16) {
+                                    fl_edge_issued += 2.0 * nt * 16.0 * 16.0 * ((jb - j3 + 3) / 4 * 4);
+                                    tile_carry = true;
+                                    jb = j3;
+                                }
+                            }
                             cutp[0] = ja; cutp[4] = jb;
                             for (int q = 0; q < 3; q++) {
                                 const double *col = vv + std::min<int64_t>((int64_t)t * 64 + 16 * (q + 1), c.nnu - 1);
@@ -3408,6 +3445,14 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
                             for (int q = 1; q < 5; q++) cutp[q] = std::max(cutp[q], cutp[q - 1]);
                             for (int q = 0; q < 4; q++) fl_edge_issued += 2.0 * nt * 16.0 * (q + 1) * 16.0 * ((cutp[q + 1] - cutp[q] + 3) / 4 * 4);
                         } else {
+                            if (tnodes_on) {
+                                const int u3 = (int)(std::upper_bound(nl + ja, nl + jb, v0[0] + g.cut - tolc) - nl);
+                                if (u3 - ja >= 16) {
+                                    fl_edge_issued += 2.0 * nt * 16.0 * 16.0 * ((u3 - ja + 3) / 4 * 4);
+                                    tile_carry = true;
+                                    ja = u3;
+                                }
+                            }
                             cutp[0] = ja; cutp[4] = jb;
                             for (int q = 0; q < 3; q++) {
                                 const double *col = vv + std::min<int64_t>((int64_t)t * 64 + 16 * q + 15, c.nnu - 1);
@@ -3417,8 +3462,10 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
                             for (int q = 0; q < 4; q++) fl_edge_issued += 2.0 * nt * 16.0 * (4 - q) * 16.0 * ((cutp[q + 1] - cutp[q] + 3) / 4 * 4);
                         }
                     };
+                    tile_carry = false;
                     end_piece(w.W0, e.eL, (e.far3 & 1) ? 3 : 4, true);
                     end_piece(e.eR, w.W1, (e.far3 & 2) ? 3 : 4, false);
+                    if (tile_carry) fl_edge_issued += 16.0 * 2048.0;
                     if (e.mL1 > e.mL0) { piece(e.mL0, e.mL3, 3, 1); piece(e.mL3, e.mL1, 4, 1); }
                     if (e.mR1 > e.mR0) { piece(e.mR3, e.mR1, 3, 1); piece(e.mR0, e.mR3, 4, 1); }
                     if (e.cR > e.cL) piece(e.cL, e.cR, (e.far3 & 4) ? 8 : 4, 2);

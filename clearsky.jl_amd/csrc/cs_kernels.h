@@ -1822,13 +1822,15 @@ template <int SPLIT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_voigt_edge_mx(const double *__restrict__ nu, int64_t nnu, int64_t L, const LineHot *__restrict__ hot,
                                                        const WaveWin *__restrict__ win, const EdgeZone *__restrict__ edge, int ntile, int K,
                                                        double cut, double *__restrict__ sigma, int fuse, ChebApply A, int Kpad,
-                                                       const double *__restrict__ gnul, int phases)
+                                                       const double *__restrict__ gnul, int phases, const double *__restrict__ tnodes,
+                                                       const double *__restrict__ tC)
 {
     // phases (SPLIT = 1): the far lines of a cut-off edge reach only the first (left end) or last (right end) columns of the tile, and
     // the reach grows with the line index -- so the window end is cut where the next 16-column sub-tile comes into reach, and each
     // part multiplies only the sub-tiles it can reach (a per-step test of "sub-tile all masked" cost what it saved; these are four
     // loops with the sub-tile count fixed at compile time).  gnul: the table's line positions (state-independent).
     __shared__ double part[SPLIT > 1 ? 4 : 1][SPLIT > 1 ? 16 : 1][SPLIT > 1 ? CS_MX_PITCH : 1];
+    __shared__ double trn[SPLIT == 1 ? 4 : 1][SPLIT == 1 ? 16 : 1][SPLIT == 1 ? 18 : 1];   // (the node path's transpose, per wave)
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     // (2-D grid, tile blocks fastest: consecutive blocks are neighbouring tiles of ONE state group, whose pieces overlap by half --
     // the XCD-aware 1-D order of k_cheb_apply_mfma, all groups of a tile block back to back on one XCD, costs 0.43 -> 0.57 ms at C3)
@@ -1880,31 +1882,91 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     // left pieces ascending, right pieces descending: far lines first; three terms where they do
     const bool ph = SPLIT == 1 && phases && gnul;
     const double tolc = 1e-9 * (fabs(__shfl(vn[0], 0)) + cut + 1.0);
-    if (ph && e.eL - w.W0 >= 48) {   // (shorter ends: the four partial loops and their step fill cost more than the skipped sub-tiles -- C5: 0.350 -> 0.386 ms)
-        // J[q]: first line of [W0, eL) whose cut-off reaches sub-tile q + 1 (its first column): one vector load per 64 lines and ballots
+    // (shorter ends: the four partial loops and their step fill cost more than the skipped sub-tiles -- C5: 0.350 -> 0.386 ms)
+    const bool phL = ph && e.eL - w.W0 >= 48, phR = ph && w.W1 - e.eR >= 48;
+    // Round 5: the lines of a window end that are inside the cut-off of EVERY point of the tile (they are in this end only because
+    // the tile's 128-point interval has points they do not reach) need no mask and are 23+ cm^-1 = 29 half-widths of the tile away:
+    // their sum is a polynomial of low degree across the tile, formed on 16 Chebyshev nodes of the tile (one sub-tile per matrix step
+    // instead of four) and carried to the 64 points by the tile's 64 x 16 matrix tC (k_cheb_setup with 16 nodes; tnodes = NULL: off).
+    const bool nd = tnodes != nullptr;
+    int J[4] = {e.eL, e.eL, e.eL, e.eL}, U[4] = {w.W1, w.W1, w.W1, e.eR};   // J[3] .. eL, eR .. U[3]: the lines that go to the nodes
+    if (phL) {
+        // J[q]: first line of [W0, eL) whose cut-off reaches sub-tile q + 1 (its first column); J[3]: ... the tile's last point.  One
+        // vector load per 64 lines and ballots
         const int p0 = w.W0, p1 = e.eL;
-        int J[3] = {p1, p1, p1};
-        const double a0 = __shfl(vn[1], 0) - cut - tolc, a1 = __shfl(vn[2], 0) - cut - tolc, a2 = __shfl(vn[3], 0) - cut - tolc;
+        const double a0 = __shfl(vn[1], 0) - cut - tolc, a1 = __shfl(vn[2], 0) - cut - tolc, a2 = __shfl(vn[3], 0) - cut - tolc,
+                     a3 = __shfl(vn[3], 15) - cut + tolc;
+        bool f0 = false, f1 = false, f2 = false, f3 = false;
         for (int base = p0; base < p1; base += 64) {
             const int j = base + lane;
             const double x = gnul[j < p1 ? j : p1 - 1];
             const uint64_t m0 = __builtin_amdgcn_ballot_w64(j < p1 && x >= a0), m1 = __builtin_amdgcn_ballot_w64(j < p1 && x >= a1),
-                           m2 = __builtin_amdgcn_ballot_w64(j < p1 && x >= a2);
-            if (m0 != 0 && J[0] == p1) J[0] = base + __builtin_ctzll(m0);
-            if (m1 != 0 && J[1] == p1) J[1] = base + __builtin_ctzll(m1);
-            if (m2 != 0 && J[2] == p1) J[2] = base + __builtin_ctzll(m2);
+                           m2 = __builtin_amdgcn_ballot_w64(j < p1 && x >= a2), m3 = __builtin_amdgcn_ballot_w64(j < p1 && x >= a3);
+            if (m0 != 0 && !f0) { J[0] = base + __builtin_ctzll(m0); f0 = true; }
+            if (m1 != 0 && !f1) { J[1] = base + __builtin_ctzll(m1); f1 = true; }
+            if (m2 != 0 && !f2) { J[2] = base + __builtin_ctzll(m2); f2 = true; }
+            if (m3 != 0 && !f3) { J[3] = base + __builtin_ctzll(m3); f3 = true; }
         }
-        J[1] = max(J[1], J[0]); J[2] = max(J[2], J[1]);
+        J[1] = max(J[1], J[0]); J[2] = max(J[2], J[1]); J[3] = max(J[3], J[2]);
+        if (!nd || p1 - J[3] < 16) J[3] = p1;     // (too few for a trip of their own)
+    }
+    if (phR) {
+        // U[q]: first line of [eR, W1) whose cut-off no longer reaches sub-tile q (its last column); lines from U[q] on need the
+        // sub-tiles q + 1 .. 3 only.  U[3]: first line that no longer reaches the tile's FIRST point: [eR, U[3]) reach every point
+        const int p0 = e.eR, p1 = w.W1;
+        const double b0 = __shfl(vn[0], 15) + cut + tolc, b1 = __shfl(vn[1], 15) + cut + tolc, b2 = __shfl(vn[2], 15) + cut + tolc,
+                     b3 = __shfl(vn[0], 0) + cut - tolc;
+        bool f0 = false, f1 = false, f2 = false, f3 = false;
+        U[3] = p1;
+        for (int base = p0; base < p1; base += 64) {
+            const int j = base + lane;
+            const double x = gnul[j < p1 ? j : p1 - 1];
+            const uint64_t m0 = __builtin_amdgcn_ballot_w64(j < p1 && x > b0), m1 = __builtin_amdgcn_ballot_w64(j < p1 && x > b1),
+                           m2 = __builtin_amdgcn_ballot_w64(j < p1 && x > b2), m3 = __builtin_amdgcn_ballot_w64(j < p1 && x > b3);
+            if (m0 != 0 && !f0) { U[0] = base + __builtin_ctzll(m0); f0 = true; }
+            if (m1 != 0 && !f1) { U[1] = base + __builtin_ctzll(m1); f1 = true; }
+            if (m2 != 0 && !f2) { U[2] = base + __builtin_ctzll(m2); f2 = true; }
+            if (m3 != 0 && !f3) { U[3] = base + __builtin_ctzll(m3); f3 = true; }
+        }
+        U[1] = max(U[1], U[0]); U[2] = max(U[2], U[1]); U[3] = min(U[3], U[0]);
+        if (!nd || U[3] - p0 < 16) U[3] = p0;
+    }
+    if (SPLIT == 1 && nd && ((phL && J[3] < e.eL) || (phR && U[3] > e.eR))) {   // (wave-uniform)
+        v4f64_sep af[1] = {v4f64_sep{0.0, 0.0, 0.0, 0.0}};
+        const double vf[1] = {tnodes[(size_t)tile * 16 + lr]};
+        if (phL && J[3] < e.eL) {
+            if (e.far3 & 1) sep_run<3, 0, 1, 0, 1>(af, vf, hk, J[3], e.eL, true, lq, 0.0); else sep_run<4, 0, 1, 0, 1>(af, vf, hk, J[3], e.eL, true, lq, 0.0);
+        }
+        if (phR && U[3] > e.eR) {
+            if (e.far3 & 2) sep_run<3, 0, 1, 0, 1>(af, vf, hk, e.eR, U[3], false, lq, 0.0); else sep_run<4, 0, 1, 0, 1>(af, vf, hk, e.eR, U[3], false, lq, 0.0);
+        }
+        // acc[state][point] += sum_m af[state][m] tC[tile][m][point]: af goes through LDS from the D layout (state 4r + lq, node lr) to the A
+        // layout (state lr, node lq of a group of four), as in mx_far_pieces
+#pragma unroll
+        for (int r = 0; r < 4; r++) trn[wv][4 * r + lq][lr] = af[0][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        const double *__restrict__ Cp = tC + (size_t)tile * 16 * 64;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            const double a = trn[wv][lr][4 * kk + lq];
+#pragma unroll
+            for (int st2 = 0; st2 < 4; st2++)
+                acc[st2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Cp[(size_t)(4 * kk + lq) * 64 + 16 * st2 + lr], acc[st2], 0, 0, 0);
+        }
+    }
+    if (phL) {
+        const int p0 = w.W0;
         if (e.far3 & 1) {
             sep_run<3, 1, 1, 0>(acc, vn, hk, p0, J[0], true, lq, cut);
             sep_run<3, 1, 2, 0>(acc, vn, hk, J[0], J[1], true, lq, cut);
             sep_run<3, 1, 3, 0>(acc, vn, hk, J[1], J[2], true, lq, cut);
-            sep_run<3, 1, 4, 0>(acc, vn, hk, J[2], p1, true, lq, cut);
+            sep_run<3, 1, 4, 0>(acc, vn, hk, J[2], J[3], true, lq, cut);
         } else {
             sep_run<4, 1, 1, 0>(acc, vn, hk, p0, J[0], true, lq, cut);
             sep_run<4, 1, 2, 0>(acc, vn, hk, J[0], J[1], true, lq, cut);
             sep_run<4, 1, 3, 0>(acc, vn, hk, J[1], J[2], true, lq, cut);
-            sep_run<4, 1, 4, 0>(acc, vn, hk, J[2], p1, true, lq, cut);
+            sep_run<4, 1, 4, 0>(acc, vn, hk, J[2], J[3], true, lq, cut);
         }
     } else {
         run(w.W0, e.eL, true, ja, jb);
@@ -1914,32 +1976,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         run(e.mL0, e.mL3, true, ja, jb); sep_run<3, 1>(acc, vn, hk, ja, jb, true, lq, cut);
         run(e.mL3, e.mL1, true, ja, jb); sep_run<4, 1>(acc, vn, hk, ja, jb, true, lq, cut);
     }
-    if (ph && w.W1 - e.eR >= 48) {
-        // U[q]: first line of [eR, W1) whose cut-off no longer reaches sub-tile q (its last column); lines from U[q] on need the
-        // sub-tiles q + 1 .. 3 only
-        const int p0 = e.eR, p1 = w.W1;
-        int U[3] = {p1, p1, p1};
-        const double b0 = __shfl(vn[0], 15) + cut + tolc, b1 = __shfl(vn[1], 15) + cut + tolc, b2 = __shfl(vn[2], 15) + cut + tolc;
-        for (int base = p0; base < p1; base += 64) {
-            const int j = base + lane;
-            const double x = gnul[j < p1 ? j : p1 - 1];
-            const uint64_t m0 = __builtin_amdgcn_ballot_w64(j < p1 && x > b0), m1 = __builtin_amdgcn_ballot_w64(j < p1 && x > b1),
-                           m2 = __builtin_amdgcn_ballot_w64(j < p1 && x > b2);
-            if (m0 != 0 && U[0] == p1) U[0] = base + __builtin_ctzll(m0);
-            if (m1 != 0 && U[1] == p1) U[1] = base + __builtin_ctzll(m1);
-            if (m2 != 0 && U[2] == p1) U[2] = base + __builtin_ctzll(m2);
-        }
-        U[1] = max(U[1], U[0]); U[2] = max(U[2], U[1]);
+    if (phR) {
+        const int p1 = w.W1;
         if (e.far3 & 2) {
             sep_run<3, 1, 1, 3>(acc, vn, hk, U[2], p1, false, lq, cut);
             sep_run<3, 1, 2, 2>(acc, vn, hk, U[1], U[2], false, lq, cut);
             sep_run<3, 1, 3, 1>(acc, vn, hk, U[0], U[1], false, lq, cut);
-            sep_run<3, 1, 4, 0>(acc, vn, hk, p0, U[0], false, lq, cut);
+            sep_run<3, 1, 4, 0>(acc, vn, hk, U[3], U[0], false, lq, cut);
         } else {
             sep_run<4, 1, 1, 3>(acc, vn, hk, U[2], p1, false, lq, cut);
             sep_run<4, 1, 2, 2>(acc, vn, hk, U[1], U[2], false, lq, cut);
             sep_run<4, 1, 3, 1>(acc, vn, hk, U[0], U[1], false, lq, cut);
-            sep_run<4, 1, 4, 0>(acc, vn, hk, p0, U[0], false, lq, cut);
+            sep_run<4, 1, 4, 0>(acc, vn, hk, U[3], U[0], false, lq, cut);
         }
     } else {
         run(e.eR, w.W1, false, ja, jb);
