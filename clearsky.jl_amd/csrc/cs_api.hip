@@ -2923,7 +2923,10 @@ static int sigma_impl(cs_ctx *ctx, hipStream_t s, hipEvent_t *ev, int &e, bool *
     const bool short_aside = fuse && c.rtg.streams;
     // long grids: where the cascade is in use anyway (four levels and up) it runs on the node-sum stream as well, beside the per-point
     // kernels, instead of between them and the flux kernel (BASELINE configs[4]: four launches, 0.32 ms of the main stream)
-    const bool casc_on = nl_itp >= 2 && ctx->tune[12] != 2 && (ctx->tune[12] == 1 || cascade_pays(nl_itp));
+    // ... and with the node sums on a side stream the cascade is off the step's critical path whatever the number of levels: that stream
+    // ends long before the other two at full size (the bench column: 1.34 against 1.60 and 1.86 ms into the step), so folding three levels
+    // into one there makes the carry to the grid a third of its matrix products and of its reads of C (round 5: 1.880 -> 1.872 ms)
+    const bool casc_on = nl_itp >= 2 && ctx->tune[12] != 2 && (ctx->tune[12] == 1 || cascade_pays(nl_itp) || fk.pending);
     if (apply.ngas == 1 && fk.pending && !(ctx->tune[15] & 256) && nl_itp >= 2 && (short_aside || casc_on)) {
         const double *Rc[CS_MAX_LEVEL];
         for (int l = 0; l < CS_MAX_LEVEL; l++) Rc[l] = c.cheb.Rc[l].as<double>();
