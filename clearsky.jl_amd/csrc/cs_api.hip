@@ -743,6 +743,7 @@ struct Interp {
     bool mxzones_one_thread = false;   // cs_set_tuning key 15 | 16: k_mxzones instead of k_mxzones16
     const double *tnodes = nullptr, *tC = nullptr;   // ChebGrid::tnodes, tC where the grid allows (tile_nodes_ok) and cs_set_tuning key 23 = 0
     int far_split = 0;                 // cs_set_tuning key 22: waves per tile of k_voigt_far (1, 2, 4; 0 = by grid size)
+    bool far_shared_full = false;      // cs_set_tuning key 17: far pieces of an item the four waves of a block share on all 64 nodes (A/B)
     int mxzones_merge = 0;             // cs_set_tuning key 21: the piece tables as blocks of k_gas_setup's launch (k_gas_setup_mx) -- 0 = on grids below 1024 tiles, 1 = never, 2 = always
     bool near_both = true;             // both tiers of the near-line pairs in one launch where a wave takes one tile (cs_set_tuning key 16 | 4: off)
     int near_prio = 0;                 // cs_set_tuning key 16: issue priority for k_voigt_sub / k_voigt_near (0 = from 512 tiles on, 1 = never, 2 = always)
@@ -768,6 +769,7 @@ static void interp_settings(const cs_ctx *ctx, Interp &itp)   // the cs_set_tuni
     itp.near_memset = ctx->tune[19] != 0;
     itp.mxzones_merge = ctx->tune[21];
     itp.far_split = ctx->tune[22];
+    itp.far_shared_full = ctx->tune[17] != 0;
     if (ctx->tune[23]) itp.tnodes = itp.tC = nullptr;     // (cs_set_tuning key 23 = 1: every window-end line at the points, A/B)
 }
 
@@ -893,8 +895,16 @@ int gas_interp_build(const cs_ctx *ctx, GasInterp &gi, ChebGrid &g, const std::v
         if (gi.l0 >= g.nlev) { gi.nlev = 0; gi.l0 = 0; return CS_OK; }   // too few lines: every pair directly
     }
     // far pieces of a level (the lines beyond its parent's set): at least cut-off minus the parent's width from the interval
-    for (int l = 0; l < g.nlev; l++)
+    // The carry from those nodes to the interval's 64 is a FIXED matrix in the interval's own coordinate, while both node sets are
+    // doubles near nu: a sample taken half an ulp(nu) from its ideal place is off by 2 (ulp / 2) / distance of a 1/dnu^2 wing, and
+    // nothing downstream knows (the 64-node sums go through matrices built from the stored nodes themselves, and the tile nodes of
+    // k_voigt_edge_mx likewise).  Fewer nodes only where ulp / distance <= 8e-14 (cut-off 25 cm^-1 at 2500 cm^-1: 2.4e-14 / 3.7e-14;
+    // a cut-off of 1 cm^-1 there would give 9e-13 -- tests/test_gpu_fuzz.py::test_interp_fuzz[8] once the short grids took this path)
+    const double ulp_hi = std::nextafter(std::fabs(nu[nnu - 1]), INFINITY) - std::fabs(nu[nnu - 1]);
+    for (int l = 0; l < g.nlev; l++) {
         gi.nfar[l] = (l > gi.l0 && g.span[l - 1] > 0.0 && g.span[l] > 0.0) ? far_node_count(cut - g.span[l - 1], 0.5 * g.span[l]) : CS_NC;
+        if (gi.nfar[l] < CS_NC && !(ulp_hi <= 8e-14 * (cut - g.span[l - 1]))) gi.nfar[l] = CS_NC;
+    }
     for (int l = 0; l < g.nlev; l++) {
         std::vector<WaveWin> iwin;
         wave_windows(nul, g0, g1, nu, nnu, cut, iwin, g.itv[l]);
@@ -1303,7 +1313,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
                 mf.nlev = itp.nlev;
                 for (int l = 0; l < itp.nlev; l++) { mf.ioff[l] = itp.ioff[l]; mf.nfar[l] = itp.nfar[l] > 0 ? itp.nfar[l] : CS_NC; }
                 mf.ioff[itp.nlev] = itp.nItot;
-                mf.R = itp.R;
+                mf.R = (itp.far_shared_full && nsplit == nq) ? nullptr : itp.R;
                 CS_LAUNCH(k_cheb_nodes_mx, dim3(nblk_mx), dim3(256), 0, s, itp.nodes, G.L, hot, itp.sep, itp.nItot, q0, nsplit, kn,
                                    itp.Kpad, ngrp, itp.F, itp.iz, mf);
             }
@@ -1443,7 +1453,7 @@ void launch_gas(hipStream_t s, int shape, const GasTable &G, int64_t jrange0, in
             else   // short grid: four waves per (tile, group)
                 CS_LAUNCH(k_voigt_edge_mx<4>, dim3((unsigned)nt64, (unsigned)((kn + 15) / 16)), dim3(256), 0, s, dnu, nnu, G.L, hot, win,
                           itp.edge, nt64, kn, cut, sigma, fuse ? 1 : 0, Afuse, itp.Kpad, G.nu.as<double>(), itp.edge_phases,
-                          (const double *)nullptr, (const double *)nullptr);
+                          (const double *)nullptr, (const double *)nullptr);   // (the 16-node path in the shared form: 16 more matrix steps per WAVE, no gain measured)
         }
         if (evg) (void)hipEventRecord(evg[5], s);
         if (!lor && !near_fork) launch_near(s, sigma);
@@ -3321,7 +3331,8 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
             nsplit_w += q0w;   // intervals below this index are split
         }
         auto far_nodes = [&](int q, int p) {
-            if (ctx->tune[11] || (p != 0 && p != 3) || q < nsplit_w) return (int)CS_NC;
+            // (since round 5 the shared items take their far pieces on fewer nodes as well; key 17: not where every item is shared)
+            if (ctx->tune[11] || (p != 0 && p != 3) || (ctx->tune[17] && nsplit_w >= nItot)) return (int)CS_NC;
             int l = 0;
             while (l + 1 < nlev && q >= c.cheb.ioff[l + 1]) l++;
             return g.itp.nfar[l] > 0 ? g.itp.nfar[l] : (int)CS_NC;
@@ -3422,15 +3433,15 @@ int cs_column_work(cs_ctx *ctx, int64_t *out)
                     bool tile_carry = false;
                     auto end_piece = [&](int ja, int jb, int nt, bool left) {
                         if (jb <= ja) return;
+                        // the lines inside the cut-off of every point of the tile: on 16 nodes of the tile (one sub-tile per step) + the carry
+                        // to the points, 16 matrix instructions per (tile, group) that has any
+                        const bool tnodes_on = c.cheb.tile_nodes_ok && !ctx->tune[23];
                         if (!phased || jb - ja < 48) { piece(ja, jb, nt, 1); return; }
                         const double issued0 = fl_edge_issued;
                         piece(ja, jb, nt, 1);              // (for the useful flops)
                         fl_edge_issued = issued0;
                         const double tolc = 1e-9 * (std::fabs(v0[0]) + g.cut + 1.0);
                         int cutp[5];
-                        // the lines inside the cut-off of every point of the tile: on 16 nodes of the tile (one sub-tile per step) + the carry
-                        // to the points, 16 matrix instructions per (tile, group) that has any
-                        const bool tnodes_on = c.cheb.tile_nodes_ok && !ctx->tune[23];
                         if (left) {
                             if (tnodes_on) {
                                 const int j3 = (int)(std::lower_bound(nl + ja, nl + jb, *(v1 - 1) - g.cut + tolc) - nl);

@@ -1058,9 +1058,19 @@ __device__ __forceinline__ void sepzones_body(unsigned bid, const SepArgs &a)
 struct MxFar { int nlev, ioff[CS_MAX_LEVEL + 1], nfar[CS_MAX_LEVEL]; const double *R; };   // nfar[l]: 16, 32 or 64 (= as before); R = NULL: 64 everywhere
 template <int NST>
 __device__ __forceinline__ void mx_far_pieces(v4f64_sep (&acc)[4], const SepZone &z, const LineHot *__restrict__ hk, double vlo, double vhi,
-                                              int lr, int lq, int S0k, int S1k, const double *__restrict__ R, double (*__restrict__ tr)[CS_MX_PITCH])
+                                              int lr, int lq, int S0k, int S1k, const double *__restrict__ R, double (*__restrict__ tr)[CS_MX_PITCH],
+                                              int wq = 0, int nq = 1)
 {
+    // wq / nq: this wave's run of every part when the four waves of a block share the item (nq = 4: short grids, where every interval
+    // size is shared -- round 5; the carry below is linear, so each wave carries its own partial sum into its own accumulators)
     constexpr int n = 16 * NST;
+    auto mine = [&](int pa, int pb, bool asc, int &ja, int &jb) {   // (as `quarter` in k_cheb_nodes_mx: runs of a multiple of 4 lines, wave 0 at the far end)
+        if (nq == 1) { ja = pa; jb = pb; return; }
+        const int run = ((pb - pa + 15) >> 4) << 2;
+        ja = asc ? pa + wq * run : max(pb - (wq + 1) * run, pa);
+        jb = asc ? min(ja + run, pb) : pb - wq * run;
+    };
+    int ja, jb;
     const double cen = 0.5 * (vlo + vhi), h = 0.5 * (vhi - vlo);
     double vf[NST];
     v4f64_sep af[NST];
@@ -1070,12 +1080,12 @@ __device__ __forceinline__ void mx_far_pieces(v4f64_sep (&acc)[4], const SepZone
         af[st] = v4f64_sep{0.0, 0.0, 0.0, 0.0};
     }
     if (z.b[0] > z.a[0]) {   // left of the interval, ascending: the 3-term part (the far end) first
-        if (z.m[0] > z.a[0]) sep_run<3, 0, NST, 0, NST>(af, vf, hk, z.a[0], z.m[0], true, lq, 0.0, 0.0, -0x7fffffff, S0k);
-        if (z.b[0] > z.m[0]) sep_run<4, 0, NST, 0, NST>(af, vf, hk, z.m[0], z.b[0], true, lq, 0.0, 0.0, -0x7fffffff, S0k);
+        if (z.m[0] > z.a[0]) { mine(z.a[0], z.m[0], true, ja, jb); sep_run<3, 0, NST, 0, NST>(af, vf, hk, ja, jb, true, lq, 0.0, 0.0, -0x7fffffff, S0k); }
+        if (z.b[0] > z.m[0]) { mine(z.m[0], z.b[0], true, ja, jb); sep_run<4, 0, NST, 0, NST>(af, vf, hk, ja, jb, true, lq, 0.0, 0.0, -0x7fffffff, S0k); }
     }
     if (z.b[3] > z.a[3]) {   // right of it, descending
-        if (z.b[3] > z.m[3]) sep_run<3, 0, NST, 0, NST>(af, vf, hk, z.m[3], z.b[3], false, lq, 0.0, 0.0, S1k);
-        if (z.m[3] > z.a[3]) sep_run<4, 0, NST, 0, NST>(af, vf, hk, z.a[3], z.m[3], false, lq, 0.0, 0.0, S1k);
+        if (z.b[3] > z.m[3]) { mine(z.m[3], z.b[3], false, ja, jb); sep_run<3, 0, NST, 0, NST>(af, vf, hk, ja, jb, false, lq, 0.0, 0.0, S1k); }
+        if (z.m[3] > z.a[3]) { mine(z.a[3], z.m[3], false, ja, jb); sep_run<4, 0, NST, 0, NST>(af, vf, hk, ja, jb, false, lq, 0.0, 0.0, S1k); }
     }
     // acc[state][m] += sum_j af[state][j] R[m][j]: af goes through LDS from the D layout (state 4r + lq, node lr) to the A layout
     // (state lr, node lq of a group of four)
@@ -1142,14 +1152,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             jb = asc ? min(ja + run, pb) : pb - wv * run;
         };
         bool far_done = false;
-        if (!split && far.R) {   // (wave-uniform) the far pieces on 16 or 32 nodes where the interval's size allows
+        if (far.R) {   // (wave-uniform) the far pieces on 16 or 32 nodes where the interval's size allows; in a shared item every wave its own
+                       // quarter of them (the largest size has no far pieces on fewer nodes: only short grids, where every size is shared, get here so)
             int l = 0;
             while (l + 1 < far.nlev && T >= far.ioff[l + 1]) l++;
             const int nf = far.nfar[l];
             if (nf < CS_NC && (z.b[0] > z.a[0] || z.b[3] > z.a[3])) {
                 const double vhi = nodes[(size_t)T * CS_NC], vlo = nodes[(size_t)T * CS_NC + CS_NC - 1];
-                if (nf == 16) mx_far_pieces<1>(acc, z, hk, vlo, vhi, lr, lq, S0k, S1k, far.R, part[wv]);
-                else mx_far_pieces<2>(acc, z, hk, vlo, vhi, lr, lq, S0k, S1k, far.R, part[wv]);
+                if (nf == 16) mx_far_pieces<1>(acc, z, hk, vlo, vhi, lr, lq, S0k, S1k, far.R, part[wv], split ? wv : 0, split ? 4 : 1);
+                else mx_far_pieces<2>(acc, z, hk, vlo, vhi, lr, lq, S0k, S1k, far.R, part[wv], split ? wv : 0, split ? 4 : 1);
                 far_done = true;
             }
         }
@@ -1931,13 +1942,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         U[1] = max(U[1], U[0]); U[2] = max(U[2], U[1]); U[3] = min(U[3], U[0]);
         if (!nd || U[3] - p0 < 16) U[3] = p0;
     }
-    if (SPLIT == 1 && nd && ((phL && J[3] < e.eL) || (phR && U[3] > e.eR))) {   // (wave-uniform)
+    const bool ndL = phL && J[3] < e.eL, ndR = phR && U[3] > e.eR;
+    if (SPLIT == 1 && nd && (ndL || ndR)) {   // (wave-uniform)
         v4f64_sep af[1] = {v4f64_sep{0.0, 0.0, 0.0, 0.0}};
         const double vf[1] = {tnodes[(size_t)tile * 16 + lr]};
-        if (phL && J[3] < e.eL) {
+        if (ndL) {
             if (e.far3 & 1) sep_run<3, 0, 1, 0, 1>(af, vf, hk, J[3], e.eL, true, lq, 0.0); else sep_run<4, 0, 1, 0, 1>(af, vf, hk, J[3], e.eL, true, lq, 0.0);
         }
-        if (phR && U[3] > e.eR) {
+        if (ndR) {
             if (e.far3 & 2) sep_run<3, 0, 1, 0, 1>(af, vf, hk, e.eR, U[3], false, lq, 0.0); else sep_run<4, 0, 1, 0, 1>(af, vf, hk, e.eR, U[3], false, lq, 0.0);
         }
         // acc[state][point] += sum_m af[state][m] tC[tile][m][point]: af goes through LDS from the D layout (state 4r + lq, node lr) to the A

@@ -63,7 +63,8 @@ int cs_set_merge(cs_ctx *ctx, int on);
  *   key 11: the far pieces of an interval's matrix-core node sums (the lines beyond its parent's set: 3.8 .. 12 half-widths away on
  *          the bench grid) are summed on 32 or 16 nodes and carried to the interval's 64 (0, default), or on all 64 (1);
  *   key 12: the node sums of a level are added into the next smaller level's (a 64 x 64 matrix per interval) and only the smallest
- *          interval size is carried to the grid (k_cheb_cascade) -- 0 (default) with four or more levels in use, 1 always, 2 never;
+ *          interval size is carried to the grid (k_cheb_cascade) -- 0 (default) with four or more levels in use and, on the node-sum side
+ *          stream (key 2), from two levels on (it is off the critical path there), 1 always, 2 never;
  *   key 13: the vector-unit node kernel with four waves per (interval, state), a quarter of every window each -- 0 (default) on
  *          grids of fewer than 16384 (interval, state) waves (a nu-shard), 1 always, 2 never;
  *   key 14: k_voigt_edge_mx cuts a cut-off edge where the next 16-column sub-tile of the tile comes into the lines' reach and
@@ -90,7 +91,11 @@ int cs_set_merge(cs_ctx *ctx, int on);
  *   key 21: the piece tables of the matrix-core kernels as blocks of k_gas_setup's launch, computing the zones they need themselves
  *          (k_gas_setup_mx) -- 0 (default) on grids below 1024 tiles, 1 never (k_mxzones16 as its own launch), 2 always (A/B; same tables);
  *   key 22: waves per 64-point tile of k_voigt_far: 1, 2 or 4 (0, default: by the number of (tile, state) waves) (A/B).
- *   (keys 17, 18, 20 are unused.)
+ *   key 23: the window-end lines of k_voigt_edge_mx inside the cut-off of every point of a tile at the points, masked, like the others (1)
+ *          instead of on 16 Chebyshev nodes of the tile (0, default, where the grid allows: cut-off far beyond tile + smallest interval) (A/B).
+ *   key 17: where the four waves of a block share every item of k_cheb_nodes_mx (short grids), the far pieces of an interval on all 64
+ *          nodes (1) instead of on its level's 16 or 32, a quarter of the lines per wave (0, default) (A/B).
+ *   (keys 18, 20 are unused.)
  * Applies to every later cs_column_setup / cs_column_run of the context. */
 int cs_set_tuning(cs_ctx *ctx, int key, int value);
 
