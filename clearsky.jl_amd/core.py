@@ -268,9 +268,9 @@ class Context:
         check(lib().cs_set_merge(self._h, int(bool(on))))
 
     def set_tuning(self, key: int, value: int):
-        """A/B switches (cs_set_tuning), keys 0..16: where the interpolated wings are applied, matrix-core kernels on short grids,
-        side streams, interpolation margin, hipGraph replay, flux sweeps per stream, series radius rank, PHCO2 core and node counts,
-        low-order far pieces, level cascade, split node kernel -- include/clearsky_hip.h describes each."""
+        """A/B switches (cs_set_tuning, a lab entry point: include/clearsky_hip_dev.h describes each key): where the interpolated
+        wings are applied, matrix-core kernels on short grids, side streams, interpolation margin, hipGraph replay, flux sweeps per
+        stream, series radius rank, PHCO2 core and node counts, low-order far pieces, level cascade, fused flux tail, ..."""
         check(lib().cs_set_tuning(self._h, int(key), int(value)))
 
     def slot_of(self, sl: SpectralLines, keep=()) -> int:
