@@ -149,6 +149,48 @@ def test_interp_fuzz(cs, O, seed):
     on.close(); off.close(); onv.close()
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_interp_fuzz_long(cs, seed):
+    """The same on grids LONG enough for the forms a short grid never reaches (every grid above is below 141 tiles): one
+    (tile, group) per wave in k_voigt_edge_mx with its phases and the 16-node path of its window ends, one (interval, group) per
+    wave in k_cheb_nodes_mx with its far pieces on 16 / 32 nodes -- or on 64 where the node positions' rounding says so (seeds
+    with a small cut-off or a large nu; round 5: a latent 7e-13 at cut-off 1 cm^-1).  Interpolation on vs off at 2e-13."""
+    rng = np.random.default_rng(9500 + seed)
+    cut = [25.0, 5.0, 1.0, 25.0, 8.0, 60.0][seed]
+    nlev_target = int(rng.integers(1, 4))
+    n = int(rng.integers(92_000, 120_000))                          # >= 1438 tiles, >= 719 intervals: with three state groups both kernels
+                                                                     # take one item per wave (cs_api.hip: mx_big)
+    dnu = 1.5 * cut / 2.3 / (128 * 2 ** (nlev_target - 1)) * float(rng.uniform(0.55, 0.95))
+    c0 = float(rng.uniform(300, 2500))
+    span = dnu * (n - 1)
+    kind = ["uniform", "jitter", "random", "log", "jitter", "uniform"][seed]
+    if kind == "uniform":
+        nu = c0 + dnu * np.arange(n)
+    elif kind == "random":
+        nu = np.unique(c0 + np.sort(rng.uniform(0, span, n)))
+    elif kind == "log":
+        nu = np.unique(c0 * np.exp(np.linspace(0, np.log1p(span / c0), n)))
+    else:
+        nu = c0 + dnu * (np.arange(n) + rng.uniform(-0.4, 0.4, n))
+    M = int(rng.choice([1, 2, 6]))
+    L = int(min(60_000, max(4_000, 12.0 * (span + 4 * cut))))       # ~12 lines per cm^-1: every level stays in use
+    sl = _table(cs, rng, M, L, c0 - 2 * cut - 5, c0 + span + 2 * cut + 5)
+    K = int(rng.integers(33, 48))                                    # three state groups
+    T = rng.uniform(150, 350, K)
+    P = np.sort(10 ** rng.uniform(0, 5.3, K))
+    Pp = P * rng.uniform(0, 1, K)
+    on, off = cs.Context(0), cs.Context(0)
+    off.set_interp(False)
+    on.set_matrix_cores(2)     # (whatever the table's density)
+    a = cs.shape_batch(sl, "voigt", nu, list(T), list(P), list(Pp), cut, on)
+    b = cs.shape_batch(sl, "voigt", nu, list(T), list(P), list(Pp), cut, off)
+    plan = cs.interp_plan(nu, cut)
+    assert len(plan) >= 1, plan
+    assert np.array_equal(a == 0, b == 0)
+    assert relerr(a, b, floor=1e-280) < 2e-13, (seed, kind, cut, len(nu), plan, relerr(a, b, floor=1e-280))
+    on.close(); off.close()
+
+
 def test_interp_column_mixed_gases(cs, O):
     """Two Voigt gases with different cut-offs (levels follow the narrower one), a Lorentz gas in between, gray term, stellar
     beam: on vs off and vs the oracle."""
