@@ -220,3 +220,37 @@ def test_interp_column_mixed_gases(cs, O):
                              [25.0, 25.0, 8.0], col.conc, S_toa=col.S_toa[idx], albedo=col.albedo[idx], theta_s=0.5, nstream=4,
                              sigma_gray=1e-27)
     assert relerr(Fon.tau[:, idx], r["tau"]) < 1e-11
+
+
+@pytest.mark.parametrize("kind,cut", [("jitter", 5.0), ("log", 25.0)])
+def test_interp_column_long_nonuniform(cs, kind, cut):
+    """A whole column on a long NON-UNIFORM grid (the bench grids are uniform): three streams, level cascade on the node-sum
+    stream, tile nodes of the window ends, k_cheb_apply_mfma + k_rt -- interpolation on vs off: sigma at the nodes, tau, fluxes."""
+    rng = np.random.default_rng(4242)
+    n = 100_000
+    if kind == "jitter":
+        dnu = 0.004
+        nu = 1800.0 + dnu * (np.arange(n) + rng.uniform(-0.4, 0.4, n))
+    else:
+        nu = np.unique(400.0 * np.exp(np.linspace(0.0, np.log(6.0), n)))       # 400 .. 2400 cm^-1, spacing 0.007 .. 0.043
+    lo, hi = nu[0] - 2 * cut - 5, nu[-1] + 2 * cut + 5
+    g1 = cs.DirectGas(_table(cs, rng, 2, int(15 * (hi - lo)), lo, hi), 4e-4, nu, dnu_cut=cut)
+    g2 = cs.DirectGas(_table(cs, rng, 1, int(8 * (hi - lo)), lo, hi), 3e-3, nu, dnu_cut=cut)
+    P = cs.pressuregrid(2.0, 1e5, 34)
+    T = np.linspace(200.0, 290.0, 34)
+    out = {}
+    for flag in (True, False):
+        ctx = cs.Context(0)
+        ctx.set_interp(flag)
+        col = cs.Column(P, 9.8, T, 0.029, 0.0, 0.0, g1, g2, core=cs.Discretized(5, 2), ctx=ctx)
+        col.run()
+        F = cs.FluxPack(len(P), len(nu))
+        F.Fup[:], F.Fdn[:] = col.fetch(F.tau, F.Mup, F.Mdn)
+        out[flag] = (F, col.sigma_nodes(), col.work())
+        ctx.close()
+    Fon, son, won = out[True]
+    Foff, soff, woff = out[False]
+    assert won["levels"] >= 2 and woff["levels"] == 0
+    assert won["direct_evals_matrix"] > 0 and won["node_evals_matrix"] > 0, won       # (the matrix-core forms are what ran)
+    assert relerr(son, soff) < 2e-13 and relerr(Fon.tau, Foff.tau) < 2e-13
+    assert relerr(Fon.Fup, Foff.Fup) < 2e-13 and np.max(np.abs(Fon.Mup - Foff.Mup)) < 1e-12 * np.max(Foff.Mup)   # (M: exp(-tau m) of a tau at 2e-13)
